@@ -1,0 +1,121 @@
+"""TEST INFRASTRUCTURE — not product code.
+
+CPU (numpy) restatement of the *device* permutation generator used by the HIP path when
+``rng="philox"`` (``squidpy_amd/csrc/sqgr_rng.h``): Philox4x32-10 derives eight 32-bit round
+keys per (seed, permutation index, library); a keyed 8-round Feistel network over
+``bits = max(8, ceil(log2 n))`` bits with cycle walking turns them into a bijection of
+``[0, n)``.  The reference (squidpy) has no such generator — it uses numpy PCG64 shuffles
+(`/root/reference/src/squidpy/_utils.py:240-241`, ``gr/_nhood.py:533-538``) — so this file
+does not follow a reference file; it exists so that the GPU permutation test can be checked
+*bit for bit* (same permutations => same counts => same z-scores) and so that the statistical
+quality of the generator can be tested against numpy's shuffles on the CPU.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+PHILOX_M0 = np.uint64(0xD2511F53)
+PHILOX_M1 = np.uint64(0xCD9E8D57)
+PHILOX_W0 = 0x9E3779B9
+PHILOX_W1 = 0xBB67AE85
+FEISTEL_C1 = np.uint64(0xD2511F)
+FEISTEL_C2 = np.uint64(0xCD9E8D)
+N_ROUNDS = 8
+MASK32 = np.uint64(0xFFFFFFFF)
+MASK24 = np.uint64(0xFFFFFF)
+
+
+def philox4x32_10(ctr: np.ndarray, key: tuple[int, int]) -> np.ndarray:
+    """Vectorised Philox4x32-10.  ``ctr``: (..., 4) uint32; ``key``: two 32-bit ints."""
+    c = [ctr[..., i].astype(np.uint64) for i in range(4)]
+    k0, k1 = int(key[0]) & 0xFFFFFFFF, int(key[1]) & 0xFFFFFFFF
+    for _ in range(10):
+        p0 = PHILOX_M0 * c[0]
+        p1 = PHILOX_M1 * c[2]
+        hi0, lo0 = p0 >> np.uint64(32), p0 & MASK32
+        hi1, lo1 = p1 >> np.uint64(32), p1 & MASK32
+        c = [hi1 ^ c[1] ^ np.uint64(k0), lo1, hi0 ^ c[3] ^ np.uint64(k1), lo0]
+        k0 = (k0 + PHILOX_W0) & 0xFFFFFFFF
+        k1 = (k1 + PHILOX_W1) & 0xFFFFFFFF
+    return np.stack(c, axis=-1).astype(np.uint32)
+
+
+def round_keys(seed: int, perms: np.ndarray, lib: int = 0) -> np.ndarray:
+    """Round keys, shape (len(perms), 8) uint32, for global permutation indices ``perms``."""
+    perms = np.asarray(perms, dtype=np.uint64)
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    key = (seed & 0xFFFFFFFF, seed >> 32)
+    out = []
+    for j in (0, 1):
+        ctr = np.stack(
+            [
+                (perms & MASK32).astype(np.uint32),
+                (perms >> np.uint64(32)).astype(np.uint32),
+                np.full(perms.shape, lib, dtype=np.uint32),
+                np.full(perms.shape, j, dtype=np.uint32),
+            ],
+            axis=-1,
+        )
+        out.append(philox4x32_10(ctr, key))
+    return np.concatenate(out, axis=-1)
+
+
+def domain_bits(n: int) -> int:
+    b = 0
+    while (1 << b) < n:
+        b += 1
+    return max(8, b)
+
+
+def _F(v: np.ndarray, k: np.uint64) -> np.ndarray:
+    t = (v ^ k) & MASK24
+    u = (t * FEISTEL_C1) & MASK32
+    u ^= u >> np.uint64(15)
+    w = ((u & MASK24) * FEISTEL_C2) & MASK32
+    return w >> np.uint64(16)
+
+
+def feistel(x: np.ndarray, bits: int, rk: np.ndarray) -> np.ndarray:
+    """One application of the keyed bijection of [0, 2**bits).  ``rk``: (8,) uint32."""
+    rb = bits // 2
+    lb = bits - rb
+    ml, mr = np.uint64((1 << lb) - 1), np.uint64((1 << rb) - 1)
+    x = x.astype(np.uint64)
+    a, b = x >> np.uint64(rb), x & mr
+    for r in range(N_ROUNDS):
+        k = np.uint64(int(rk[r]))
+        if r % 2 == 0:
+            a = a ^ (_F(b, k) & ml)
+        else:
+            b = b ^ (_F(a, k) & mr)
+    return (a << np.uint64(rb)) | b
+
+
+def permutation(n: int, rk: np.ndarray) -> np.ndarray:
+    """pi with pi[i] = image of i under the cycle-walked bijection of [0, n); int64 (n,)."""
+    if n <= 1:
+        return np.zeros(n, dtype=np.int64)
+    bits = domain_bits(n)
+    x = feistel(np.arange(n, dtype=np.uint64), bits, rk)
+    bad = x >= np.uint64(n)
+    while bad.any():
+        x[bad] = feistel(x[bad], bits, rk)
+        bad = x >= np.uint64(n)
+    return x.astype(np.int64)
+
+
+def shuffled_labels(
+    labels: np.ndarray, seed: int, perm: int, lib_ids: np.ndarray | None = None, n_libs: int = 0
+) -> np.ndarray:
+    """Label vector of global permutation ``perm``: out[i] = labels[pi(i)] (per library if given)."""
+    labels = np.asarray(labels)
+    if lib_ids is None:
+        rk = round_keys(seed, np.array([perm]))[0]
+        return labels[permutation(len(labels), rk)]
+    out = np.empty_like(labels)
+    for lib in range(n_libs):
+        idx = np.where(lib_ids == lib)[0]
+        rk = round_keys(seed, np.array([perm]), lib=lib)[0]
+        out[idx] = labels[idx][permutation(len(idx), rk)]
+    return out
