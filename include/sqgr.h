@@ -1,0 +1,121 @@
+/*
+ * sqgr.h — C ABI of libsqgr.so, the MI355X (gfx950) implementation of Squidpy's `sq.gr`
+ * spatial-statistics hot path.
+ *
+ * The reference (scverse/squidpy) has no FFI on this path: its kernels are numba-JIT Python
+ * (SURVEY.md §8b).  Each entry point below therefore replaces a *Python-level* reference
+ * function, cited as file:line under /root/reference/src/squidpy; INTEGRATION.md shows the
+ * ctypes binding a Squidpy maintainer would add at those call sites.
+ *
+ * Conventions
+ *   - plain C, every function returns 0 (SQGR_OK) or a negative sqgr_status; never throws.
+ *     `sqgr_last_error()` returns a thread-local human-readable message for the last failure.
+ *   - all array arguments are caller-owned HOST pointers (C-contiguous), copied in/out by the
+ *     library and never retained after return, except inside explicit handles
+ *     (sqgr_graph, sqgr_nhood, sqgr_points, sqgr_autocorr), which keep DEVICE copies.
+ *   - a context owns one device and one HIP stream; a context is not thread-safe, distinct
+ *     contexts may be used from distinct threads (one process per GPU is the intended use).
+ *   - calls are synchronous on return unless documented otherwise.
+ *   - there is NO CPU fallback anywhere in this library: without a usable HIP device
+ *     `sqgr_ctx_create` fails.
+ */
+#ifndef SQGR_H
+#define SQGR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SQGR_ABI_VERSION 1
+
+typedef enum sqgr_status {
+    SQGR_OK = 0,
+    SQGR_ERR_INVALID = -1,     /* bad argument (null pointer, out-of-range label, K <= 1, ...) */
+    SQGR_ERR_HIP = -2,         /* a HIP runtime call failed; message has the hipError string   */
+    SQGR_ERR_NOMEM = -3,       /* device or host allocation failed                               */
+    SQGR_ERR_UNSUPPORTED = -4, /* valid request outside what the kernels implement               */
+    SQGR_ERR_NODEVICE = -5     /* no HIP device / device index out of range                      */
+} sqgr_status;
+
+typedef struct sqgr_ctx sqgr_ctx;
+typedef struct sqgr_graph sqgr_graph;
+typedef struct sqgr_nhood sqgr_nhood;
+typedef struct sqgr_points sqgr_points;
+typedef struct sqgr_autocorr sqgr_autocorr;
+
+/* ------------------------------------------------------------------ library / context */
+int sqgr_abi_version(void);
+const char* sqgr_last_error(void);
+int sqgr_device_count(int* out_count);
+int sqgr_ctx_create(int device, sqgr_ctx** out_ctx);
+int sqgr_ctx_destroy(sqgr_ctx* ctx);
+int sqgr_ctx_sync(sqgr_ctx* ctx);
+/* name[0..len) <- device name, *cu_count <- compute units, *hbm_bytes <- total device memory */
+int sqgr_ctx_device_info(sqgr_ctx* ctx, char* name, int len, int* cu_count, int64_t* hbm_bytes);
+
+/* Per-kernel HIP-event timing on the context's own stream (used by bench.py for the roofline
+ * figure).  While enabled every kernel launch is bracketed by hipEventRecord on ctx's stream.
+ * sqgr_timer_get sums elapsed ms and launches of all kernels whose name starts with `prefix`. */
+int sqgr_timer_enable(sqgr_ctx* ctx, int enable);
+int sqgr_timer_reset(sqgr_ctx* ctx);
+int sqgr_timer_get(sqgr_ctx* ctx, const char* prefix, double* total_ms, int64_t* launches);
+/* writes a ';'-separated list "name:launches:ms" of everything timed so far */
+int sqgr_timer_report(sqgr_ctx* ctx, char* buf, int len);
+
+/* ------------------------------------------------------------------ spatial graph (CSR)
+ * Device-resident copy of `adata.obsp[<key>_connectivities]` (scipy CSR): what
+ * gr/_nhood.py:194,205 and gr/_ppatterns.py:212 read.  `data` may be NULL (binarised use).
+ * indptr: int64[n+1]; indices: int32[nnz]; data: float32[nnz]. */
+int sqgr_graph_create(sqgr_ctx* ctx, int64_t n, int64_t nnz, const int64_t* indptr, const int32_t* indices,
+                      const float* data, sqgr_graph** out_graph);
+int sqgr_graph_destroy(sqgr_graph* g);
+
+/* ------------------------------------------------------------------ nhood_enrichment
+ * replaces the generated numba kernel `_nenrich_{K}_{parallel}` (gr/_nhood.py:54-141):
+ *   out[a*K+b] = sum_{i: lab_i=a} #{j in N(i): lab_j=b}      (uint32, edges binarised)
+ * labels: int32[n] in [0,K).  2 <= K <= 256. */
+int sqgr_nhood_counts(sqgr_ctx* ctx, const sqgr_graph* g, const int32_t* labels, int32_t K, uint32_t* out_counts);
+
+/* Injected permutations: the body of `_nhood_enrichment_helper` (gr/_nhood.py:530-539) with the
+ * shuffled label vectors supplied by the caller (e.g. numpy's PCG64 shuffles, for exact parity):
+ *   labels: uint8[n_perms][n];  out_counts: uint32[n_perms][K][K]. */
+int sqgr_nhood_counts_batch(sqgr_ctx* ctx, const sqgr_graph* g, const uint8_t* labels, int64_t n_perms, int32_t K,
+                            uint32_t* out_counts);
+
+/* A resident permutation-test problem: graph + base labels (+ optional libraries) on the device.
+ * lib_ids: int32[n] in [0,n_libs) or NULL (gr/_utils.py:185-213 `_shuffle_group` semantics:
+ * labels are shuffled independently inside each library). */
+int sqgr_nhood_create(sqgr_ctx* ctx, const sqgr_graph* g, const int32_t* labels, int32_t K, const int32_t* lib_ids,
+                      int32_t n_libs, sqgr_nhood** out_plan);
+int sqgr_nhood_destroy(sqgr_nhood* plan);
+
+/* Runs permutations [perm_begin, perm_end) of the test entirely on the device: replaces
+ * `parallelize(_nhood_enrichment_helper, ...)` (gr/_nhood.py:215-230).  Label shuffles are generated
+ * on the GPU by a counter-based generator keyed by (seed, global permutation index, library):
+ * Philox4x32-10 round keys + 8-round Feistel bijection with cycle walking (csrc/sqgr_rng.h,
+ * restated in oracle/devrng.py), so results do not depend on how a permutation range is split
+ * across calls, devices or ranks.
+ *   shift:      int64[K*K] or NULL(=0): d = count - shift is what gets accumulated (exact integers)
+ *   out_sum:    int64[K*K]   sum_p d           out_sumsq: uint64[K*K]  sum_p d*d
+ *   out_perms:  uint32[(perm_end-perm_begin)*K*K] or NULL — the per-permutation counts. */
+int sqgr_nhood_run(sqgr_nhood* plan, uint64_t seed, int64_t perm_begin, int64_t perm_end, const int64_t* shift,
+                   int64_t* out_sum, uint64_t* out_sumsq, uint32_t* out_perms);
+
+/* Debug/parity hook: the shuffled label vector of one global permutation index, uint8[n]. */
+int sqgr_nhood_shuffled_labels(sqgr_nhood* plan, uint64_t seed, int64_t perm, uint8_t* out_labels);
+
+/* tuning knobs (0 = library default): perms per CSR pass (16|32), count blocks per batch, batches per launch */
+int sqgr_nhood_tune(sqgr_nhood* plan, int32_t perms_per_pass, int32_t blocks_per_batch, int32_t batches_per_launch);
+
+/* weighted K x K edge sums: `_interaction_matrix` (gr/_nhood.py:412-429); out: float64[K*K].
+ * weights != 0 uses graph data (must have been uploaded), else 1 per stored edge. */
+int sqgr_interaction_matrix(sqgr_ctx* ctx, const sqgr_graph* g, const int32_t* labels, int32_t K, int32_t weights,
+                            double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SQGR_H */

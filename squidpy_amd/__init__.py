@@ -1,0 +1,11 @@
+"""squidpy_amd — MI355X-native implementation of Squidpy's ``sq.gr`` spatial-statistics hot path.
+
+``import squidpy_amd as sq; sq.gr.nhood_enrichment(adata, ...)`` mirrors ``squidpy.gr`` for
+``nhood_enrichment``, ``spatial_autocorr``, ``co_occurrence``, ``ripley`` (and ``interaction_matrix``).
+All compute runs in ``libsqgr.so`` (hand-written HIP for gfx950); there is no CPU fallback."""
+
+from . import gr
+from ._anndata_lite import AnnDataLite
+
+__all__ = ["gr", "AnnDataLite"]
+__version__ = "0.1.0"

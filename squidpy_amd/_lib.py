@@ -1,0 +1,311 @@
+"""ctypes binding of ``libsqgr.so`` (C ABI declared in ``include/sqgr.h``).
+
+This is the only way the Python front-end computes anything: there is no CPU fallback.  If the shared
+library has not been built (``python -m squidpy_amd._build``) or no HIP device is usable, the functions
+here raise :class:`SqgrError` / :class:`OSError` loudly."""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from typing import Any
+
+import numpy as np
+
+from ._build import LIB_PATH
+
+c_i32p = C.POINTER(C.c_int32)
+c_i64p = C.POINTER(C.c_int64)
+c_u64p = C.POINTER(C.c_uint64)
+c_u32p = C.POINTER(C.c_uint32)
+c_u8p = C.POINTER(C.c_uint8)
+c_f32p = C.POINTER(C.c_float)
+c_f64p = C.POINTER(C.c_double)
+
+# name -> (restype, argtypes); every symbol declared in include/sqgr.h must be listed here
+# (tests/test_abi.py cross-checks this table against the header and the built library).
+SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
+    "sqgr_abi_version": (C.c_int, []),
+    "sqgr_last_error": (C.c_char_p, []),
+    "sqgr_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "sqgr_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "sqgr_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "sqgr_ctx_sync": (C.c_int, [C.c_void_p]),
+    "sqgr_ctx_device_info": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), c_i64p]),
+    "sqgr_timer_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "sqgr_timer_reset": (C.c_int, [C.c_void_p]),
+    "sqgr_timer_get": (C.c_int, [C.c_void_p, C.c_char_p, c_f64p, c_i64p]),
+    "sqgr_timer_report": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "sqgr_graph_create": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, c_i64p, c_i32p, c_f32p, C.POINTER(C.c_void_p)]),
+    "sqgr_graph_destroy": (C.c_int, [C.c_void_p]),
+    "sqgr_nhood_counts": (C.c_int, [C.c_void_p, C.c_void_p, c_i32p, C.c_int32, c_u32p]),
+    "sqgr_nhood_counts_batch": (C.c_int, [C.c_void_p, C.c_void_p, c_u8p, C.c_int64, C.c_int32, c_u32p]),
+    "sqgr_nhood_create": (C.c_int, [C.c_void_p, C.c_void_p, c_i32p, C.c_int32, c_i32p, C.c_int32, C.POINTER(C.c_void_p)]),
+    "sqgr_nhood_destroy": (C.c_int, [C.c_void_p]),
+    "sqgr_nhood_run": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, c_i64p, c_i64p, c_u64p, c_u32p]),
+    "sqgr_nhood_shuffled_labels": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, c_u8p]),
+    "sqgr_nhood_tune": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "sqgr_interaction_matrix": (C.c_int, [C.c_void_p, C.c_void_p, c_i32p, C.c_int32, C.c_int32, c_f64p]),
+}
+
+
+class SqgrError(RuntimeError):
+    """A libsqgr call returned a negative status."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(f"libsqgr error {status}: {message}")
+        self.status = status
+
+
+_lib: C.CDLL | None = None
+_lock = threading.Lock()
+
+
+def load_library(path: str | None = None) -> C.CDLL:
+    """dlopen the in-tree ``libsqgr.so`` and set the prototypes.  Raises if it is missing."""
+    global _lib
+    with _lock:
+        if _lib is not None and path is None:
+            return _lib
+        p = path or os.environ.get("SQGR_LIBRARY") or LIB_PATH
+        if not os.path.exists(p):
+            raise OSError(
+                f"{p} not found: build the HIP extension first (`python -m squidpy_amd._build`). "
+                "squidpy_amd has no CPU fallback."
+            )
+        lib = C.CDLL(p)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        if lib.sqgr_abi_version() != 1:
+            raise OSError(f"{p}: ABI version {lib.sqgr_abi_version()} != 1")
+        if path is None:
+            _lib = lib
+        return lib
+
+
+def _check(lib: C.CDLL, rc: int) -> None:
+    if rc != 0:
+        raise SqgrError(rc, (lib.sqgr_last_error() or b"").decode(errors="replace"))
+
+
+def _ptr(a: np.ndarray | None, ctype: Any) -> Any:
+    if a is None:
+        return None
+    return a.ctypes.data_as(ctype)
+
+
+def _as(a: Any, dtype: Any) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def device_count() -> int:
+    lib = load_library()
+    n = C.c_int(0)
+    rc = lib.sqgr_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+class Context:
+    """One device + one HIP stream (``sqgr_ctx``)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        _check(self.lib, self.lib.sqgr_ctx_create(int(device), C.byref(h)))
+        self.h = h
+        self.device = int(device)
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.lib.sqgr_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self) -> None:  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self) -> None:
+        _check(self.lib, self.lib.sqgr_ctx_sync(self.h))
+
+    def device_info(self) -> dict[str, Any]:
+        buf = C.create_string_buffer(256)
+        cu = C.c_int(0)
+        mem = C.c_int64(0)
+        _check(self.lib, self.lib.sqgr_ctx_device_info(self.h, buf, 256, C.byref(cu), C.byref(mem)))
+        return {"name": buf.value.decode(), "cu_count": cu.value, "hbm_bytes": mem.value}
+
+    # ---- kernel timers (HIP events on this context's stream)
+    def timer_enable(self, on: bool = True) -> None:
+        _check(self.lib, self.lib.sqgr_timer_enable(self.h, int(on)))
+
+    def timer_reset(self) -> None:
+        _check(self.lib, self.lib.sqgr_timer_reset(self.h))
+
+    def timer_get(self, prefix: str) -> tuple[float, int]:
+        ms = C.c_double(0)
+        cnt = C.c_int64(0)
+        _check(self.lib, self.lib.sqgr_timer_get(self.h, prefix.encode(), C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
+    def timer_report(self) -> dict[str, tuple[int, float]]:
+        buf = C.create_string_buffer(16384)
+        _check(self.lib, self.lib.sqgr_timer_report(self.h, buf, 16384))
+        out = {}
+        for item in buf.value.decode().split(";"):
+            if item:
+                name, cnt, ms = item.rsplit(":", 2)
+                out[name] = (int(cnt), float(ms))
+        return out
+
+
+_default_ctx: dict[int, Context] = {}
+
+
+def default_context(device: int | None = None) -> Context:
+    """Process-wide context for ``device`` (default: ``LOCAL_RANK`` or 0) — one process per GPU."""
+    if device is None:
+        device = int(os.environ.get("SQGR_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        n = device_count()
+        if n > 0:
+            device %= n
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+class Graph:
+    """Device-resident CSR (``sqgr_graph``) built from a scipy sparse matrix."""
+
+    def __init__(self, ctx: Context, adj: Any, with_data: bool = True):
+        from scipy import sparse
+
+        adj = sparse.csr_matrix(adj) if not sparse.isspmatrix_csr(adj) else adj
+        if adj.shape[0] != adj.shape[1]:
+            raise ValueError(f"Expected a square adjacency matrix, found shape `{adj.shape}`.")
+        self.ctx = ctx
+        self.n = adj.shape[0]
+        self.nnz = int(adj.nnz)
+        indptr = _as(adj.indptr, np.int64)
+        indices = _as(adj.indices, np.int32)
+        data = _as(adj.data, np.float32) if with_data else None
+        h = C.c_void_p()
+        _check(
+            ctx.lib,
+            ctx.lib.sqgr_graph_create(
+                ctx.h, self.n, self.nnz, _ptr(indptr, c_i64p), _ptr(indices, c_i32p), _ptr(data, c_f32p), C.byref(h)
+            ),
+        )
+        self.h = h
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.ctx.lib.sqgr_graph_destroy(self.h)
+            self.h = None
+
+    def __del__(self) -> None:  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def nhood_counts(ctx: Context, g: Graph, labels: np.ndarray, n_cls: int) -> np.ndarray:
+    labels = _as(labels, np.int32)
+    out = np.zeros((n_cls, n_cls), dtype=np.uint32)
+    _check(ctx.lib, ctx.lib.sqgr_nhood_counts(ctx.h, g.h, _ptr(labels, c_i32p), n_cls, _ptr(out, c_u32p)))
+    return out
+
+
+def nhood_counts_batch(ctx: Context, g: Graph, labels: np.ndarray, n_cls: int) -> np.ndarray:
+    """labels: (P, N) integer array of shuffled label vectors -> uint32 (P, K, K)."""
+    labels = np.asarray(labels)
+    if labels.ndim != 2 or labels.shape[1] != g.n:
+        raise ValueError(f"Expected labels of shape (n_perms, {g.n}), found {labels.shape}.")
+    if labels.size and (labels.min() < 0 or labels.max() >= n_cls):
+        raise ValueError("label outside [0, n_cls)")
+    lab8 = _as(labels, np.uint8)
+    out = np.zeros((labels.shape[0], n_cls, n_cls), dtype=np.uint32)
+    _check(
+        ctx.lib,
+        ctx.lib.sqgr_nhood_counts_batch(ctx.h, g.h, _ptr(lab8, c_u8p), labels.shape[0], n_cls, _ptr(out, c_u32p)),
+    )
+    return out
+
+
+def interaction_matrix(ctx: Context, g: Graph, labels: np.ndarray, n_cls: int, weights: bool) -> np.ndarray:
+    labels = _as(labels, np.int32)
+    out = np.zeros((n_cls, n_cls), dtype=np.float64)
+    _check(
+        ctx.lib, ctx.lib.sqgr_interaction_matrix(ctx.h, g.h, _ptr(labels, c_i32p), n_cls, int(weights), _ptr(out, c_f64p))
+    )
+    return out
+
+
+class NhoodPlan:
+    """Resident permutation-test problem (``sqgr_nhood``)."""
+
+    def __init__(self, ctx: Context, g: Graph, labels: np.ndarray, n_cls: int, lib_ids: np.ndarray | None = None, n_libs: int = 0):
+        self.ctx, self.g, self.n_cls = ctx, g, int(n_cls)
+        labels = _as(labels, np.int32)
+        if len(labels) != g.n:
+            raise ValueError(f"Expected {g.n} labels, found {len(labels)}.")
+        lib = _as(lib_ids, np.int32) if lib_ids is not None else None
+        h = C.c_void_p()
+        _check(
+            ctx.lib,
+            ctx.lib.sqgr_nhood_create(
+                ctx.h, g.h, _ptr(labels, c_i32p), self.n_cls, _ptr(lib, c_i32p), int(n_libs) if lib is not None else 0, C.byref(h)
+            ),
+        )
+        self.h = h
+
+    def tune(self, perms_per_pass: int = 0, blocks_per_batch: int = 0, batches_per_launch: int = 0) -> None:
+        _check(self.ctx.lib, self.ctx.lib.sqgr_nhood_tune(self.h, perms_per_pass, blocks_per_batch, batches_per_launch))
+
+    def run(
+        self, seed: int, perm_begin: int, perm_end: int, shift: np.ndarray | None = None, return_perms: bool = False
+    ) -> tuple[np.ndarray, np.ndarray, np.ndarray | None]:
+        """-> (sum_d int64 (K,K), sum_d2 uint64 (K,K), perms uint32 (P,K,K) | None) with d = count - shift."""
+        k = self.n_cls
+        s = _as(shift, np.int64).reshape(-1) if shift is not None else None
+        out_sum = np.zeros((k, k), dtype=np.int64)
+        out_sq = np.zeros((k, k), dtype=np.uint64)
+        perms = np.zeros((max(perm_end - perm_begin, 0), k, k), dtype=np.uint32) if return_perms else None
+        _check(
+            self.ctx.lib,
+            self.ctx.lib.sqgr_nhood_run(
+                self.h,
+                C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF),
+                int(perm_begin),
+                int(perm_end),
+                _ptr(s, c_i64p),
+                _ptr(out_sum, c_i64p),
+                _ptr(out_sq, c_u64p),
+                _ptr(perms, c_u32p),
+            ),
+        )
+        return out_sum, out_sq, perms
+
+    def shuffled_labels(self, seed: int, perm: int) -> np.ndarray:
+        out = np.zeros(self.g.n, dtype=np.uint8)
+        _check(
+            self.ctx.lib,
+            self.ctx.lib.sqgr_nhood_shuffled_labels(self.h, C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), int(perm), _ptr(out, c_u8p)),
+        )
+        return out
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.ctx.lib.sqgr_nhood_destroy(self.h)
+            self.h = None
+
+    def __del__(self) -> None:  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,124 @@
+// Internal helpers shared by the libsqgr translation units (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/sqgr.h"
+
+namespace sqgr {
+
+void set_error(const char* fmt, ...);
+
+#define SQGR_HIP(call)                                                                              \
+    do {                                                                                            \
+        hipError_t e__ = (call);                                                                    \
+        if (e__ != hipSuccess) {                                                                    \
+            ::sqgr::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return (e__ == hipErrorOutOfMemory) ? SQGR_ERR_NOMEM : SQGR_ERR_HIP;                   \
+        }                                                                                           \
+    } while (0)
+
+#define SQGR_REQUIRE(cond, ...)            \
+    do {                                   \
+        if (!(cond)) {                     \
+            ::sqgr::set_error(__VA_ARGS__); \
+            return SQGR_ERR_INVALID;       \
+        }                                  \
+    } while (0)
+
+#define SQGR_TRY(expr)            \
+    do {                          \
+        int rc__ = (expr);        \
+        if (rc__ != SQGR_OK) return rc__; \
+    } while (0)
+
+struct TimedLaunch {
+    int name_id;
+    hipEvent_t start, stop;
+};
+
+}  // namespace sqgr
+
+struct sqgr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int cu_count = 0;
+    bool timing = false;
+    std::vector<std::string> timer_names;
+    std::map<std::string, int> timer_ids;
+    std::vector<sqgr::TimedLaunch> launches;      // unresolved event pairs
+    std::vector<double> timer_ms;                 // resolved totals per name id
+    std::vector<int64_t> timer_count;
+    std::vector<hipEvent_t> event_pool;
+
+    int timer_id(const char* name);
+    int begin_launch(const char* name, sqgr::TimedLaunch* tl);
+    int end_launch(const sqgr::TimedLaunch& tl);
+    int resolve_timers();
+};
+
+namespace sqgr {
+
+// RAII bracket: records start/stop events on ctx->stream around a kernel launch when timing is on.
+struct LaunchTimer {
+    sqgr_ctx* ctx;
+    TimedLaunch tl;
+    bool active;
+    LaunchTimer(sqgr_ctx* c, const char* name) : ctx(c), active(false) {
+        if (ctx->timing) active = (ctx->begin_launch(name, &tl) == SQGR_OK);
+    }
+    ~LaunchTimer() {
+        if (active) ctx->end_launch(tl);
+    }
+};
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    int alloc(size_t count) {
+        release();
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            set_error("hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+            return SQGR_ERR_NOMEM;
+        }
+        n = count;
+        return SQGR_OK;
+    }
+    int ensure(size_t count) { return (count <= n && p) ? SQGR_OK : alloc(count); }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace sqgr
+
+struct sqgr_graph {
+    sqgr_ctx* ctx = nullptr;
+    int64_t n = 0, nnz = 0;
+    sqgr::DevBuf<int64_t> indptr;   // [n+1]
+    sqgr::DevBuf<int32_t> indices;  // [nnz]
+    sqgr::DevBuf<int32_t> erow;     // [nnz] row of every stored edge (COO expansion, built on device)
+    sqgr::DevBuf<float> data;       // [nnz] or empty
+    bool has_data = false;
+};

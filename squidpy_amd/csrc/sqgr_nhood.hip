@@ -1,0 +1,700 @@
+// libsqgr: neighbourhood-enrichment permutation test on the device-resident CSR graph.
+//
+// Reference semantics (scverse/squidpy, src/squidpy/gr/_nhood.py):
+//   :54-141   generated numba kernel  count[a,b] = sum_{i: lab_i=a} #{j in N(i): lab_j=b}  (uint32)
+//   :516-547  per permutation: shuffle labels (per library: gr/_utils.py:185-213), count again
+//   :231      zscore = (count - mean_p) / std_p
+//
+// MI355X design: B (16 or 32) permutations are processed per pass over the graph.
+//   k_shuffle : thread per spot; B keyed Feistel bijections -> shuffled labels written as ONE B-byte
+//               row per spot: slab[spot][b] (uint8).  One 16/32-byte gather later serves B permutations.
+//   k_count   : edge-parallel over the COO view (erow, indices); 4 lanes per edge, each lane owns B/4
+//               permutations; K*K*B counters live in LDS, laid out [pair][b] so that the 32 lanes of a
+//               DS lane group hit distinct banks (B=32) — ds_add_u32 without bank conflicts; block-local
+//               histograms are written out as partials (plain coalesced stores, no global atomics).
+//   k_reduce  : thread per (pair, b): sums the partials over blocks -> exact per-permutation count,
+//               accumulates d=count-shift and d*d in 64-bit integers (order independent, deterministic).
+#include "sqgr_common.h"
+#include "sqgr_rng.h"
+
+namespace sqgr {
+
+constexpr int COUNT_THREADS = 1024;
+constexpr size_t LDS_BUDGET = 160 * 1024;
+
+struct LibInfo {
+    FeistelDomain dom;
+    uint32_t off;  // offset of this library's block inside the gather table
+};
+
+// ---------------------------------------------------------------------------------------------- key generation
+__global__ void k_keygen(uint64_t seed, int64_t perm0, int64_t nperm, int n_libs, uint32_t* __restrict__ keys) {
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= nperm * n_libs) return;
+    int64_t p = t / n_libs;
+    uint32_t lib = (uint32_t)(t % n_libs);
+    uint32_t rk[8];
+    round_keys(seed, (uint64_t)(perm0 + p), lib, rk);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) keys[t * 8 + i] = rk[i];
+}
+
+// ---------------------------------------------------------------------------------------------- label shuffle
+// slab[(batch*n + i)*B + b] = table[ off_lib + pi_{perm,lib}( rank_i ) ]
+template <int B, bool HAS_LIBS>
+__global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint8_t* __restrict__ table,
+                                                 const uint32_t* __restrict__ keys, FeistelDomain dom0, int n_libs,
+                                                 const int32_t* __restrict__ lib_of, const int32_t* __restrict__ rank_of,
+                                                 const LibInfo* __restrict__ libs, uint8_t* __restrict__ slab_all) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int batch = blockIdx.y;
+    const uint32_t* kb = keys + (size_t)batch * B * n_libs * 8;
+    uint32_t out[B / 4];
+    FeistelDomain dom = dom0;
+    uint32_t x0 = (uint32_t)i, off = 0, lib = 0;
+    if (HAS_LIBS) {
+        lib = (uint32_t)lib_of[i];
+        LibInfo li = libs[lib];
+        dom = li.dom;
+        off = li.off;
+        x0 = (uint32_t)rank_of[i];
+    }
+#pragma unroll
+    for (int w = 0; w < B / 4; ++w) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int b = w * 4 + j;
+            const uint32_t* rk = kb + ((size_t)b * n_libs + lib) * 8;  // uniform (scalar loads) when !HAS_LIBS
+            uint32_t x = feistel_perm(x0, dom, rk);
+            word |= (uint32_t)table[off + x] << (8 * j);
+        }
+        out[w] = word;
+    }
+    uint4* dst = reinterpret_cast<uint4*>(slab_all + ((size_t)batch * n + i) * B);
+#pragma unroll
+    for (int v = 0; v < B / 16; ++v) dst[v] = make_uint4(out[4 * v], out[4 * v + 1], out[4 * v + 2], out[4 * v + 3]);
+}
+
+// injected permutations: lab[(p)*n + i] (perm-major, host order) -> slab rows
+template <int B>
+__global__ __launch_bounds__(256) void k_transpose_labels(int64_t n, const uint8_t* __restrict__ lab, int64_t nperm_valid,
+                                                          uint8_t* __restrict__ slab_all) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int batch = blockIdx.y;
+    uint8_t* dst = slab_all + ((size_t)batch * n + i) * B;
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        int64_t p = (int64_t)batch * B + b;
+        dst[b] = p < nperm_valid ? lab[(size_t)p * n + i] : (uint8_t)0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- counting
+// Block -> edge chunk with XCD affinity: hardware places block b on XCD (b % 8); give each XCD one
+// contiguous eighth of the edge list so halo rows shared by neighbouring chunks stay in one L2.
+__device__ __forceinline__ int xcd_chunk(int b, int nblk) {
+    if (nblk % 8 != 0) return b;
+    return (b & 7) * (nblk >> 3) + (b >> 3);
+}
+
+// byte j of the lane's B/4 label bytes (kept in scalars: a dynamically indexed array would go to scratch)
+template <int B>
+__device__ __forceinline__ uint32_t label_byte(uint32_t lo, uint32_t hi, int j) {
+    if constexpr (B == 16) {
+        return (lo >> (8 * j)) & 0xffu;
+    } else {
+        const uint32_t w = (j & 4) ? hi : lo;
+        return (w >> (8 * (j & 3))) & 0xffu;
+    }
+}
+
+// B = 16 | 32 permutations; 4 lanes per edge, lane q owns permutations [q*B/4, (q+1)*B/4).
+// LDS histogram layout: word = pair*B + b  (pair = la*K + lb).
+template <int B, int MIN_WAVES>
+__global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(int64_t nnz, const int32_t* __restrict__ erow,
+                                                                    const int32_t* __restrict__ indices,
+                                                                    const uint8_t* __restrict__ slab_all, int64_t n, int K,
+                                                                    int hist_words, int64_t edges_per_block,
+                                                                    uint32_t* __restrict__ partial_all) {
+    extern __shared__ uint32_t hist[];
+    constexpr int BPL = B / 4;  // label bytes per lane
+    const int tid = threadIdx.x;
+    for (int i = tid; i < hist_words; i += COUNT_THREADS) hist[i] = 0;
+    __syncthreads();
+
+    const uint8_t* slab = slab_all + (size_t)blockIdx.y * n * B;
+    const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
+    const int64_t e0 = (int64_t)chunk * edges_per_block;
+    const int64_t e1 = min(nnz, e0 + edges_per_block);
+    const int q = tid & 3;
+    const int el = tid >> 2;
+    for (int64_t e = e0 + el; e < e1; e += COUNT_THREADS / 4) {
+        const int32_t r = erow[e];
+        const int32_t c = indices[e];
+        uint32_t la_lo, la_hi = 0, lb_lo, lb_hi = 0;
+        if constexpr (B == 16) {
+            la_lo = *reinterpret_cast<const uint32_t*>(slab + (size_t)r * B + q * BPL);
+            lb_lo = *reinterpret_cast<const uint32_t*>(slab + (size_t)c * B + q * BPL);
+        } else {
+            const uint2 a = *reinterpret_cast<const uint2*>(slab + (size_t)r * B + q * BPL);
+            const uint2 b = *reinterpret_cast<const uint2*>(slab + (size_t)c * B + q * BPL);
+            la_lo = a.x; la_hi = a.y;
+            lb_lo = b.x; lb_hi = b.y;
+        }
+#pragma unroll
+        for (int s = 0; s < BPL; ++s) {
+            const int j = (s + el) & (BPL - 1);  // staggered so a DS lane group covers all B banks
+            const uint32_t pair = label_byte<B>(la_lo, la_hi, j) * (uint32_t)K + label_byte<B>(lb_lo, lb_hi, j);
+            atomicAdd(&hist[pair * B + q * BPL + j], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t* dst = partial_all + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * hist_words;
+    for (int i = tid; i < hist_words; i += COUNT_THREADS) dst[i] = hist[i];
+}
+
+// Large-K variants: BE (< 16) permutations [b0, b0+BE) of a 16-wide slab per pass; BE == 0: K*K does not
+// fit LDS at all -> device-scope atomics straight into the (single) partial.
+template <int BE>
+__global__ __launch_bounds__(COUNT_THREADS) void k_count_wide(int64_t nnz, const int32_t* __restrict__ erow,
+                                                              const int32_t* __restrict__ indices,
+                                                              const uint8_t* __restrict__ slab_all, int64_t n, int K, int b0,
+                                                              int64_t edges_per_block, int partial_blocks,
+                                                              uint32_t* __restrict__ partial_all) {
+    extern __shared__ uint32_t hist[];
+    constexpr int B = 16;
+    const int K2 = K * K;
+    const int tid = threadIdx.x;
+    const int hw = K2 * (BE > 0 ? BE : 1);
+    if (BE > 0) {
+        for (int i = tid; i < hw; i += COUNT_THREADS) hist[i] = 0;
+        __syncthreads();
+    }
+    const uint8_t* slab = slab_all + (size_t)blockIdx.y * n * B;
+    uint32_t* dst = partial_all + ((size_t)blockIdx.y * partial_blocks + (BE > 0 ? blockIdx.x : 0)) * ((size_t)K2 * B);
+    const int64_t e0 = (int64_t)blockIdx.x * edges_per_block;
+    const int64_t e1 = min(nnz, e0 + edges_per_block);
+    for (int64_t e = e0 + tid; e < e1; e += COUNT_THREADS) {
+        const uint8_t* ra = slab + (size_t)erow[e] * B;
+        const uint8_t* rb = slab + (size_t)indices[e] * B;
+        if (BE > 0) {
+#pragma unroll
+            for (int bb = 0; bb < BE; ++bb) {
+                uint32_t pair = (uint32_t)ra[b0 + bb] * K + rb[b0 + bb];
+                atomicAdd(&hist[pair * BE + bb], 1u);
+            }
+        } else {
+            for (int b = 0; b < B; ++b) {
+                uint32_t pair = (uint32_t)ra[b] * K + rb[b];
+                atomicAdd(&dst[(size_t)pair * B + b], 1u);
+            }
+        }
+    }
+    if (BE > 0) {
+        __syncthreads();
+        for (int i = tid; i < hw; i += COUNT_THREADS) {
+            int pair = i / BE, bb = i % BE;
+            dst[(size_t)pair * B + b0 + bb] = hist[i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- reduction
+// word w = pair*B + b.  acc slots are private to (batch, w): no atomics, bit-reproducible.
+__global__ __launch_bounds__(256) void k_reduce(const uint32_t* __restrict__ partial_all, int nblk, int hist_words, int B,
+                                                int K2, const int64_t* __restrict__ shift, int64_t perm_batch0,
+                                                int64_t perm_begin, int64_t perm_end, int64_t* __restrict__ acc_sum,
+                                                uint64_t* __restrict__ acc_sq, uint32_t* __restrict__ perms_out) {
+    int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= hist_words) return;
+    const int batch = blockIdx.y;
+    const uint32_t* src = partial_all + (size_t)batch * nblk * hist_words + w;
+    uint64_t c = 0;
+    for (int k = 0; k < nblk; ++k) c += src[(size_t)k * hist_words];
+    const int pair = w / B, b = w % B;
+    const int64_t p = perm_batch0 + (int64_t)batch * B + b;
+    if (p >= perm_end) return;
+    const int64_t d = (int64_t)c - shift[pair];
+    const size_t slot = (size_t)batch * hist_words + w;
+    acc_sum[slot] += d;
+    acc_sq[slot] += (uint64_t)(d * d);
+    if (perms_out) perms_out[(size_t)(p - perm_begin) * K2 + pair] = (uint32_t)c;
+}
+
+__global__ void k_finalize(const int64_t* __restrict__ acc_sum, const uint64_t* __restrict__ acc_sq, int nbatch,
+                           int hist_words, int B, int K2, int64_t* __restrict__ out_sum, uint64_t* __restrict__ out_sq) {
+    int pair = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pair >= K2) return;
+    int64_t s = 0;
+    uint64_t q = 0;
+    for (int batch = 0; batch < nbatch; ++batch)
+        for (int b = 0; b < B; ++b) {
+            size_t slot = (size_t)batch * hist_words + (size_t)pair * B + b;
+            s += acc_sum[slot];
+            q += acc_sq[slot];
+        }
+    out_sum[pair] = s;
+    out_sq[pair] = q;
+}
+
+// observed counts / interaction matrix: one pass, thread per edge
+template <bool WEIGHTED>
+__global__ __launch_bounds__(256) void k_edge_pairs(int64_t nnz, const int32_t* __restrict__ erow,
+                                                    const int32_t* __restrict__ indices, const float* __restrict__ data,
+                                                    const int32_t* __restrict__ labels, int K,
+                                                    unsigned long long* __restrict__ out_u64, double* __restrict__ out_f64) {
+    int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= nnz) return;
+    int la = labels[erow[e]], lb = labels[indices[e]];
+    if (la < 0 || lb < 0) return;  // masked (NaN category) spots: interaction_matrix semantics
+    if (WEIGHTED)
+        atomicAdd(&out_f64[la * K + lb], (double)data[e]);
+    else
+        atomicAdd(&out_u64[la * K + lb], 1ull);
+}
+
+}  // namespace sqgr
+
+using namespace sqgr;
+
+// dynamic LDS above 64 KiB must be opted into per kernel
+template <typename KernelT>
+static int allow_lds(KernelT kernel, size_t bytes) {
+    if (bytes > 64 * 1024)
+        SQGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return SQGR_OK;
+}
+
+template <int BE>
+static void launch_wide(dim3 grid, size_t lds, hipStream_t st, int64_t nnz, const int32_t* erow, const int32_t* indices,
+                        const uint8_t* slab, int64_t n, int K, int b0, int64_t epb, int pblocks, uint32_t* partial) {
+    (void)allow_lds(k_count_wide<BE>, lds);
+    k_count_wide<BE><<<grid, COUNT_THREADS, lds, st>>>(nnz, erow, indices, slab, n, K, b0, epb, pblocks, partial);
+}
+
+struct sqgr_nhood {
+    sqgr_ctx* ctx = nullptr;
+    const sqgr_graph* g = nullptr;
+    int64_t n = 0;
+    int K = 0, K2 = 0;
+    int n_libs = 1;
+    bool has_libs = false;
+    FeistelDomain dom0{};
+    DevBuf<uint8_t> table;
+    DevBuf<int32_t> lib_of, rank_of;
+    DevBuf<LibInfo> libs;
+    // tuning
+    int B = 16;
+    int nblk = 0;
+    int nbatch = 4;
+    // workspace
+    DevBuf<uint32_t> keys;
+    DevBuf<uint8_t> slab;
+    DevBuf<uint32_t> partial;
+    DevBuf<int64_t> acc_sum;
+    DevBuf<uint64_t> acc_sq;
+    DevBuf<int64_t> shift, fin_sum;
+    DevBuf<uint64_t> fin_sq;
+    DevBuf<uint32_t> perms_dev;
+    DevBuf<uint8_t> stage;
+
+    int hist_words() const { return K2 * B; }
+    int be() const {  // permutations whose histograms fit LDS together (for the B=16 slab)
+        for (int b : {16, 8, 4, 2, 1})
+            if ((size_t)K2 * b * 4 <= LDS_BUDGET) return b;
+        return 0;
+    }
+    int partial_blocks() const { return (B == 16 && be() == 0) ? 1 : nblk; }
+    int resolve_tuning();
+    int ensure_workspace(bool need_perms);
+    int count_batches(int nb);  // slab -> partial for nb batches
+    int reduce_batches(int nb, int64_t perm_batch0, int64_t perm_begin, int64_t perm_end, uint32_t* perms_out_dev);
+};
+
+int sqgr_nhood::resolve_tuning() {
+    if (B == 32 && (size_t)K2 * 32 * 4 > LDS_BUDGET) B = 16;
+    if (B != 16 && B != 32) B = 16;
+    const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
+    if (nblk <= 0) {
+        // LDS decides residency: one 1024-thread block per CU unless two histograms fit
+        size_t lds = (size_t)K2 * (B == 32 ? 32 : (be() > 0 ? be() : 1)) * 4;
+        nblk = (lds * 2 <= LDS_BUDGET) ? 2 * cus : cus;
+    }
+    if (nbatch <= 0) nbatch = 4;
+    return SQGR_OK;
+}
+
+int sqgr_nhood::ensure_workspace(bool need_perms) {
+    SQGR_TRY(resolve_tuning());
+    const size_t hw = (size_t)hist_words();
+    SQGR_TRY(keys.ensure((size_t)nbatch * B * n_libs * 8));
+    SQGR_TRY(slab.ensure((size_t)nbatch * n * B));
+    SQGR_TRY(partial.ensure((size_t)nbatch * partial_blocks() * hw));
+    SQGR_TRY(acc_sum.ensure((size_t)nbatch * hw));
+    SQGR_TRY(acc_sq.ensure((size_t)nbatch * hw));
+    SQGR_TRY(shift.ensure((size_t)K2));
+    SQGR_TRY(fin_sum.ensure((size_t)K2));
+    SQGR_TRY(fin_sq.ensure((size_t)K2));
+    (void)need_perms;
+    return SQGR_OK;
+}
+
+int sqgr_nhood::count_batches(int nb) {
+    const int64_t nnz = g->nnz;
+    hipStream_t st = ctx->stream;
+    const int hw = hist_words();
+    if (B == 32) {
+        const int64_t epb = ceil_div(ceil_div(nnz, nblk), 256) * 256;
+        LaunchTimer t(ctx, "nhood_count_b32");
+        SQGR_TRY(allow_lds(k_count<32, 4>, (size_t)hw * 4));
+        k_count<32, 4><<<dim3(nblk, nb), COUNT_THREADS, (size_t)hw * 4, st>>>(nnz, g->erow.p, g->indices.p, slab.p, n, K, hw,
+                                                                           epb, partial.p);
+    } else if (be() == 16) {
+        const int64_t epb = ceil_div(ceil_div(nnz, nblk), 256) * 256;
+        LaunchTimer t(ctx, "nhood_count_b16");
+        if ((size_t)hw * 4 * 2 <= LDS_BUDGET)
+            k_count<16, 8><<<dim3(nblk, nb), COUNT_THREADS, (size_t)hw * 4, st>>>(nnz, g->erow.p, g->indices.p, slab.p, n, K,
+                                                                               hw, epb, partial.p);
+        else if (allow_lds(k_count<16, 4>, (size_t)hw * 4) == SQGR_OK)
+            k_count<16, 4><<<dim3(nblk, nb), COUNT_THREADS, (size_t)hw * 4, st>>>(nnz, g->erow.p, g->indices.p, slab.p, n, K,
+                                                                               hw, epb, partial.p);
+    } else {
+        const int e = be();
+        const int64_t epb = ceil_div(nnz, nblk);
+        LaunchTimer t(ctx, "nhood_count_wide");
+        if (e == 0) {
+            SQGR_HIP(hipMemsetAsync(partial.p, 0, (size_t)nb * hw * 4, st));
+            k_count_wide<0><<<dim3(nblk, nb), COUNT_THREADS, 0, st>>>(nnz, g->erow.p, g->indices.p, slab.p, n, K, 0, epb, 1,
+                                                                     partial.p);
+        } else {
+            for (int b0 = 0; b0 < 16; b0 += e) {
+                const size_t lds = (size_t)K2 * e * 4;
+                switch (e) {
+                    case 8: launch_wide<8>(dim3(nblk, nb), lds, st, nnz, g->erow.p, g->indices.p, slab.p, n, K, b0, epb, nblk, partial.p); break;
+                    case 4: launch_wide<4>(dim3(nblk, nb), lds, st, nnz, g->erow.p, g->indices.p, slab.p, n, K, b0, epb, nblk, partial.p); break;
+                    case 2: launch_wide<2>(dim3(nblk, nb), lds, st, nnz, g->erow.p, g->indices.p, slab.p, n, K, b0, epb, nblk, partial.p); break;
+                    default: launch_wide<1>(dim3(nblk, nb), lds, st, nnz, g->erow.p, g->indices.p, slab.p, n, K, b0, epb, nblk, partial.p); break;
+                }
+            }
+        }
+    }
+    SQGR_HIP(hipGetLastError());
+    return SQGR_OK;
+}
+
+int sqgr_nhood::reduce_batches(int nb, int64_t perm_batch0, int64_t perm_begin, int64_t perm_end, uint32_t* perms_out_dev) {
+    const int hw = hist_words();
+    LaunchTimer t(ctx, "nhood_reduce");
+    k_reduce<<<dim3((unsigned)ceil_div(hw, 256), nb), 256, 0, ctx->stream>>>(partial.p, partial_blocks(), hw, B, K2, shift.p,
+                                                                            perm_batch0, perm_begin, perm_end, acc_sum.p,
+                                                                            acc_sq.p, perms_out_dev);
+    SQGR_HIP(hipGetLastError());
+    return SQGR_OK;
+}
+
+static int check_labels(const int32_t* labels, int64_t n, int K, bool allow_negative) {
+    for (int64_t i = 0; i < n; ++i) {
+        if (labels[i] >= K || (labels[i] < 0 && !allow_negative)) {
+            set_error("labels[%lld]=%d outside [0,%d)", (long long)i, labels[i], K);
+            return SQGR_ERR_INVALID;
+        }
+    }
+    return SQGR_OK;
+}
+
+static int edge_pairs(sqgr_ctx* ctx, const sqgr_graph* g, const int32_t* labels, int32_t K, bool weighted, bool allow_negative,
+                      unsigned long long* out_u64, double* out_f64) {
+    SQGR_REQUIRE(ctx && g && labels, "ctx/graph/labels is NULL");
+    SQGR_REQUIRE(g->ctx == ctx, "graph belongs to a different context");
+    SQGR_REQUIRE(K >= 1, "K=%d", K);
+    SQGR_TRY(check_labels(labels, g->n, K, allow_negative));
+    SQGR_HIP(hipSetDevice(ctx->device));
+    DevBuf<int32_t> dl;
+    DevBuf<unsigned long long> du;
+    DevBuf<double> dd;
+    const size_t K2 = (size_t)K * K;
+    SQGR_TRY(dl.alloc((size_t)g->n));
+    SQGR_HIP(hipMemcpyAsync(dl.p, labels, (size_t)g->n * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (weighted) {
+        SQGR_REQUIRE(g->has_data, "graph was uploaded without edge data; weights unavailable");
+        SQGR_TRY(dd.alloc(K2));
+        SQGR_HIP(hipMemsetAsync(dd.p, 0, K2 * 8, ctx->stream));
+    } else {
+        SQGR_TRY(du.alloc(K2));
+        SQGR_HIP(hipMemsetAsync(du.p, 0, K2 * 8, ctx->stream));
+    }
+    if (g->nnz > 0) {
+        LaunchTimer t(ctx, "nhood_edge_pairs");
+        unsigned grid = (unsigned)ceil_div(g->nnz, 256);
+        if (weighted)
+            k_edge_pairs<true><<<grid, 256, 0, ctx->stream>>>(g->nnz, g->erow.p, g->indices.p, g->data.p, dl.p, K, nullptr, dd.p);
+        else
+            k_edge_pairs<false><<<grid, 256, 0, ctx->stream>>>(g->nnz, g->erow.p, g->indices.p, nullptr, dl.p, K, du.p, nullptr);
+        SQGR_HIP(hipGetLastError());
+    }
+    if (weighted)
+        SQGR_HIP(hipMemcpyAsync(out_f64, dd.p, K2 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    else
+        SQGR_HIP(hipMemcpyAsync(out_u64, du.p, K2 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SQGR_HIP(hipStreamSynchronize(ctx->stream));
+    return SQGR_OK;
+}
+
+extern "C" {
+
+int sqgr_nhood_counts(sqgr_ctx* ctx, const sqgr_graph* g, const int32_t* labels, int32_t K, uint32_t* out_counts) {
+    SQGR_REQUIRE(out_counts, "out_counts is NULL");
+    SQGR_REQUIRE(K >= 2, "Expected at least `2` clusters, found `%d`.", K);  // gr/_nhood.py:107-108
+    std::vector<unsigned long long> tmp((size_t)K * K);
+    SQGR_TRY(edge_pairs(ctx, g, labels, K, false, false, tmp.data(), nullptr));
+    for (size_t i = 0; i < tmp.size(); ++i) out_counts[i] = (uint32_t)tmp[i];  // uint32 like the reference (wraps)
+    return SQGR_OK;
+}
+
+int sqgr_interaction_matrix(sqgr_ctx* ctx, const sqgr_graph* g, const int32_t* labels, int32_t K, int32_t weights,
+                            double* out) {
+    SQGR_REQUIRE(out, "out is NULL");
+    if (weights) return edge_pairs(ctx, g, labels, K, true, true, nullptr, out);
+    std::vector<unsigned long long> tmp((size_t)K * K);
+    SQGR_TRY(edge_pairs(ctx, g, labels, K, false, true, tmp.data(), nullptr));
+    for (size_t i = 0; i < tmp.size(); ++i) out[i] = (double)tmp[i];
+    return SQGR_OK;
+}
+
+int sqgr_nhood_create(sqgr_ctx* ctx, const sqgr_graph* g, const int32_t* labels, int32_t K, const int32_t* lib_ids,
+                      int32_t n_libs, sqgr_nhood** out_plan) {
+    SQGR_REQUIRE(ctx && g && out_plan, "ctx/graph/out_plan is NULL");
+    *out_plan = nullptr;
+    SQGR_REQUIRE(g->ctx == ctx, "graph belongs to a different context");
+    SQGR_REQUIRE(K >= 2, "Expected at least `2` clusters, found `%d`.", K);
+    if (K > 256) {
+        set_error("K=%d > 256 clusters is not supported by the uint8 label slab", K);
+        return SQGR_ERR_UNSUPPORTED;
+    }
+    const int64_t n = g->n;
+    if (labels) SQGR_TRY(check_labels(labels, n, K, false));
+    SQGR_HIP(hipSetDevice(ctx->device));
+    sqgr_nhood* p = new sqgr_nhood();
+    p->ctx = ctx;
+    p->g = g;
+    p->n = n;
+    p->K = K;
+    p->K2 = K * K;
+    p->dom0 = make_domain((uint32_t)n);
+    int rc = SQGR_OK;
+    do {
+        std::vector<uint8_t> table((size_t)n, 0);
+        if (lib_ids && n_libs >= 1) {
+            p->has_libs = true;
+            p->n_libs = n_libs;
+            std::vector<int64_t> cnt((size_t)n_libs, 0);
+            for (int64_t i = 0; i < n; ++i) {
+                if (lib_ids[i] < 0 || lib_ids[i] >= n_libs) {
+                    set_error("lib_ids[%lld]=%d outside [0,%d)", (long long)i, lib_ids[i], n_libs);
+                    rc = SQGR_ERR_INVALID;
+                    break;
+                }
+                cnt[lib_ids[i]]++;
+            }
+            if (rc != SQGR_OK) break;
+            std::vector<LibInfo> libs((size_t)n_libs);
+            std::vector<int64_t> off((size_t)n_libs + 1, 0);
+            for (int l = 0; l < n_libs; ++l) off[l + 1] = off[l] + cnt[l];
+            for (int l = 0; l < n_libs; ++l) {
+                libs[l].dom = make_domain((uint32_t)(cnt[l] > 0 ? cnt[l] : 1));
+                libs[l].off = (uint32_t)off[l];
+            }
+            std::vector<int32_t> rank((size_t)n);
+            std::vector<int64_t> fill((size_t)n_libs, 0);
+            for (int64_t i = 0; i < n; ++i) {  // ranks in position order == np.where(libraries == c)[0]
+                int l = lib_ids[i];
+                rank[i] = (int32_t)fill[l];
+                if (labels) table[off[l] + fill[l]] = (uint8_t)labels[i];
+                fill[l]++;
+            }
+            if ((rc = p->lib_of.alloc((size_t)n)) != SQGR_OK) break;
+            if ((rc = p->rank_of.alloc((size_t)n)) != SQGR_OK) break;
+            if ((rc = p->libs.alloc((size_t)n_libs)) != SQGR_OK) break;
+            hipError_t e = hipMemcpy(p->lib_of.p, lib_ids, (size_t)n * 4, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(p->rank_of.p, rank.data(), (size_t)n * 4, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(p->libs.p, libs.data(), (size_t)n_libs * sizeof(LibInfo), hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                set_error("library upload failed: %s", hipGetErrorString(e));
+                rc = SQGR_ERR_HIP;
+                break;
+            }
+        } else if (labels) {
+            for (int64_t i = 0; i < n; ++i) table[i] = (uint8_t)labels[i];
+        }
+        if ((rc = p->table.alloc((size_t)n)) != SQGR_OK) break;
+        hipError_t e = hipMemcpy(p->table.p, table.data(), (size_t)n, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            set_error("label upload failed: %s", hipGetErrorString(e));
+            rc = SQGR_ERR_HIP;
+        }
+    } while (0);
+    if (rc != SQGR_OK) {
+        delete p;
+        return rc;
+    }
+    *out_plan = p;
+    return SQGR_OK;
+}
+
+int sqgr_nhood_destroy(sqgr_nhood* plan) {
+    if (!plan) return SQGR_OK;
+    (void)hipSetDevice(plan->ctx->device);
+    delete plan;
+    return SQGR_OK;
+}
+
+int sqgr_nhood_tune(sqgr_nhood* plan, int32_t perms_per_pass, int32_t blocks_per_batch, int32_t batches_per_launch) {
+    SQGR_REQUIRE(plan, "plan is NULL");
+    SQGR_REQUIRE(perms_per_pass == 0 || perms_per_pass == 16 || perms_per_pass == 32, "perms_per_pass must be 0, 16 or 32");
+    SQGR_REQUIRE(blocks_per_batch >= 0 && blocks_per_batch <= 65535 && batches_per_launch >= 0 && batches_per_launch <= 1024,
+                 "tuning value out of range");
+    plan->B = perms_per_pass ? perms_per_pass : 16;
+    plan->nblk = blocks_per_batch;
+    plan->nbatch = batches_per_launch ? batches_per_launch : 4;
+    // force re-allocation with the new geometry
+    plan->keys.release(); plan->slab.release(); plan->partial.release(); plan->acc_sum.release(); plan->acc_sq.release();
+    return SQGR_OK;
+}
+
+static int launch_shuffle(sqgr_nhood* p, int nb) {
+    const unsigned gx = (unsigned)ceil_div(p->n, 256);
+    LaunchTimer t(p->ctx, "nhood_shuffle");
+    hipStream_t st = p->ctx->stream;
+    if (p->B == 32) {
+        if (p->has_libs)
+            k_shuffle<32, true><<<dim3(gx, nb), 256, 0, st>>>(p->n, p->table.p, p->keys.p, p->dom0, p->n_libs, p->lib_of.p, p->rank_of.p, p->libs.p, p->slab.p);
+        else
+            k_shuffle<32, false><<<dim3(gx, nb), 256, 0, st>>>(p->n, p->table.p, p->keys.p, p->dom0, 1, nullptr, nullptr, nullptr, p->slab.p);
+    } else {
+        if (p->has_libs)
+            k_shuffle<16, true><<<dim3(gx, nb), 256, 0, st>>>(p->n, p->table.p, p->keys.p, p->dom0, p->n_libs, p->lib_of.p, p->rank_of.p, p->libs.p, p->slab.p);
+        else
+            k_shuffle<16, false><<<dim3(gx, nb), 256, 0, st>>>(p->n, p->table.p, p->keys.p, p->dom0, 1, nullptr, nullptr, nullptr, p->slab.p);
+    }
+    SQGR_HIP(hipGetLastError());
+    return SQGR_OK;
+}
+
+int sqgr_nhood_run(sqgr_nhood* plan, uint64_t seed, int64_t perm_begin, int64_t perm_end, const int64_t* shift,
+                   int64_t* out_sum, uint64_t* out_sumsq, uint32_t* out_perms) {
+    SQGR_REQUIRE(plan && out_sum && out_sumsq, "plan/out_sum/out_sumsq is NULL");
+    SQGR_REQUIRE(perm_begin >= 0 && perm_end >= perm_begin, "bad permutation range [%lld,%lld)", (long long)perm_begin,
+                 (long long)perm_end);
+    sqgr_nhood* p = plan;
+    sqgr_ctx* ctx = p->ctx;
+    SQGR_HIP(hipSetDevice(ctx->device));
+    SQGR_TRY(p->ensure_workspace(out_perms != nullptr));
+    hipStream_t st = ctx->stream;
+    const int B = p->B, K2 = p->K2, hw = p->hist_words();
+    const int64_t nperm = perm_end - perm_begin;
+    const int64_t per_launch = (int64_t)p->nbatch * B;
+    if (shift)
+        SQGR_HIP(hipMemcpyAsync(p->shift.p, shift, (size_t)K2 * 8, hipMemcpyHostToDevice, st));
+    else
+        SQGR_HIP(hipMemsetAsync(p->shift.p, 0, (size_t)K2 * 8, st));
+    SQGR_HIP(hipMemsetAsync(p->acc_sum.p, 0, (size_t)p->nbatch * hw * 8, st));
+    SQGR_HIP(hipMemsetAsync(p->acc_sq.p, 0, (size_t)p->nbatch * hw * 8, st));
+    if (out_perms && nperm > 0) SQGR_TRY(p->perms_dev.ensure((size_t)nperm * K2));
+    for (int64_t p0 = perm_begin; p0 < perm_end; p0 += per_launch) {
+        const int64_t todo = (perm_end - p0 < per_launch) ? perm_end - p0 : per_launch;
+        const int nb = (int)ceil_div(todo, B);
+        {
+            LaunchTimer t(ctx, "nhood_keygen");
+            const int64_t nk = (int64_t)nb * B * p->n_libs;
+            k_keygen<<<(unsigned)ceil_div(nk, 256), 256, 0, st>>>(seed, p0, (int64_t)nb * B, p->n_libs, p->keys.p);
+            SQGR_HIP(hipGetLastError());
+        }
+        SQGR_TRY(launch_shuffle(p, nb));
+        SQGR_TRY(p->count_batches(nb));
+        SQGR_TRY(p->reduce_batches(nb, p0, perm_begin, perm_end, out_perms ? p->perms_dev.p : nullptr));
+    }
+    {
+        LaunchTimer t(ctx, "nhood_finalize");
+        k_finalize<<<(unsigned)ceil_div(K2, 256), 256, 0, st>>>(p->acc_sum.p, p->acc_sq.p, p->nbatch, hw, B, K2, p->fin_sum.p,
+                                                               p->fin_sq.p);
+        SQGR_HIP(hipGetLastError());
+    }
+    SQGR_HIP(hipMemcpyAsync(out_sum, p->fin_sum.p, (size_t)K2 * 8, hipMemcpyDeviceToHost, st));
+    SQGR_HIP(hipMemcpyAsync(out_sumsq, p->fin_sq.p, (size_t)K2 * 8, hipMemcpyDeviceToHost, st));
+    if (out_perms && nperm > 0)
+        SQGR_HIP(hipMemcpyAsync(out_perms, p->perms_dev.p, (size_t)nperm * K2 * 4, hipMemcpyDeviceToHost, st));
+    SQGR_HIP(hipStreamSynchronize(st));
+    return SQGR_OK;
+}
+
+int sqgr_nhood_shuffled_labels(sqgr_nhood* plan, uint64_t seed, int64_t perm, uint8_t* out_labels) {
+    SQGR_REQUIRE(plan && out_labels && perm >= 0, "plan/out_labels is NULL or perm < 0");
+    sqgr_nhood* p = plan;
+    sqgr_ctx* ctx = p->ctx;
+    SQGR_HIP(hipSetDevice(ctx->device));
+    SQGR_TRY(p->ensure_workspace(false));
+    hipStream_t st = ctx->stream;
+    const int B = p->B;
+    k_keygen<<<(unsigned)ceil_div((int64_t)B * p->n_libs, 256), 256, 0, st>>>(seed, perm, B, p->n_libs, p->keys.p);
+    SQGR_HIP(hipGetLastError());
+    SQGR_TRY(launch_shuffle(p, 1));
+    std::vector<uint8_t> rows((size_t)p->n * B);
+    SQGR_HIP(hipMemcpyAsync(rows.data(), p->slab.p, rows.size(), hipMemcpyDeviceToHost, st));
+    SQGR_HIP(hipStreamSynchronize(st));
+    for (int64_t i = 0; i < p->n; ++i) out_labels[i] = rows[(size_t)i * B];
+    return SQGR_OK;
+}
+
+int sqgr_nhood_counts_batch(sqgr_ctx* ctx, const sqgr_graph* g, const uint8_t* labels, int64_t n_perms, int32_t K,
+                            uint32_t* out_counts) {
+    SQGR_REQUIRE(ctx && g && labels && out_counts, "ctx/graph/labels/out is NULL");
+    SQGR_REQUIRE(n_perms >= 0, "n_perms < 0");
+    const int64_t n = g->n;
+    for (int64_t t = 0; t < n_perms * n; ++t)
+        SQGR_REQUIRE(labels[t] < K, "labels[%lld]=%d outside [0,%d)", (long long)t, (int)labels[t], K);
+    sqgr_nhood* p = nullptr;
+    SQGR_TRY(sqgr_nhood_create(ctx, g, nullptr, K, nullptr, 0, &p));
+    int rc = SQGR_OK;
+    do {
+        if ((rc = p->ensure_workspace(true)) != SQGR_OK) break;
+        const int B = p->B, K2 = p->K2, hw = p->hist_words();
+        const int64_t per_launch = (int64_t)p->nbatch * B;
+        hipStream_t st = ctx->stream;
+        if ((rc = p->stage.ensure((size_t)per_launch * n)) != SQGR_OK) break;
+        if ((rc = p->perms_dev.ensure((size_t)(n_perms > 0 ? n_perms : 1) * K2)) != SQGR_OK) break;
+        hipError_t e = hipMemsetAsync(p->shift.p, 0, (size_t)K2 * 8, st);
+        if (e == hipSuccess) e = hipMemsetAsync(p->acc_sum.p, 0, (size_t)p->nbatch * hw * 8, st);
+        if (e == hipSuccess) e = hipMemsetAsync(p->acc_sq.p, 0, (size_t)p->nbatch * hw * 8, st);
+        for (int64_t p0 = 0; p0 < n_perms && e == hipSuccess && rc == SQGR_OK; p0 += per_launch) {
+            const int64_t todo = (n_perms - p0 < per_launch) ? n_perms - p0 : per_launch;
+            const int nb = (int)ceil_div(todo, B);
+            e = hipMemcpyAsync(p->stage.p, labels + (size_t)p0 * n, (size_t)todo * n, hipMemcpyHostToDevice, st);
+            if (e != hipSuccess) break;
+            {
+                LaunchTimer t(ctx, "nhood_transpose_labels");
+                if (B == 32)
+                    k_transpose_labels<32><<<dim3((unsigned)ceil_div(n, 256), nb), 256, 0, st>>>(n, p->stage.p, todo, p->slab.p);
+                else
+                    k_transpose_labels<16><<<dim3((unsigned)ceil_div(n, 256), nb), 256, 0, st>>>(n, p->stage.p, todo, p->slab.p);
+            }
+            if ((rc = p->count_batches(nb)) != SQGR_OK) break;
+            if ((rc = p->reduce_batches(nb, p0, 0, n_perms, p->perms_dev.p)) != SQGR_OK) break;
+            e = hipStreamSynchronize(st);  // stage buffer is reused by the next chunk
+        }
+        if (rc != SQGR_OK) break;
+        if (e == hipSuccess && n_perms > 0)
+            e = hipMemcpyAsync(out_counts, p->perms_dev.p, (size_t)n_perms * K2 * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            set_error("nhood_counts_batch failed: %s", hipGetErrorString(e));
+            rc = SQGR_ERR_HIP;
+        }
+    } while (0);
+    sqgr_nhood_destroy(p);
+    return rc;
+}
+
+}  // extern "C"

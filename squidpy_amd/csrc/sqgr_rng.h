@@ -1,0 +1,97 @@
+// Counter-based permutation generator for the on-device label shuffles (gfx950).
+//
+//   round keys : Philox4x32-10( counter = (perm_lo, perm_hi, library, j), key = (seed_lo, seed_hi) ),
+//                j = 0,1  ->  8 x 32-bit keys per (seed, global permutation index, library)
+//   bijection  : 8-round alternating Feistel network on bits = max(8, ceil(log2 n)) bits whose round
+//                function uses only full-rate 24-bit multiplies (v_mul_u32_u24) and xor-shifts,
+//                cycle-walked into [0, n).
+//
+// oracle/devrng.py restates this file bit for bit; tests/test_devrng.py checks both the Philox
+// known-answer vectors and the statistical quality (uniformity over S_n for small n, agreement of
+// permutation-test moments with numpy's PCG64 shuffles).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace sqgr {
+
+constexpr uint32_t PHILOX_M0 = 0xD2511F53u, PHILOX_M1 = 0xCD9E8D57u;
+constexpr uint32_t PHILOX_W0 = 0x9E3779B9u, PHILOX_W1 = 0xBB67AE85u;
+constexpr uint32_t FEISTEL_C1 = 0xD2511Fu, FEISTEL_C2 = 0xCD9E8Du;
+constexpr int FEISTEL_ROUNDS = 8;
+
+__host__ __device__ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)PHILOX_M0 * c[0];
+        uint64_t p1 = (uint64_t)PHILOX_M1 * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += PHILOX_W0;
+        k1 += PHILOX_W1;
+    }
+}
+
+__host__ __device__ inline void round_keys(uint64_t seed, uint64_t perm, uint32_t lib, uint32_t rk[8]) {
+    for (uint32_t j = 0; j < 2; ++j) {
+        uint32_t c[4] = {(uint32_t)perm, (uint32_t)(perm >> 32), lib, j};
+        philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        rk[4 * j + 0] = c[0]; rk[4 * j + 1] = c[1]; rk[4 * j + 2] = c[2]; rk[4 * j + 3] = c[3];
+    }
+}
+
+__host__ __device__ inline int domain_bits(uint32_t n) {
+    int b = 0;
+    while (b < 32 && (1ull << b) < n) ++b;
+    return b < 8 ? 8 : b;
+}
+
+// round function: two 24x24-bit multiplies (low 32 bits of each product) with an xor-shift between.
+__device__ __forceinline__ uint32_t feistel_F(uint32_t v, uint32_t k) {
+    uint32_t t = (v ^ k) & 0xFFFFFFu;
+    uint32_t u = __umul24(t, FEISTEL_C1);
+    u ^= u >> 15;
+    uint32_t w = __umul24(u & 0xFFFFFFu, FEISTEL_C2);
+    return w >> 16;
+}
+
+struct FeistelDomain {
+    uint32_t n;       // target domain [0, n)
+    uint32_t rb;      // low-half width
+    uint32_t ml, mr;  // masks of the high / low half
+};
+
+__host__ __device__ inline FeistelDomain make_domain(uint32_t n) {
+    FeistelDomain d;
+    int bits = domain_bits(n);
+    d.n = n;
+    d.rb = (uint32_t)(bits / 2);
+    d.mr = (1u << d.rb) - 1u;
+    d.ml = (1u << (bits - bits / 2)) - 1u;
+    return d;
+}
+
+__device__ __forceinline__ uint32_t feistel_once(uint32_t x, const FeistelDomain& d, const uint32_t* __restrict__ rk) {
+    uint32_t a = x >> d.rb, b = x & d.mr;
+#pragma unroll
+    for (int r = 0; r < FEISTEL_ROUNDS; r += 2) {
+        a ^= feistel_F(b, rk[r]) & d.ml;
+        b ^= feistel_F(a, rk[r + 1]) & d.mr;
+    }
+    return (a << d.rb) | b;
+}
+
+// image of x (< n) under the cycle-walked bijection of [0, n)
+__device__ __forceinline__ uint32_t feistel_perm(uint32_t x, const FeistelDomain& d, const uint32_t* __restrict__ rk) {
+    do {
+        x = feistel_once(x, d, rk);
+    } while (x >= d.n);
+    return x;
+}
+
+}  // namespace sqgr

@@ -1,0 +1,5 @@
+"""``squidpy_amd.gr`` — the MI355X-native ``sq.gr`` spatial-statistics hot path."""
+
+from ._nhood import NhoodEnrichmentResult, interaction_matrix, nhood_enrichment
+
+__all__ = ["nhood_enrichment", "interaction_matrix", "NhoodEnrichmentResult"]

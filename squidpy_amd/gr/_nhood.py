@@ -1,0 +1,234 @@
+"""``nhood_enrichment`` / ``interaction_matrix`` with the reference's signatures on the MI355X path.
+
+Reference: /root/reference/src/squidpy/gr/_nhood.py:146-242 (nhood_enrichment), :349-429
+(interaction_matrix).  All counting and all label shuffling run in ``libsqgr.so`` (HIP); the host only
+validates, uploads and turns exact integer moments into z-scores."""
+
+from __future__ import annotations
+
+import math
+from typing import Any, NamedTuple
+
+import numpy as np
+import pandas as pd
+
+from .. import _dist
+from .._constants import Key
+from .._lib import Context, Graph, NhoodPlan, default_context, interaction_matrix as _intmat, nhood_counts, nhood_counts_batch
+from .._utils import (
+    _assert_categorical_obs,
+    _assert_connectivity_key,
+    _save_data,
+    assert_positive,
+    category_codes,
+    extract_adata_if_sdata,
+    get_n_processes,
+    resolve_seed,
+    spawn_generators,
+)
+
+__all__ = ["nhood_enrichment", "interaction_matrix", "NhoodEnrichmentResult"]
+
+
+class NhoodEnrichmentResult(NamedTuple):
+    """Result of nhood_enrichment (gr/_nhood.py:44-48)."""
+
+    zscore: np.ndarray
+    counts: np.ndarray
+
+
+def expected_counts(labels: np.ndarray, n_cls: int, nnz: int) -> np.ndarray:
+    """Integer shift ~ E[count] under shuffling, nnz * p_a * p_b: keeps the accumulated d = count - shift small.
+    Any integer shift gives the same exact result; this one just keeps sum d^2 far from 2**64."""
+    n = len(labels)
+    freq = np.bincount(labels, minlength=n_cls).astype(np.float64) / max(n, 1)
+    return np.rint(nnz * np.outer(freq, freq)).astype(np.int64)
+
+
+def zscore_from_moments(count: np.ndarray, shift: np.ndarray, sum_d: np.ndarray, sum_d2: np.ndarray, n_perms: int) -> np.ndarray:
+    """(count - mean) / std with population std (gr/_nhood.py:231), from exact integer moments.
+
+    mean = shift + S1/P and var = (P*S2 - S1^2)/P^2 are evaluated in exact integer arithmetic and rounded
+    once, so the result equals numpy's float64 ``perms.mean/std`` up to its own rounding (~1e-13 rel.)."""
+    k = count.shape[0]
+    P = int(n_perms)
+    mean = np.empty((k, k), dtype=np.float64)
+    std = np.empty((k, k), dtype=np.float64)
+    sh, s1, s2 = shift.reshape(-1), sum_d.reshape(-1), sum_d2.reshape(-1)
+    for i in range(k * k):
+        a, b = int(s1[i]), int(s2[i])
+        mean.flat[i] = (int(sh[i]) * P + a) / P
+        std.flat[i] = math.sqrt((P * b - a * a) / (P * P))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return (count.astype(np.float64) - mean) / std
+
+
+def nhood_enrichment(
+    adata: Any,
+    cluster_key: str,
+    library_key: str | None = None,
+    connectivity_key: str | None = None,
+    n_perms: int = 1000,
+    numba_parallel: bool = False,
+    seed: int | None = None,
+    copy: bool = False,
+    n_jobs: int | None = None,
+    backend: str = "loky",
+    show_progress_bar: bool = True,
+    *,
+    table_key: str | None = None,
+    rng: str = "philox",
+    device: int | None = None,
+) -> NhoodEnrichmentResult | None:
+    """Compute neighborhood enrichment by permutation test (drop-in for ``squidpy.gr.nhood_enrichment``).
+
+    Same positional parameters, defaults, validation errors and ``adata.uns`` slots as the reference.
+    ``numba_parallel``, ``n_jobs``, ``backend`` and ``show_progress_bar`` are accepted (and ``n_jobs``
+    validated) but do not influence the GPU path.
+
+    Extra keyword-only parameters
+    -----------------------------
+    rng
+        ``"philox"`` (default): label shuffles are generated on the GPU by the counter-based generator of
+        ``csrc/sqgr_rng.h`` keyed by ``(seed, permutation index, library)``; results are reproducible for a
+        given ``seed`` and independent of the number of GPUs, but follow a different stream than numpy.
+        ``"numpy"``: the reference's own PCG64 shuffles (``SeedSequence(seed).spawn(n_perms)``) are drawn on
+        the host and injected, reproducing Squidpy's z-scores for that ``seed`` exactly (slower).
+    device
+        HIP device index (default: ``LOCAL_RANK`` or 0).
+
+    When a ``torch.distributed`` process group is initialised, the permutation range is split across ranks
+    and the integer moments are all-reduced (RCCL); every rank returns the full result.
+    """
+    adata = extract_adata_if_sdata(adata, table_key=table_key)
+    connectivity_key = Key.obsp.spatial_conn(connectivity_key)
+    _assert_categorical_obs(adata, cluster_key)
+    _assert_connectivity_key(adata, connectivity_key)
+    assert_positive(n_perms, name="n_perms")
+    if rng not in ("philox", "numpy"):
+        raise ValueError(f"Invalid option `{rng}` for `rng`. Valid options are: `['philox', 'numpy']`.")
+
+    adj = adata.obsp[connectivity_key]
+    int_clust, n_cls = category_codes(adata.obs[cluster_key])
+    if library_key is not None:
+        _assert_categorical_obs(adata, key=library_key)
+        lib_codes, n_libs = category_codes(adata.obs[library_key])
+    else:
+        lib_codes, n_libs = None, 0
+    if n_cls <= 1:
+        raise ValueError(f"Expected at least `2` clusters, found `{n_cls}`.")  # gr/_nhood.py:107-108
+    get_n_processes(n_jobs)
+
+    ctx = default_context(device)
+    graph = Graph(ctx, adj, with_data=False)
+    try:
+        count = nhood_counts(ctx, graph, int_clust, n_cls)
+        if rng == "numpy":
+            zscore = _zscore_numpy_streams(ctx, graph, int_clust, n_cls, lib_codes, n_libs, seed, n_perms, count)
+        else:
+            rank, world = _dist.world()
+            lo, hi = _dist.shard_range(n_perms, rank, world)
+            shift = expected_counts(int_clust, n_cls, graph.nnz)
+            plan = NhoodPlan(ctx, graph, int_clust, n_cls, lib_codes, n_libs)
+            try:
+                key = _broadcast_seed(resolve_seed(seed))
+                s1, s2, _ = plan.run(key, lo, hi, shift)
+            finally:
+                plan.close()
+            s1, s2 = _dist.allreduce_sum_([s1, s2])
+            zscore = zscore_from_moments(count, shift, s1, s2, n_perms)
+    finally:
+        graph.close()
+
+    if copy:
+        return NhoodEnrichmentResult(zscore=zscore, counts=count)
+    _save_data(adata, attr="uns", key=Key.uns.nhood_enrichment(cluster_key), data={"zscore": zscore, "count": count})
+    return None
+
+
+def _broadcast_seed(key: int) -> int:
+    """All ranks must use rank 0's key when ``seed=None`` drew fresh entropy."""
+    if not _dist.is_distributed():
+        return key
+    arr = np.array([key if _dist.world()[0] == 0 else 0], dtype=np.uint64)
+    return int(_dist.allreduce_sum_([arr])[0][0])
+
+
+def _zscore_numpy_streams(
+    ctx: Context,
+    graph: Graph,
+    int_clust: np.ndarray,
+    n_cls: int,
+    lib_codes: np.ndarray | None,
+    n_libs: int,
+    seed: int | None,
+    n_perms: int,
+    count: np.ndarray,
+    chunk_bytes: int = 1 << 28,
+) -> np.ndarray:
+    """``rng="numpy"``: the reference's streams (gr/_nhood.py:213, 530-539) drawn on the host, counted on
+    the GPU, and reduced with the reference's own float64 ``mean``/``std`` (gr/_nhood.py:231)."""
+    gens = spawn_generators(seed, n_perms)
+    n = len(int_clust)
+    base = int_clust.astype(np.uint8)
+    per = max(1, min(n_perms, chunk_bytes // max(n, 1)))
+    perms = np.empty((n_perms, n_cls, n_cls), dtype=np.float64)
+    lib_idx = [np.where(lib_codes == c)[0] for c in range(n_libs)] if lib_codes is not None else None
+    for p0 in range(0, n_perms, per):
+        p1 = min(n_perms, p0 + per)
+        lab = np.empty((p1 - p0, n), dtype=np.uint8)
+        for k, ix in enumerate(range(p0, p1)):
+            r = gens[ix]
+            if lib_idx is None:
+                lab[k] = base
+                r.shuffle(lab[k])
+            else:  # gr/_utils.py:185-213
+                for idx in lib_idx:
+                    grp = base[idx].copy()
+                    r.shuffle(grp)
+                    lab[k, idx] = grp
+        perms[p0:p1] = nhood_counts_batch(ctx, graph, lab, n_cls)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return (count - perms.mean(axis=0)) / perms.std(axis=0)
+
+
+def interaction_matrix(
+    adata: Any,
+    cluster_key: str,
+    connectivity_key: str | None = None,
+    normalized: bool = False,
+    copy: bool = False,
+    weights: bool = False,
+    *,
+    table_key: str | None = None,
+    device: int | None = None,
+) -> np.ndarray | None:
+    """Compute interaction matrix for clusters (drop-in for ``squidpy.gr.interaction_matrix``,
+    gr/_nhood.py:349-429): spots with a NaN category are masked out, edges summed by label pair."""
+    adata = extract_adata_if_sdata(adata, table_key=table_key)
+    connectivity_key = Key.obsp.spatial_conn(connectivity_key)
+    _assert_categorical_obs(adata, cluster_key)
+    _assert_connectivity_key(adata, connectivity_key)
+
+    cats = adata.obs[cluster_key]
+    codes = cats.cat.codes.to_numpy().astype(np.int32)  # -1 for NaN: masked on the device
+    if not (codes >= 0).any():
+        raise RuntimeError(f"After removing NaNs in `adata.obs[{cluster_key!r}]`, none remain.")
+    g = adata.obsp[connectivity_key]
+    n_cats = len(cats.cat.categories)
+    is_int = pd.api.types.is_bool_dtype(g.dtype) or pd.api.types.is_integer_dtype(g.dtype)
+
+    ctx = default_context(device)
+    graph = Graph(ctx, g, with_data=weights)
+    try:
+        out = _intmat(ctx, graph, codes, n_cats, weights)
+    finally:
+        graph.close()
+    output = out.astype(int) if is_int else out
+    if normalized:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            output = output / output.sum(axis=1).reshape((-1, 1))
+    if copy:
+        return output
+    _save_data(adata, attr="uns", key=Key.uns.interaction_matrix(cluster_key), data=output)
+    return None

@@ -1,0 +1,227 @@
+"""GPU parity tests of the nhood_enrichment path: libsqgr (HIP) vs the CPU oracle.  Integer results are
+compared bit for bit; z-scores at the tolerance written next to each assertion."""
+
+from __future__ import annotations
+
+import numpy as np
+import pandas as pd
+import pytest
+import scipy.sparse as sp
+
+from oracle import devrng
+from oracle import restate as O
+from tests.helpers import codes, hex_adata, knn_graph
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    from squidpy_amd import _lib
+
+    return _lib
+
+
+@pytest.fixture(scope="module")
+def ctx(L):
+    return L.default_context()
+
+
+def _golden_graph(golden):
+    n = len(golden["nhood_indptr"]) - 1
+    return sp.csr_matrix(
+        (np.ones(len(golden["nhood_indices"]), np.float32), golden["nhood_indices"], golden["nhood_indptr"]), shape=(n, n)
+    )
+
+
+def test_counts_match_reference_kernel_golden(L, ctx, golden):
+    g = L.Graph(ctx, _golden_graph(golden))
+    k = int(golden["nhood_k"])
+    c = L.nhood_counts(ctx, g, golden["nhood_labels"], k)
+    assert c.dtype == np.uint32
+    np.testing.assert_array_equal(c, golden["nhood_count"])  # bit-exact integer counts
+
+
+def test_interaction_matrix_known_answers(L, ctx, golden):
+    """reference tests/graph/test_nhood.py:153-173."""
+    n = 5
+    adj = sp.csr_matrix((golden["intmat_data"].astype(np.float32), golden["intmat_indices"], golden["intmat_indptr"]), shape=(n, n))
+    g = L.Graph(ctx, adj)
+    np.testing.assert_array_equal(L.interaction_matrix(ctx, g, golden["intmat_cats"], 2, True), [[5, 1], [2, 3]])
+    np.testing.assert_array_equal(L.interaction_matrix(ctx, g, golden["intmat_cats"], 2, False), [[4, 1], [2, 2]])
+    np.testing.assert_array_equal(L.nhood_counts(ctx, g, golden["intmat_cats"], 2), [[4, 1], [2, 2]])
+    # NaN (code -1) spots are masked
+    cats = golden["intmat_cats"].copy()
+    cats[0] = -1
+    ref = O.interaction_matrix(adj[1:, :][:, 1:].tocsr().data, adj[1:, :][:, 1:].tocsr().indices, adj[1:, :][:, 1:].tocsr().indptr, cats[1:], 2, True)
+    np.testing.assert_array_equal(L.interaction_matrix(ctx, g, cats, 2, True), ref)
+
+
+def test_injected_numpy_permutations_reproduce_reference_zscore(L, ctx, golden):
+    """The reference's PCG64 shuffles injected -> per-permutation counts and z-score identical (==) to the
+    output of the reference's own `_nhood_enrichment_helper` + gr/_nhood.py:231."""
+    g = L.Graph(ctx, _golden_graph(golden))
+    k = int(golden["nhood_k"])
+    P = golden["nhood_perms"].shape[0]
+    lab = O.nhood_perm_labels_numpy(golden["nhood_labels"], int(golden["nhood_seed"]), P)
+    perms = L.nhood_counts_batch(ctx, g, lab, k)
+    np.testing.assert_array_equal(perms, golden["nhood_perms"].astype(np.uint32))
+    z = O.nhood_zscore(golden["nhood_count"], perms.astype(np.float64))
+    np.testing.assert_array_equal(z, golden["nhood_zscore"])
+
+
+@pytest.mark.parametrize("n", [1, 7, 49, 300, 5000])
+def test_device_shuffle_matches_oracle_generator(L, ctx, n):
+    rng = np.random.default_rng(n)
+    k = 5
+    labels = rng.integers(0, k, n)
+    adj = sp.identity(n, format="csr", dtype=np.float32)
+    g = L.Graph(ctx, adj)
+    plan = L.NhoodPlan(ctx, g, labels, k)
+    for perm in (0, 1, 17, 2**33 + 5):
+        got = plan.shuffled_labels(seed=1234, perm=perm)
+        exp = devrng.shuffled_labels(labels, 1234, perm)
+        np.testing.assert_array_equal(got, exp)
+        assert np.array_equal(np.sort(got), np.sort(labels))
+
+
+@pytest.mark.parametrize("B", [16, 32])
+def test_philox_permutation_test_bit_exact_vs_oracle(L, ctx, golden, B):
+    adj = _golden_graph(golden)
+    g = L.Graph(ctx, adj)
+    k = int(golden["nhood_k"])
+    labels = golden["nhood_labels"].astype(np.int32)
+    plan = L.NhoodPlan(ctx, g, labels, k)
+    plan.tune(B, 0, 2)
+    seed, P = 99, 75  # not a multiple of the batch: exercises the masked tail
+    shift = np.arange(k * k, dtype=np.int64).reshape(k, k) * 3 - 7
+    s1, s2, perms = plan.run(seed, 0, P, shift, return_perms=True)
+    ref = O.nhood_perm_counts_philox(adj.indices, adj.indptr, labels, k, seed, 0, P)
+    np.testing.assert_array_equal(perms, ref.astype(np.uint32))
+    d = ref.astype(np.int64) - shift
+    np.testing.assert_array_equal(s1, d.sum(0))
+    np.testing.assert_array_equal(s2, (d * d).sum(0).astype(np.uint64))
+    # split invariance: any partition of the permutation range gives the same exact moments
+    a1, a2, _ = plan.run(seed, 0, 20, shift)
+    b1, b2, _ = plan.run(seed, 20, P, shift)
+    np.testing.assert_array_equal(a1 + b1, s1)
+    np.testing.assert_array_equal(a2 + b2, s2)
+
+
+def test_philox_library_shuffle_bit_exact_vs_oracle(L, ctx, golden):
+    adj = _golden_graph(golden)
+    g = L.Graph(ctx, adj)
+    k = int(golden["nhood_k"])
+    labels = golden["nhood_labels"].astype(np.int32)
+    libs = golden["nhood_lib_codes"]
+    plan = L.NhoodPlan(ctx, g, labels, k, libs, 3)
+    _, _, perms = plan.run(5, 3, 40, None, return_perms=True)
+    ref = O.nhood_perm_counts_philox(adj.indices, adj.indptr, labels, k, 5, 3, 40, libs, 3)
+    np.testing.assert_array_equal(perms, ref.astype(np.uint32))
+    for perm in (0, 9):
+        got = plan.shuffled_labels(5, perm)
+        for c in range(3):  # label multiset preserved inside every library (reference test_shuffle_group)
+            assert np.array_equal(np.sort(got[libs == c]), np.sort(labels[libs == c]))
+
+
+@pytest.mark.parametrize("k", [2, 30, 46, 60, 100, 150, 210, 256])
+def test_all_cluster_count_regimes(L, ctx, k):
+    """K decides which count kernel runs (LDS B=16, narrower LDS passes, device atomics): all bit-exact."""
+    rng = np.random.default_rng(k)
+    n = 1500
+    adj = knn_graph(rng.random((n, 2)), 6)
+    labels = rng.integers(0, k, n).astype(np.int32)
+    g = L.Graph(ctx, adj)
+    np.testing.assert_array_equal(L.nhood_counts(ctx, g, labels, k), O.nhood_counts(adj.indices, adj.indptr, labels, k))
+    plan = L.NhoodPlan(ctx, g, labels, k)
+    _, _, perms = plan.run(3, 0, 19, None, return_perms=True)
+    ref = O.nhood_perm_counts_philox(adj.indices, adj.indptr, labels, k, 3, 0, 19)
+    np.testing.assert_array_equal(perms, ref.astype(np.uint32))
+
+
+def test_ragged_and_empty_rows(L, ctx):
+    """Rows without neighbours, self loops, duplicate and explicit-zero entries all count like the reference."""
+    rng = np.random.default_rng(0)
+    n, k = 400, 4
+    rows = rng.integers(0, n // 2, 3000)  # upper half of the rows is empty
+    cols = rng.integers(0, n, 3000)
+    adj = sp.csr_matrix((rng.integers(0, 2, 3000).astype(np.float32), (rows, cols)), shape=(n, n))  # sums duplicates
+    adj = adj + sp.identity(n, format="csr", dtype=np.float32)  # self loops
+    adj = sp.csr_matrix(adj)
+    labels = rng.integers(0, k, n).astype(np.int32)
+    g = L.Graph(ctx, adj)
+    np.testing.assert_array_equal(L.nhood_counts(ctx, g, labels, k), O.nhood_counts(adj.indices, adj.indptr, labels, k))
+    empty = sp.csr_matrix((n, n), dtype=np.float32)
+    g0 = L.Graph(ctx, empty)
+    assert L.nhood_counts(ctx, g0, labels, k).sum() == 0
+    plan = L.NhoodPlan(ctx, g0, labels, k)
+    s1, s2, _ = plan.run(1, 0, 10)
+    assert not s1.any() and not s2.any()
+
+
+def test_frontend_config1_hex_grid(L):
+    """BASELINE config 1 shape: 5 000-spot hex grid, 10 clusters, n_perms=1000 (front-end, both rng modes)."""
+    import squidpy_amd as sq
+
+    adata = hex_adata(50, 100, 10, seed=0)
+    adj = adata.obsp["spatial_connectivities"]
+    lab = codes(adata, "cluster")
+    res = sq.gr.nhood_enrichment(adata, "cluster", n_perms=1000, seed=0, copy=True)
+    count_ref = O.nhood_counts(adj.indices, adj.indptr, lab, 10)
+    np.testing.assert_array_equal(res.counts, count_ref)
+    assert res.counts.dtype == np.uint32 and res.zscore.dtype == np.float64 and res.zscore.shape == (10, 10)
+    ref = O.nhood_perm_counts_philox(adj.indices, adj.indptr, lab, 10, 0, 0, 1000)
+    z_ref = O.nhood_zscore(count_ref, ref)
+    np.testing.assert_allclose(res.zscore, z_ref, rtol=1e-9, atol=1e-12)  # exact-integer moments vs numpy mean/std
+    # rng="numpy" reproduces Squidpy's own streams: equal (==) to the reference restatement
+    res_np = sq.gr.nhood_enrichment(adata, "cluster", n_perms=200, seed=7, copy=True, rng="numpy")
+    perms_np = O.nhood_perm_counts_numpy(adj.indices, adj.indptr, lab, 10, 7, 200)
+    np.testing.assert_array_equal(res_np.zscore, O.nhood_zscore(count_ref, perms_np))
+    # statistical agreement between the two generators: same null distribution
+    z2 = O.nhood_zscore(count_ref, O.nhood_perm_counts_numpy(adj.indices, adj.indptr, lab, 10, 1, 1000))
+    assert np.abs(res.zscore - z2).max() < 0.35 * max(1.0, np.abs(z2).max() * 0.1 + 1)
+    np.testing.assert_allclose(ref.mean(0), perms_np.mean(0), rtol=0.02)
+    np.testing.assert_allclose(ref.std(0), perms_np.std(0), rtol=0.2)
+
+
+def test_frontend_slots_reproducibility_and_libraries(L):
+    """reference tests/graph/test_nhood.py:20-70 ported: dtypes/shapes, seed reproducibility, count invariance."""
+    import squidpy_amd as sq
+
+    adata = hex_adata(30, 40, 5, seed=3, n_libs=3)
+    assert sq.gr.nhood_enrichment(adata, "cluster", n_perms=50, seed=42) is None
+    slot = adata.uns["cluster_nhood_enrichment"]
+    assert set(slot) == {"zscore", "count"}
+    assert slot["zscore"].dtype == np.float64 and slot["count"].dtype == np.uint32
+    assert slot["zscore"].shape == slot["count"].shape == (5, 5)
+    r1 = sq.gr.nhood_enrichment(adata, "cluster", n_perms=50, seed=42, copy=True, n_jobs=2, backend="threading")
+    r2 = sq.gr.nhood_enrichment(adata, "cluster", n_perms=50, seed=43, copy=True, numba_parallel=True)
+    np.testing.assert_array_equal(r1.zscore, slot["zscore"])
+    np.testing.assert_array_equal(r1.counts, r2.counts)
+    assert not np.allclose(r1.zscore, r2.zscore)
+    rl = sq.gr.nhood_enrichment(adata, "cluster", library_key="library", n_perms=50, seed=42, copy=True)
+    np.testing.assert_array_equal(rl.counts, r1.counts)
+    assert not np.allclose(rl.zscore, r1.zscore)
+    adj = adata.obsp["spatial_connectivities"]
+    ref = O.nhood_perm_counts_philox(adj.indices, adj.indptr, codes(adata, "cluster"), 5, 42, 0, 50, codes(adata, "library"), 3)
+    np.testing.assert_allclose(rl.zscore, O.nhood_zscore(rl.counts, ref), rtol=1e-9)
+    # interaction_matrix front-end
+    im = sq.gr.interaction_matrix(adata, "cluster", copy=True)
+    np.testing.assert_array_equal(im, O.nhood_counts(adj.indices, adj.indptr, codes(adata, "cluster"), 5).astype(float))
+
+
+def test_config2_size_properties(L, ctx):
+    """BASELINE config 2 size (1e5 spots, 20 clusters): counts bit-exact vs oracle; permutation counts obey the
+    size-independent invariants (every permutation's counts sum to nnz; row sums follow the label degrees)."""
+    rows, cols, k = 250, 400, 20
+    adj = O.hex_grid_graph(rows, cols)
+    rng = np.random.default_rng(0)
+    labels = rng.integers(0, k, rows * cols).astype(np.int32)
+    g = L.Graph(ctx, adj)
+    np.testing.assert_array_equal(L.nhood_counts(ctx, g, labels, k), O.nhood_counts(adj.indices, adj.indptr, labels, k))
+    plan = L.NhoodPlan(ctx, g, labels, k)
+    s1, s2, perms = plan.run(11, 0, 100, None, return_perms=True)
+    assert (perms.reshape(100, -1).sum(1) == adj.nnz).all()
+    np.testing.assert_array_equal(s1, perms.astype(np.int64).sum(0))
+    ref = O.nhood_perm_counts_philox(adj.indices, adj.indptr, labels, k, 11, 0, 3)
+    np.testing.assert_array_equal(perms[:3], ref.astype(np.uint32))
