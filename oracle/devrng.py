@@ -2,9 +2,9 @@
 
 CPU (numpy) restatement of the *device* permutation generator used by the HIP path when
 ``rng="philox"`` (``squidpy_amd/csrc/sqgr_rng.h``): Philox4x32-10 derives eight 32-bit round
-keys per (seed, permutation index, library); a keyed 8-round Feistel network over
-``bits = max(8, ceil(log2 n))`` bits with cycle walking turns them into a bijection of
-``[0, n)``.  The reference (squidpy) has no such generator — it uses numpy PCG64 shuffles
+keys per (seed, permutation index, library); a keyed 8-round additive Feistel network over the
+mixed-radix domain ``A x B >= n`` (``A ~ B ~ sqrt(n)``, both >= 16) with cycle walking turns them into a
+bijection of ``[0, n)``.  The reference (squidpy) has no such generator — it uses numpy PCG64 shuffles
 (`/root/reference/src/squidpy/_utils.py:240-241`, ``gr/_nhood.py:533-538``) — so this file
 does not follow a reference file; it exists so that the GPU permutation test can be checked
 *bit for bit* (same permutations => same counts => same z-scores) and so that the statistical
@@ -12,6 +12,8 @@ quality of the generator can be tested against numpy's shuffles on the CPU.
 """
 
 from __future__ import annotations
+
+import math
 
 import numpy as np
 
@@ -61,11 +63,12 @@ def round_keys(seed: int, perms: np.ndarray, lib: int = 0) -> np.ndarray:
     return np.concatenate(out, axis=-1)
 
 
-def domain_bits(n: int) -> int:
-    b = 0
-    while (1 << b) < n:
-        b += 1
-    return max(8, b)
+def domain_dims(n: int) -> tuple[int, int]:
+    """Mixed-radix domain A x B >= n, A ~ B ~ sqrt(n), both >= 16 (sqgr_rng.h: make_domain)."""
+    a = math.isqrt(n - 1) + 1 if n > 1 else n
+    A = max(16, a)
+    B = max(16, -(-n // A))
+    return A, B
 
 
 def _F(v: np.ndarray, k: np.uint64) -> np.ndarray:
@@ -76,31 +79,29 @@ def _F(v: np.ndarray, k: np.uint64) -> np.ndarray:
     return w >> np.uint64(16)
 
 
-def feistel(x: np.ndarray, bits: int, rk: np.ndarray) -> np.ndarray:
-    """One application of the keyed bijection of [0, 2**bits).  ``rk``: (8,) uint32."""
-    rb = bits // 2
-    lb = bits - rb
-    ml, mr = np.uint64((1 << lb) - 1), np.uint64((1 << rb) - 1)
-    x = x.astype(np.uint64)
-    a, b = x >> np.uint64(rb), x & mr
-    for r in range(N_ROUNDS):
-        k = np.uint64(int(rk[r]))
-        if r % 2 == 0:
-            a = a ^ (_F(b, k) & ml)
-        else:
-            b = b ^ (_F(a, k) & mr)
-    return (a << np.uint64(rb)) | b
+def feistel(a: np.ndarray, b: np.ndarray, A: int, B: int, rk: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+    """One application of the keyed bijection of [0, A) x [0, B).  ``rk``: (8,) uint32."""
+    A64, B64 = np.uint64(A), np.uint64(B)
+    for r in range(0, N_ROUNDS, 2):
+        a = a + ((_F(b, np.uint64(int(rk[r]))) * A64) >> np.uint64(16))
+        a = np.where(a >= A64, a - A64, a)
+        b = b + ((_F(a, np.uint64(int(rk[r + 1]))) * B64) >> np.uint64(16))
+        b = np.where(b >= B64, b - B64, b)
+    return a, b
 
 
 def permutation(n: int, rk: np.ndarray) -> np.ndarray:
     """pi with pi[i] = image of i under the cycle-walked bijection of [0, n); int64 (n,)."""
     if n <= 1:
         return np.zeros(n, dtype=np.int64)
-    bits = domain_bits(n)
-    x = feistel(np.arange(n, dtype=np.uint64), bits, rk)
+    A, B = domain_dims(n)
+    x = np.arange(n, dtype=np.uint64)
+    a, b = feistel(x // np.uint64(B), x % np.uint64(B), A, B, rk)
+    x = a * np.uint64(B) + b
     bad = x >= np.uint64(n)
     while bad.any():
-        x[bad] = feistel(x[bad], bits, rk)
+        a[bad], b[bad] = feistel(a[bad], b[bad], A, B, rk)
+        x = a * np.uint64(B) + b
         bad = x >= np.uint64(n)
     return x.astype(np.int64)
 
@@ -108,14 +109,18 @@ def permutation(n: int, rk: np.ndarray) -> np.ndarray:
 def shuffled_labels(
     labels: np.ndarray, seed: int, perm: int, lib_ids: np.ndarray | None = None, n_libs: int = 0
 ) -> np.ndarray:
-    """Label vector of global permutation ``perm``: out[i] = labels[pi(i)] (per library if given)."""
+    """Label vector of global permutation ``perm``.
+
+    The base vector is taken sorted by label (inside each library): a uniformly random arrangement of
+    a multiset does not depend on the base order, and a sorted base turns the device's label lookup into a
+    binary search over K boundaries instead of a memory gather:  out[i] = sort(labels)[pi(rank_i)]."""
     labels = np.asarray(labels)
     if lib_ids is None:
         rk = round_keys(seed, np.array([perm]))[0]
-        return labels[permutation(len(labels), rk)]
+        return np.sort(labels)[permutation(len(labels), rk)]
     out = np.empty_like(labels)
     for lib in range(n_libs):
         idx = np.where(lib_ids == lib)[0]
         rk = round_keys(seed, np.array([perm]), lib=lib)[0]
-        out[idx] = labels[idx][permutation(len(idx), rk)]
+        out[idx] = np.sort(labels[idx])[permutation(len(idx), rk)]
     return out

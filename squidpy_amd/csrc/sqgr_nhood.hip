@@ -17,15 +17,12 @@
 #include "sqgr_common.h"
 #include "sqgr_rng.h"
 
+#include <type_traits>
+
 namespace sqgr {
 
 constexpr int COUNT_THREADS = 1024;
 constexpr size_t LDS_BUDGET = 160 * 1024;
-
-struct LibInfo {
-    FeistelDomain dom;
-    uint32_t off;  // offset of this library's block inside the gather table
-};
 
 // ---------------------------------------------------------------------------------------------- key generation
 __global__ void k_keygen(uint64_t seed, int64_t perm0, int64_t nperm, int n_libs, uint32_t* __restrict__ keys) {
@@ -40,26 +37,33 @@ __global__ void k_keygen(uint64_t seed, int64_t perm0, int64_t nperm, int n_libs
 }
 
 // ---------------------------------------------------------------------------------------------- label shuffle
-// slab[(batch*n + i)*B + b] = table[ off_lib + pi_{perm,lib}( rank_i ) ]
+// A uniformly random arrangement of the label multiset does not depend on the order of the base vector, so
+// the base is taken *sorted by label* (inside each library): the label at sorted rank x is
+//   #{k >= 1 : cum[k] <= x},   cum[k] = number of spots with label < k,
+// found by a branch-free binary search in an LDS-resident boundary table (KPAD entries per library, padded
+// with UINT_MAX) -- no memory gather.   slab[(batch*n + i)*B + b] = label_at_rank( pi_{perm,lib}(rank_i) )
 template <int B, bool HAS_LIBS>
-__global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint8_t* __restrict__ table,
+__global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __restrict__ cum, int kpad,
                                                  const uint32_t* __restrict__ keys, FeistelDomain dom0, int n_libs,
                                                  const int32_t* __restrict__ lib_of, const int32_t* __restrict__ rank_of,
-                                                 const LibInfo* __restrict__ libs, uint8_t* __restrict__ slab_all) {
+                                                 const FeistelDomain* __restrict__ libdoms, uint8_t* __restrict__ slab_all) {
+    extern __shared__ uint32_t s_cum[];
+    for (int t = threadIdx.x; t < n_libs * kpad; t += 256) s_cum[t] = cum[t];
+    __syncthreads();
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int batch = blockIdx.y;
     const uint32_t* kb = keys + (size_t)batch * B * n_libs * 8;
     uint32_t out[B / 4];
     FeistelDomain dom = dom0;
-    uint32_t x0 = (uint32_t)i, off = 0, lib = 0;
+    uint32_t x0 = (uint32_t)i, lib = 0;
     if (HAS_LIBS) {
         lib = (uint32_t)lib_of[i];
-        LibInfo li = libs[lib];
-        dom = li.dom;
-        off = li.off;
+        dom = libdoms[lib];
         x0 = (uint32_t)rank_of[i];
     }
+    const uint32_t* tab = s_cum + lib * kpad;
+    const uint32_t a0 = x0 / dom.B, b0 = x0 - a0 * dom.B;  // one division per spot, shared by all B permutations
 #pragma unroll
     for (int w = 0; w < B / 4; ++w) {
         uint32_t word = 0;
@@ -67,8 +71,10 @@ __global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint8_t* __res
         for (int j = 0; j < 4; ++j) {
             const int b = w * 4 + j;
             const uint32_t* rk = kb + ((size_t)b * n_libs + lib) * 8;  // uniform (scalar loads) when !HAS_LIBS
-            uint32_t x = feistel_perm(x0, dom, rk);
-            word |= (uint32_t)table[off + x] << (8 * j);
+            const uint32_t x = feistel_perm_ab(a0, b0, dom, rk);
+            uint32_t pos = 0;  // largest index with tab[pos] <= x  (tab[0] == 0)
+            for (int step = kpad >> 1; step > 0; step >>= 1) pos += (tab[pos + step] <= x) ? step : 0;
+            word |= pos << (8 * j);
         }
         out[w] = word;
     }
@@ -100,55 +106,80 @@ __device__ __forceinline__ int xcd_chunk(int b, int nblk) {
     return (b & 7) * (nblk >> 3) + (b >> 3);
 }
 
-// byte j of the lane's B/4 label bytes (kept in scalars: a dynamically indexed array would go to scratch)
-template <int B>
-__device__ __forceinline__ uint32_t label_byte(uint32_t lo, uint32_t hi, int j) {
-    if constexpr (B == 16) {
-        return (lo >> (8 * j)) & 0xffu;
-    } else {
-        const uint32_t w = (j & 4) ? hi : lo;
-        return (w >> (8 * (j & 3))) & 0xffu;
-    }
-}
-
-// B = 16 | 32 permutations; 4 lanes per edge, lane q owns permutations [q*B/4, (q+1)*B/4).
-// LDS histogram layout: word = pair*B + b  (pair = la*K + lb).
+// B = 16 | 32 permutations; 4 lanes per edge, lane q owns the B/4 permutations [q*B/4, (q+1)*B/4) = B/4 label
+// bytes of the slab rows of both endpoints.  LDS histogram layout: word = pair*B + b  (pair = la*K + lb).
+// Step s of lane (edge slot el, q) handles byte (s + el) mod B/4, so the 32 lanes of a DS lane group touch
+// B distinct banks (conflict-free for B = 32).  The stagger costs nothing per step: the label words are rotated
+// once per edge (v_alignbit) so that byte extraction is static, and the per-step bank offsets are loop invariant.
 template <int B, int MIN_WAVES>
-__global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(int64_t nnz, const int32_t* __restrict__ erow,
+__global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz, const int32_t* __restrict__ erow,
                                                                     const int32_t* __restrict__ indices,
                                                                     const uint8_t* __restrict__ slab_all, int64_t n, int K,
-                                                                    int hist_words, int64_t edges_per_block,
+                                                                    int hist_words, uint32_t edges_per_block,
                                                                     uint32_t* __restrict__ partial_all) {
     extern __shared__ uint32_t hist[];
     constexpr int BPL = B / 4;  // label bytes per lane
+    constexpr int LOGW = (B == 32) ? 7 : 6;  // log2(bytes of one pair's B counters)
     const int tid = threadIdx.x;
     for (int i = tid; i < hist_words; i += COUNT_THREADS) hist[i] = 0;
     __syncthreads();
 
     const uint8_t* slab = slab_all + (size_t)blockIdx.y * n * B;
-    const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
-    const int64_t e0 = (int64_t)chunk * edges_per_block;
-    const int64_t e1 = min(nnz, e0 + edges_per_block);
-    const int q = tid & 3;
-    const int el = tid >> 2;
-    for (int64_t e = e0 + el; e < e1; e += COUNT_THREADS / 4) {
-        const int32_t r = erow[e];
-        const int32_t c = indices[e];
-        uint32_t la_lo, la_hi = 0, lb_lo, lb_hi = 0;
-        if constexpr (B == 16) {
-            la_lo = *reinterpret_cast<const uint32_t*>(slab + (size_t)r * B + q * BPL);
-            lb_lo = *reinterpret_cast<const uint32_t*>(slab + (size_t)c * B + q * BPL);
-        } else {
-            const uint2 a = *reinterpret_cast<const uint2*>(slab + (size_t)r * B + q * BPL);
-            const uint2 b = *reinterpret_cast<const uint2*>(slab + (size_t)c * B + q * BPL);
-            la_lo = a.x; la_hi = a.y;
-            lb_lo = b.x; lb_hi = b.y;
+    const uint32_t chunk = (uint32_t)xcd_chunk(blockIdx.x, gridDim.x);
+    const uint32_t e0 = chunk * edges_per_block;
+    const uint32_t e1 = min(nnz, e0 + edges_per_block);
+    const uint32_t q = tid & 3;
+    const uint32_t el = tid >> 2;
+    const uint32_t rot = (el & (BPL - 1)) * 8;  // bits to rotate right
+    uint32_t bank_ofs[BPL];                      // byte offset of this lane's counter inside a pair, per step
+#pragma unroll
+    for (int s = 0; s < BPL; ++s) bank_ofs[s] = (q * BPL + ((s + el) & (BPL - 1))) * 4;
+    const uint32_t qoff = q * BPL;
+    char* hist_bytes = reinterpret_cast<char*>(hist);
+
+    // U edges per lane per iteration: all index loads, then all slab-row gathers, are in flight together, so the
+    // two dependent memory latencies are paid once per U edges (LDS caps residency at 16-32 waves per CU).
+    constexpr int U = 4;
+    constexpr uint32_t STRIDE = COUNT_THREADS / 4;
+    using Row = typename std::conditional<B == 16, uint32_t, uint2>::type;
+    const uint32_t last = nnz - 1;
+    for (uint32_t e = e0 + el; e < e1; e += U * STRIDE) {
+        uint32_t r[U], c[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t eu = min(e + u * STRIDE, last);  // clamped: loads stay in bounds, tail is predicated below
+            r[u] = (uint32_t)erow[eu];
+            c[u] = (uint32_t)indices[eu];
+        }
+        Row ra[U], rb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            ra[u] = *reinterpret_cast<const Row*>(slab + (r[u] * B + qoff));
+            rb[u] = *reinterpret_cast<const Row*>(slab + (c[u] * B + qoff));
         }
 #pragma unroll
-        for (int s = 0; s < BPL; ++s) {
-            const int j = (s + el) & (BPL - 1);  // staggered so a DS lane group covers all B banks
-            const uint32_t pair = label_byte<B>(la_lo, la_hi, j) * (uint32_t)K + label_byte<B>(lb_lo, lb_hi, j);
-            atomicAdd(&hist[pair * B + q * BPL + j], 1u);
+        for (int u = 0; u < U; ++u) {
+            const uint32_t inc = (e + u * STRIDE < e1) ? 1u : 0u;  // branch-free tail: out-of-range edges add 0
+            uint32_t la[2], lb[2];
+            if constexpr (B == 16) {
+                la[0] = __builtin_amdgcn_alignbit(ra[u], ra[u], rot);
+                lb[0] = __builtin_amdgcn_alignbit(rb[u], rb[u], rot);
+            } else {
+                const bool sw = (rot & 32) != 0;
+                const uint32_t alo = sw ? ra[u].y : ra[u].x, ahi = sw ? ra[u].x : ra[u].y;
+                const uint32_t blo = sw ? rb[u].y : rb[u].x, bhi = sw ? rb[u].x : rb[u].y;
+                la[0] = __builtin_amdgcn_alignbit(ahi, alo, rot);
+                la[1] = __builtin_amdgcn_alignbit(alo, ahi, rot);
+                lb[0] = __builtin_amdgcn_alignbit(bhi, blo, rot);
+                lb[1] = __builtin_amdgcn_alignbit(blo, bhi, rot);
+            }
+#pragma unroll
+            for (int s = 0; s < BPL; ++s) {
+                const uint32_t va = (la[s >> 2] >> (8 * (s & 3))) & 0xffu;  // static byte extraction
+                const uint32_t vb = (lb[s >> 2] >> (8 * (s & 3))) & 0xffu;
+                const uint32_t pair = __umul24(va, (uint32_t)K) + vb;
+                atomicAdd(reinterpret_cast<uint32_t*>(hist_bytes + ((pair << LOGW) + bank_ofs[s])), inc);
+            }
         }
     }
     __syncthreads();
@@ -204,16 +235,24 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_wide(int64_t nnz, const
 
 // ---------------------------------------------------------------------------------------------- reduction
 // word w = pair*B + b.  acc slots are private to (batch, w): no atomics, bit-reproducible.
+// 256 threads = 64 words x 4 slices of the block loop (combined through LDS).
 __global__ __launch_bounds__(256) void k_reduce(const uint32_t* __restrict__ partial_all, int nblk, int hist_words, int B,
                                                 int K2, const int64_t* __restrict__ shift, int64_t perm_batch0,
                                                 int64_t perm_begin, int64_t perm_end, int64_t* __restrict__ acc_sum,
                                                 uint64_t* __restrict__ acc_sq, uint32_t* __restrict__ perms_out) {
-    int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= hist_words) return;
+    __shared__ unsigned long long part[4][64];
+    const int wl = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int w = blockIdx.x * 64 + wl;
     const int batch = blockIdx.y;
-    const uint32_t* src = partial_all + (size_t)batch * nblk * hist_words + w;
-    uint64_t c = 0;
-    for (int k = 0; k < nblk; ++k) c += src[(size_t)k * hist_words];
+    unsigned long long c = 0;
+    if (w < hist_words) {
+        const uint32_t* src = partial_all + (size_t)batch * nblk * hist_words + w;
+        for (int k = slice; k < nblk; k += 4) c += src[(size_t)k * hist_words];
+    }
+    part[slice][wl] = c;
+    __syncthreads();
+    if (slice != 0 || w >= hist_words) return;
+    c = part[0][wl] + part[1][wl] + part[2][wl] + part[3][wl];
     const int pair = w / B, b = w % B;
     const int64_t p = perm_batch0 + (int64_t)batch * B + b;
     if (p >= perm_end) return;
@@ -283,9 +322,10 @@ struct sqgr_nhood {
     int n_libs = 1;
     bool has_libs = false;
     FeistelDomain dom0{};
-    DevBuf<uint8_t> table;
+    DevBuf<uint32_t> cum;  // [n_libs][kpad] label boundaries of the label-sorted base
+    int kpad = 0;
     DevBuf<int32_t> lib_of, rank_of;
-    DevBuf<LibInfo> libs;
+    DevBuf<FeistelDomain> libs;
     // tuning
     int B = 16;
     int nblk = 0;
@@ -346,20 +386,24 @@ int sqgr_nhood::count_batches(int nb) {
     const int64_t nnz = g->nnz;
     hipStream_t st = ctx->stream;
     const int hw = hist_words();
+    if (nnz == 0) {  // no edges: every count is zero
+        SQGR_HIP(hipMemsetAsync(partial.p, 0, (size_t)nb * partial_blocks() * hw * 4, st));
+        return SQGR_OK;
+    }
     if (B == 32) {
-        const int64_t epb = ceil_div(ceil_div(nnz, nblk), 256) * 256;
+        const uint32_t epb = (uint32_t)(ceil_div(ceil_div(nnz, nblk), 256) * 256);
         LaunchTimer t(ctx, "nhood_count_b32");
         SQGR_TRY(allow_lds(k_count<32, 4>, (size_t)hw * 4));
-        k_count<32, 4><<<dim3(nblk, nb), COUNT_THREADS, (size_t)hw * 4, st>>>(nnz, g->erow.p, g->indices.p, slab.p, n, K, hw,
+        k_count<32, 4><<<dim3(nblk, nb), COUNT_THREADS, (size_t)hw * 4, st>>>((uint32_t)nnz, g->erow.p, g->indices.p, slab.p, n, K, hw,
                                                                            epb, partial.p);
     } else if (be() == 16) {
-        const int64_t epb = ceil_div(ceil_div(nnz, nblk), 256) * 256;
+        const uint32_t epb = (uint32_t)(ceil_div(ceil_div(nnz, nblk), 256) * 256);
         LaunchTimer t(ctx, "nhood_count_b16");
         if ((size_t)hw * 4 * 2 <= LDS_BUDGET)
-            k_count<16, 8><<<dim3(nblk, nb), COUNT_THREADS, (size_t)hw * 4, st>>>(nnz, g->erow.p, g->indices.p, slab.p, n, K,
+            k_count<16, 8><<<dim3(nblk, nb), COUNT_THREADS, (size_t)hw * 4, st>>>((uint32_t)nnz, g->erow.p, g->indices.p, slab.p, n, K,
                                                                                hw, epb, partial.p);
         else if (allow_lds(k_count<16, 4>, (size_t)hw * 4) == SQGR_OK)
-            k_count<16, 4><<<dim3(nblk, nb), COUNT_THREADS, (size_t)hw * 4, st>>>(nnz, g->erow.p, g->indices.p, slab.p, n, K,
+            k_count<16, 4><<<dim3(nblk, nb), COUNT_THREADS, (size_t)hw * 4, st>>>((uint32_t)nnz, g->erow.p, g->indices.p, slab.p, n, K,
                                                                                hw, epb, partial.p);
     } else {
         const int e = be();
@@ -388,7 +432,7 @@ int sqgr_nhood::count_batches(int nb) {
 int sqgr_nhood::reduce_batches(int nb, int64_t perm_batch0, int64_t perm_begin, int64_t perm_end, uint32_t* perms_out_dev) {
     const int hw = hist_words();
     LaunchTimer t(ctx, "nhood_reduce");
-    k_reduce<<<dim3((unsigned)ceil_div(hw, 256), nb), 256, 0, ctx->stream>>>(partial.p, partial_blocks(), hw, B, K2, shift.p,
+    k_reduce<<<dim3((unsigned)ceil_div(hw, 64), nb), 256, 0, ctx->stream>>>(partial.p, partial_blocks(), hw, B, K2, shift.p,
                                                                             perm_batch0, perm_begin, perm_end, acc_sum.p,
                                                                             acc_sq.p, perms_out_dev);
     SQGR_HIP(hipGetLastError());
@@ -475,6 +519,10 @@ int sqgr_nhood_create(sqgr_ctx* ctx, const sqgr_graph* g, const int32_t* labels,
         return SQGR_ERR_UNSUPPORTED;
     }
     const int64_t n = g->n;
+    if (n > (int64_t)1 << 27 || g->nnz > (int64_t)0xFFF00000u) {
+        set_error("graph too large for 32-bit slab offsets (n=%lld, nnz=%lld)", (long long)n, (long long)g->nnz);
+        return SQGR_ERR_UNSUPPORTED;
+    }
     if (labels) SQGR_TRY(check_labels(labels, n, K, false));
     SQGR_HIP(hipSetDevice(ctx->device));
     sqgr_nhood* p = new sqgr_nhood();
@@ -486,51 +534,56 @@ int sqgr_nhood_create(sqgr_ctx* ctx, const sqgr_graph* g, const int32_t* labels,
     p->dom0 = make_domain((uint32_t)n);
     int rc = SQGR_OK;
     do {
-        std::vector<uint8_t> table((size_t)n, 0);
-        if (lib_ids && n_libs >= 1) {
-            p->has_libs = true;
-            p->n_libs = n_libs;
-            std::vector<int64_t> cnt((size_t)n_libs, 0);
-            for (int64_t i = 0; i < n; ++i) {
-                if (lib_ids[i] < 0 || lib_ids[i] >= n_libs) {
-                    set_error("lib_ids[%lld]=%d outside [0,%d)", (long long)i, lib_ids[i], n_libs);
+        const bool libs_on = lib_ids && n_libs >= 1;
+        p->has_libs = libs_on;
+        p->n_libs = libs_on ? n_libs : 1;
+        p->kpad = 2;
+        while (p->kpad < K) p->kpad <<= 1;
+        if ((size_t)p->n_libs * p->kpad > 16384) {
+            set_error("n_libs * next_pow2(K) = %d * %d exceeds the 64 KiB LDS boundary table", p->n_libs, p->kpad);
+            rc = SQGR_ERR_UNSUPPORTED;
+            break;
+        }
+        // label histogram per library -> boundaries cum[l][k] = #{members of l with label < k}, padded with UINT_MAX
+        std::vector<int64_t> cnt((size_t)p->n_libs, 0);
+        std::vector<uint32_t> hist((size_t)p->n_libs * K, 0);
+        std::vector<int32_t> rank;
+        if (libs_on) rank.resize((size_t)n);
+        for (int64_t i = 0; i < n; ++i) {
+            int l = 0;
+            if (libs_on) {
+                l = lib_ids[i];
+                if (l < 0 || l >= n_libs) {
+                    set_error("lib_ids[%lld]=%d outside [0,%d)", (long long)i, l, n_libs);
                     rc = SQGR_ERR_INVALID;
                     break;
                 }
-                cnt[lib_ids[i]]++;
+                rank[i] = (int32_t)cnt[l];  // ranks in position order == np.where(libraries == c)[0]
             }
-            if (rc != SQGR_OK) break;
-            std::vector<LibInfo> libs((size_t)n_libs);
-            std::vector<int64_t> off((size_t)n_libs + 1, 0);
-            for (int l = 0; l < n_libs; ++l) off[l + 1] = off[l] + cnt[l];
-            for (int l = 0; l < n_libs; ++l) {
-                libs[l].dom = make_domain((uint32_t)(cnt[l] > 0 ? cnt[l] : 1));
-                libs[l].off = (uint32_t)off[l];
+            cnt[l]++;
+            if (labels) hist[(size_t)l * K + labels[i]]++;
+        }
+        if (rc != SQGR_OK) break;
+        std::vector<uint32_t> cum((size_t)p->n_libs * p->kpad, 0xFFFFFFFFu);
+        std::vector<FeistelDomain> doms((size_t)p->n_libs);
+        for (int l = 0; l < p->n_libs; ++l) {
+            uint32_t run = 0;
+            for (int k = 0; k < K; ++k) {
+                cum[(size_t)l * p->kpad + k] = run;
+                run += hist[(size_t)l * K + k];
             }
-            std::vector<int32_t> rank((size_t)n);
-            std::vector<int64_t> fill((size_t)n_libs, 0);
-            for (int64_t i = 0; i < n; ++i) {  // ranks in position order == np.where(libraries == c)[0]
-                int l = lib_ids[i];
-                rank[i] = (int32_t)fill[l];
-                if (labels) table[off[l] + fill[l]] = (uint8_t)labels[i];
-                fill[l]++;
-            }
+            doms[l] = make_domain((uint32_t)(cnt[l] > 0 ? cnt[l] : 1));
+        }
+        if ((rc = p->cum.alloc(cum.size())) != SQGR_OK) break;
+        hipError_t e = hipMemcpy(p->cum.p, cum.data(), cum.size() * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess && libs_on) {
             if ((rc = p->lib_of.alloc((size_t)n)) != SQGR_OK) break;
             if ((rc = p->rank_of.alloc((size_t)n)) != SQGR_OK) break;
             if ((rc = p->libs.alloc((size_t)n_libs)) != SQGR_OK) break;
-            hipError_t e = hipMemcpy(p->lib_of.p, lib_ids, (size_t)n * 4, hipMemcpyHostToDevice);
+            e = hipMemcpy(p->lib_of.p, lib_ids, (size_t)n * 4, hipMemcpyHostToDevice);
             if (e == hipSuccess) e = hipMemcpy(p->rank_of.p, rank.data(), (size_t)n * 4, hipMemcpyHostToDevice);
-            if (e == hipSuccess) e = hipMemcpy(p->libs.p, libs.data(), (size_t)n_libs * sizeof(LibInfo), hipMemcpyHostToDevice);
-            if (e != hipSuccess) {
-                set_error("library upload failed: %s", hipGetErrorString(e));
-                rc = SQGR_ERR_HIP;
-                break;
-            }
-        } else if (labels) {
-            for (int64_t i = 0; i < n; ++i) table[i] = (uint8_t)labels[i];
+            if (e == hipSuccess) e = hipMemcpy(p->libs.p, doms.data(), (size_t)n_libs * sizeof(FeistelDomain), hipMemcpyHostToDevice);
         }
-        if ((rc = p->table.alloc((size_t)n)) != SQGR_OK) break;
-        hipError_t e = hipMemcpy(p->table.p, table.data(), (size_t)n, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             set_error("label upload failed: %s", hipGetErrorString(e));
             rc = SQGR_ERR_HIP;
@@ -568,17 +621,16 @@ static int launch_shuffle(sqgr_nhood* p, int nb) {
     const unsigned gx = (unsigned)ceil_div(p->n, 256);
     LaunchTimer t(p->ctx, "nhood_shuffle");
     hipStream_t st = p->ctx->stream;
+    const size_t lds = (size_t)p->n_libs * p->kpad * 4;
+#define SQGR_SHUFFLE(BB, LIBS)                                                                                          \
+    k_shuffle<BB, LIBS><<<dim3(gx, nb), 256, lds, st>>>(p->n, p->cum.p, p->kpad, p->keys.p, p->dom0, p->n_libs, p->lib_of.p, \
+                                                        p->rank_of.p, p->libs.p, p->slab.p)
     if (p->B == 32) {
-        if (p->has_libs)
-            k_shuffle<32, true><<<dim3(gx, nb), 256, 0, st>>>(p->n, p->table.p, p->keys.p, p->dom0, p->n_libs, p->lib_of.p, p->rank_of.p, p->libs.p, p->slab.p);
-        else
-            k_shuffle<32, false><<<dim3(gx, nb), 256, 0, st>>>(p->n, p->table.p, p->keys.p, p->dom0, 1, nullptr, nullptr, nullptr, p->slab.p);
+        if (p->has_libs) SQGR_SHUFFLE(32, true); else SQGR_SHUFFLE(32, false);
     } else {
-        if (p->has_libs)
-            k_shuffle<16, true><<<dim3(gx, nb), 256, 0, st>>>(p->n, p->table.p, p->keys.p, p->dom0, p->n_libs, p->lib_of.p, p->rank_of.p, p->libs.p, p->slab.p);
-        else
-            k_shuffle<16, false><<<dim3(gx, nb), 256, 0, st>>>(p->n, p->table.p, p->keys.p, p->dom0, 1, nullptr, nullptr, nullptr, p->slab.p);
+        if (p->has_libs) SQGR_SHUFFLE(16, true); else SQGR_SHUFFLE(16, false);
     }
+#undef SQGR_SHUFFLE
     SQGR_HIP(hipGetLastError());
     return SQGR_OK;
 }

@@ -2,9 +2,9 @@
 //
 //   round keys : Philox4x32-10( counter = (perm_lo, perm_hi, library, j), key = (seed_lo, seed_hi) ),
 //                j = 0,1  ->  8 x 32-bit keys per (seed, global permutation index, library)
-//   bijection  : 8-round alternating Feistel network on bits = max(8, ceil(log2 n)) bits whose round
-//                function uses only full-rate 24-bit multiplies (v_mul_u32_u24) and xor-shifts,
-//                cycle-walked into [0, n).
+//   bijection  : 8-round alternating additive Feistel network on the mixed-radix domain A x B >= n
+//                (A ~ B ~ sqrt(n), both >= 16) whose round function uses only full-rate 24-bit multiplies
+//                (v_mul_u32_u24) and xor-shifts, cycle-walked into [0, n).
 //
 // oracle/devrng.py restates this file bit for bit; tests/test_devrng.py checks both the Philox
 // known-answer vectors and the statistical quality (uniformity over S_n for small n, agreement of
@@ -45,53 +45,61 @@ __host__ __device__ inline void round_keys(uint64_t seed, uint64_t perm, uint32_
     }
 }
 
-__host__ __device__ inline int domain_bits(uint32_t n) {
-    int b = 0;
-    while (b < 32 && (1ull << b) < n) ++b;
-    return b < 8 ? 8 : b;
-}
-
-// round function: two 24x24-bit multiplies (low 32 bits of each product) with an xor-shift between.
+// round function: two 24x24-bit multiplies (low 32 bits of each product, v_mul_u32_u24 reads only the low
+// 24 bits of its operands) with an xor-shift between; 16 well-mixed bits out.
 __device__ __forceinline__ uint32_t feistel_F(uint32_t v, uint32_t k) {
-    uint32_t t = (v ^ k) & 0xFFFFFFu;
-    uint32_t u = __umul24(t, FEISTEL_C1);
+    uint32_t u = __umul24(v ^ k, FEISTEL_C1);
     u ^= u >> 15;
-    uint32_t w = __umul24(u & 0xFFFFFFu, FEISTEL_C2);
+    uint32_t w = __umul24(u, FEISTEL_C2);
     return w >> 16;
 }
 
+// Mixed-radix domain A x B >= n with A ~ B ~ sqrt(n) (both >= 16, < 2^16): x <-> (a, b), x = a*B + b.
+// The excess A*B - n is < A + B, so cycle walking almost never iterates (no wave divergence), unlike a
+// power-of-two domain whose excess can approach n.
 struct FeistelDomain {
-    uint32_t n;       // target domain [0, n)
-    uint32_t rb;      // low-half width
-    uint32_t ml, mr;  // masks of the high / low half
+    uint32_t n;  // target domain [0, n)
+    uint32_t A;  // radix of the high digit
+    uint32_t B;  // radix of the low digit
 };
+
+__host__ __device__ inline uint32_t isqrt_ceil(uint32_t n) {
+    uint32_t r = 0;
+    while ((uint64_t)r * r < n) ++r;  // host-side only in practice (domain construction)
+    return r;
+}
 
 __host__ __device__ inline FeistelDomain make_domain(uint32_t n) {
     FeistelDomain d;
-    int bits = domain_bits(n);
     d.n = n;
-    d.rb = (uint32_t)(bits / 2);
-    d.mr = (1u << d.rb) - 1u;
-    d.ml = (1u << (bits - bits / 2)) - 1u;
+    uint32_t a = isqrt_ceil(n);
+    d.A = a < 16u ? 16u : a;
+    uint32_t b = (n + d.A - 1) / d.A;
+    d.B = b < 16u ? 16u : b;
     return d;
 }
 
-__device__ __forceinline__ uint32_t feistel_once(uint32_t x, const FeistelDomain& d, const uint32_t* __restrict__ rk) {
-    uint32_t a = x >> d.rb, b = x & d.mr;
-#pragma unroll
-    for (int r = 0; r < FEISTEL_ROUNDS; r += 2) {
-        a ^= feistel_F(b, rk[r]) & d.ml;
-        b ^= feistel_F(a, rk[r + 1]) & d.mr;
-    }
-    return (a << d.rb) | b;
-}
-
-// image of x (< n) under the cycle-walked bijection of [0, n)
-__device__ __forceinline__ uint32_t feistel_perm(uint32_t x, const FeistelDomain& d, const uint32_t* __restrict__ rk) {
+// image of x (< n) under the cycle-walked keyed bijection of [0, n): 8 alternating additive Feistel rounds
+//   a <- (a + (F(b,k_r) * A >> 16)) mod A ;  b <- (b + (F(a,k_r+1) * B >> 16)) mod B
+__device__ __forceinline__ uint32_t feistel_perm_ab(uint32_t a, uint32_t b, const FeistelDomain& d,
+                                                    const uint32_t* __restrict__ rk) {
+    uint32_t x;
     do {
-        x = feistel_once(x, d, rk);
+#pragma unroll
+        for (int r = 0; r < FEISTEL_ROUNDS; r += 2) {
+            uint32_t s = a + (__umul24(feistel_F(b, rk[r]), d.A) >> 16);
+            a = min(s, s - d.A);  // s < 2A: subtract A when s >= A (unsigned wrap makes the other branch huge)
+            uint32_t t = b + (__umul24(feistel_F(a, rk[r + 1]), d.B) >> 16);
+            b = min(t, t - d.B);
+        }
+        x = a * d.B + b;
     } while (x >= d.n);
     return x;
+}
+
+__device__ __forceinline__ uint32_t feistel_perm(uint32_t x, const FeistelDomain& d, const uint32_t* __restrict__ rk) {
+    const uint32_t a = x / d.B;
+    return feistel_perm_ab(a, x - a * d.B, d, rk);
 }
 
 }  // namespace sqgr
