@@ -329,7 +329,7 @@ struct sqgr_nhood {
     // tuning
     int B = 16;
     int nblk = 0;
-    int nbatch = 4;
+    int nbatch = 16;
     // workspace
     DevBuf<uint32_t> keys;
     DevBuf<uint8_t> slab;
@@ -359,11 +359,11 @@ int sqgr_nhood::resolve_tuning() {
     if (B != 16 && B != 32) B = 16;
     const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
     if (nblk <= 0) {
-        // LDS decides residency: one 1024-thread block per CU unless two histograms fit
-        size_t lds = (size_t)K2 * (B == 32 ? 32 : (be() > 0 ? be() : 1)) * 4;
-        nblk = (lds * 2 <= LDS_BUDGET) ? 2 * cus : cus;
+        // one 1024-thread block per CU: measured best on MI355X (sweep in profiles/nhood_sweep_r01.txt) — more blocks
+        // only add partial-histogram traffic (nblk * K*K*B*4 bytes written and re-read per batch)
+        nblk = cus;
     }
-    if (nbatch <= 0) nbatch = 4;
+    if (nbatch <= 0) nbatch = 16;
     return SQGR_OK;
 }
 
@@ -611,7 +611,7 @@ int sqgr_nhood_tune(sqgr_nhood* plan, int32_t perms_per_pass, int32_t blocks_per
                  "tuning value out of range");
     plan->B = perms_per_pass ? perms_per_pass : 16;
     plan->nblk = blocks_per_batch;
-    plan->nbatch = batches_per_launch ? batches_per_launch : 4;
+    plan->nbatch = batches_per_launch ? batches_per_launch : 16;
     // force re-allocation with the new geometry
     plan->keys.release(); plan->slab.release(); plan->partial.release(); plan->acc_sum.release(); plan->acc_sq.release();
     return SQGR_OK;

@@ -183,3 +183,20 @@ def test_restatement_equals_literal_source_on_fresh_inputs():
     np.testing.assert_array_equal(
         O.occur_count(x, y, thr, labs, k), pp["_occur_count"](x, y, thr, labs, 90, k, len(thr))
     )
+
+
+def test_c_port_matches_golden(golden):
+    """oracle/c/sqgr_cpu.c (the timed CPU baseline) reproduces the reference kernels' outputs."""
+    from oracle import cport
+
+    k = int(golden["nhood_k"])
+    c = cport.nenrich(golden["nhood_indices"], golden["nhood_indptr"], golden["nhood_labels"], k)
+    np.testing.assert_array_equal(c, golden["nhood_count"])
+    np.testing.assert_array_equal(cport.nenrich(golden["nhood_indices"], golden["nhood_indptr"], golden["nhood_labels"], k, parallel=True), c)
+    for name in ("lattice", "jitter"):
+        xy = golden[f"cooc_{name}_xy"].astype(np.float32)
+        cc = cport.occur_count(xy[:, 0], xy[:, 1], golden[f"cooc_{name}_interval"][1:] ** 2, golden[f"cooc_{name}_labs"], 4)
+        np.testing.assert_array_equal(cc, golden[f"cooc_{name}_counts"])
+    g = _csr(golden, "autocorr_g")
+    np.testing.assert_allclose(cport.morans_i(g, golden["autocorr_vals"]), golden["unpinned_moran_score"], rtol=1e-12)
+    np.testing.assert_allclose(cport.gearys_c(g, golden["autocorr_vals"]), golden["unpinned_geary_score"], rtol=1e-12)
