@@ -115,6 +115,18 @@ int sqgr_nhood_tune(sqgr_nhood* plan, int32_t perms_per_pass, int32_t blocks_per
 int sqgr_interaction_matrix(sqgr_ctx* ctx, const sqgr_graph* g, const int32_t* labels, int32_t K, int32_t weights,
                             double* out);
 
+/* ------------------------------------------------------------------ co_occurrence
+ * replaces the numba kernel `_occur_count` (gr/_ppatterns.py:283-310):
+ *   out[(a*K+b)*L + r] = #{ i != j : lab_i=a, lab_j=b, d2_ij <= thr2[r] },  d2 = dx*dx + dy*dy in float32
+ * x, y: float32[n]; labels: int32[n] in [0,K); thr2: float32[L] squared thresholds (any order).
+ * fma = 0: products and sum rounded separately (numpy / literal-source semantics, the oracle of record);
+ * fma = 1: d2 = fma(dx,dx,dy*dy) (what LLVM may emit for numba's fastmath=True on an FMA host).
+ * Only row tiles t with t % shard_count == shard_index are swept (each unordered tile pair once, credited to
+ * both (a,b) and (b,a)); summing the outputs of all shards gives the full counts (multi-GPU: all-reduce). */
+int sqgr_cooccur_counts(sqgr_ctx* ctx, const float* x, const float* y, const int32_t* labels, int64_t n, int32_t K,
+                        const float* thr2, int32_t L, int32_t fma, int32_t shard_index, int32_t shard_count,
+                        int64_t* out_counts);
+
 #ifdef __cplusplus
 }
 #endif

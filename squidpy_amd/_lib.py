@@ -47,6 +47,10 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "sqgr_nhood_shuffled_labels": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, c_u8p]),
     "sqgr_nhood_tune": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "sqgr_interaction_matrix": (C.c_int, [C.c_void_p, C.c_void_p, c_i32p, C.c_int32, C.c_int32, c_f64p]),
+    "sqgr_cooccur_counts": (
+        C.c_int,
+        [C.c_void_p, c_f32p, c_f32p, c_i32p, C.c_int64, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_i64p],
+    ),
 }
 
 
@@ -309,3 +313,30 @@ class NhoodPlan:
             self.close()
         except Exception:
             pass
+
+
+def cooccur_counts(
+    ctx: Context,
+    x: np.ndarray,
+    y: np.ndarray,
+    labels: np.ndarray,
+    n_cls: int,
+    thr2: np.ndarray,
+    fma: bool = False,
+    shard_index: int = 0,
+    shard_count: int = 1,
+) -> np.ndarray:
+    """`_occur_count` on the GPU -> int64 (K, K, L)."""
+    x, y = _as(x, np.float32), _as(y, np.float32)
+    labels, thr2 = _as(labels, np.int32), _as(thr2, np.float32)
+    if not (len(x) == len(y) == len(labels)):
+        raise ValueError("x, y and labels must have the same length")
+    out = np.zeros((n_cls, n_cls, len(thr2)), dtype=np.int64)
+    _check(
+        ctx.lib,
+        ctx.lib.sqgr_cooccur_counts(
+            ctx.h, _ptr(x, c_f32p), _ptr(y, c_f32p), _ptr(labels, c_i32p), len(x), n_cls, _ptr(thr2, c_f32p), len(thr2),
+            int(fma), shard_index, shard_count, _ptr(out, c_i64p),
+        ),
+    )
+    return out

@@ -1,5 +1,6 @@
 """``squidpy_amd.gr`` — the MI355X-native ``sq.gr`` spatial-statistics hot path."""
 
 from ._nhood import NhoodEnrichmentResult, interaction_matrix, nhood_enrichment
+from ._ppatterns import co_occurrence
 
-__all__ = ["nhood_enrichment", "interaction_matrix", "NhoodEnrichmentResult"]
+__all__ = ["nhood_enrichment", "interaction_matrix", "NhoodEnrichmentResult", "co_occurrence"]

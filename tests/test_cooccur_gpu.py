@@ -1,0 +1,111 @@
+"""GPU parity tests of co_occurrence: pair counts bit-exact vs the oracle / the reference kernel's golden output."""
+
+from __future__ import annotations
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from oracle import restate as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    from squidpy_amd import _lib
+
+    return _lib
+
+
+@pytest.fixture(scope="module")
+def ctx(L):
+    return L.default_context()
+
+
+@pytest.mark.parametrize("name", ["lattice", "jitter"])
+def test_counts_match_reference_kernel_golden(L, ctx, golden, name):
+    """Output of the reference's literal `_occur_count` (lattice data puts many pairs exactly on thresholds)."""
+    xy = golden[f"cooc_{name}_xy"].astype(np.float32)
+    labs = golden[f"cooc_{name}_labs"]
+    interval = golden[f"cooc_{name}_interval"]
+    counts = L.cooccur_counts(ctx, xy[:, 0], xy[:, 1], labs, 4, interval[1:] ** 2)
+    np.testing.assert_array_equal(counts, golden[f"cooc_{name}_counts"])
+
+
+@pytest.mark.parametrize("n,k,l", [(1, 2, 3), (2, 2, 1), (255, 3, 7), (256, 1, 5), (257, 5, 49), (1500, 7, 20), (3000, 30, 49)])
+def test_counts_bit_exact_vs_oracle(L, ctx, n, k, l):
+    rng = np.random.default_rng(n + k)
+    x = (rng.random(n) * 1000).astype(np.float32)
+    y = (rng.random(n) * 700).astype(np.float32)
+    labs = rng.integers(0, k, n).astype(np.int32)
+    thr = (np.linspace(5, 600, l, dtype=np.float32)) ** 2
+    got = L.cooccur_counts(ctx, x, y, labs, k, thr)
+    np.testing.assert_array_equal(got, O.occur_count(x, y, thr, labs, k))
+    # sharded sweeps (multi-GPU partition) sum to the same counts
+    parts = sum(L.cooccur_counts(ctx, x, y, labs, k, thr, shard_index=s, shard_count=3) for s in range(3))
+    np.testing.assert_array_equal(parts, got)
+
+
+def test_edge_cases(L, ctx):
+    rng = np.random.default_rng(5)
+    n, k = 700, 6
+    x = rng.integers(0, 12, n).astype(np.float32)  # heavy duplication: many d2 == 0 and exact ties
+    y = rng.integers(0, 12, n).astype(np.float32)
+    labs = rng.integers(0, k - 2, n).astype(np.int32)  # two empty categories
+    thr = np.array([25.0, 0.0, 4.0, 4.0, 1e9, 2.0, np.inf], dtype=np.float32)  # unsorted, duplicates, zero, inf
+    got = L.cooccur_counts(ctx, x, y, labs, k, thr)
+    np.testing.assert_array_equal(got, O.occur_count(x, y, thr, labs, k))
+    assert got[k - 1].sum() == 0 and got[:, k - 1].sum() == 0
+    assert got[..., 6].sum() == n * (n - 1)  # every ordered pair is within an infinite radius
+    # fma only changes decisions for pairs sitting on a threshold; on generic data it agrees
+    xr, yr = (rng.random(n) * 50).astype(np.float32), (rng.random(n) * 50).astype(np.float32)
+    t2 = np.linspace(1, 60, 9, dtype=np.float32) ** 2
+    a = L.cooccur_counts(ctx, xr, yr, labs, k, t2)
+    b = L.cooccur_counts(ctx, xr, yr, labs, k, t2, fma=True)
+    assert np.abs(a - b).sum() <= 4
+
+
+def test_frontend_matches_reference_pipeline(L, golden):
+    import squidpy_amd as sq
+
+    for name in ("lattice", "jitter"):
+        xy = golden[f"cooc_{name}_xy"]
+        labs = golden[f"cooc_{name}_labs"]
+        adata = sq.AnnDataLite(
+            obs=pd.DataFrame({"cl": pd.Categorical.from_codes(labs, ["a", "b", "c", "d"])}), obsm={"spatial": xy}
+        )
+        occ, interval = sq.gr.co_occurrence(adata, "cl", interval=12, copy=True)
+        np.testing.assert_array_equal(interval, golden[f"cooc_{name}_interval"])
+        np.testing.assert_allclose(occ, golden[f"cooc_{name}_occ"], rtol=1e-12, atol=0)  # float64 ratios of exact counts
+        assert occ.dtype == np.float64 and occ.shape == (4, 4, 11)
+    # reference tests/graph/test_ppatterns.py:169-207 ported
+    assert sq.gr.co_occurrence(adata, "cl") is None
+    slot = adata.uns["cl_co_occurrence"]
+    assert set(slot) == {"occ", "interval"} and slot["occ"].ndim == 3 and slot["occ"].shape[2] == 49
+    assert slot["interval"].dtype == np.float32 and len(slot["interval"]) == 50
+    occ2, iv2 = sq.gr.co_occurrence(adata, "cl", interval=[30.0, 10.0, 20.0], copy=True)
+    np.testing.assert_array_equal(iv2, np.array([10, 20, 30], dtype=np.float32))
+    assert occ2.shape == (4, 4, 2)
+    with pytest.raises(ValueError, match="Expected interval to be of length"):
+        sq.gr.co_occurrence(adata, "cl", interval=[5.0])
+    with pytest.warns(FutureWarning, match="deprecated"):
+        sq.gr.co_occurrence(adata, "cl", n_jobs=2, copy=True)
+
+
+def test_medium_size_invariants(L, ctx):
+    """2e4 points (oracle too slow for a full compare): total ordered pairs within an infinite radius = N(N-1);
+    counts are symmetric under (a,b) transposition; a sampled sub-block equals the oracle."""
+    rng = np.random.default_rng(1)
+    n, k = 20000, 8
+    xy = O.hex_grid(100, 200) + rng.normal(0, 5, (n, 2))
+    x, y = xy[:, 0].astype(np.float32), xy[:, 1].astype(np.float32)
+    labs = rng.integers(0, k, n).astype(np.int32)
+    thr = np.append(np.linspace(100, 9000, 30, dtype=np.float32) ** 2, np.float32(np.inf))
+    got = L.cooccur_counts(ctx, x, y, labs, k, thr)
+    assert got[..., -1].sum() == n * (n - 1)
+    np.testing.assert_array_equal(got, np.transpose(got, (1, 0, 2)))
+    assert (np.diff(got, axis=2) >= 0).all()
+    sel = np.where(labs < 2)[0][:1500]
+    sub = L.cooccur_counts(ctx, x[sel], y[sel], labs[sel], 2, thr)
+    np.testing.assert_array_equal(sub, O.occur_count(x[sel], y[sel], thr, labs[sel], 2))
