@@ -127,6 +127,26 @@ int sqgr_cooccur_counts(sqgr_ctx* ctx, const float* x, const float* y, const int
                         const float* thr2, int32_t L, int32_t fma, int32_t shard_index, int32_t shard_count,
                         int64_t* out_counts);
 
+/* ------------------------------------------------------------------ spatial_autocorr (Moran's I / Geary's C)
+ * A resident block of features on one graph: vals float64[G][n] (gene-major, the reference's `vals`,
+ * gr/_ppatterns.py:154-185).  The graph must carry its weights (row-normalised by the caller when
+ * `transformation=True`, gr/_ppatterns.py:212-214).  mode: 0 = Moran's I, 1 = Geary's C. */
+int sqgr_autocorr_create(sqgr_ctx* ctx, const sqgr_graph* g, const double* vals, int64_t G, sqgr_autocorr** out);
+int sqgr_autocorr_destroy(sqgr_autocorr* h);
+/* observed statistic: replaces `score = func(g, vals)` (gr/_ppatterns.py:216; scanpy.metrics.morans_i/gearys_c);
+ * constant features -> NaN.  out_scores: float64[G]. */
+int sqgr_autocorr_scores(sqgr_autocorr* h, int32_t mode, double* out_scores);
+/* permutation scores: replaces `parallelize(_score_helper, ...)` (gr/_ppatterns.py:225-232, 258-280):
+ *   out_sims[p][g] = func(g[idx_p, :], vals)[g]        (rows of the graph permuted, values fixed)
+ * perm_idx: int32[P][n] caller-supplied permutations (e.g. numpy's `rng.permutation(n)` streams) or NULL to
+ * generate permutations [perm_begin, perm_end) on the device (csrc/sqgr_rng.h, keyed by seed and the global
+ * permutation index => independent of how the range is split).  out_sims: float64[P][G], P = perm_end-perm_begin. */
+int sqgr_autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_idx, uint64_t seed, int64_t perm_begin,
+                        int64_t perm_end, double* out_sims);
+/* parity hook: the device generator's permutations, int32[perm_end-perm_begin][n] (<= 32768 per call) */
+int sqgr_autocorr_perm_indices(sqgr_ctx* ctx, int64_t n, uint64_t seed, int64_t perm_begin, int64_t perm_end,
+                               int32_t* out_idx);
+
 #ifdef __cplusplus
 }
 #endif

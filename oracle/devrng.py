@@ -124,3 +124,11 @@ def shuffled_labels(
         rk = round_keys(seed, np.array([perm]), lib=lib)[0]
         out[idx] = np.sort(labels[idx])[permutation(len(idx), rk)]
     return out
+
+
+AUTOCORR_STREAM = 0x5A17  # "library" word of the Philox counter for spatial_autocorr permutations
+
+
+def autocorr_permutation(n: int, seed: int, perm: int) -> np.ndarray:
+    """Row permutation ``idx`` of global permutation ``perm`` for spatial_autocorr (sqgr_autocorr.hip:k_perm_indices)."""
+    return permutation(n, round_keys(seed, np.array([perm]), lib=AUTOCORR_STREAM)[0])

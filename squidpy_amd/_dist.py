@@ -62,13 +62,12 @@ def allreduce_sum_(arrays: list[np.ndarray]) -> list[np.ndarray]:
     return out
 
 
-def allgather_concat(a: np.ndarray, axis: int = 0) -> np.ndarray:
-    """Concatenate equally-typed float64 blocks from all ranks along ``axis`` (autocorr sims)."""
+def allgather_object(a: np.ndarray) -> list[np.ndarray]:
+    """One copy of ``a`` from every rank, in rank order (autocorr: feature blocks are gathered, not reduced)."""
     if not is_distributed():
-        return a
-    import torch
+        return [a]
     import torch.distributed as dist
 
     objs: list = [None] * dist.get_world_size()
     dist.all_gather_object(objs, a)
-    return np.concatenate(objs, axis=axis)
+    return objs

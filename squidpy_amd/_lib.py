@@ -47,6 +47,11 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "sqgr_nhood_shuffled_labels": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, c_u8p]),
     "sqgr_nhood_tune": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "sqgr_interaction_matrix": (C.c_int, [C.c_void_p, C.c_void_p, c_i32p, C.c_int32, C.c_int32, c_f64p]),
+    "sqgr_autocorr_create": (C.c_int, [C.c_void_p, C.c_void_p, c_f64p, C.c_int64, C.POINTER(C.c_void_p)]),
+    "sqgr_autocorr_destroy": (C.c_int, [C.c_void_p]),
+    "sqgr_autocorr_scores": (C.c_int, [C.c_void_p, C.c_int32, c_f64p]),
+    "sqgr_autocorr_perms": (C.c_int, [C.c_void_p, C.c_int32, c_i32p, C.c_uint64, C.c_int64, C.c_int64, c_f64p]),
+    "sqgr_autocorr_perm_indices": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_int64, C.c_int64, c_i32p]),
     "sqgr_cooccur_counts": (
         C.c_int,
         [C.c_void_p, c_f32p, c_f32p, c_i32p, C.c_int64, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_i64p],
@@ -338,5 +343,61 @@ def cooccur_counts(
             ctx.h, _ptr(x, c_f32p), _ptr(y, c_f32p), _ptr(labels, c_i32p), len(x), n_cls, _ptr(thr2, c_f32p), len(thr2),
             int(fma), shard_index, shard_count, _ptr(out, c_i64p),
         ),
+    )
+    return out
+
+
+class AutocorrPlan:
+    """Resident feature block for Moran's I / Geary's C (``sqgr_autocorr``).  ``vals``: (G, N) float64."""
+
+    MODES = {"moran": 0, "geary": 1}
+
+    def __init__(self, ctx: Context, g: Graph, vals: np.ndarray):
+        vals = _as(vals, np.float64)
+        if vals.ndim != 2 or vals.shape[1] != g.n:
+            raise ValueError(f"Expected vals of shape (n_features, {g.n}), found {vals.shape}.")
+        self.ctx, self.g, self.G = ctx, g, vals.shape[0]
+        h = C.c_void_p()
+        _check(ctx.lib, ctx.lib.sqgr_autocorr_create(ctx.h, g.h, _ptr(vals, c_f64p), self.G, C.byref(h)))
+        self.h = h
+
+    def scores(self, mode: str) -> np.ndarray:
+        out = np.zeros(self.G, dtype=np.float64)
+        _check(self.ctx.lib, self.ctx.lib.sqgr_autocorr_scores(self.h, self.MODES[mode], _ptr(out, c_f64p)))
+        return out
+
+    def perms(self, mode: str, perm_idx: np.ndarray | None = None, seed: int = 0, perm_begin: int = 0, perm_end: int = 0) -> np.ndarray:
+        if perm_idx is not None:
+            perm_idx = _as(perm_idx, np.int32)
+            if perm_idx.ndim != 2 or perm_idx.shape[1] != self.g.n:
+                raise ValueError(f"Expected perm_idx of shape (n_perms, {self.g.n}), found {perm_idx.shape}.")
+            perm_begin, perm_end = 0, perm_idx.shape[0]
+        out = np.zeros((perm_end - perm_begin, self.G), dtype=np.float64)
+        _check(
+            self.ctx.lib,
+            self.ctx.lib.sqgr_autocorr_perms(
+                self.h, self.MODES[mode], _ptr(perm_idx, c_i32p), C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF),
+                int(perm_begin), int(perm_end), _ptr(out, c_f64p),
+            ),
+        )
+        return out
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.ctx.lib.sqgr_autocorr_destroy(self.h)
+            self.h = None
+
+    def __del__(self) -> None:  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def autocorr_perm_indices(ctx: Context, n: int, seed: int, perm_begin: int, perm_end: int) -> np.ndarray:
+    out = np.zeros((perm_end - perm_begin, n), dtype=np.int32)
+    _check(
+        ctx.lib,
+        ctx.lib.sqgr_autocorr_perm_indices(ctx.h, n, C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), perm_begin, perm_end, _ptr(out, c_i32p)),
     )
     return out

@@ -1,6 +1,6 @@
 """``squidpy_amd.gr`` — the MI355X-native ``sq.gr`` spatial-statistics hot path."""
 
 from ._nhood import NhoodEnrichmentResult, interaction_matrix, nhood_enrichment
-from ._ppatterns import co_occurrence
+from ._ppatterns import co_occurrence, spatial_autocorr
 
-__all__ = ["nhood_enrichment", "interaction_matrix", "NhoodEnrichmentResult", "co_occurrence"]
+__all__ = ["nhood_enrichment", "interaction_matrix", "NhoodEnrichmentResult", "co_occurrence", "spatial_autocorr"]

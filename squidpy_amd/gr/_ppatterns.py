@@ -13,17 +13,28 @@ import numpy as np
 
 from .. import _dist
 from .._constants import Key
-from .._lib import cooccur_counts, default_context
+import pandas as pd
+from scipy import sparse
+
+from .._constants import SpatialAutocorr
+from .._lib import AutocorrPlan, Graph, cooccur_counts, default_context
+from .._stats import multipletests_pvals, p_value_calc
 from .._utils import (
     _assert_categorical_obs,
+    _assert_connectivity_key,
     _assert_spatial_basis,
     _save_data,
+    assert_key_in_adata,
+    assert_positive,
     category_codes,
     deprecated_params,
     extract_adata_if_sdata,
+    get_n_processes,
+    resolve_seed,
+    spawn_generators,
 )
 
-__all__ = ["co_occurrence"]
+__all__ = ["spatial_autocorr", "co_occurrence"]
 
 fp = np.float32
 ip = np.int32
@@ -109,3 +120,169 @@ def co_occurrence(
         return out, interval
     _save_data(adata, attr="uns", key=Key.uns.co_occurrence(cluster_key), data={"occ": out, "interval": interval})
     return None
+
+
+def _extract_vals(adata: Any, attr: str, genes: Any, layer: str | None, use_raw: bool) -> tuple[Any, Any]:
+    """gr/_ppatterns.py:154-194: ``vals`` as (n_features, N) plus the feature index."""
+
+    def extract_X(genes: Any) -> tuple[Any, Any]:
+        if genes is None:
+            if "highly_variable" in adata.var:
+                genes = adata[:, adata.var["highly_variable"]].var_names.values
+            else:
+                genes = adata.var_names.values
+        elif isinstance(genes, str):
+            genes = [genes]
+        if not use_raw:
+            subset = adata[:, genes]
+            return (subset.X if layer is None else subset.layers[layer]).T, genes
+        if getattr(adata, "raw", None) is None:
+            raise AttributeError("No `.raw` attribute found. Try specifying `use_raw=False`.")
+        genes = list(set(genes) & set(adata.raw.var_names))
+        return adata.raw[:, genes].X.T, genes
+
+    def extract_obs(cols: Any) -> tuple[Any, Any]:
+        if cols is None:
+            df = adata.obs.select_dtypes(include=np.number)
+            return df.T.to_numpy(), df.columns
+        if isinstance(cols, str):
+            cols = [cols]
+        return adata.obs[cols].T.to_numpy(), cols
+
+    def extract_obsm(ixs: Any) -> tuple[Any, Any]:
+        assert_key_in_adata(adata, layer, attr="obsm")
+        if ixs is None:
+            ixs = list(np.arange(adata.obsm[layer].shape[1]))
+        ixs = list(np.ravel([ixs]))
+        return adata.obsm[layer][:, ixs].T, ixs
+
+    if attr == "X":
+        return extract_X(genes)
+    if attr == "obs":
+        return extract_obs(genes)
+    if attr == "obsm":
+        return extract_obsm(genes)
+    raise NotImplementedError(f"Extracting from `adata.{attr}` is not yet implemented.")
+
+
+def spatial_autocorr(
+    adata: Any,
+    connectivity_key: str = Key.obsp.spatial_conn(),
+    genes: str | int | Sequence[str] | Sequence[int] | None = None,
+    mode: str = "moran",
+    transformation: bool = True,
+    n_perms: int | None = None,
+    two_tailed: bool = False,
+    corr_method: str | None = "fdr_bh",
+    attr: str = "X",
+    layer: str | None = None,
+    seed: int | None = None,
+    use_raw: bool = False,
+    copy: bool = False,
+    n_jobs: int | None = None,
+    backend: str = "loky",
+    show_progress_bar: bool = True,
+    *,
+    table_key: str | None = None,
+    rng: str = "philox",
+    device: int | None = None,
+    gene_block: int = 2048,
+) -> pd.DataFrame | None:
+    """Calculate Global Autocorrelation Statistic — Moran's I or Geary's C (drop-in for
+    ``squidpy.gr.spatial_autocorr``, gr/_ppatterns.py:56-255).
+
+    Same parameters, value extraction (``attr`` in X/obs/obsm, ``layer``, ``use_raw``, HVG default), statistics
+    (``I``/``C``, ``pval_norm``, ``var_norm``, and with ``n_perms``: ``pval_z_sim``, ``pval_sim``, ``var_sim``),
+    ``{pval}_{corr_method}`` columns, sort order and ``adata.uns['moranI'|'gearyC']`` slot as the reference.
+
+    Extra keyword-only parameters: ``rng`` — ``"philox"`` (default) draws the row permutations on the GPU, keyed by
+    ``(seed, permutation index)``; ``"numpy"`` draws the reference's ``rng.permutation(N)`` streams on the host and
+    injects them (reproduces Squidpy's permutation columns for that ``seed``); ``device``; ``gene_block`` — features
+    resident on the GPU at a time.  With a ``torch.distributed`` process group, feature blocks are split across ranks
+    and the score columns gathered.
+    """
+    adata = extract_adata_if_sdata(adata, table_key=table_key)
+    _assert_connectivity_key(adata, connectivity_key)
+    if rng not in ("philox", "numpy"):
+        raise ValueError(f"Invalid option `{rng}` for `rng`. Valid options are: `['philox', 'numpy']`.")
+    vals, index = _extract_vals(adata, attr, genes, layer, use_raw)
+
+    mode = SpatialAutocorr(mode)
+    if mode == SpatialAutocorr.MORAN:
+        stat, expected, ascending = "I", -1.0 / (adata.shape[0] - 1), False
+    else:
+        stat, expected, ascending = "C", 1.0, True
+
+    g = sparse.csr_matrix(adata.obsp[connectivity_key]).copy()
+    if transformation:  # row-normalize (in the matrix dtype, like sklearn.preprocessing.normalize(copy=False))
+        from sklearn.preprocessing import normalize
+
+        normalize(g, norm="l1", axis=1, copy=False)
+
+    get_n_processes(n_jobs)
+    if n_perms is not None:
+        assert_positive(n_perms, name="n_perms")
+    n = g.shape[0]
+    n_feat = vals.shape[0]
+    perm_idx = None
+    if n_perms is not None and rng == "numpy":
+        gens = spawn_generators(seed, n_perms)
+        perm_idx = np.stack([gens[p].permutation(n) for p in range(n_perms)]).astype(np.int32)
+    key = resolve_seed(seed)
+
+    ctx = default_context(device)
+    graph = Graph(ctx, g, with_data=True)
+    rank, world = _dist.world()
+    blocks = [(b0, min(n_feat, b0 + gene_block)) for b0 in range(0, n_feat, max(int(gene_block), 1))]
+    score = np.full(n_feat, np.nan)
+    sims = np.full((n_perms, n_feat), np.nan) if n_perms is not None else None
+    try:
+        for bi, (b0, b1) in enumerate(blocks):
+            if bi % world != rank:
+                continue
+            blk = vals[b0:b1]
+            blk = np.asarray(blk.toarray() if sparse.issparse(blk) else blk, dtype=np.float64)
+            plan = AutocorrPlan(ctx, graph, blk)
+            try:
+                score[b0:b1] = plan.scores(mode.s)
+                if n_perms is not None:
+                    sims[:, b0:b1] = plan.perms(mode.s, perm_idx=perm_idx, seed=key, perm_begin=0, perm_end=n_perms)
+            finally:
+                plan.close()
+    finally:
+        graph.close()
+    if world > 1:
+        score = _merge_blocks(score, blocks, world, axis=0)
+        if sims is not None:
+            sims = _merge_blocks(sims, blocks, world, axis=1)
+    if np.isnan(score).any():
+        import warnings
+
+        warnings.warn("Some features are constant or contain NaN: their statistic is NaN.", UserWarning, stacklevel=2)
+
+    with np.errstate(divide="ignore", invalid="ignore"):
+        pval_results = p_value_calc(score, sims, g, mode.s, expected, two_tailed)
+
+    df = pd.DataFrame({stat: score, **pval_results}, index=index)
+    if corr_method is not None:
+        for pv in [c for c in df.columns if "pval" in c]:
+            df[f"{pv}_{corr_method}"] = multipletests_pvals(df[pv].values, method=corr_method)
+    df.sort_values(by=stat, ascending=ascending, inplace=True)
+
+    if copy:
+        return df
+    _save_data(adata, attr="uns", key=mode.s + stat, data=df)
+    return None
+
+
+def _merge_blocks(a: np.ndarray, blocks: list[tuple[int, int]], world: int, axis: int) -> np.ndarray:
+    """Every rank filled only its own feature blocks (NaN elsewhere): gather and take each block from its owner."""
+    parts = _dist.allgather_object(a)
+    out = a.copy()
+    for bi, (b0, b1) in enumerate(blocks):
+        src = parts[bi % world]
+        if axis == 0:
+            out[b0:b1] = src[b0:b1]
+        else:
+            out[:, b0:b1] = src[:, b0:b1]
+    return out
