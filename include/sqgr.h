@@ -147,6 +147,20 @@ int sqgr_autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_idx,
 int sqgr_autocorr_perm_indices(sqgr_ctx* ctx, int64_t n, uint64_t seed, int64_t perm_begin, int64_t perm_end,
                                int32_t* out_idx);
 
+/* ------------------------------------------------------------------ ripley (K/L pair counts, F/G kNN distances)
+ * metric: 0 euclidean, 1 manhattan, 2 chebyshev (sklearn KDTree arithmetic: per-coordinate accumulation, no FMA).
+ *
+ * sqgr_pair_counts replaces `KDTree(points).two_point_correlation(points, support, dualtree=True) - m`
+ * (gr/_ripley.py:220-222): out[s] = #{ordered i != j : dist_ij <= r_s}.  xy: float64[m][2]; thr: float64[S]
+ * ascending.  For metric 0 the comparison is done on the squared distance: pass thr[s] = the largest float64 t with
+ * fl(sqrt(t)) <= r_s (so that `d2 <= t` == `sqrt(d2) <= r_s` bit for bit); for metrics 1/2 pass the radii. */
+int sqgr_pair_counts(sqgr_ctx* ctx, const double* xy, int64_t m, const double* thr, int32_t S, int32_t metric,
+                     int64_t* out_counts);
+/* sqgr_knn_dist replaces `NearestNeighbors(n_neighbors=k).fit(ref).kneighbors(query)[0]` (gr/_ripley.py:144-150,
+ * 163-169): out float64[nq][k] ascending; for metric 0 the SQUARED distances (caller applies sqrt). 1 <= k <= 16. */
+int sqgr_knn_dist(sqgr_ctx* ctx, const double* query, int64_t nq, const double* ref, int64_t nr, int32_t k, int32_t metric,
+                  double* out);
+
 #ifdef __cplusplus
 }
 #endif

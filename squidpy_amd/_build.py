@@ -39,7 +39,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     procs = []
     for src in sources():
         obj = src[:-4] + ".o"
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj,
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-c", src, "-o", obj,
                "-Wall", "-Wno-unused-function"]
         if verbose:
             print(" ".join(cmd), flush=True)

@@ -52,6 +52,8 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "sqgr_autocorr_scores": (C.c_int, [C.c_void_p, C.c_int32, c_f64p]),
     "sqgr_autocorr_perms": (C.c_int, [C.c_void_p, C.c_int32, c_i32p, C.c_uint64, C.c_int64, C.c_int64, c_f64p]),
     "sqgr_autocorr_perm_indices": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_int64, C.c_int64, c_i32p]),
+    "sqgr_pair_counts": (C.c_int, [C.c_void_p, c_f64p, C.c_int64, c_f64p, C.c_int32, C.c_int32, c_i64p]),
+    "sqgr_knn_dist": (C.c_int, [C.c_void_p, c_f64p, C.c_int64, c_f64p, C.c_int64, C.c_int32, C.c_int32, c_f64p]),
     "sqgr_cooccur_counts": (
         C.c_int,
         [C.c_void_p, c_f32p, c_f32p, c_i32p, C.c_int64, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_i64p],
@@ -401,3 +403,53 @@ def autocorr_perm_indices(ctx: Context, n: int, seed: int, perm_begin: int, perm
         ctx.lib.sqgr_autocorr_perm_indices(ctx.h, n, C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), perm_begin, perm_end, _ptr(out, c_i32p)),
     )
     return out
+
+
+METRICS = {
+    "euclidean": 0, "l2": 0, "minkowski": 0, "p": 0,  # sklearn's default minkowski p=2
+    "manhattan": 1, "cityblock": 1, "l1": 1,
+    "chebyshev": 2, "infinity": 2,
+}
+
+
+def sqrt_thresholds(radii: np.ndarray) -> np.ndarray:
+    """For every radius r the largest float64 t with ``sqrt(t) <= r`` (IEEE correctly-rounded sqrt), so that the
+    device can decide ``sqrt(d2) <= r`` as ``d2 <= t`` without a square root.  Negative radii -> -1 (nothing)."""
+    r = np.asarray(radii, dtype=np.float64)
+    t = r * r
+    t[r < 0] = -1.0
+    ok = r >= 0
+    for _ in range(8):  # a handful of ulps at most
+        up = np.nextafter(t, np.inf)
+        grow = ok & np.isfinite(up) & (np.sqrt(np.where(ok, up, 0.0)) <= r)
+        shrink = ok & (np.sqrt(np.where(ok, t, 0.0)) > r)
+        if not (grow.any() or shrink.any()):
+            break
+        t = np.where(grow, up, t)
+        t = np.where(shrink, np.nextafter(t, -np.inf), t)
+    return t
+
+
+def pair_counts(ctx: Context, xy: np.ndarray, support: np.ndarray, metric: str = "euclidean") -> np.ndarray:
+    """#ordered non-self pairs within every radius of ``support`` (ascending) -> int64 (S,)."""
+    xy = _as(xy, np.float64)
+    support = _as(support, np.float64)
+    m = METRICS[metric]
+    thr = sqrt_thresholds(support) if m == 0 else support
+    out = np.zeros(len(support), dtype=np.int64)
+    _check(ctx.lib, ctx.lib.sqgr_pair_counts(ctx.h, _ptr(xy, c_f64p), xy.shape[0], _ptr(thr, c_f64p), len(thr), m, _ptr(out, c_i64p)))
+    return out
+
+
+def knn_dist(ctx: Context, query: np.ndarray, ref: np.ndarray, k: int, metric: str = "euclidean") -> np.ndarray:
+    """k nearest-neighbour distances of every query point -> float64 (nq, k), ascending."""
+    query, ref = _as(query, np.float64), _as(ref, np.float64)
+    m = METRICS[metric]
+    if k > ref.shape[0]:
+        raise ValueError(
+            f"Expected n_neighbors <= n_samples_fit, but n_neighbors = {k}, n_samples_fit = {ref.shape[0]}, "
+            f"n_samples = {query.shape[0]}"
+        )
+    out = np.zeros((query.shape[0], k), dtype=np.float64)
+    _check(ctx.lib, ctx.lib.sqgr_knn_dist(ctx.h, _ptr(query, c_f64p), query.shape[0], _ptr(ref, c_f64p), ref.shape[0], k, m, _ptr(out, c_f64p)))
+    return np.sqrt(out) if m == 0 else out

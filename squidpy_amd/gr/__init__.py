@@ -2,5 +2,6 @@
 
 from ._nhood import NhoodEnrichmentResult, interaction_matrix, nhood_enrichment
 from ._ppatterns import co_occurrence, spatial_autocorr
+from ._ripley import ripley
 
-__all__ = ["nhood_enrichment", "interaction_matrix", "NhoodEnrichmentResult", "co_occurrence", "spatial_autocorr"]
+__all__ = ["nhood_enrichment", "interaction_matrix", "NhoodEnrichmentResult", "co_occurrence", "spatial_autocorr", "ripley"]

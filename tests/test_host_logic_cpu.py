@@ -1,0 +1,117 @@
+"""CPU tests of host-side logic that needs no GPU: argument validation (errors are raised before any device work),
+slot-name constants, n_jobs rules, sqrt thresholds, sharding arithmetic, exact z-score moments."""
+
+from __future__ import annotations
+
+import numpy as np
+import pandas as pd
+import pytest
+import scipy.sparse as sp
+
+import squidpy_amd as sq
+from squidpy_amd import _dist, _lib, _utils
+from squidpy_amd._constants import Key, RipleyStat, SpatialAutocorr
+from squidpy_amd.gr._nhood import expected_counts, zscore_from_moments
+
+
+def _adata():
+    n = 20
+    obs = pd.DataFrame({"cl": pd.Categorical.from_codes(np.arange(n) % 3, ["a", "b", "c"]), "num": np.arange(n)})
+    return sq.AnnDataLite(X=np.ones((n, 4)), obs=obs, obsm={"spatial": np.random.rand(n, 2)}, obsp={"spatial_connectivities": sp.identity(n, format="csr")})
+
+
+def test_slot_names_match_reference():
+    assert Key.obsp.spatial_conn() == "spatial_connectivities"
+    assert Key.obsp.spatial_conn("foo") == "foo_connectivities" and Key.obsp.spatial_conn("foo_connectivities") == "foo_connectivities"
+    assert Key.uns.nhood_enrichment("cl") == "cl_nhood_enrichment" and Key.uns.co_occurrence("cl") == "cl_co_occurrence"
+    assert Key.uns.ripley("cl", "L") == "cl_ripley_L" and Key.uns.interaction_matrix("cl") == "cl_interactions"
+    assert SpatialAutocorr("moran").s == "moran" and RipleyStat("F").s == "F"
+    with pytest.raises(ValueError, match=r"Invalid option `x` for `SpatialAutocorr`. Valid options are: `\['moran', 'geary'\]`."):
+        SpatialAutocorr("x")
+
+
+def test_validation_errors_like_reference():
+    adata = _adata()
+    with pytest.raises(KeyError, match="Cluster key `nope` not found"):
+        sq.gr.nhood_enrichment(adata, "nope")
+    with pytest.raises(TypeError, match="to be `categorical`"):
+        sq.gr.nhood_enrichment(adata, "num")
+    with pytest.raises(KeyError, match="Spatial connectivity key `x_connectivities` not found"):
+        sq.gr.nhood_enrichment(adata, "cl", connectivity_key="x")
+    with pytest.raises(ValueError, match="Expected `n_perms` to be positive"):
+        sq.gr.nhood_enrichment(adata, "cl", n_perms=0)
+    with pytest.raises(ValueError, match="Invalid option `foo` for `rng`"):
+        sq.gr.nhood_enrichment(adata, "cl", rng="foo")
+    with pytest.raises(KeyError, match="Spatial basis `nope` not found"):
+        sq.gr.co_occurrence(adata, "cl", spatial_key="nope")
+    with pytest.raises(KeyError, match="Cluster key `nope` not found"):
+        sq.gr.ripley(adata, "nope")
+    one = _adata()
+    one.obs["cl"] = pd.Categorical(["a"] * 20)
+    with pytest.raises(ValueError, match="Expected at least `2` clusters, found `1`."):
+        sq.gr.nhood_enrichment(one, "cl")
+
+    class SData:
+        tables = {"t": adata}
+
+    with pytest.raises(TypeError, match="table_key"):
+        sq.gr.nhood_enrichment(SData(), "cl")
+    with pytest.raises(ValueError, match="Table 'zz' not found"):
+        sq.gr.nhood_enrichment(SData(), "cl", table_key="zz")
+
+
+def test_n_jobs_rules():
+    """reference tests/utils/test_n_jobs.py: None -> 1, -1 -> all, 0 and < -1 raise, too many clamps."""
+    assert _utils.get_n_processes(None) == 1
+    assert _utils.get_n_processes(-1) == _utils._cpu_count()
+    assert _utils.get_n_processes(1) == 1
+    for bad in (0, -2):
+        with pytest.raises(ValueError, match="Number of cores must be"):
+            _utils.get_n_processes(bad)
+    assert _utils.get_n_processes(10**6) == _utils._cpu_count()
+
+
+def test_sqrt_thresholds_exact():
+    rng = np.random.default_rng(0)
+    r = np.concatenate([[0.0, 1.0, 2.0, 1e-8, 1e8, 3.0, 5.0, 13.0], rng.random(2000) * 100, np.linspace(0, 25, 50)])
+    t = _lib.sqrt_thresholds(r)
+    assert (np.sqrt(t) <= r).all() and (np.sqrt(np.nextafter(t, np.inf)) > r).all()
+    assert (_lib.sqrt_thresholds(np.array([-1.0])) < 0).all()
+
+
+def test_shard_range_partitions():
+    for n in (0, 1, 7, 100, 10007):
+        for w in (1, 2, 3, 8):
+            parts = [_dist.shard_range(n, r, w) for r in range(w)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in parts]
+            assert max(sizes) - min(sizes) <= 1
+    assert _dist.world() == (0, 1) and not _dist.is_distributed()
+    a = np.arange(4, dtype=np.int64)
+    assert _dist.allreduce_sum_([a])[0] is a
+
+
+def test_exact_moments_zscore_matches_numpy():
+    rng = np.random.default_rng(1)
+    k, P = 4, 257
+    perms = rng.integers(1000, 5000, size=(P, k, k)).astype(np.float64)
+    count = rng.integers(1000, 5000, size=(k, k)).astype(np.uint32)
+    shift = rng.integers(2000, 4000, size=(k, k))
+    d = perms.astype(np.int64) - shift
+    z = zscore_from_moments(count, shift, d.sum(0), (d * d).sum(0).astype(np.uint64), P)
+    np.testing.assert_allclose(z, (count - perms.mean(0)) / perms.std(0), rtol=1e-11)
+    z0 = zscore_from_moments(count, shift, np.zeros((k, k), np.int64), np.zeros((k, k), np.uint64), P)
+    assert np.isinf(z0).any() or np.isnan(z0).any()  # zero variance -> inf/nan like the reference (no guarding)
+    e = expected_counts(np.array([0, 0, 1, 1]), 2, 100)
+    assert e.sum() == 100 and e.dtype == np.int64
+
+
+def test_anndata_lite_subsetting():
+    adata = _adata()
+    adata.var["highly_variable"] = [True, False, True, False]
+    sub = adata[:, adata.var["highly_variable"]]
+    assert sub.shape == (20, 2) and list(sub.var_names) == ["g0", "g2"]
+    assert adata[:, ["g1"]].X.shape == (20, 1)
+    with pytest.raises(KeyError):
+        adata[:, ["zzz"]]

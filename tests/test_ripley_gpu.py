@@ -1,0 +1,112 @@
+"""GPU parity tests of ripley: pair counts bit-exact vs sklearn's KDTree (what the reference calls), kNN distances
+equal to sklearn's NearestNeighbors, whole-function results equal to the oracle's restatement of gr/_ripley.py."""
+
+from __future__ import annotations
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from oracle import restate as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    from squidpy_amd import _lib
+
+    return _lib
+
+
+@pytest.fixture(scope="module")
+def ctx(L):
+    return L.default_context()
+
+
+def test_pair_counts_golden_l_function(L, ctx, golden):
+    pts, support = golden["ripley_points"], golden["ripley_support"]
+    pairs = L.pair_counts(ctx, pts, support)
+    k_est = (pairs / 400) / (400 / 2500.0)
+    np.testing.assert_array_equal(np.sqrt(k_est / np.pi), golden["ripley_l"])  # output of the reference's `_l_function`
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "manhattan", "chebyshev"])
+@pytest.mark.parametrize("m", [2, 255, 256, 257, 3000])
+def test_pair_counts_equal_kdtree(L, ctx, metric, m):
+    from sklearn.neighbors import KDTree
+
+    rng = np.random.default_rng(m)
+    pts = np.round(rng.random((m, 2)) * 40, 1)  # coarse grid of coordinates: many exact distance ties with radii
+    support = np.linspace(0, 25, 50)
+    ref = KDTree(pts, metric=metric).two_point_correlation(pts, support, dualtree=True) - m
+    np.testing.assert_array_equal(L.pair_counts(ctx, pts, support, metric), ref)
+    if metric == "euclidean":
+        np.testing.assert_array_equal(L.pair_counts(ctx, pts, support), O.pair_counts_bruteforce(pts, support))
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "manhattan", "chebyshev"])
+@pytest.mark.parametrize("k", [1, 2, 3, 5, 9])
+def test_knn_equals_sklearn(L, ctx, metric, k):
+    from sklearn.neighbors import NearestNeighbors
+
+    rng = np.random.default_rng(k)
+    ref = np.round(rng.random((1500, 2)) * 100, 2)
+    qry = np.round(rng.random((700, 2)) * 100, 2)
+    exp, _ = NearestNeighbors(metric=metric, n_neighbors=k).fit(ref).kneighbors(qry, n_neighbors=k)
+    np.testing.assert_array_equal(L.knn_dist(ctx, qry, ref, k, metric), exp)
+    with pytest.raises(ValueError, match="Expected n_neighbors <= n_samples_fit"):
+        L.knn_dist(ctx, qry, ref[:1], 2, metric)
+
+
+def _adata(n=900, k=3, seed=0):
+    import squidpy_amd as sq
+
+    rng = np.random.default_rng(seed)
+    xy = rng.random((n, 2)) * 500
+    lab = rng.integers(0, k, n)
+    xy[lab == 0] = xy[lab == 0] * 0.5 + 100  # one clustered population
+    obs = pd.DataFrame({"cl": pd.Categorical.from_codes(lab, [f"c{i}" for i in range(k)])})
+    return sq.AnnDataLite(obs=obs, obsm={"spatial": xy})
+
+
+@pytest.mark.parametrize("mode", ["F", "G", "L"])
+def test_ripley_equals_reference_restatement(L, mode):
+    import squidpy_amd as sq
+
+    adata = _adata()
+    res = sq.gr.ripley(adata, "cl", mode=mode, n_simulations=12, n_observations=150, n_steps=20, seed=3, copy=True)
+    ref = O.ripley(adata.obsm["spatial"], adata.obs["cl"].values, mode=mode, n_simulations=12, n_observations=150, n_steps=20, seed=3)
+    np.testing.assert_array_equal(res["bins"], ref["bins"])
+    obs = res[f"{mode}_stat"]
+    np.testing.assert_allclose(obs["stats"].to_numpy().reshape(3, 20), ref["obs"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(res["sims_stat"]["stats"].to_numpy().reshape(12, 20), ref["sims"], rtol=1e-12, atol=0)
+    np.testing.assert_array_equal(res["pvalues"], ref["pvalues"])
+
+
+def test_ripley_structure_ported_from_reference_tests(L):
+    """reference tests/graph/test_ripley.py:13-121."""
+    import squidpy_amd as sq
+
+    adata = _adata()
+    for mode in ("F", "G", "L"):
+        assert sq.gr.ripley(adata, "cl", mode=mode, n_simulations=5, n_observations=80, n_steps=11, seed=1) is None
+        res = adata.uns[f"cl_ripley_{mode}"]
+        assert set(res) == {f"{mode}_stat", "sims_stat", "bins", "pvalues"}
+        obs_df, sims_df = res[f"{mode}_stat"], res["sims_stat"]
+        assert res["bins"].shape == (11,) and obs_df.shape == (11 * 3, 3) and sims_df.shape == (11 * 5, 3)
+        assert res["pvalues"].shape == (3, 11)
+        assert list(obs_df.columns) == ["bins", "cl", "stats"] and list(sims_df.columns) == ["bins", "simulations", "stats"]
+        assert obs_df["bins"].iloc[0] == 0 and obs_df["stats"].iloc[0] == 0
+        again = sq.gr.ripley(adata, "cl", mode=mode, n_simulations=5, n_observations=80, n_steps=11, seed=1, copy=True)
+        pd.testing.assert_frame_equal(again["sims_stat"], sims_df)
+        other = sq.gr.ripley(adata, "cl", mode=mode, n_simulations=5, n_observations=80, n_steps=11, seed=2, copy=True)
+        assert not np.allclose(other["sims_stat"]["stats"], sims_df["stats"])
+        s = sims_df["stats"].to_numpy().reshape(5, 11)
+        assert not np.allclose(s[0], s[1])  # simulations differ from each other
+    with pytest.raises(ValueError, match="Unsupported metric"):
+        sq.gr.ripley(adata, "cl", mode="L", metric="cosine")
+    with pytest.raises(ValueError, match="Invalid option `Z` for `RipleyStat`"):
+        sq.gr.ripley(adata, "cl", mode="Z")
+    res = sq.gr.ripley(adata, "cl", mode="G", metric="manhattan", n_simulations=3, n_observations=50, n_steps=7, seed=0, copy=True, max_dist=100.0)
+    assert res["bins"][-1] == 100.0
