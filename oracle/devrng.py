@@ -106,6 +106,35 @@ def permutation(n: int, rk: np.ndarray) -> np.ndarray:
     return x.astype(np.int64)
 
 
+def permutation_batch(n: int, rks: np.ndarray) -> np.ndarray:
+    """Same as :func:`permutation` for many key sets at once: ``rks`` (P, 8) -> (P, n) int64 (vectorised over keys)."""
+    P = rks.shape[0]
+    if n <= 1:
+        return np.zeros((P, n), dtype=np.int64)
+    A, B = domain_dims(n)
+    A64, B64 = np.uint64(A), np.uint64(B)
+    keys = rks.astype(np.uint64)
+
+    def apply(a: np.ndarray, b: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+        for r in range(0, N_ROUNDS, 2):
+            a = a + ((_F(b, keys[:, r : r + 1]) * A64) >> np.uint64(16))
+            a = np.where(a >= A64, a - A64, a)
+            b = b + ((_F(a, keys[:, r + 1 : r + 2]) * B64) >> np.uint64(16))
+            b = np.where(b >= B64, b - B64, b)
+        return a, b
+
+    x = np.tile(np.arange(n, dtype=np.uint64), (P, 1))
+    a, b = apply(x // B64, x % B64)
+    x = a * B64 + b
+    bad = x >= np.uint64(n)
+    while bad.any():
+        a2, b2 = apply(a, b)
+        a, b = np.where(bad, a2, a), np.where(bad, b2, b)
+        x = a * B64 + b
+        bad = x >= np.uint64(n)
+    return x.astype(np.int64)
+
+
 def shuffled_labels(
     labels: np.ndarray, seed: int, perm: int, lib_ids: np.ndarray | None = None, n_libs: int = 0
 ) -> np.ndarray:

@@ -1,0 +1,97 @@
+"""Worker of tests/test_dist_gloo.py: runs under ``python -m torch.distributed.run`` with the gloo backend (CPU).
+
+Exercises the multi-GPU plumbing of the product (squidpy_amd._dist: permutation-range sharding, exact integer
+all-reduce, feature-block merge) with per-rank partial results computed by the CPU oracle standing in for the HIP
+kernels (this is test code: the product itself never touches oracle/)."""
+
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main() -> None:
+    import torch.distributed as dist
+
+    dist.init_process_group(backend="gloo")
+    from oracle import restate as O
+    from squidpy_amd import _dist
+    from squidpy_amd.gr._nhood import _broadcast_seed, expected_counts, zscore_from_moments
+    from squidpy_amd.gr._ppatterns import _merge_blocks
+
+    rank, world = _dist.world()
+    assert world == int(os.environ["WORLD_SIZE"]) and _dist.is_distributed()
+    out = {"rank": rank, "world": world}
+
+    # ---- nhood: permutation ranges + all-reduce of exact moments == single-rank result
+    rows, cols, k, P, seed = 20, 25, 4, 37, 5
+    adj = O.hex_grid_graph(rows, cols)
+    labels = np.random.default_rng(0).integers(0, k, rows * cols).astype(np.int32)
+    shift = expected_counts(labels, k, adj.nnz)
+    lo, hi = _dist.shard_range(P, rank, world)
+    mine = O.nhood_perm_counts_philox(adj.indices, adj.indptr, labels, k, seed, lo, hi).astype(np.int64)
+    d = mine - shift
+    s1, s2 = d.sum(0), (d * d).sum(0).astype(np.uint64)
+    s1, s2 = _dist.allreduce_sum_([s1, s2])
+    full = O.nhood_perm_counts_philox(adj.indices, adj.indptr, labels, k, seed, 0, P)
+    dfull = full.astype(np.int64) - shift
+    assert np.array_equal(s1, dfull.sum(0)) and np.array_equal(s2, (dfull * dfull).sum(0).astype(np.uint64))
+    count = O.nhood_counts(adj.indices, adj.indptr, labels, k)
+    z = zscore_from_moments(count, shift, s1, s2, P)
+    np.testing.assert_allclose(z, O.nhood_zscore(count, full), rtol=1e-10)
+    out["nhood_z00"] = float(z[0, 0])
+
+    # ---- seed=None: every rank ends up with rank 0's key
+    key = _broadcast_seed(1000 + rank)
+    assert key == 1000
+    # uint64 wrap-around is preserved by the int64 view
+    big = np.array([2**63 + 5], dtype=np.uint64)
+    (tot,) = _dist.allreduce_sum_([big])
+    assert int(tot[0]) == (world * (2**63 + 5)) % 2**64
+
+    # ---- co-occurrence: row-tile shards sum to the full counts (counts of disjoint point subsets as stand-in)
+    rng = np.random.default_rng(1)
+    x, y = (rng.random(300) * 50).astype(np.float32), (rng.random(300) * 50).astype(np.float32)
+    labs = rng.integers(0, 3, 300).astype(np.int32)
+    thr = np.linspace(2, 40, 6, dtype=np.float32) ** 2
+    fullc = O.occur_count(x, y, thr, labs, 3)
+    # ordered pairs (i, j) with i in this rank's slice
+    sl = slice(*_dist.shard_range(300, rank, world))
+    part = np.zeros_like(fullc)
+    dx = x[sl, None] - x[None, :]
+    dy = y[sl, None] - y[None, :]
+    d2 = dx * dx + dy * dy
+    ii = np.arange(300)[sl]
+    for r, t in enumerate(thr):
+        m = (d2 <= t) & (ii[:, None] != np.arange(300)[None, :])
+        np.add.at(part[:, :, r], (labs[sl][:, None].repeat(300, 1)[m], labs[None, :].repeat(len(ii), 0)[m]), 1)
+    (summed,) = _dist.allreduce_sum_([part])
+    assert np.array_equal(summed, fullc)
+
+    # ---- autocorr: feature blocks owned round-robin, merged by gather
+    G = 10
+    blocks = [(b0, min(G, b0 + 3)) for b0 in range(0, G, 3)]
+    score = np.full(G, np.nan)
+    sims = np.full((4, G), np.nan)
+    for bi, (b0, b1) in enumerate(blocks):
+        if bi % world == rank:
+            score[b0:b1] = np.arange(b0, b1)
+            sims[:, b0:b1] = np.arange(b0, b1)[None, :] + 100 * np.arange(4)[:, None]
+    score = _merge_blocks(score, blocks, world, axis=0)
+    sims = _merge_blocks(sims, blocks, world, axis=1)
+    assert np.array_equal(score, np.arange(G)) and np.array_equal(sims[2], np.arange(G) + 200)
+
+    dist.barrier()
+    if rank == 0:
+        print("DIST_OK " + json.dumps(out))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
