@@ -43,6 +43,7 @@ void set_error(const char* fmt, ...);
 struct TimedLaunch {
     int name_id;
     hipEvent_t start, stop;
+    hipStream_t stream;
 };
 
 }  // namespace sqgr
@@ -50,6 +51,7 @@ struct TimedLaunch {
 struct sqgr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // producer stream of two-stage pipelines (label shuffles overlap counting)
     int cu_count = 0;
     bool timing = false;
     std::vector<std::string> timer_names;
@@ -60,7 +62,7 @@ struct sqgr_ctx {
     std::vector<hipEvent_t> event_pool;
 
     int timer_id(const char* name);
-    int begin_launch(const char* name, sqgr::TimedLaunch* tl);
+    int begin_launch(const char* name, sqgr::TimedLaunch* tl, hipStream_t st);
     int end_launch(const sqgr::TimedLaunch& tl);
     int resolve_timers();
 };
@@ -72,8 +74,8 @@ struct LaunchTimer {
     sqgr_ctx* ctx;
     TimedLaunch tl;
     bool active;
-    LaunchTimer(sqgr_ctx* c, const char* name) : ctx(c), active(false) {
-        if (ctx->timing) active = (ctx->begin_launch(name, &tl) == SQGR_OK);
+    LaunchTimer(sqgr_ctx* c, const char* name, hipStream_t st = nullptr) : ctx(c), active(false) {
+        if (ctx->timing) active = (ctx->begin_launch(name, &tl, st ? st : c->stream) == SQGR_OK);
     }
     ~LaunchTimer() {
         if (active) ctx->end_launch(tl);

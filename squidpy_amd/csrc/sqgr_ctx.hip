@@ -39,8 +39,9 @@ int sqgr_ctx::timer_id(const char* name) {
     return id;
 }
 
-int sqgr_ctx::begin_launch(const char* name, TimedLaunch* tl) {
+int sqgr_ctx::begin_launch(const char* name, TimedLaunch* tl, hipStream_t st) {
     tl->name_id = timer_id(name);
+    tl->stream = st;
     for (hipEvent_t* ev : {&tl->start, &tl->stop}) {
         if (!event_pool.empty()) {
             *ev = event_pool.back();
@@ -49,12 +50,12 @@ int sqgr_ctx::begin_launch(const char* name, TimedLaunch* tl) {
             SQGR_HIP(hipEventCreate(ev));
         }
     }
-    SQGR_HIP(hipEventRecord(tl->start, stream));
+    SQGR_HIP(hipEventRecord(tl->start, st));
     return SQGR_OK;
 }
 
 int sqgr_ctx::end_launch(const TimedLaunch& tl) {
-    SQGR_HIP(hipEventRecord(tl.stop, stream));
+    SQGR_HIP(hipEventRecord(tl.stop, tl.stream));
     launches.push_back(tl);
     if (launches.size() >= 8192) return resolve_timers();
     return SQGR_OK;
@@ -63,6 +64,7 @@ int sqgr_ctx::end_launch(const TimedLaunch& tl) {
 int sqgr_ctx::resolve_timers() {
     if (launches.empty()) return SQGR_OK;
     SQGR_HIP(hipStreamSynchronize(stream));
+    SQGR_HIP(hipStreamSynchronize(stream2));
     for (const TimedLaunch& tl : launches) {
         float ms = 0.f;
         SQGR_HIP(hipEventElapsedTime(&ms, tl.start, tl.stop));
@@ -113,6 +115,7 @@ int sqgr_ctx_create(int device, sqgr_ctx** out_ctx) {
     ctx->device = device;
     ctx->cu_count = prop.multiProcessorCount;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete ctx;
         set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
@@ -126,12 +129,14 @@ int sqgr_ctx_destroy(sqgr_ctx* ctx) {
     if (!ctx) return SQGR_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream2);
     for (auto& tl : ctx->launches) {
         (void)hipEventDestroy(tl.start);
         (void)hipEventDestroy(tl.stop);
     }
     for (auto ev : ctx->event_pool) (void)hipEventDestroy(ev);
     (void)hipStreamDestroy(ctx->stream);
+    (void)hipStreamDestroy(ctx->stream2);
     delete ctx;
     return SQGR_OK;
 }
@@ -140,6 +145,7 @@ int sqgr_ctx_sync(sqgr_ctx* ctx) {
     SQGR_REQUIRE(ctx, "ctx is NULL");
     SQGR_HIP(hipSetDevice(ctx->device));
     SQGR_HIP(hipStreamSynchronize(ctx->stream));
+    SQGR_HIP(hipStreamSynchronize(ctx->stream2));
     return SQGR_OK;
 }
 

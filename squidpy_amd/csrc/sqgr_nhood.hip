@@ -17,6 +17,7 @@
 #include "sqgr_common.h"
 #include "sqgr_rng.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace sqgr {
@@ -39,30 +40,42 @@ __global__ void k_keygen(uint64_t seed, int64_t perm0, int64_t nperm, int n_libs
 // ---------------------------------------------------------------------------------------------- label shuffle
 // A uniformly random arrangement of the label multiset does not depend on the order of the base vector, so
 // the base is taken *sorted by label* (inside each library): the label at sorted rank x is
-//   #{k >= 1 : cum[k] <= x},   cum[k] = number of spots with label < k,
-// found by a branch-free binary search in an LDS-resident boundary table (KPAD entries per library, padded
-// with UINT_MAX) -- no memory gather.   slab[(batch*n + i)*B + b] = label_at_rank( pi_{perm,lib}(rank_i) )
+//   #{k >= 1 : cum[k] <= x},   cum[k] = number of spots with label < k   (cum[K] = UINT_MAX sentinel).
+// No memory gather: rank x = a*B + b arrives with its high digit a, an LDS byte table gives the label of the first
+// rank of block a, and one compare against the next boundary finishes it (a loop only if a block of B ranks holds
+// several boundaries, i.e. clusters smaller than ~sqrt(n) spots).
+//   slab[(batch*n + i)*B + b] = label_at_rank( pi_{perm,lib}(rank_i) )
+struct LibDom {
+    FeistelDomain dom;
+    uint32_t aoff;  // offset of this library's block-start table
+};
+
 template <int B, bool HAS_LIBS>
-__global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __restrict__ cum, int kpad,
-                                                 const uint32_t* __restrict__ keys, FeistelDomain dom0, int n_libs,
+__global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __restrict__ cum, int kpad, int blk_bytes,
+                                                 const uint32_t* __restrict__ keys, LibDom dom0, int n_libs,
                                                  const int32_t* __restrict__ lib_of, const int32_t* __restrict__ rank_of,
-                                                 const FeistelDomain* __restrict__ libdoms, uint8_t* __restrict__ slab_all) {
-    extern __shared__ uint32_t s_cum[];
+                                                 const LibDom* __restrict__ libdoms, uint8_t* __restrict__ slab_all) {
+    extern __shared__ uint32_t s_cum[];                                          // [n_libs][kpad]
+    uint8_t* s_blk = reinterpret_cast<uint8_t*>(s_cum + n_libs * kpad);          // [blk_bytes] label of rank a*B
+    const uint8_t* g_blk = reinterpret_cast<const uint8_t*>(cum + n_libs * kpad);
     for (int t = threadIdx.x; t < n_libs * kpad; t += 256) s_cum[t] = cum[t];
+    for (int t = threadIdx.x; t < blk_bytes; t += 256) s_blk[t] = g_blk[t];
     __syncthreads();
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int batch = blockIdx.y;
     const uint32_t* kb = keys + (size_t)batch * B * n_libs * 8;
     uint32_t out[B / 4];
-    FeistelDomain dom = dom0;
+    LibDom ld = dom0;
     uint32_t x0 = (uint32_t)i, lib = 0;
     if (HAS_LIBS) {
         lib = (uint32_t)lib_of[i];
-        dom = libdoms[lib];
+        ld = libdoms[lib];
         x0 = (uint32_t)rank_of[i];
     }
-    const uint32_t* tab = s_cum + lib * kpad;
+    const FeistelDomain dom = ld.dom;
+    const uint32_t* tab = s_cum + lib * kpad + 1;  // tab[k] = cum[k + 1]
+    const uint8_t* blk = s_blk + ld.aoff;
     const uint32_t a0 = x0 / dom.B, b0 = x0 - a0 * dom.B;  // one division per spot, shared by all B permutations
 #pragma unroll
     for (int w = 0; w < B / 4; ++w) {
@@ -71,10 +84,12 @@ __global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __re
         for (int j = 0; j < 4; ++j) {
             const int b = w * 4 + j;
             const uint32_t* rk = kb + ((size_t)b * n_libs + lib) * 8;  // uniform (scalar loads) when !HAS_LIBS
-            const uint32_t x = feistel_perm_ab(a0, b0, dom, rk);
-            uint32_t pos = 0;  // largest index with tab[pos] <= x  (tab[0] == 0)
-            for (int step = kpad >> 1; step > 0; step >>= 1) pos += (tab[pos + step] <= x) ? step : 0;
-            word |= pos << (8 * j);
+            uint32_t a;
+            const uint32_t x = feistel_perm_ab(a0, b0, dom, rk, &a);
+            uint32_t lab = blk[a];
+            lab += (x >= tab[lab]) ? 1u : 0u;
+            while (x >= tab[lab]) ++lab;  // rarely iterates (sentinel UINT_MAX stops it)
+            word |= lab << (8 * j);
         }
         out[w] = word;
     }
@@ -321,18 +336,28 @@ struct sqgr_nhood {
     int K = 0, K2 = 0;
     int n_libs = 1;
     bool has_libs = false;
-    FeistelDomain dom0{};
+    LibDom dom0{};
+    int blk_bytes = 0;
     DevBuf<uint32_t> cum;  // [n_libs][kpad] label boundaries of the label-sorted base
     int kpad = 0;
     DevBuf<int32_t> lib_of, rank_of;
-    DevBuf<FeistelDomain> libs;
+    DevBuf<LibDom> libs;
     // tuning
     int B = 16;
     int nblk = 0;
-    int nbatch = 16;
+    int nbatch = 32;
     // workspace
-    DevBuf<uint32_t> keys;
-    DevBuf<uint8_t> slab;
+    DevBuf<uint32_t> keys;   // 2 buffers (ping-pong between the shuffle and the count stream)
+    DevBuf<uint8_t> slab;    // 2 buffers
+    hipEvent_t ev_shuffled[2] = {nullptr, nullptr}, ev_counted[2] = {nullptr, nullptr};
+    ~sqgr_nhood() {
+        for (int i = 0; i < 2; ++i) {
+            if (ev_shuffled[i]) (void)hipEventDestroy(ev_shuffled[i]);
+            if (ev_counted[i]) (void)hipEventDestroy(ev_counted[i]);
+        }
+    }
+    size_t keys_stride() const { return (size_t)nbatch * B * n_libs * 8; }
+    size_t slab_stride() const { return (size_t)nbatch * n * B; }
     DevBuf<uint32_t> partial;
     DevBuf<int64_t> acc_sum;
     DevBuf<uint64_t> acc_sq;
@@ -350,7 +375,7 @@ struct sqgr_nhood {
     int partial_blocks() const { return (B == 16 && be() == 0) ? 1 : nblk; }
     int resolve_tuning();
     int ensure_workspace(bool need_perms);
-    int count_batches(int nb);  // slab -> partial for nb batches
+    int count_batches(int nb, int buf);  // slab[buf] -> partial for nb batches
     int reduce_batches(int nb, int64_t perm_batch0, int64_t perm_begin, int64_t perm_end, uint32_t* perms_out_dev);
 };
 
@@ -363,15 +388,19 @@ int sqgr_nhood::resolve_tuning() {
         // only add partial-histogram traffic (nblk * K*K*B*4 bytes written and re-read per batch)
         nblk = cus;
     }
-    if (nbatch <= 0) nbatch = 16;
+    if (nbatch <= 0) nbatch = 32;
     return SQGR_OK;
 }
 
 int sqgr_nhood::ensure_workspace(bool need_perms) {
     SQGR_TRY(resolve_tuning());
     const size_t hw = (size_t)hist_words();
-    SQGR_TRY(keys.ensure((size_t)nbatch * B * n_libs * 8));
-    SQGR_TRY(slab.ensure((size_t)nbatch * n * B));
+    SQGR_TRY(keys.ensure(2 * keys_stride()));
+    SQGR_TRY(slab.ensure(2 * slab_stride()));
+    for (int i = 0; i < 2; ++i) {
+        if (!ev_shuffled[i]) SQGR_HIP(hipEventCreateWithFlags(&ev_shuffled[i], hipEventDisableTiming));
+        if (!ev_counted[i]) SQGR_HIP(hipEventCreateWithFlags(&ev_counted[i], hipEventDisableTiming));
+    }
     SQGR_TRY(partial.ensure((size_t)nbatch * partial_blocks() * hw));
     SQGR_TRY(acc_sum.ensure((size_t)nbatch * hw));
     SQGR_TRY(acc_sq.ensure((size_t)nbatch * hw));
@@ -382,7 +411,8 @@ int sqgr_nhood::ensure_workspace(bool need_perms) {
     return SQGR_OK;
 }
 
-int sqgr_nhood::count_batches(int nb) {
+int sqgr_nhood::count_batches(int nb, int buf) {
+    const uint8_t* slab_p = slab.p + (size_t)buf * slab_stride();
     const int64_t nnz = g->nnz;
     hipStream_t st = ctx->stream;
     const int hw = hist_words();
@@ -394,16 +424,16 @@ int sqgr_nhood::count_batches(int nb) {
         const uint32_t epb = (uint32_t)(ceil_div(ceil_div(nnz, nblk), 256) * 256);
         LaunchTimer t(ctx, "nhood_count_b32");
         SQGR_TRY(allow_lds(k_count<32, 4>, (size_t)hw * 4));
-        k_count<32, 4><<<dim3(nblk, nb), COUNT_THREADS, (size_t)hw * 4, st>>>((uint32_t)nnz, g->erow.p, g->indices.p, slab.p, n, K, hw,
+        k_count<32, 4><<<dim3(nblk, nb), COUNT_THREADS, (size_t)hw * 4, st>>>((uint32_t)nnz, g->erow.p, g->indices.p, slab_p, n, K, hw,
                                                                            epb, partial.p);
     } else if (be() == 16) {
         const uint32_t epb = (uint32_t)(ceil_div(ceil_div(nnz, nblk), 256) * 256);
         LaunchTimer t(ctx, "nhood_count_b16");
         if ((size_t)hw * 4 * 2 <= LDS_BUDGET)
-            k_count<16, 8><<<dim3(nblk, nb), COUNT_THREADS, (size_t)hw * 4, st>>>((uint32_t)nnz, g->erow.p, g->indices.p, slab.p, n, K,
+            k_count<16, 8><<<dim3(nblk, nb), COUNT_THREADS, (size_t)hw * 4, st>>>((uint32_t)nnz, g->erow.p, g->indices.p, slab_p, n, K,
                                                                                hw, epb, partial.p);
         else if (allow_lds(k_count<16, 4>, (size_t)hw * 4) == SQGR_OK)
-            k_count<16, 4><<<dim3(nblk, nb), COUNT_THREADS, (size_t)hw * 4, st>>>((uint32_t)nnz, g->erow.p, g->indices.p, slab.p, n, K,
+            k_count<16, 4><<<dim3(nblk, nb), COUNT_THREADS, (size_t)hw * 4, st>>>((uint32_t)nnz, g->erow.p, g->indices.p, slab_p, n, K,
                                                                                hw, epb, partial.p);
     } else {
         const int e = be();
@@ -411,16 +441,16 @@ int sqgr_nhood::count_batches(int nb) {
         LaunchTimer t(ctx, "nhood_count_wide");
         if (e == 0) {
             SQGR_HIP(hipMemsetAsync(partial.p, 0, (size_t)nb * hw * 4, st));
-            k_count_wide<0><<<dim3(nblk, nb), COUNT_THREADS, 0, st>>>(nnz, g->erow.p, g->indices.p, slab.p, n, K, 0, epb, 1,
+            k_count_wide<0><<<dim3(nblk, nb), COUNT_THREADS, 0, st>>>(nnz, g->erow.p, g->indices.p, slab_p, n, K, 0, epb, 1,
                                                                      partial.p);
         } else {
             for (int b0 = 0; b0 < 16; b0 += e) {
                 const size_t lds = (size_t)K2 * e * 4;
                 switch (e) {
-                    case 8: launch_wide<8>(dim3(nblk, nb), lds, st, nnz, g->erow.p, g->indices.p, slab.p, n, K, b0, epb, nblk, partial.p); break;
-                    case 4: launch_wide<4>(dim3(nblk, nb), lds, st, nnz, g->erow.p, g->indices.p, slab.p, n, K, b0, epb, nblk, partial.p); break;
-                    case 2: launch_wide<2>(dim3(nblk, nb), lds, st, nnz, g->erow.p, g->indices.p, slab.p, n, K, b0, epb, nblk, partial.p); break;
-                    default: launch_wide<1>(dim3(nblk, nb), lds, st, nnz, g->erow.p, g->indices.p, slab.p, n, K, b0, epb, nblk, partial.p); break;
+                    case 8: launch_wide<8>(dim3(nblk, nb), lds, st, nnz, g->erow.p, g->indices.p, slab_p, n, K, b0, epb, nblk, partial.p); break;
+                    case 4: launch_wide<4>(dim3(nblk, nb), lds, st, nnz, g->erow.p, g->indices.p, slab_p, n, K, b0, epb, nblk, partial.p); break;
+                    case 2: launch_wide<2>(dim3(nblk, nb), lds, st, nnz, g->erow.p, g->indices.p, slab_p, n, K, b0, epb, nblk, partial.p); break;
+                    default: launch_wide<1>(dim3(nblk, nb), lds, st, nnz, g->erow.p, g->indices.p, slab_p, n, K, b0, epb, nblk, partial.p); break;
                 }
             }
         }
@@ -531,19 +561,14 @@ int sqgr_nhood_create(sqgr_ctx* ctx, const sqgr_graph* g, const int32_t* labels,
     p->n = n;
     p->K = K;
     p->K2 = K * K;
-    p->dom0 = make_domain((uint32_t)n);
+    p->dom0.dom = make_domain((uint32_t)n);
+    p->dom0.aoff = 0;
     int rc = SQGR_OK;
     do {
         const bool libs_on = lib_ids && n_libs >= 1;
         p->has_libs = libs_on;
         p->n_libs = libs_on ? n_libs : 1;
-        p->kpad = 2;
-        while (p->kpad < K) p->kpad <<= 1;
-        if ((size_t)p->n_libs * p->kpad > 16384) {
-            set_error("n_libs * next_pow2(K) = %d * %d exceeds the 64 KiB LDS boundary table", p->n_libs, p->kpad);
-            rc = SQGR_ERR_UNSUPPORTED;
-            break;
-        }
+        p->kpad = K + 1;  // K boundaries + UINT_MAX sentinel
         // label histogram per library -> boundaries cum[l][k] = #{members of l with label < k}, padded with UINT_MAX
         std::vector<int64_t> cnt((size_t)p->n_libs, 0);
         std::vector<uint32_t> hist((size_t)p->n_libs * K, 0);
@@ -565,15 +590,40 @@ int sqgr_nhood_create(sqgr_ctx* ctx, const sqgr_graph* g, const int32_t* labels,
         }
         if (rc != SQGR_OK) break;
         std::vector<uint32_t> cum((size_t)p->n_libs * p->kpad, 0xFFFFFFFFu);
-        std::vector<FeistelDomain> doms((size_t)p->n_libs);
+        std::vector<LibDom> doms((size_t)p->n_libs);
+        size_t blk_total = 0;
         for (int l = 0; l < p->n_libs; ++l) {
             uint32_t run = 0;
             for (int k = 0; k < K; ++k) {
                 cum[(size_t)l * p->kpad + k] = run;
                 run += hist[(size_t)l * K + k];
             }
-            doms[l] = make_domain((uint32_t)(cnt[l] > 0 ? cnt[l] : 1));
+            doms[l].dom = make_domain((uint32_t)(cnt[l] > 0 ? cnt[l] : 1));
+            doms[l].aoff = (uint32_t)blk_total;
+            blk_total += doms[l].dom.A;
         }
+        p->blk_bytes = (int)blk_total;
+        if ((size_t)p->n_libs * p->kpad * 4 + blk_total > 150 * 1024) {
+            set_error("library/label tables (%zu bytes) exceed the LDS budget of the shuffle kernel",
+                      (size_t)p->n_libs * p->kpad * 4 + blk_total);
+            rc = SQGR_ERR_UNSUPPORTED;
+            break;
+        }
+        // block-start table: label of sorted rank a*B for every high digit a (appended to the boundary table)
+        std::vector<uint8_t> blk(blk_total + 4, 0);
+        for (int l = 0; l < p->n_libs; ++l) {
+            const uint32_t* c = &cum[(size_t)l * p->kpad];
+            uint32_t lab = 0;
+            for (uint32_t a = 0; a < doms[l].dom.A; ++a) {
+                const uint64_t x = (uint64_t)a * doms[l].dom.B;
+                while (lab + 1 < (uint32_t)K && c[lab + 1] <= x) ++lab;
+                blk[doms[l].aoff + a] = (uint8_t)lab;
+            }
+        }
+        const size_t cum_words = cum.size();
+        cum.resize(cum_words + (blk.size() + 3) / 4);
+        memcpy(cum.data() + cum_words, blk.data(), blk.size());
+        if (!libs_on) p->dom0 = doms[0];
         if ((rc = p->cum.alloc(cum.size())) != SQGR_OK) break;
         hipError_t e = hipMemcpy(p->cum.p, cum.data(), cum.size() * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess && libs_on) {
@@ -582,7 +632,7 @@ int sqgr_nhood_create(sqgr_ctx* ctx, const sqgr_graph* g, const int32_t* labels,
             if ((rc = p->libs.alloc((size_t)n_libs)) != SQGR_OK) break;
             e = hipMemcpy(p->lib_of.p, lib_ids, (size_t)n * 4, hipMemcpyHostToDevice);
             if (e == hipSuccess) e = hipMemcpy(p->rank_of.p, rank.data(), (size_t)n * 4, hipMemcpyHostToDevice);
-            if (e == hipSuccess) e = hipMemcpy(p->libs.p, doms.data(), (size_t)n_libs * sizeof(FeistelDomain), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(p->libs.p, doms.data(), (size_t)n_libs * sizeof(LibDom), hipMemcpyHostToDevice);
         }
         if (e != hipSuccess) {
             set_error("label upload failed: %s", hipGetErrorString(e));
@@ -611,20 +661,21 @@ int sqgr_nhood_tune(sqgr_nhood* plan, int32_t perms_per_pass, int32_t blocks_per
                  "tuning value out of range");
     plan->B = perms_per_pass ? perms_per_pass : 16;
     plan->nblk = blocks_per_batch;
-    plan->nbatch = batches_per_launch ? batches_per_launch : 16;
+    plan->nbatch = batches_per_launch ? batches_per_launch : 32;
     // force re-allocation with the new geometry
     plan->keys.release(); plan->slab.release(); plan->partial.release(); plan->acc_sum.release(); plan->acc_sq.release();
     return SQGR_OK;
 }
 
-static int launch_shuffle(sqgr_nhood* p, int nb) {
+static int launch_shuffle(sqgr_nhood* p, int nb, int buf, hipStream_t st) {
     const unsigned gx = (unsigned)ceil_div(p->n, 256);
-    LaunchTimer t(p->ctx, "nhood_shuffle");
-    hipStream_t st = p->ctx->stream;
-    const size_t lds = (size_t)p->n_libs * p->kpad * 4;
-#define SQGR_SHUFFLE(BB, LIBS)                                                                                          \
-    k_shuffle<BB, LIBS><<<dim3(gx, nb), 256, lds, st>>>(p->n, p->cum.p, p->kpad, p->keys.p, p->dom0, p->n_libs, p->lib_of.p, \
-                                                        p->rank_of.p, p->libs.p, p->slab.p)
+    LaunchTimer t(p->ctx, "nhood_shuffle", st);
+    const size_t lds = (size_t)p->n_libs * p->kpad * 4 + (size_t)((p->blk_bytes + 3) / 4) * 4;
+    const uint32_t* keys = p->keys.p + (size_t)buf * p->keys_stride();
+    uint8_t* slab = p->slab.p + (size_t)buf * p->slab_stride();
+#define SQGR_SHUFFLE(BB, LIBS)                                                                                  \
+    k_shuffle<BB, LIBS><<<dim3(gx, nb), 256, lds, st>>>(p->n, p->cum.p, p->kpad, p->blk_bytes, keys, p->dom0, p->n_libs, p->lib_of.p, \
+                                                        p->rank_of.p, p->libs.p, slab)
     if (p->B == 32) {
         if (p->has_libs) SQGR_SHUFFLE(32, true); else SQGR_SHUFFLE(32, false);
     } else {
@@ -655,18 +706,31 @@ int sqgr_nhood_run(sqgr_nhood* plan, uint64_t seed, int64_t perm_begin, int64_t 
     SQGR_HIP(hipMemsetAsync(p->acc_sum.p, 0, (size_t)p->nbatch * hw * 8, st));
     SQGR_HIP(hipMemsetAsync(p->acc_sq.p, 0, (size_t)p->nbatch * hw * 8, st));
     if (out_perms && nperm > 0) SQGR_TRY(p->perms_dev.ensure((size_t)nperm * K2));
-    for (int64_t p0 = perm_begin; p0 < perm_end; p0 += per_launch) {
+    // Two-stage pipeline on two streams: shuffles (VALU-bound) of launch group g+1 overlap the counting
+    // (LDS-atomic/memory-bound) of group g; slab and key buffers ping-pong, ordered by events.
+    // (measured on MI355X: both stages are VALU-issue bound, so overlapping them gains ~0-3 %; the default keeps one
+    //  stream so per-kernel timings stay exclusive — set SQGR_NHOOD_STREAMS=2 to overlap)
+    const char* env_streams = getenv("SQGR_NHOOD_STREAMS");
+    hipStream_t sa = (env_streams && atoi(env_streams) == 2) ? ctx->stream2 : st;
+    int64_t grp = 0;
+    for (int64_t p0 = perm_begin; p0 < perm_end; p0 += per_launch, ++grp) {
         const int64_t todo = (perm_end - p0 < per_launch) ? perm_end - p0 : per_launch;
         const int nb = (int)ceil_div(todo, B);
+        const int buf = (int)(grp & 1);
+        if (grp >= 2) SQGR_HIP(hipStreamWaitEvent(sa, p->ev_counted[buf], 0));  // slab[buf] has been consumed
         {
-            LaunchTimer t(ctx, "nhood_keygen");
+            LaunchTimer t(ctx, "nhood_keygen", sa);
             const int64_t nk = (int64_t)nb * B * p->n_libs;
-            k_keygen<<<(unsigned)ceil_div(nk, 256), 256, 0, st>>>(seed, p0, (int64_t)nb * B, p->n_libs, p->keys.p);
+            k_keygen<<<(unsigned)ceil_div(nk, 256), 256, 0, sa>>>(seed, p0, (int64_t)nb * B, p->n_libs,
+                                                                 p->keys.p + (size_t)buf * p->keys_stride());
             SQGR_HIP(hipGetLastError());
         }
-        SQGR_TRY(launch_shuffle(p, nb));
-        SQGR_TRY(p->count_batches(nb));
+        SQGR_TRY(launch_shuffle(p, nb, buf, sa));
+        SQGR_HIP(hipEventRecord(p->ev_shuffled[buf], sa));
+        SQGR_HIP(hipStreamWaitEvent(st, p->ev_shuffled[buf], 0));
+        SQGR_TRY(p->count_batches(nb, buf));
         SQGR_TRY(p->reduce_batches(nb, p0, perm_begin, perm_end, out_perms ? p->perms_dev.p : nullptr));
+        SQGR_HIP(hipEventRecord(p->ev_counted[buf], st));
     }
     {
         LaunchTimer t(ctx, "nhood_finalize");
@@ -692,7 +756,7 @@ int sqgr_nhood_shuffled_labels(sqgr_nhood* plan, uint64_t seed, int64_t perm, ui
     const int B = p->B;
     k_keygen<<<(unsigned)ceil_div((int64_t)B * p->n_libs, 256), 256, 0, st>>>(seed, perm, B, p->n_libs, p->keys.p);
     SQGR_HIP(hipGetLastError());
-    SQGR_TRY(launch_shuffle(p, 1));
+    SQGR_TRY(launch_shuffle(p, 1, 0, st));
     std::vector<uint8_t> rows((size_t)p->n * B);
     SQGR_HIP(hipMemcpyAsync(rows.data(), p->slab.p, rows.size(), hipMemcpyDeviceToHost, st));
     SQGR_HIP(hipStreamSynchronize(st));
@@ -732,7 +796,7 @@ int sqgr_nhood_counts_batch(sqgr_ctx* ctx, const sqgr_graph* g, const uint8_t* l
                 else
                     k_transpose_labels<16><<<dim3((unsigned)ceil_div(n, 256), nb), 256, 0, st>>>(n, p->stage.p, todo, p->slab.p);
             }
-            if ((rc = p->count_batches(nb)) != SQGR_OK) break;
+            if ((rc = p->count_batches(nb, 0)) != SQGR_OK) break;
             if ((rc = p->reduce_batches(nb, p0, 0, n_perms, p->perms_dev.p)) != SQGR_OK) break;
             e = hipStreamSynchronize(st);  // stage buffer is reused by the next chunk
         }

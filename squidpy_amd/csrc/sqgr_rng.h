@@ -82,7 +82,7 @@ __host__ __device__ inline FeistelDomain make_domain(uint32_t n) {
 // image of x (< n) under the cycle-walked keyed bijection of [0, n): 8 alternating additive Feistel rounds
 //   a <- (a + (F(b,k_r) * A >> 16)) mod A ;  b <- (b + (F(a,k_r+1) * B >> 16)) mod B
 __device__ __forceinline__ uint32_t feistel_perm_ab(uint32_t a, uint32_t b, const FeistelDomain& d,
-                                                    const uint32_t* __restrict__ rk) {
+                                                    const uint32_t* __restrict__ rk, uint32_t* hi_digit = nullptr) {
     uint32_t x;
     do {
 #pragma unroll
@@ -94,6 +94,7 @@ __device__ __forceinline__ uint32_t feistel_perm_ab(uint32_t a, uint32_t b, cons
         }
         x = a * d.B + b;
     } while (x >= d.n);
+    if (hi_digit) *hi_digit = a;  // x == a * d.B + b
     return x;
 }
 
