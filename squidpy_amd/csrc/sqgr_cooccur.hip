@@ -22,11 +22,14 @@
 namespace sqgr {
 
 constexpr int CO_TILE = 256;
-constexpr int CO_CELLS = 2048;
+constexpr int CO_CELLS_MIN = 2048;    // d2 lookup cells (doubled up to CO_CELLS_MAX until <= 2 thresholds per 2 cells)
+constexpr int CO_CELLS_MAX = 32768;
+constexpr int CO_BATCH = 8;           // pairs in flight per thread in the branch-free kernel
 constexpr int CO_CHUNK_TILES = 64;
 
 struct CoParams {
     float inv_cell;
+    int ncells;
     int T, L, K;
     int shard_index, shard_count;
     unsigned long long* out;  // [K][K][L] per-bin (non cumulative) ordered pair counts
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(CO_TILE) void k_cooccur(const float* __restrict__ x
     const int L = p.L;
     uint32_t* hist = smem;                                          // [L][256]
     float* s_thr = reinterpret_cast<float*>(smem + L * CO_TILE);    // [L]
-    uint16_t* s_cell = reinterpret_cast<uint16_t*>(s_thr + L);      // [CO_CELLS]
+    uint16_t* s_cell = reinterpret_cast<uint16_t*>(s_thr + L + 2);  // [ncells]
     const int t = threadIdx.x;
 
     const int ti = blockIdx.x * p.shard_count + p.shard_index;
@@ -81,8 +84,8 @@ __global__ __launch_bounds__(CO_TILE) void k_cooccur(const float* __restrict__ x
     if (tj0 >= tj1) return;
 
     for (int i = t; i < L * CO_TILE; i += CO_TILE) hist[i] = 0;
-    for (int i = t; i < L; i += CO_TILE) s_thr[i] = thr[i];
-    for (int i = t; i < CO_CELLS; i += CO_TILE) s_cell[i] = cell[i];
+    for (int i = t; i < L + 2; i += CO_TILE) s_thr[i] = i < L ? thr[i] : __builtin_inff();  // +inf sentinels
+    for (int i = t; i < p.ncells; i += CO_TILE) s_cell[i] = cell[i];
     __syncthreads();
 
     const int a = tile_label[ti];
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(CO_TILE) void k_cooccur(const float* __restrict__ x
             for (int j = 0; j < vj; ++j) {
                 const float d2 = dist2<FMA>(xi, yi, xj[j], yj[j]);
                 int cellv = (int)(d2 * inv_cell);  // v_cvt_i32_f32 saturates; NaN -> 0
-                cellv = min(max(cellv, 0), CO_CELLS - 1);
+                cellv = min(max(cellv, 0), p.ncells - 1);
                 int g = s_cell[cellv];
                 while (g < L && !(d2 <= s_thr[g])) ++g;  // exact: first threshold with d2 <= thr (NaN never counts)
                 if (g < L && !(diag && j == t)) atomicAdd(my + g * CO_TILE, 1u);
@@ -117,6 +120,77 @@ __global__ __launch_bounds__(CO_TILE) void k_cooccur(const float* __restrict__ x
         if (diag) {  // ordered pairs of the diagonal tile are complete on their own: credit (a,a) once
             co_flush(hist, L, p.K, a, a, false, p.out);
         }
+    }
+    co_flush(hist, L, p.K, a, cur_b, true, p.out);
+}
+
+// Branch-free variant used whenever the lookup table is fine enough that the true bin is at most 2 above the
+// table's lower bound (checked on the host): CO_BATCH pairs per thread are in flight, so the LDS round trips
+// (cell lookup, two thresholds via one ds_read2, histogram add) overlap instead of serialising.
+template <bool FMA>
+__global__ __launch_bounds__(CO_TILE) void k_cooccur_fast(const float* __restrict__ xs, const float* __restrict__ ys,
+                                                          const int32_t* __restrict__ tile_label,
+                                                          const int32_t* __restrict__ tile_valid, const float* __restrict__ thr,
+                                                          const uint16_t* __restrict__ cell, CoParams p) {
+    extern __shared__ uint32_t smem[];
+    const int L = p.L;
+    uint32_t* hist = smem;                                          // [L][256]
+    float* s_thr = reinterpret_cast<float*>(smem + L * CO_TILE);    // [L + 2], two +inf sentinels
+    uint16_t* s_cell = reinterpret_cast<uint16_t*>(s_thr + L + 2);  // [ncells]
+    const int t = threadIdx.x;
+
+    const int ti = blockIdx.x * p.shard_count + p.shard_index;
+    if (ti >= p.T) return;
+    const int tj0 = max(ti, (int)blockIdx.y * CO_CHUNK_TILES);
+    const int tj1 = min(p.T, ((int)blockIdx.y + 1) * CO_CHUNK_TILES);
+    if (tj0 >= tj1) return;
+
+    for (int i = t; i < L * CO_TILE; i += CO_TILE) hist[i] = 0;
+    for (int i = t; i < L + 2; i += CO_TILE) s_thr[i] = i < L ? thr[i] : __builtin_inff();
+    for (int i = t; i < p.ncells; i += CO_TILE) s_cell[i] = cell[i];
+    __syncthreads();
+
+    const int a = tile_label[ti];
+    const bool active = t < tile_valid[ti];
+    const float xi = xs[(size_t)ti * CO_TILE + t];
+    const float yi = ys[(size_t)ti * CO_TILE + t];
+    const float inv_cell = p.inv_cell;
+    const int cmax = p.ncells - 1;
+    uint32_t* my = hist + t;
+
+    int cur_b = -1;
+    for (int tj = tj0; tj < tj1; ++tj) {
+        const int b = tile_label[tj];
+        if (b != cur_b) {
+            if (cur_b >= 0) co_flush(hist, L, p.K, a, cur_b, true, p.out);
+            cur_b = b;
+        }
+        const int vj = tile_valid[tj];
+        const float* __restrict__ xj = xs + (size_t)tj * CO_TILE;  // wave-uniform addresses: scalar loads; the tile is
+        const float* __restrict__ yj = ys + (size_t)tj * CO_TILE;  // zero-padded to 256 so reading past vj is safe
+        const int self = (tj == ti) ? t : -1;
+        if (active) {
+            for (int j0 = 0; j0 < vj; j0 += CO_BATCH) {
+                float d2[CO_BATCH];
+                int g[CO_BATCH];
+#pragma unroll
+                for (int u = 0; u < CO_BATCH; ++u) {
+                    d2[u] = dist2<FMA>(xi, yi, xj[j0 + u], yj[j0 + u]);
+                    int cellv = (int)(d2[u] * inv_cell);  // v_cvt_i32_f32 saturates; NaN -> 0
+                    g[u] = s_cell[min(max(cellv, 0), cmax)];
+                }
+#pragma unroll
+                for (int u = 0; u < CO_BATCH; ++u) {
+                    const float t0 = s_thr[g[u]], t1 = s_thr[g[u] + 1];  // adjacent: one ds_read2_b32
+                    // thresholds ascend, so !(d2 <= t1) implies !(d2 <= t0): bin = g + c0 + c1 (no branches)
+                    const int c0 = !(d2[u] <= t0), c1 = !(d2[u] <= t1);
+                    const int gg = g[u] + c0 + c1;
+                    const int ok = (int)(gg < L) & (int)(j0 + u < vj) & (int)(j0 + u != self) & (int)(d2[u] == d2[u]);
+                    atomicAdd(my + min(gg, L - 1) * CO_TILE, (uint32_t)ok);
+                }
+            }
+        }
+        if (tj == ti) co_flush(hist, L, p.K, a, a, false, p.out);  // diagonal tile: ordered pairs complete, credit (a,a) once
     }
     co_flush(hist, L, p.K, a, cur_b, true, p.out);
 }
@@ -131,7 +205,7 @@ extern "C" int sqgr_cooccur_counts(sqgr_ctx* ctx, const float* x, const float* y
     SQGR_REQUIRE(ctx && x && y && labels && thr2 && out_counts, "null argument");
     SQGR_REQUIRE(n >= 0 && K >= 1 && L >= 1, "bad sizes n=%lld K=%d L=%d", (long long)n, K, L);
     SQGR_REQUIRE(shard_count >= 1 && shard_index >= 0 && shard_index < shard_count, "bad shard %d/%d", shard_index, shard_count);
-    const size_t lds = (size_t)L * CO_TILE * 4 + (size_t)L * 4 + CO_CELLS * 2;
+    const size_t lds = (size_t)L * CO_TILE * 4 + (size_t)(L + 2) * 4 + CO_CELLS_MIN * 2;
     if (lds > 160 * 1024 || L > 65535) {
         set_error("L=%d thresholds need %zu bytes of LDS (> 160 KiB)", L, lds);
         return SQGR_ERR_UNSUPPORTED;
@@ -182,16 +256,45 @@ extern "C" int sqgr_cooccur_counts(sqgr_ctx* ctx, const float* x, const float* y
     std::vector<unsigned long long> hist_host((size_t)K * K * L, 0ull);
     if (L_eff > 0) {
         const float tmax = thr_s[L_eff - 1];
-        const float inv_cell = (tmax > 0.f && std::isfinite(tmax)) ? (float)((double)CO_CELLS / (double)tmax) : 0.f;
-        std::vector<uint16_t> cell(CO_CELLS, 0);
-        if (inv_cell > 0.f && std::isfinite(inv_cell)) {
-            for (int c = 0; c < CO_CELLS; ++c) {
-                // every d2 landing in cell c is >= (c-1)/inv_cell (one full cell of slack absorbs float rounding)
-                const double lo = (c >= 1) ? ((double)(c - 1) / (double)inv_cell) * (1.0 - 1e-5) : -1.0;
-                int g = 0;
-                while (g < L_eff && (double)thr_s[g] < lo) ++g;
-                cell[c] = (uint16_t)g;
+        const bool table_ok = tmax > 0.f && std::isfinite(tmax);
+        const size_t lds_fixed = (size_t)L_eff * CO_TILE * 4 + (size_t)(L_eff + 2) * 4;
+        int ncells = CO_CELLS_MIN;
+        float inv_cell = 0.f;
+        std::vector<uint16_t> cell;
+        bool fast = false;
+        for (;; ncells *= 2) {
+            inv_cell = table_ok ? (float)((double)ncells / (double)tmax) : 0.f;
+            cell.assign((size_t)ncells, 0);
+            int worst = L_eff;  // max (true bin - table lower bound) over all cells
+            if (inv_cell > 0.f && std::isfinite(inv_cell)) {
+                worst = 0;
+                for (int c = 0; c < ncells; ++c) {
+                    // every d2 landing in cell c lies in [(c-1)/inv_cell, (c+2)/inv_cell): a full cell of slack on both
+                    // sides absorbs the float rounding of d2 * inv_cell
+                    const double lo = (c >= 1) ? ((double)(c - 1) / (double)inv_cell) * (1.0 - 1e-5) : -1.0;
+                    const double hi = (c == ncells - 1) ? (double)INFINITY : ((double)(c + 2) / (double)inv_cell) * (1.0 + 1e-5);
+                    int g = 0;
+                    while (g < L_eff && (double)thr_s[g] < lo) ++g;
+                    int gh = g;
+                    while (gh < L_eff && (double)thr_s[gh] < hi) ++gh;
+                    cell[c] = (uint16_t)g;
+                    worst = std::max(worst, gh - g);
+                }
             }
+            fast = worst <= 2;
+            if (fast || ncells * 2 > CO_CELLS_MAX || lds_fixed + (size_t)ncells * 4 > 160 * 1024) break;
+        }
+        if (!fast && lds_fixed + (size_t)ncells * 2 > 160 * 1024) {  // fall back to the smallest table
+            ncells = CO_CELLS_MIN;
+            inv_cell = table_ok ? (float)((double)ncells / (double)tmax) : 0.f;
+            cell.assign((size_t)ncells, 0);
+            if (inv_cell > 0.f && std::isfinite(inv_cell))
+                for (int c = 0; c < ncells; ++c) {
+                    const double lo = (c >= 1) ? ((double)(c - 1) / (double)inv_cell) * (1.0 - 1e-5) : -1.0;
+                    int g = 0;
+                    while (g < L_eff && (double)thr_s[g] < lo) ++g;
+                    cell[c] = (uint16_t)g;
+                }
         }
         DevBuf<float> d_x, d_y, d_thr;
         DevBuf<int32_t> d_tl, d_tv;
@@ -202,7 +305,7 @@ extern "C" int sqgr_cooccur_counts(sqgr_ctx* ctx, const float* x, const float* y
         SQGR_TRY(d_thr.alloc((size_t)L_eff));
         SQGR_TRY(d_tl.alloc((size_t)T));
         SQGR_TRY(d_tv.alloc((size_t)T));
-        SQGR_TRY(d_cell.alloc(CO_CELLS));
+        SQGR_TRY(d_cell.alloc((size_t)ncells));
         SQGR_TRY(d_out.alloc((size_t)K * K * L_eff));
         hipStream_t st = ctx->stream;
         SQGR_HIP(hipMemcpyAsync(d_x.p, xs.data(), xs.size() * 4, hipMemcpyHostToDevice, st));
@@ -210,22 +313,25 @@ extern "C" int sqgr_cooccur_counts(sqgr_ctx* ctx, const float* x, const float* y
         SQGR_HIP(hipMemcpyAsync(d_thr.p, thr_s.data(), (size_t)L_eff * 4, hipMemcpyHostToDevice, st));
         SQGR_HIP(hipMemcpyAsync(d_tl.p, tile_label.data(), (size_t)T * 4, hipMemcpyHostToDevice, st));
         SQGR_HIP(hipMemcpyAsync(d_tv.p, tile_valid.data(), (size_t)T * 4, hipMemcpyHostToDevice, st));
-        SQGR_HIP(hipMemcpyAsync(d_cell.p, cell.data(), CO_CELLS * 2, hipMemcpyHostToDevice, st));
+        SQGR_HIP(hipMemcpyAsync(d_cell.p, cell.data(), (size_t)ncells * 2, hipMemcpyHostToDevice, st));
         SQGR_HIP(hipMemsetAsync(d_out.p, 0, (size_t)K * K * L_eff * 8, st));
-        CoParams p{inv_cell, (int)T, L_eff, K, shard_index, shard_count, d_out.p};
-        const size_t lds_eff = (size_t)L_eff * CO_TILE * 4 + (size_t)L_eff * 4 + CO_CELLS * 2;
+        CoParams p{inv_cell, ncells, (int)T, L_eff, K, shard_index, shard_count, d_out.p};
+        const size_t lds_eff = lds_fixed + (size_t)ncells * 2;
         dim3 grid((unsigned)ceil_div(T, shard_count), (unsigned)ceil_div(T, CO_CHUNK_TILES));
         {
-            LaunchTimer tm(ctx, fma ? "cooccur_pairs_fma" : "cooccur_pairs");
-            if (fma) {
-                if (lds_eff > 64 * 1024)
-                    SQGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooccur<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eff));
-                k_cooccur<true><<<grid, CO_TILE, lds_eff, st>>>(d_x.p, d_y.p, d_tl.p, d_tv.p, d_thr.p, d_cell.p, p);
+            LaunchTimer tm(ctx, fast ? (fma ? "cooccur_pairs_fast_fma" : "cooccur_pairs_fast") : (fma ? "cooccur_pairs_fma" : "cooccur_pairs"));
+#define SQGR_CO(KERNEL)                                                                                                          \
+    do {                                                                                                                         \
+        if (lds_eff > 64 * 1024)                                                                                                 \
+            SQGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eff)); \
+        KERNEL<<<grid, CO_TILE, lds_eff, st>>>(d_x.p, d_y.p, d_tl.p, d_tv.p, d_thr.p, d_cell.p, p);                             \
+    } while (0)
+            if (fast) {
+                if (fma) SQGR_CO(k_cooccur_fast<true>); else SQGR_CO(k_cooccur_fast<false>);
             } else {
-                if (lds_eff > 64 * 1024)
-                    SQGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooccur<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eff));
-                k_cooccur<false><<<grid, CO_TILE, lds_eff, st>>>(d_x.p, d_y.p, d_tl.p, d_tv.p, d_thr.p, d_cell.p, p);
+                if (fma) SQGR_CO(k_cooccur<true>); else SQGR_CO(k_cooccur<false>);
             }
+#undef SQGR_CO
             SQGR_HIP(hipGetLastError());
         }
         std::vector<unsigned long long> tmp((size_t)K * K * L_eff);
