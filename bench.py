@@ -150,7 +150,7 @@ def moran_secondary(ctx, world: int, rank: int, fence, steps: int, with_cpu: boo
         import torch
         import torch.distributed as dist
 
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     cnt, ms = kernels.get("autocorr_perm_dot_moran", (0, 0.0))
@@ -227,8 +227,12 @@ def main() -> None:
         import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+        backend = os.environ.get("SQGR_DIST_BACKEND", "nccl")  # "gloo" lets one GPU host several ranks (testing only)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1)))
+        else:
+            dist.init_process_group(backend=backend)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
@@ -236,7 +240,7 @@ def main() -> None:
     from squidpy_amd._synthetic import hex_grid_graph
     from squidpy_amd.gr._nhood import expected_counts, zscore_from_moments
 
-    ctx = _lib.default_context(local_rank)
+    ctx = _lib.default_context(local_rank % max(_lib.device_count(), 1))
     adj = hex_grid_graph(args.rows, args.cols)
     n, nnz = adj.shape[0], int(adj.nnz)
     labels = np.random.default_rng(0).integers(0, N_CLS, n).astype(np.int32)
@@ -278,7 +282,7 @@ def main() -> None:
     kernels = ctx.timer_report()
     ctx.timer_enable(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

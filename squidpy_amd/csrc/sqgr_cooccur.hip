@@ -24,6 +24,7 @@ namespace sqgr {
 constexpr int CO_TILE = 256;
 constexpr int CO_CELLS_MIN = 2048;    // d2 lookup cells (doubled up to CO_CELLS_MAX until <= 2 thresholds per 2 cells)
 constexpr int CO_CELLS_MAX = 32768;
+constexpr int CO_LMAX = 120;          // thresholds per sweep: (L+?)*1 KiB of private histogram columns must fit LDS
 constexpr int CO_BATCH = 8;           // pairs in flight per thread in the branch-free kernel
 constexpr int CO_CHUNK_TILES = 64;
 
@@ -205,11 +206,7 @@ extern "C" int sqgr_cooccur_counts(sqgr_ctx* ctx, const float* x, const float* y
     SQGR_REQUIRE(ctx && x && y && labels && thr2 && out_counts, "null argument");
     SQGR_REQUIRE(n >= 0 && K >= 1 && L >= 1, "bad sizes n=%lld K=%d L=%d", (long long)n, K, L);
     SQGR_REQUIRE(shard_count >= 1 && shard_index >= 0 && shard_index < shard_count, "bad shard %d/%d", shard_index, shard_count);
-    const size_t lds = (size_t)L * CO_TILE * 4 + (size_t)(L + 2) * 4 + CO_CELLS_MIN * 2;
-    if (lds > 160 * 1024 || L > 65535) {
-        set_error("L=%d thresholds need %zu bytes of LDS (> 160 KiB)", L, lds);
-        return SQGR_ERR_UNSUPPORTED;
-    }
+    SQGR_REQUIRE(L <= 65535, "L=%d thresholds: too many", L);
     std::fill(out_counts, out_counts + (size_t)K * K * L, (int64_t)0);
     if (n == 0) return SQGR_OK;
     SQGR_HIP(hipSetDevice(ctx->device));
@@ -253,10 +250,19 @@ extern "C" int sqgr_cooccur_counts(sqgr_ctx* ctx, const float* x, const float* y
     for (int r = 0; r < L; ++r) thr_s[r] = thr2[order[r]];
     int L_eff = L;
     while (L_eff > 0 && std::isnan(thr_s[L_eff - 1])) --L_eff;  // NaN thresholds count nothing
-    std::vector<unsigned long long> hist_host((size_t)K * K * L, 0ull);
-    if (L_eff > 0) {
-        const float tmax = thr_s[L_eff - 1];
-        const bool table_ok = tmax > 0.f && std::isfinite(tmax);
+    // cum_host[ab][g] = #{pairs of label pair ab with d2 <= thr_s[g]}.  Thresholds are swept in chunks of <= CO_LMAX
+    // bins (LDS capacity); a chunk's cumulative histogram is already the full cumulative count for its thresholds,
+    // because every d2 below the chunk's first threshold lands in the chunk's bin 0.
+    std::vector<unsigned long long> cum_host((size_t)K * K * L, 0ull);
+    const int L_all = L_eff;
+    const float* thr_all = thr_s.data();
+    for (int s0 = 0; s0 < L_all; s0 += CO_LMAX) {
+        const int L_eff = std::min(CO_LMAX, L_all - s0);
+        const float* thr_s = thr_all + s0;
+        float tmax = 0.f;  // the lookup table spans [0, largest finite threshold]; +inf thresholds live past its last cell
+        for (int g = 0; g < L_eff; ++g)
+            if (std::isfinite(thr_s[g])) tmax = std::max(tmax, thr_s[g]);
+        const bool table_ok = tmax > 0.f;
         const size_t lds_fixed = (size_t)L_eff * CO_TILE * 4 + (size_t)(L_eff + 2) * 4;
         int ncells = CO_CELLS_MIN;
         float inv_cell = 0.f;
@@ -310,7 +316,7 @@ extern "C" int sqgr_cooccur_counts(sqgr_ctx* ctx, const float* x, const float* y
         hipStream_t st = ctx->stream;
         SQGR_HIP(hipMemcpyAsync(d_x.p, xs.data(), xs.size() * 4, hipMemcpyHostToDevice, st));
         SQGR_HIP(hipMemcpyAsync(d_y.p, ys.data(), ys.size() * 4, hipMemcpyHostToDevice, st));
-        SQGR_HIP(hipMemcpyAsync(d_thr.p, thr_s.data(), (size_t)L_eff * 4, hipMemcpyHostToDevice, st));
+        SQGR_HIP(hipMemcpyAsync(d_thr.p, thr_s, (size_t)L_eff * 4, hipMemcpyHostToDevice, st));
         SQGR_HIP(hipMemcpyAsync(d_tl.p, tile_label.data(), (size_t)T * 4, hipMemcpyHostToDevice, st));
         SQGR_HIP(hipMemcpyAsync(d_tv.p, tile_valid.data(), (size_t)T * 4, hipMemcpyHostToDevice, st));
         SQGR_HIP(hipMemcpyAsync(d_cell.p, cell.data(), (size_t)ncells * 2, hipMemcpyHostToDevice, st));
@@ -337,16 +343,16 @@ extern "C" int sqgr_cooccur_counts(sqgr_ctx* ctx, const float* x, const float* y
         std::vector<unsigned long long> tmp((size_t)K * K * L_eff);
         SQGR_HIP(hipMemcpyAsync(tmp.data(), d_out.p, tmp.size() * 8, hipMemcpyDeviceToHost, st));
         SQGR_HIP(hipStreamSynchronize(st));
-        for (size_t ab = 0; ab < (size_t)K * K; ++ab)
-            for (int g = 0; g < L_eff; ++g) hist_host[ab * L + g] = tmp[ab * L_eff + g];
-    }
-    // ---- bins -> cumulative counts in the caller's threshold order
-    for (size_t ab = 0; ab < (size_t)K * K; ++ab) {
-        unsigned long long run = 0;
-        for (int g = 0; g < L; ++g) {
-            if (g < L_eff) run += hist_host[ab * L + g];
-            out_counts[ab * L + order[g]] = (g < L_eff) ? (int64_t)run : 0;
+        for (size_t ab = 0; ab < (size_t)K * K; ++ab) {
+            unsigned long long run = 0;
+            for (int g = 0; g < L_eff; ++g) {
+                run += tmp[ab * L_eff + g];
+                cum_host[ab * L + s0 + g] = run;
+            }
         }
     }
+    // ---- cumulative counts back in the caller's threshold order (NaN thresholds count nothing)
+    for (size_t ab = 0; ab < (size_t)K * K; ++ab)
+        for (int g = 0; g < L; ++g) out_counts[ab * L + order[g]] = (g < L_all) ? (int64_t)cum_host[ab * L + g] : 0;
     return SQGR_OK;
 }

@@ -109,3 +109,13 @@ def test_medium_size_invariants(L, ctx):
     sel = np.where(labs < 2)[0][:1500]
     sub = L.cooccur_counts(ctx, x[sel], y[sel], labs[sel], 2, thr)
     np.testing.assert_array_equal(sub, O.occur_count(x[sel], y[sel], thr, labs[sel], 2))
+
+
+def test_many_thresholds_are_swept_in_chunks(L, ctx):
+    """L = 300 radii exceed one LDS histogram: the library sweeps threshold chunks; counts stay bit-exact."""
+    rng = np.random.default_rng(8)
+    n, k = 600, 3
+    x, y = (rng.random(n) * 90).astype(np.float32), (rng.random(n) * 90).astype(np.float32)
+    labs = rng.integers(0, k, n).astype(np.int32)
+    thr = rng.permutation(np.linspace(0.5, 120, 300, dtype=np.float32) ** 2)  # also unsorted
+    np.testing.assert_array_equal(L.cooccur_counts(ctx, x, y, labs, k, thr), O.occur_count(x, y, thr, labs, k))
