@@ -3,8 +3,8 @@
 CPU (numpy) restatement of the *device* permutation generator used by the HIP path when
 ``rng="philox"`` (``squidpy_amd/csrc/sqgr_rng.h``): Philox4x32-10 derives eight 32-bit round
 keys per (seed, permutation index, library); a keyed 8-round additive Feistel network over the
-mixed-radix domain ``A x B >= n`` (``A ~ B ~ sqrt(n)``, both >= 16) with cycle walking turns them into a
-bijection of ``[0, n)``.  The reference (squidpy) has no such generator — it uses numpy PCG64 shuffles
+mixed-radix domain ``A x B >= n`` (``A`` = power of two ~ sqrt(n), ``B = ceil(n / A)``, both >= 16) with cycle
+walking turns them into a bijection of ``[0, n)``.  The reference (squidpy) has no such generator — it uses numpy PCG64 shuffles
 (`/root/reference/src/squidpy/_utils.py:240-241`, ``gr/_nhood.py:533-538``) — so this file
 does not follow a reference file; it exists so that the GPU permutation test can be checked
 *bit for bit* (same permutations => same counts => same z-scores) and so that the statistical
@@ -64,9 +64,12 @@ def round_keys(seed: int, perms: np.ndarray, lib: int = 0) -> np.ndarray:
 
 
 def domain_dims(n: int) -> tuple[int, int]:
-    """Mixed-radix domain A x B >= n, A ~ B ~ sqrt(n), both >= 16 (sqgr_rng.h: make_domain)."""
-    a = math.isqrt(n - 1) + 1 if n > 1 else n
-    A = max(16, a)
+    """Mixed-radix domain A x B >= n: A = power of two ~ sqrt(n), B = ceil(n / A), both >= 16
+    (sqgr_rng.h: make_domain)."""
+    r = math.isqrt(n - 1) + 1 if n > 1 else n  # ceil(sqrt(n))
+    A = 16
+    while A < r:
+        A <<= 1
     B = max(16, -(-n // A))
     return A, B
 
@@ -83,8 +86,7 @@ def feistel(a: np.ndarray, b: np.ndarray, A: int, B: int, rk: np.ndarray) -> tup
     """One application of the keyed bijection of [0, A) x [0, B).  ``rk``: (8,) uint32."""
     A64, B64 = np.uint64(A), np.uint64(B)
     for r in range(0, N_ROUNDS, 2):
-        a = a + ((_F(b, np.uint64(int(rk[r]))) * A64) >> np.uint64(16))
-        a = np.where(a >= A64, a - A64, a)
+        a = (a + _F(b, np.uint64(int(rk[r])))) & (A64 - np.uint64(1))
         b = b + ((_F(a, np.uint64(int(rk[r + 1]))) * B64) >> np.uint64(16))
         b = np.where(b >= B64, b - B64, b)
     return a, b
@@ -117,8 +119,7 @@ def permutation_batch(n: int, rks: np.ndarray) -> np.ndarray:
 
     def apply(a: np.ndarray, b: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
         for r in range(0, N_ROUNDS, 2):
-            a = a + ((_F(b, keys[:, r : r + 1]) * A64) >> np.uint64(16))
-            a = np.where(a >= A64, a - A64, a)
+            a = (a + _F(b, keys[:, r : r + 1])) & (A64 - np.uint64(1))
             b = b + ((_F(a, keys[:, r + 1 : r + 2]) * B64) >> np.uint64(16))
             b = np.where(b >= B64, b - B64, b)
         return a, b

@@ -3,8 +3,8 @@
 //   round keys : Philox4x32-10( counter = (perm_lo, perm_hi, library, j), key = (seed_lo, seed_hi) ),
 //                j = 0,1  ->  8 x 32-bit keys per (seed, global permutation index, library)
 //   bijection  : 8-round alternating additive Feistel network on the mixed-radix domain A x B >= n
-//                (A ~ B ~ sqrt(n), both >= 16) whose round function uses only full-rate 24-bit multiplies
-//                (v_mul_u32_u24) and xor-shifts, cycle-walked into [0, n).
+//                (A = power of two ~ sqrt(n), B = ceil(n / A), both >= 16) whose round function uses only
+//                full-rate 24-bit multiplies (v_mul_u32_u24) and xor-shifts, cycle-walked into [0, n).
 //
 // oracle/devrng.py restates this file bit for bit; tests/test_devrng.py checks both the Philox
 // known-answer vectors and the statistical quality (uniformity over S_n for small n, agreement of
@@ -54,9 +54,9 @@ __device__ __forceinline__ uint32_t feistel_F(uint32_t v, uint32_t k) {
     return w >> 16;
 }
 
-// Mixed-radix domain A x B >= n with A ~ B ~ sqrt(n) (both >= 16, < 2^16): x <-> (a, b), x = a*B + b.
-// The excess A*B - n is < A + B, so cycle walking almost never iterates (no wave divergence), unlike a
-// power-of-two domain whose excess can approach n.
+// Mixed-radix domain A x B >= n, x <-> (a, b), x = a*B + b:  A = power of two ~ sqrt(n) (so the a-rounds reduce with
+// one AND and are exactly uniform), B = ceil(n / A); both >= 16 and < 2^16.  The excess A*B - n is < A, so cycle
+// walking almost never iterates (no wave divergence), unlike a power-of-two domain whose excess can approach n.
 struct FeistelDomain {
     uint32_t n;  // target domain [0, n)
     uint32_t A;  // radix of the high digit
@@ -72,25 +72,26 @@ __host__ __device__ inline uint32_t isqrt_ceil(uint32_t n) {
 __host__ __device__ inline FeistelDomain make_domain(uint32_t n) {
     FeistelDomain d;
     d.n = n;
-    uint32_t a = isqrt_ceil(n);
-    d.A = a < 16u ? 16u : a;
+    const uint32_t r = isqrt_ceil(n);
+    uint32_t a = 16u;
+    while (a < r) a <<= 1;
+    d.A = a;
     uint32_t b = (n + d.A - 1) / d.A;
     d.B = b < 16u ? 16u : b;
     return d;
 }
 
 // image of x (< n) under the cycle-walked keyed bijection of [0, n): 8 alternating additive Feistel rounds
-//   a <- (a + (F(b,k_r) * A >> 16)) mod A ;  b <- (b + (F(a,k_r+1) * B >> 16)) mod B
+//   a <- (a + F(b,k_r)) mod A  (A = 2^m: one AND) ;  b <- (b + (F(a,k_r+1) * B >> 16)) mod B
 __device__ __forceinline__ uint32_t feistel_perm_ab(uint32_t a, uint32_t b, const FeistelDomain& d,
                                                     const uint32_t* __restrict__ rk, uint32_t* hi_digit = nullptr) {
     uint32_t x;
     do {
 #pragma unroll
         for (int r = 0; r < FEISTEL_ROUNDS; r += 2) {
-            uint32_t s = a + (__umul24(feistel_F(b, rk[r]), d.A) >> 16);
-            a = min(s, s - d.A);  // s < 2A: subtract A when s >= A (unsigned wrap makes the other branch huge)
+            a = (a + feistel_F(b, rk[r])) & (d.A - 1u);
             uint32_t t = b + (__umul24(feistel_F(a, rk[r + 1]), d.B) >> 16);
-            b = min(t, t - d.B);
+            b = min(t, t - d.B);  // t < 2B: subtract B when t >= B (unsigned wrap makes the other branch huge)
         }
         x = a * d.B + b;
     } while (x >= d.n);

@@ -178,10 +178,12 @@ def test_frontend_config1_hex_grid(L):
     perms_np = O.nhood_perm_counts_numpy(adj.indices, adj.indptr, lab, 10, 7, 200)
     np.testing.assert_array_equal(res_np.zscore, O.nhood_zscore(count_ref, perms_np))
     # statistical agreement between the two generators: same null distribution
-    z2 = O.nhood_zscore(count_ref, O.nhood_perm_counts_numpy(adj.indices, adj.indptr, lab, 10, 1, 1000))
+    perms_np1000 = O.nhood_perm_counts_numpy(adj.indices, adj.indptr, lab, 10, 1, 1000)
+    z2 = O.nhood_zscore(count_ref, perms_np1000)
     assert np.abs(res.zscore - z2).max() < 0.35 * max(1.0, np.abs(z2).max() * 0.1 + 1)
-    np.testing.assert_allclose(ref.mean(0), perms_np.mean(0), rtol=0.02)
-    np.testing.assert_allclose(ref.std(0), perms_np.std(0), rtol=0.2)
+    np.testing.assert_allclose(ref.mean(0), perms_np1000.mean(0), rtol=0.02)
+    # std of 1000 draws has a relative standard error of 1/sqrt(2000) = 2.2 %: 0.16 is ~5 sigma of the difference
+    np.testing.assert_allclose(ref.std(0), perms_np1000.std(0), rtol=0.16)
 
 
 def test_frontend_slots_reproducibility_and_libraries(L):
