@@ -104,6 +104,20 @@ int sqgr_nhood_destroy(sqgr_nhood* plan);
 int sqgr_nhood_run(sqgr_nhood* plan, uint64_t seed, int64_t perm_begin, int64_t perm_end, const int64_t* shift,
                    int64_t* out_sum, uint64_t* out_sumsq, uint32_t* out_perms);
 
+/* The same test with numpy's OWN random streams reproduced bit for bit on the device: permutation p is
+ * shuffled by numpy's algorithm (PCG64 + Generator.shuffle's reverse Fisher-Yates with masked rejection; with libraries the
+ * per-library sub-shuffles of `_shuffle_group`, gr/_utils.py:185-213) starting from generator state
+ *   pcg_states[4*p .. 4*p+3] = {state_hi, state_lo, inc_hi, inc_lo}
+ * = `np.random.PCG64(SeedSequence(seed).spawn(n_perms)[p]).state["state"]`, i.e. the state of `generators[p]` of
+ * `spawn_generators` (_utils.py:240-241).  Outputs as sqgr_nhood_run; with out_perms the caller can apply the reference's
+ * float64 `perms.mean/std` (gr/_nhood.py:231) and obtain Squidpy's z-scores for that seed exactly. */
+int sqgr_nhood_run_pcg64(sqgr_nhood* plan, const uint64_t* pcg_states, int64_t n_perms, const int64_t* shift, int64_t* out_sum,
+                         uint64_t* out_sumsq, uint32_t* out_perms);
+
+/* numpy's `Generator.permutation(n)` for n_perms generator states (layout as above), on the device:
+ * out_idx int32[n_perms][n] — the row permutations of `_score_helper` (gr/_ppatterns.py:269-271). */
+int sqgr_pcg64_permutations(sqgr_ctx* ctx, int64_t n, const uint64_t* pcg_states, int64_t n_perms, int32_t* out_idx);
+
 /* Debug/parity hook: the shuffled label vector of one global permutation index, uint8[n]. */
 int sqgr_nhood_shuffled_labels(sqgr_nhood* plan, uint64_t seed, int64_t perm, uint8_t* out_labels);
 

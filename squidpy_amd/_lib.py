@@ -44,6 +44,8 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "sqgr_nhood_create": (C.c_int, [C.c_void_p, C.c_void_p, c_i32p, C.c_int32, c_i32p, C.c_int32, C.POINTER(C.c_void_p)]),
     "sqgr_nhood_destroy": (C.c_int, [C.c_void_p]),
     "sqgr_nhood_run": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, c_i64p, c_i64p, c_u64p, c_u32p]),
+    "sqgr_nhood_run_pcg64": (C.c_int, [C.c_void_p, c_u64p, C.c_int64, c_i64p, c_i64p, c_u64p, c_u32p]),
+    "sqgr_pcg64_permutations": (C.c_int, [C.c_void_p, C.c_int64, c_u64p, C.c_int64, c_i32p]),
     "sqgr_nhood_shuffled_labels": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, c_u8p]),
     "sqgr_nhood_tune": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "sqgr_interaction_matrix": (C.c_int, [C.c_void_p, C.c_void_p, c_i32p, C.c_int32, C.c_int32, c_f64p]),
@@ -302,6 +304,28 @@ class NhoodPlan:
         )
         return out_sum, out_sq, perms
 
+    def run_pcg64(
+        self, states: np.ndarray, shift: np.ndarray | None = None, return_perms: bool = False
+    ) -> tuple[np.ndarray, np.ndarray, np.ndarray | None]:
+        """Same as :meth:`run` with numpy's own streams reproduced on the device; ``states``: (P, 4) uint64 rows
+        ``[state_hi, state_lo, inc_hi, inc_lo]`` of the PCG64 generators (see ``_utils.pcg64_states``)."""
+        k = self.n_cls
+        states = _as(states, np.uint64)
+        if states.ndim != 2 or states.shape[1] != 4:
+            raise ValueError(f"Expected states of shape (n_perms, 4), found {states.shape}.")
+        s = _as(shift, np.int64).reshape(-1) if shift is not None else None
+        out_sum = np.zeros((k, k), dtype=np.int64)
+        out_sq = np.zeros((k, k), dtype=np.uint64)
+        perms = np.zeros((states.shape[0], k, k), dtype=np.uint32) if return_perms else None
+        _check(
+            self.ctx.lib,
+            self.ctx.lib.sqgr_nhood_run_pcg64(
+                self.h, _ptr(states, c_u64p), states.shape[0], _ptr(s, c_i64p), _ptr(out_sum, c_i64p), _ptr(out_sq, c_u64p),
+                _ptr(perms, c_u32p),
+            ),
+        )
+        return out_sum, out_sq, perms
+
     def shuffled_labels(self, seed: int, perm: int) -> np.ndarray:
         out = np.zeros(self.g.n, dtype=np.uint8)
         _check(
@@ -453,3 +477,11 @@ def knn_dist(ctx: Context, query: np.ndarray, ref: np.ndarray, k: int, metric: s
     out = np.zeros((query.shape[0], k), dtype=np.float64)
     _check(ctx.lib, ctx.lib.sqgr_knn_dist(ctx.h, _ptr(query, c_f64p), query.shape[0], _ptr(ref, c_f64p), ref.shape[0], k, m, _ptr(out, c_f64p)))
     return np.sqrt(out) if m == 0 else out
+
+
+def pcg64_permutations(ctx: Context, n: int, states: np.ndarray) -> np.ndarray:
+    """numpy's ``Generator.permutation(n)`` for every generator state in ``states`` (P, 4), computed on the device."""
+    states = _as(states, np.uint64)
+    out = np.zeros((states.shape[0], n), dtype=np.int32)
+    _check(ctx.lib, ctx.lib.sqgr_pcg64_permutations(ctx.h, n, _ptr(states, c_u64p), states.shape[0], _ptr(out, c_i32p)))
+    return out

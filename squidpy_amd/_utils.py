@@ -136,3 +136,16 @@ def resolve_seed(seed: int | None) -> int:
     if seed is None:
         return int.from_bytes(os.urandom(8), "little")
     return int(seed) & 0xFFFFFFFFFFFFFFFF
+
+
+def pcg64_states(seed: int | None, n: int, begin: int = 0, end: int | None = None) -> np.ndarray:
+    """Initial PCG64 states of ``spawn_generators(seed, n)[begin:end]`` as (k, 4) uint64 rows
+    ``[state_hi, state_lo, inc_hi, inc_lo]`` — what the device needs to continue numpy's streams bit for bit."""
+    end = n if end is None else end
+    mask = (1 << 64) - 1
+    seqs = np.random.SeedSequence(seed).spawn(n)[begin:end]
+    out = np.empty((len(seqs), 4), dtype=np.uint64)
+    for k, s in enumerate(seqs):
+        st = np.random.PCG64(s).state["state"]
+        out[k] = (st["state"] >> 64, st["state"] & mask, st["inc"] >> 64, st["inc"] & mask)
+    return out

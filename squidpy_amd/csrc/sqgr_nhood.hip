@@ -17,6 +17,7 @@
 #include "sqgr_common.h"
 #include "sqgr_rng.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -310,6 +311,109 @@ __global__ __launch_bounds__(256) void k_edge_pairs(int64_t nnz, const int32_t* 
         atomicAdd(&out_u64[la * K + lb], 1ull);
 }
 
+// ---------------------------------------------------------------------------------------------- numpy-compatible streams
+// Bit-for-bit numpy on the device ("next" row f-1 of SURVEY.md §8): permutation p is shuffled by numpy's own
+// algorithm — PCG64 (128-bit LCG, XSL-RR output, 32-bit halves buffered low first) driving the reverse
+// Fisher-Yates of Generator.shuffle with masked rejection sampling — from the generator state that
+// `np.random.default_rng(SeedSequence(seed).spawn(n)[p])` starts in (computed by numpy on the host, 32 bytes per
+// permutation).  Fisher-Yates is inherently sequential, so the parallelism is ONE THREAD PER PERMUTATION: tens of
+// thousands of permutations advance in lock-step, each on its own column of a [position][permutation] byte matrix
+// (the access to row i is coalesced across threads, the access to row j is the scattered one).
+struct Pcg64 {
+    uint64_t lo, hi, inc_lo, inc_hi;
+    uint32_t buf;
+    bool has;
+};
+
+__device__ __forceinline__ uint64_t pcg64_next64(Pcg64& g) {
+    const uint64_t ML = 0x4385DF649FCCF645ull, MH = 0x2360ED051FC65DA4ull;  // PCG_DEFAULT_MULTIPLIER_128
+    const uint64_t plo = g.lo * ML;
+    const uint64_t phi = __umul64hi(g.lo, ML) + g.lo * MH + g.hi * ML;
+    const uint64_t nlo = plo + g.inc_lo;
+    const uint64_t nhi = phi + g.inc_hi + (nlo < plo ? 1ull : 0ull);
+    g.lo = nlo;
+    g.hi = nhi;
+    const uint64_t x = nhi ^ nlo;
+    const unsigned rot = (unsigned)(nhi >> 58);
+    return (x >> rot) | (x << ((64u - rot) & 63u));
+}
+
+__device__ __forceinline__ uint32_t pcg64_next32(Pcg64& g) {
+    if (g.has) {
+        g.has = false;
+        return g.buf;
+    }
+    const uint64_t v = pcg64_next64(g);
+    g.has = true;
+    g.buf = (uint32_t)(v >> 32);
+    return (uint32_t)v;
+}
+
+// W[pos * stride + p]: column p = the array numpy would shuffle for permutation p (positions grouped by library,
+// libraries in category order == the order `_shuffle_group` visits them, gr/_utils.py:207-212).
+template <typename T, bool ARANGE>
+__global__ __launch_bounds__(64) void k_pcg_shuffle(int64_t n, int n_libs, const uint32_t* __restrict__ lib_off,
+                                                    const T* __restrict__ base_pos, const uint64_t* __restrict__ states,
+                                                    int64_t P, int64_t stride, T* __restrict__ W) {
+    const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    Pcg64 g;
+    g.hi = states[4 * p + 0];
+    g.lo = states[4 * p + 1];
+    g.inc_hi = states[4 * p + 2];
+    g.inc_lo = states[4 * p + 3];
+    g.has = false;
+    g.buf = 0;
+    T* col = W + p;
+    for (int64_t e = 0; e < n; ++e) col[e * stride] = ARANGE ? (T)e : base_pos[e];
+    for (int l = 0; l < n_libs; ++l) {
+        const uint32_t off = lib_off[l];
+        const uint32_t m = lib_off[l + 1] - off;
+        if (m < 2) continue;
+        T* sub = col + (int64_t)off * stride;
+        uint32_t mask = m - 1;  // smallest all-ones mask >= i, maintained as i decreases
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        for (uint32_t i = m - 1; i >= 1; --i) {
+            if ((mask >> 1) >= i) mask >>= 1;
+            uint32_t j;
+            do {
+                j = pcg64_next32(g) & mask;
+            } while (j > i);
+            const T a = sub[(int64_t)i * stride], b = sub[(int64_t)j * stride];
+            sub[(int64_t)i * stride] = b;
+            sub[(int64_t)j * stride] = a;
+        }
+    }
+}
+
+// columns of W -> slab rows of the batched count kernel: slab[(batch*n + i)*B + b] = W[pos(i)][p0 + batch*B + b]
+template <int B, bool HAS_LIBS>
+__global__ __launch_bounds__(256) void k_columns_to_slab(int64_t n, int64_t stride, const uint8_t* __restrict__ W, int64_t p0,
+                                                         const int32_t* __restrict__ lib_of, const int32_t* __restrict__ rank_of,
+                                                         const uint32_t* __restrict__ lib_off, uint8_t* __restrict__ slab_all) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int batch = blockIdx.y;
+    const int64_t pos = HAS_LIBS ? (int64_t)lib_off[lib_of[i]] + rank_of[i] : i;
+    const uint4* src = reinterpret_cast<const uint4*>(W + pos * stride + p0 + (int64_t)batch * B);  // 16-byte aligned
+    uint4* dst = reinterpret_cast<uint4*>(slab_all + ((size_t)batch * n + i) * B);
+#pragma unroll
+    for (int v = 0; v < B / 16; ++v) dst[v] = src[v];
+}
+
+// idx[p][i] = W[i][p]  (autocorr row permutations)
+__global__ __launch_bounds__(256) void k_columns_to_rows_i32(int64_t n, int64_t stride, const int32_t* __restrict__ W, int64_t P,
+                                                             int32_t* __restrict__ idx) {
+    __shared__ int32_t tile[32][33];
+    const int64_t i0 = (int64_t)blockIdx.x * 32, q0 = (int64_t)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8)
+        tile[r][tx] = (i0 + r < n && q0 + tx < P) ? W[(i0 + r) * stride + q0 + tx] : 0;
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (q0 + r < P && i0 + tx < n) idx[(size_t)(q0 + r) * n + i0 + tx] = tile[tx][r];
+}
+
 }  // namespace sqgr
 
 using namespace sqgr;
@@ -342,6 +446,11 @@ struct sqgr_nhood {
     int kpad = 0;
     DevBuf<int32_t> lib_of, rank_of;
     DevBuf<LibDom> libs;
+    DevBuf<uint8_t> base_pos;   // base labels in library-grouped position order (numpy-compatible mode)
+    DevBuf<uint32_t> lib_off;   // [n_libs + 1] first position of every library
+    DevBuf<uint8_t> wcol;       // [position][stride] column workspace of the numpy-compatible shuffle
+    DevBuf<uint64_t> pcg_states;
+    bool has_labels = false;
     // tuning
     int B = 16;
     int nblk = 0;
@@ -624,6 +733,23 @@ int sqgr_nhood_create(sqgr_ctx* ctx, const sqgr_graph* g, const int32_t* labels,
         cum.resize(cum_words + (blk.size() + 3) / 4);
         memcpy(cum.data() + cum_words, blk.data(), blk.size());
         if (!libs_on) p->dom0 = doms[0];
+        {   // numpy-compatible mode: labels in library-grouped position order + library offsets
+            std::vector<uint32_t> off((size_t)p->n_libs + 1, 0);
+            for (int l = 0; l < p->n_libs; ++l) off[l + 1] = off[l] + (uint32_t)cnt[l];
+            std::vector<uint8_t> base((size_t)n, 0);
+            if (labels)
+                for (int64_t i = 0; i < n; ++i) base[libs_on ? off[lib_ids[i]] + (uint32_t)rank[i] : (uint32_t)i] = (uint8_t)labels[i];
+            p->has_labels = labels != nullptr;
+            if ((rc = p->base_pos.alloc((size_t)n)) != SQGR_OK) break;
+            if ((rc = p->lib_off.alloc(off.size())) != SQGR_OK) break;
+            hipError_t e2 = hipMemcpy(p->base_pos.p, base.data(), (size_t)n, hipMemcpyHostToDevice);
+            if (e2 == hipSuccess) e2 = hipMemcpy(p->lib_off.p, off.data(), off.size() * 4, hipMemcpyHostToDevice);
+            if (e2 != hipSuccess) {
+                set_error("label upload failed: %s", hipGetErrorString(e2));
+                rc = SQGR_ERR_HIP;
+                break;
+            }
+        }
         if ((rc = p->cum.alloc(cum.size())) != SQGR_OK) break;
         hipError_t e = hipMemcpy(p->cum.p, cum.data(), cum.size() * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess && libs_on) {
@@ -811,6 +937,104 @@ int sqgr_nhood_counts_batch(sqgr_ctx* ctx, const sqgr_graph* g, const uint8_t* l
     } while (0);
     sqgr_nhood_destroy(p);
     return rc;
+}
+
+int sqgr_nhood_run_pcg64(sqgr_nhood* plan, const uint64_t* pcg_states, int64_t n_perms, const int64_t* shift, int64_t* out_sum,
+                         uint64_t* out_sumsq, uint32_t* out_perms) {
+    SQGR_REQUIRE(plan && pcg_states && out_sum && out_sumsq && n_perms >= 0, "null argument or n_perms < 0");
+    sqgr_nhood* p = plan;
+    SQGR_REQUIRE(p->has_labels, "plan was created without labels");
+    sqgr_ctx* ctx = p->ctx;
+    SQGR_HIP(hipSetDevice(ctx->device));
+    SQGR_TRY(p->ensure_workspace(out_perms != nullptr));
+    hipStream_t st = ctx->stream;
+    const int B = p->B, K2 = p->K2, hw = p->hist_words();
+    const int64_t n = p->n;
+    if (shift)
+        SQGR_HIP(hipMemcpyAsync(p->shift.p, shift, (size_t)K2 * 8, hipMemcpyHostToDevice, st));
+    else
+        SQGR_HIP(hipMemsetAsync(p->shift.p, 0, (size_t)K2 * 8, st));
+    SQGR_HIP(hipMemsetAsync(p->acc_sum.p, 0, (size_t)p->nbatch * hw * 8, st));
+    SQGR_HIP(hipMemsetAsync(p->acc_sq.p, 0, (size_t)p->nbatch * hw * 8, st));
+    if (out_perms && n_perms > 0) SQGR_TRY(p->perms_dev.ensure((size_t)n_perms * K2));
+    // permutations per chunk: one thread each; the column matrix takes n bytes per permutation (<= 25 % of free HBM)
+    size_t free_b = 0, total_b = 0;
+    SQGR_HIP(hipMemGetInfo(&free_b, &total_b));
+    int64_t budget = (int64_t)std::min<size_t>(free_b / 4, (size_t)64 << 30);
+    int64_t chunk = std::max<int64_t>(64, std::min<int64_t>(budget / std::max<int64_t>(n, 1), 1 << 17));
+    chunk = std::min<int64_t>(chunk, ceil_div(std::max<int64_t>(n_perms, 1), 64) * 64) / 64 * 64;
+    const int64_t stride = chunk;  // multiple of 64 => 16-byte aligned slab gathers
+    SQGR_TRY(p->wcol.ensure((size_t)n * stride));
+    SQGR_TRY(p->pcg_states.ensure((size_t)chunk * 4));
+    const int64_t per_launch = (int64_t)p->nbatch * B;
+    for (int64_t c0 = 0; c0 < n_perms; c0 += chunk) {
+        const int64_t pc = std::min(chunk, n_perms - c0);
+        SQGR_HIP(hipMemcpyAsync(p->pcg_states.p, pcg_states + (size_t)c0 * 4, (size_t)pc * 32, hipMemcpyHostToDevice, st));
+        {
+            LaunchTimer t(ctx, "nhood_pcg64_shuffle");
+            k_pcg_shuffle<uint8_t, false><<<(unsigned)ceil_div(pc, 64), 64, 0, st>>>(n, p->n_libs, p->lib_off.p, p->base_pos.p,
+                                                                                    p->pcg_states.p, pc, stride, p->wcol.p);
+            SQGR_HIP(hipGetLastError());
+        }
+        for (int64_t q0 = 0; q0 < pc; q0 += per_launch) {
+            const int64_t todo = std::min(per_launch, pc - q0);
+            const int nb = (int)ceil_div(todo, B);
+            {
+                LaunchTimer t(ctx, "nhood_columns_to_slab");
+                dim3 grid((unsigned)ceil_div(n, 256), nb);
+#define SQGR_C2S(BB, LIBS) k_columns_to_slab<BB, LIBS><<<grid, 256, 0, st>>>(n, stride, p->wcol.p, q0, p->lib_of.p, p->rank_of.p, p->lib_off.p, p->slab.p)
+                if (B == 32) { if (p->has_libs) SQGR_C2S(32, true); else SQGR_C2S(32, false); }
+                else { if (p->has_libs) SQGR_C2S(16, true); else SQGR_C2S(16, false); }
+#undef SQGR_C2S
+                SQGR_HIP(hipGetLastError());
+            }
+            SQGR_TRY(p->count_batches(nb, 0));
+            // columns past `pc` of the last batch hold stale data: reduce masks permutations >= n_perms
+            SQGR_TRY(p->reduce_batches(nb, c0 + q0, 0, c0 + pc, out_perms ? p->perms_dev.p : nullptr));
+        }
+    }
+    {
+        LaunchTimer t(ctx, "nhood_finalize");
+        k_finalize<<<(unsigned)ceil_div(K2, 256), 256, 0, st>>>(p->acc_sum.p, p->acc_sq.p, p->nbatch, hw, B, K2, p->fin_sum.p,
+                                                               p->fin_sq.p);
+        SQGR_HIP(hipGetLastError());
+    }
+    SQGR_HIP(hipMemcpyAsync(out_sum, p->fin_sum.p, (size_t)K2 * 8, hipMemcpyDeviceToHost, st));
+    SQGR_HIP(hipMemcpyAsync(out_sumsq, p->fin_sq.p, (size_t)K2 * 8, hipMemcpyDeviceToHost, st));
+    if (out_perms && n_perms > 0)
+        SQGR_HIP(hipMemcpyAsync(out_perms, p->perms_dev.p, (size_t)n_perms * K2 * 4, hipMemcpyDeviceToHost, st));
+    SQGR_HIP(hipStreamSynchronize(st));
+    return SQGR_OK;
+}
+
+int sqgr_pcg64_permutations(sqgr_ctx* ctx, int64_t n, const uint64_t* pcg_states, int64_t n_perms, int32_t* out_idx) {
+    SQGR_REQUIRE(ctx && pcg_states && out_idx && n > 0 && n < (int64_t)0x7fffffff && n_perms >= 0, "bad argument");
+    if (n_perms == 0) return SQGR_OK;
+    SQGR_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int64_t chunk = std::max<int64_t>(64, std::min<int64_t>(ceil_div(n_perms, 64) * 64, (((int64_t)8 << 30) / (n * 4)) / 64 * 64));
+    DevBuf<int32_t> W, idx;
+    DevBuf<uint64_t> states;
+    DevBuf<uint32_t> off;
+    SQGR_TRY(W.alloc((size_t)n * chunk));
+    SQGR_TRY(idx.alloc((size_t)chunk * n));
+    SQGR_TRY(states.alloc((size_t)chunk * 4));
+    SQGR_TRY(off.alloc(2));
+    const uint32_t off_h[2] = {0u, (uint32_t)n};
+    SQGR_HIP(hipMemcpyAsync(off.p, off_h, 8, hipMemcpyHostToDevice, st));
+    for (int64_t c0 = 0; c0 < n_perms; c0 += chunk) {
+        const int64_t pc = std::min(chunk, n_perms - c0);
+        SQGR_HIP(hipMemcpyAsync(states.p, pcg_states + (size_t)c0 * 4, (size_t)pc * 32, hipMemcpyHostToDevice, st));
+        {
+            LaunchTimer t(ctx, "autocorr_pcg64_permutation");
+            k_pcg_shuffle<int32_t, true><<<(unsigned)ceil_div(pc, 64), 64, 0, st>>>(n, 1, off.p, nullptr, states.p, pc, chunk, W.p);
+            k_columns_to_rows_i32<<<dim3((unsigned)ceil_div(n, 32), (unsigned)ceil_div(pc, 32)), 256, 0, st>>>(n, chunk, W.p, pc, idx.p);
+            SQGR_HIP(hipGetLastError());
+        }
+        SQGR_HIP(hipMemcpyAsync(out_idx + (size_t)c0 * n, idx.p, (size_t)pc * n * 4, hipMemcpyDeviceToHost, st));
+        SQGR_HIP(hipStreamSynchronize(st));
+    }
+    return SQGR_OK;
 }
 
 }  // extern "C"

@@ -23,6 +23,7 @@ from .._utils import (
     category_codes,
     extract_adata_if_sdata,
     get_n_processes,
+    pcg64_states,
     resolve_seed,
     spawn_generators,
 )
@@ -92,8 +93,11 @@ def nhood_enrichment(
         ``"philox"`` (default): label shuffles are generated on the GPU by the counter-based generator of
         ``csrc/sqgr_rng.h`` keyed by ``(seed, permutation index, library)``; results are reproducible for a
         given ``seed`` and independent of the number of GPUs, but follow a different stream than numpy.
-        ``"numpy"``: the reference's own PCG64 shuffles (``SeedSequence(seed).spawn(n_perms)``) are drawn on
-        the host and injected, reproducing Squidpy's z-scores for that ``seed`` exactly (slower).
+        ``"numpy"``: the reference's own streams (``SeedSequence(seed).spawn(n_perms)`` -> PCG64 ->
+        ``Generator.shuffle``) are reproduced bit for bit *on the GPU* (one thread per permutation), and the z-score
+        is formed with the reference's float64 ``perms.mean/std``: Squidpy's z-scores for that ``seed``, exactly
+        (about 10x slower than ``"philox"``, still orders of magnitude faster than the CPU).
+        ``"numpy-host"``: same streams drawn by numpy on the host and injected (cross-check path).
     device
         HIP device index (default: ``LOCAL_RANK`` or 0).
 
@@ -105,8 +109,8 @@ def nhood_enrichment(
     _assert_categorical_obs(adata, cluster_key)
     _assert_connectivity_key(adata, connectivity_key)
     assert_positive(n_perms, name="n_perms")
-    if rng not in ("philox", "numpy"):
-        raise ValueError(f"Invalid option `{rng}` for `rng`. Valid options are: `['philox', 'numpy']`.")
+    if rng not in ("philox", "numpy", "numpy-host"):
+        raise ValueError(f"Invalid option `{rng}` for `rng`. Valid options are: `['philox', 'numpy', 'numpy-host']`.")
 
     adj = adata.obsp[connectivity_key]
     int_clust, n_cls = category_codes(adata.obs[cluster_key])
@@ -123,8 +127,21 @@ def nhood_enrichment(
     graph = Graph(ctx, adj, with_data=False)
     try:
         count = nhood_counts(ctx, graph, int_clust, n_cls)
-        if rng == "numpy":
+        if rng == "numpy-host":
             zscore = _zscore_numpy_streams(ctx, graph, int_clust, n_cls, lib_codes, n_libs, seed, n_perms, count)
+        elif rng == "numpy":
+            rank, world = _dist.world()
+            lo, hi = _dist.shard_range(n_perms, rank, world)
+            if seed is None:
+                seed = _broadcast_seed(resolve_seed(None))
+            plan = NhoodPlan(ctx, graph, int_clust, n_cls, lib_codes, n_libs)
+            try:
+                _, _, perms = plan.run_pcg64(pcg64_states(seed, n_perms, lo, hi), return_perms=True)
+            finally:
+                plan.close()
+            perms = np.concatenate(_dist.allgather_object(perms), axis=0).astype(np.float64)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                zscore = (count - perms.mean(axis=0)) / perms.std(axis=0)  # gr/_nhood.py:231 verbatim
         else:
             rank, world = _dist.world()
             lo, hi = _dist.shard_range(n_perms, rank, world)

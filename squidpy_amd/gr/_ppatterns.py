@@ -17,7 +17,7 @@ import pandas as pd
 from scipy import sparse
 
 from .._constants import SpatialAutocorr
-from .._lib import AutocorrPlan, Graph, cooccur_counts, default_context
+from .._lib import AutocorrPlan, Graph, cooccur_counts, default_context, pcg64_permutations
 from .._stats import multipletests_pvals, p_value_calc
 from .._utils import (
     _assert_categorical_obs,
@@ -30,6 +30,7 @@ from .._utils import (
     deprecated_params,
     extract_adata_if_sdata,
     get_n_processes,
+    pcg64_states,
     resolve_seed,
     spawn_generators,
 )
@@ -196,15 +197,15 @@ def spatial_autocorr(
     ``{pval}_{corr_method}`` columns, sort order and ``adata.uns['moranI'|'gearyC']`` slot as the reference.
 
     Extra keyword-only parameters: ``rng`` — ``"philox"`` (default) draws the row permutations on the GPU, keyed by
-    ``(seed, permutation index)``; ``"numpy"`` draws the reference's ``rng.permutation(N)`` streams on the host and
-    injects them (reproduces Squidpy's permutation columns for that ``seed``); ``device``; ``gene_block`` — features
+    ``(seed, permutation index)``; ``"numpy"`` reproduces the reference's ``rng.permutation(N)`` streams bit for bit on the GPU
+    (Squidpy's permutation columns for that ``seed``; ``"numpy-host"`` draws them with numpy on the host); ``device``; ``gene_block`` — features
     resident on the GPU at a time.  With a ``torch.distributed`` process group, feature blocks are split across ranks
     and the score columns gathered.
     """
     adata = extract_adata_if_sdata(adata, table_key=table_key)
     _assert_connectivity_key(adata, connectivity_key)
-    if rng not in ("philox", "numpy"):
-        raise ValueError(f"Invalid option `{rng}` for `rng`. Valid options are: `['philox', 'numpy']`.")
+    if rng not in ("philox", "numpy", "numpy-host"):
+        raise ValueError(f"Invalid option `{rng}` for `rng`. Valid options are: `['philox', 'numpy', 'numpy-host']`.")
     vals, index = _extract_vals(adata, attr, genes, layer, use_raw)
 
     mode = SpatialAutocorr(mode)
@@ -225,12 +226,14 @@ def spatial_autocorr(
     n = g.shape[0]
     n_feat = vals.shape[0]
     perm_idx = None
-    if n_perms is not None and rng == "numpy":
+    key = resolve_seed(seed)
+    ctx = default_context(device)
+    if n_perms is not None and rng == "numpy-host":
         gens = spawn_generators(seed, n_perms)
         perm_idx = np.stack([gens[p].permutation(n) for p in range(n_perms)]).astype(np.int32)
-    key = resolve_seed(seed)
+    elif n_perms is not None and rng == "numpy":  # numpy's `rng.permutation(N)` streams reproduced on the device
+        perm_idx = pcg64_permutations(ctx, n, pcg64_states(seed if seed is not None else key, n_perms))
 
-    ctx = default_context(device)
     graph = Graph(ctx, g, with_data=True)
     rank, world = _dist.world()
     blocks = [(b0, min(n_feat, b0 + gene_block)) for b0 in range(0, n_feat, max(int(gene_block), 1))]

@@ -182,3 +182,13 @@ def test_statistical_properties_under_permutation(L, ctx):
     sc = plan.perms("geary", seed=4, perm_begin=0, perm_end=200)
     assert abs(si.mean() + 1.0 / (n - 1)) < 5e-4 and abs(sc.mean() - 1.0) < 2e-3
     assert plan.scores("moran")[0] > si[:, 0].max() + 0.3 and plan.scores("geary")[0] < sc[:, 0].min() - 0.3
+
+
+def test_numpy_device_streams_equal_host_streams(L):
+    """rng="numpy" (PCG64 permutations generated on the GPU) gives exactly the frame of rng="numpy-host"."""
+    import squidpy_amd as sq
+
+    adata = _adata(n=400, G=24)
+    a = sq.gr.spatial_autocorr(adata, mode="geary", n_perms=40, seed=5, copy=True, rng="numpy")
+    b = sq.gr.spatial_autocorr(adata, mode="geary", n_perms=40, seed=5, copy=True, rng="numpy-host")
+    pd.testing.assert_frame_equal(a, b)

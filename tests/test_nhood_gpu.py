@@ -227,3 +227,52 @@ def test_config2_size_properties(L, ctx):
     np.testing.assert_array_equal(s1, perms.astype(np.int64).sum(0))
     ref = O.nhood_perm_counts_philox(adj.indices, adj.indptr, labels, k, 11, 0, 3)
     np.testing.assert_array_equal(perms[:3], ref.astype(np.uint32))
+
+
+def test_numpy_streams_reproduced_on_device(L, ctx, golden):
+    """numpy's PCG64 + Generator.shuffle on the GPU, bit for bit — per-permutation counts equal the
+    reference helper's golden output; with libraries the `_shuffle_group` semantics; z-score == the reference's."""
+    import squidpy_amd as sq
+    from squidpy_amd._utils import pcg64_states
+
+    adj = _golden_graph(golden)
+    g = L.Graph(ctx, adj)
+    k = int(golden["nhood_k"])
+    labels = golden["nhood_labels"].astype(np.int32)
+    seed = int(golden["nhood_seed"])
+    P = golden["nhood_perms"].shape[0]
+    plan = L.NhoodPlan(ctx, g, labels, k)
+    s1, s2, perms = plan.run_pcg64(pcg64_states(seed, P), return_perms=True)
+    np.testing.assert_array_equal(perms, golden["nhood_perms"].astype(np.uint32))
+    np.testing.assert_array_equal(s1, perms.astype(np.int64).sum(0))
+    plan_l = L.NhoodPlan(ctx, g, labels, k, golden["nhood_lib_codes"], 3)
+    _, _, perms_l = plan_l.run_pcg64(pcg64_states(seed, P), return_perms=True)
+    np.testing.assert_array_equal(perms_l, golden["nhood_perms_lib"].astype(np.uint32))
+    # front-end: rng="numpy" (device) == rng="numpy-host" == golden z-score of the reference
+    obs = pd.DataFrame({"cl": pd.Categorical.from_codes(labels, list("abcde")), "lib": pd.Categorical.from_codes(golden["nhood_lib_codes"], ["x", "y", "z"])})
+    adata = sq.AnnDataLite(obs=obs, obsp={"spatial_connectivities": adj})
+    z_dev = sq.gr.nhood_enrichment(adata, "cl", n_perms=P, seed=seed, copy=True, rng="numpy").zscore
+    z_host = sq.gr.nhood_enrichment(adata, "cl", n_perms=P, seed=seed, copy=True, rng="numpy-host").zscore
+    np.testing.assert_array_equal(z_dev, golden["nhood_zscore"])
+    np.testing.assert_array_equal(z_host, golden["nhood_zscore"])
+    zl = sq.gr.nhood_enrichment(adata, "cl", library_key="lib", n_perms=P, seed=seed, copy=True, rng="numpy").zscore
+    np.testing.assert_array_equal(zl, O.nhood_zscore(golden["nhood_count"], golden["nhood_perms_lib"]))
+
+
+@pytest.mark.parametrize("n", [2, 77, 5000, 70001])
+def test_numpy_permutation_streams_on_device(L, ctx, n):
+    from squidpy_amd._utils import pcg64_states
+
+    P = 70 if n < 10000 else 5
+    got = L.pcg64_permutations(ctx, n, pcg64_states(13, P))
+    np.testing.assert_array_equal(got, O.autocorr_perm_indices(n, 13, P))
+    labels = np.random.default_rng(0).integers(0, 7, n)
+    g = L.Graph(ctx, sp.identity(n, format="csr", dtype=np.float32))
+    plan = L.NhoodPlan(ctx, g, labels, 7)
+    _, _, perms = plan.run_pcg64(pcg64_states(13, P), return_perms=True)
+    ref = O.nhood_perm_counts_numpy(g_identity_indices(n), np.arange(n + 1), labels, 7, 13, P)
+    np.testing.assert_array_equal(perms, ref.astype(np.uint32))
+
+
+def g_identity_indices(n):
+    return np.arange(n)
