@@ -360,6 +360,20 @@ def main() -> None:
         }
         if secondary is not None:
             out["secondary"] = secondary
+        if world == 1:  # bonus leg: the same test with numpy's own PCG64 streams reproduced bit for bit on the GPU
+            from squidpy_amd._utils import pcg64_states
+
+            n_exact = 8192
+            states = pcg64_states(0, n_exact)
+            plan.run_pcg64(states[:64], shift)
+            t1 = time.perf_counter()
+            plan.run_pcg64(states, shift)
+            out["numpy_stream_mode"] = {
+                "value": n_exact / (time.perf_counter() - t1),
+                "unit": "permutations/s",
+                "note": "rng='numpy': PCG64 + Generator.shuffle reproduced on the device (one thread per permutation); "
+                "z-scores equal Squidpy's for the same seed bit for bit",
+            }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(adj, labels)
             out["speedup_vs_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"]
