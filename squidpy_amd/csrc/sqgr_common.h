@@ -121,6 +121,7 @@ struct sqgr_graph {
     sqgr::DevBuf<int64_t> indptr;   // [n+1]
     sqgr::DevBuf<int32_t> indices;  // [nnz]
     sqgr::DevBuf<int32_t> erow;     // [nnz] row of every stored edge (COO expansion, built on device)
+    sqgr::DevBuf<int2> coo;         // [nnz] (row, col) pairs: one 8-byte load per edge in the nhood count kernel
     sqgr::DevBuf<float> data;       // [nnz] or empty
     bool has_data = false;
 };

@@ -13,7 +13,8 @@ void set_error(const char* fmt, ...) {
 }
 
 // one thread per edge: erow[e] = row owning edge e (binary search in indptr; built once per graph)
-__global__ void k_expand_rows(const int64_t* __restrict__ indptr, int64_t n, int64_t nnz, int32_t* __restrict__ erow) {
+__global__ void k_expand_rows(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, int64_t n, int64_t nnz,
+                              int32_t* __restrict__ erow, int2* __restrict__ coo) {
     int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (e >= nnz) return;
     int64_t lo = 0, hi = n;  // find largest r with indptr[r] <= e
@@ -22,6 +23,7 @@ __global__ void k_expand_rows(const int64_t* __restrict__ indptr, int64_t n, int
         if (indptr[mid] <= e) lo = mid; else hi = mid;
     }
     erow[e] = (int32_t)lo;
+    coo[e] = make_int2((int)lo, indices[e]);
 }
 
 }  // namespace sqgr
@@ -231,6 +233,7 @@ int sqgr_graph_create(sqgr_ctx* ctx, int64_t n, int64_t nnz, const int64_t* indp
         if ((rc = g->indptr.alloc((size_t)n + 1)) != SQGR_OK) break;
         if ((rc = g->indices.alloc((size_t)nnz)) != SQGR_OK) break;
         if ((rc = g->erow.alloc((size_t)nnz)) != SQGR_OK) break;
+        if ((rc = g->coo.alloc((size_t)nnz)) != SQGR_OK) break;
         if (data && (rc = g->data.alloc((size_t)nnz)) != SQGR_OK) break;
         hipError_t e = hipMemcpyAsync(g->indptr.p, indptr, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess && nnz)
@@ -239,7 +242,7 @@ int sqgr_graph_create(sqgr_ctx* ctx, int64_t n, int64_t nnz, const int64_t* indp
             e = hipMemcpyAsync(g->data.p, data, (size_t)nnz * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess && nnz) {
             LaunchTimer t(ctx, "graph_expand_rows");
-            k_expand_rows<<<(unsigned)ceil_div(nnz, 256), 256, 0, ctx->stream>>>(g->indptr.p, n, nnz, g->erow.p);
+            k_expand_rows<<<(unsigned)ceil_div(nnz, 256), 256, 0, ctx->stream>>>(g->indptr.p, g->indices.p, n, nnz, g->erow.p, g->coo.p);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

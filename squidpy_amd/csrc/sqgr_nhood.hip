@@ -62,10 +62,11 @@ __global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __re
     for (int t = threadIdx.x; t < n_libs * kpad; t += 256) s_cum[t] = cum[t];
     for (int t = threadIdx.x; t < blk_bytes; t += 256) s_blk[t] = g_blk[t];
     __syncthreads();
-    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= n) return;
     const int batch = blockIdx.y;
     const uint32_t* kb = keys + (size_t)batch * B * n_libs * 8;
+    // grid-stride over spots: the launch may be throttled to a few blocks per CU so that the (LDS-atomic bound) count
+    // kernel of the previous launch group can share the CUs (SQGR_NHOOD_STREAMS=2)
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     uint32_t out[B / 4];
     LibDom ld = dom0;
     uint32_t x0 = (uint32_t)i, lib = 0;
@@ -97,6 +98,7 @@ __global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __re
     uint4* dst = reinterpret_cast<uint4*>(slab_all + ((size_t)batch * n + i) * B);
 #pragma unroll
     for (int v = 0; v < B / 16; ++v) dst[v] = make_uint4(out[4 * v], out[4 * v + 1], out[4 * v + 2], out[4 * v + 3]);
+    }
 }
 
 // injected permutations: lab[(p)*n + i] (perm-major, host order) -> slab rows
@@ -128,12 +130,14 @@ __device__ __forceinline__ int xcd_chunk(int b, int nblk) {
 // B distinct banks (conflict-free for B = 32).  The stagger costs nothing per step: the label words are rotated
 // once per edge (v_alignbit) so that byte extraction is static, and the per-step bank offsets are loop invariant.
 template <int B, int MIN_WAVES>
-__global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz, const int32_t* __restrict__ erow,
-                                                                    const int32_t* __restrict__ indices,
+__global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz, const int2* __restrict__ coo,
                                                                     const uint8_t* __restrict__ slab_all, int64_t n, int K,
                                                                     int hist_words, uint32_t edges_per_block,
                                                                     uint32_t* __restrict__ partial_all) {
     extern __shared__ uint32_t hist[];
+    // this kernel is bound by LDS-atomic throughput and needs few VALU slots; when the VALU-bound shuffle kernel of the
+    // next launch group shares the CU (SQGR_NHOOD_STREAMS=2), issue priority keeps the LDS pipe fed
+    __builtin_amdgcn_s_setprio(3);
     constexpr int BPL = B / 4;  // label bytes per lane
     constexpr int LOGW = (B == 32) ? 7 : 6;  // log2(bytes of one pair's B counters)
     const int tid = threadIdx.x;
@@ -153,37 +157,52 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
     const uint32_t qoff = q * BPL;
     char* hist_bytes = reinterpret_cast<char*>(hist);
 
-    // U edges per lane per iteration: all index loads, then all slab-row gathers, are in flight together, so the
-    // two dependent memory latencies are paid once per U edges (LDS caps residency at 16-32 waves per CU).
+    // The 4 lanes of a quad share U = 4 consecutive edges per iteration: lane q loads the (row, col) pair of edge
+    // eb + q with ONE 8-byte load (a wave reads 64 consecutive pairs: one coalesced 512-byte request) and the quad
+    // exchanges them with DPP quad_perm broadcasts (VALU, no LDS, no extra memory instructions).  All slab-row
+    // gathers of the 4 edges are then in flight together, so the two dependent memory latencies are paid once per
+    // 4 edges (LDS caps residency at 16-32 waves per CU).
+    // Software pipeline, two stages deep: while iteration k is histogrammed, the slab rows of iteration k+1 and the
+    // (row, col) pairs of iteration k+2 are in flight (every load gets a full processing phase of slack).
     constexpr int U = 4;
-    constexpr uint32_t STRIDE = COUNT_THREADS / 4;
+    constexpr uint32_t STEP = (COUNT_THREADS / 4) * U;
     using Row = typename std::conditional<B == 16, uint32_t, uint2>::type;
     const uint32_t last = nnz - 1;
-    for (uint32_t e = e0 + el; e < e1; e += U * STRIDE) {
+    auto gather_rows = [&](const int2 mine, Row (&ra)[U], Row (&rb)[U]) {
         uint32_t r[U], c[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t eu = min(e + u * STRIDE, last);  // clamped: loads stay in bounds, tail is predicated below
-            r[u] = (uint32_t)erow[eu];
-            c[u] = (uint32_t)indices[eu];
-        }
-        Row ra[U], rb[U];
+        r[0] = (uint32_t)__builtin_amdgcn_update_dpp(0, mine.x, 0x00, 0xF, 0xF, false);  // quad_perm:[0,0,0,0]
+        c[0] = (uint32_t)__builtin_amdgcn_update_dpp(0, mine.y, 0x00, 0xF, 0xF, false);
+        r[1] = (uint32_t)__builtin_amdgcn_update_dpp(0, mine.x, 0x55, 0xF, 0xF, false);  // quad_perm:[1,1,1,1]
+        c[1] = (uint32_t)__builtin_amdgcn_update_dpp(0, mine.y, 0x55, 0xF, 0xF, false);
+        r[2] = (uint32_t)__builtin_amdgcn_update_dpp(0, mine.x, 0xAA, 0xF, 0xF, false);  // quad_perm:[2,2,2,2]
+        c[2] = (uint32_t)__builtin_amdgcn_update_dpp(0, mine.y, 0xAA, 0xF, 0xF, false);
+        r[3] = (uint32_t)__builtin_amdgcn_update_dpp(0, mine.x, 0xFF, 0xF, 0xF, false);  // quad_perm:[3,3,3,3]
+        c[3] = (uint32_t)__builtin_amdgcn_update_dpp(0, mine.y, 0xFF, 0xF, 0xF, false);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             ra[u] = *reinterpret_cast<const Row*>(slab + (r[u] * B + qoff));
             rb[u] = *reinterpret_cast<const Row*>(slab + (c[u] * B + qoff));
         }
+    };
+    uint32_t e = e0 + el * U;
+    Row cur_a[U], cur_b[U];
+    gather_rows(coo[min(e + q, last)], cur_a, cur_b);                     // rows of iteration 0
+    int2 nxt_rc = coo[min(e + STEP + q, last)];                           // pairs of iteration 1 (clamped: in bounds)
+    for (; e < e1; e += STEP) {
+        Row nxt_a[U], nxt_b[U];
+        gather_rows(nxt_rc, nxt_a, nxt_b);                                // rows of iteration k+1
+        nxt_rc = coo[min(e + 2 * STEP + q, last)];                        // pairs of iteration k+2
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint32_t inc = (e + u * STRIDE < e1) ? 1u : 0u;  // branch-free tail: out-of-range edges add 0
+            const uint32_t inc = (e + u < e1) ? 1u : 0u;  // branch-free tail: out-of-range edges add 0
             uint32_t la[2], lb[2];
             if constexpr (B == 16) {
-                la[0] = __builtin_amdgcn_alignbit(ra[u], ra[u], rot);
-                lb[0] = __builtin_amdgcn_alignbit(rb[u], rb[u], rot);
+                la[0] = __builtin_amdgcn_alignbit(cur_a[u], cur_a[u], rot);
+                lb[0] = __builtin_amdgcn_alignbit(cur_b[u], cur_b[u], rot);
             } else {
                 const bool sw = (rot & 32) != 0;
-                const uint32_t alo = sw ? ra[u].y : ra[u].x, ahi = sw ? ra[u].x : ra[u].y;
-                const uint32_t blo = sw ? rb[u].y : rb[u].x, bhi = sw ? rb[u].x : rb[u].y;
+                const uint32_t alo = sw ? cur_a[u].y : cur_a[u].x, ahi = sw ? cur_a[u].x : cur_a[u].y;
+                const uint32_t blo = sw ? cur_b[u].y : cur_b[u].x, bhi = sw ? cur_b[u].x : cur_b[u].y;
                 la[0] = __builtin_amdgcn_alignbit(ahi, alo, rot);
                 la[1] = __builtin_amdgcn_alignbit(alo, ahi, rot);
                 lb[0] = __builtin_amdgcn_alignbit(bhi, blo, rot);
@@ -196,6 +215,11 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
                 const uint32_t pair = __umul24(va, (uint32_t)K) + vb;
                 atomicAdd(reinterpret_cast<uint32_t*>(hist_bytes + ((pair << LOGW) + bank_ofs[s])), inc);
             }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            cur_a[u] = nxt_a[u];
+            cur_b[u] = nxt_b[u];
         }
     }
     __syncthreads();
@@ -533,16 +557,16 @@ int sqgr_nhood::count_batches(int nb, int buf) {
         const uint32_t epb = (uint32_t)(ceil_div(ceil_div(nnz, nblk), 256) * 256);
         LaunchTimer t(ctx, "nhood_count_b32");
         SQGR_TRY(allow_lds(k_count<32, 4>, (size_t)hw * 4));
-        k_count<32, 4><<<dim3(nblk, nb), COUNT_THREADS, (size_t)hw * 4, st>>>((uint32_t)nnz, g->erow.p, g->indices.p, slab_p, n, K, hw,
+        k_count<32, 4><<<dim3(nblk, nb), COUNT_THREADS, (size_t)hw * 4, st>>>((uint32_t)nnz, g->coo.p, slab_p, n, K, hw,
                                                                            epb, partial.p);
     } else if (be() == 16) {
         const uint32_t epb = (uint32_t)(ceil_div(ceil_div(nnz, nblk), 256) * 256);
         LaunchTimer t(ctx, "nhood_count_b16");
         if ((size_t)hw * 4 * 2 <= LDS_BUDGET)
-            k_count<16, 8><<<dim3(nblk, nb), COUNT_THREADS, (size_t)hw * 4, st>>>((uint32_t)nnz, g->erow.p, g->indices.p, slab_p, n, K,
+            k_count<16, 8><<<dim3(nblk, nb), COUNT_THREADS, (size_t)hw * 4, st>>>((uint32_t)nnz, g->coo.p, slab_p, n, K,
                                                                                hw, epb, partial.p);
         else if (allow_lds(k_count<16, 4>, (size_t)hw * 4) == SQGR_OK)
-            k_count<16, 4><<<dim3(nblk, nb), COUNT_THREADS, (size_t)hw * 4, st>>>((uint32_t)nnz, g->erow.p, g->indices.p, slab_p, n, K,
+            k_count<16, 4><<<dim3(nblk, nb), COUNT_THREADS, (size_t)hw * 4, st>>>((uint32_t)nnz, g->coo.p, slab_p, n, K,
                                                                                hw, epb, partial.p);
     } else {
         const int e = be();
@@ -794,7 +818,9 @@ int sqgr_nhood_tune(sqgr_nhood* plan, int32_t perms_per_pass, int32_t blocks_per
 }
 
 static int launch_shuffle(sqgr_nhood* p, int nb, int buf, hipStream_t st) {
-    const unsigned gx = (unsigned)ceil_div(p->n, 256);
+    unsigned gx = (unsigned)ceil_div(p->n, 256);
+    const char* env_blocks = getenv("SQGR_SHUFFLE_BLOCKS_PER_CU");  // throttle (only useful with SQGR_NHOOD_STREAMS=2)
+    if (env_blocks && atoi(env_blocks) > 0) gx = std::min<unsigned>(gx, (unsigned)(atoi(env_blocks) * p->ctx->cu_count) / (unsigned)nb + 1);
     LaunchTimer t(p->ctx, "nhood_shuffle", st);
     const size_t lds = (size_t)p->n_libs * p->kpad * 4 + (size_t)((p->blk_bytes + 3) / 4) * 4;
     const uint32_t* keys = p->keys.p + (size_t)buf * p->keys_stride();

@@ -17,7 +17,7 @@ plan = L.NhoodPlan(ctx, g, labels, K)
 bperm = 4 * adj.nnz + 4 * (adj.shape[0] + 1) + 2 * adj.shape[0]
 for B in (16, 32):
     for nblk in (256,):
-        for nbatch in (4, 8, 16, 32):
+        for nbatch in (8, 32):
             plan.tune(B, nblk, nbatch)
             plan.run(1, 0, B * nbatch)  # warm
             ctx.timer_enable(True); ctx.timer_reset()
