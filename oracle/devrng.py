@@ -2,9 +2,9 @@
 
 CPU (numpy) restatement of the *device* permutation generator used by the HIP path when
 ``rng="philox"`` (``squidpy_amd/csrc/sqgr_rng.h``): Philox4x32-10 derives eight 32-bit round
-keys per (seed, permutation index, library); a keyed 8-round additive Feistel network over the
-mixed-radix domain ``A x B >= n`` (``A`` = power of two ~ sqrt(n), ``B = ceil(n / A)``, both >= 16) with cycle
-walking turns them into a bijection of ``[0, n)``.  The reference (squidpy) has no such generator — it uses numpy PCG64 shuffles
+keys per (seed, permutation index, library), of which the low 16 bits are used; a keyed 8-round additive
+Feistel network in 16-bit arithmetic over the mixed-radix domain ``A x B >= n`` (``A`` = power of two ~ sqrt(n),
+``B = ceil(n / A)``, both >= 16) with cycle walking turns them into a bijection of ``[0, n)``.  The reference (squidpy) has no such generator — it uses numpy PCG64 shuffles
 (`/root/reference/src/squidpy/_utils.py:240-241`, ``gr/_nhood.py:533-538``) — so this file
 does not follow a reference file; it exists so that the GPU permutation test can be checked
 *bit for bit* (same permutations => same counts => same z-scores) and so that the statistical
@@ -21,8 +21,8 @@ PHILOX_M0 = np.uint64(0xD2511F53)
 PHILOX_M1 = np.uint64(0xCD9E8D57)
 PHILOX_W0 = 0x9E3779B9
 PHILOX_W1 = 0xBB67AE85
-FEISTEL_C1 = np.uint64(0xD2511F)
-FEISTEL_C2 = np.uint64(0xCD9E8D)
+FEISTEL_C1 = np.uint64(0x88B5)
+FEISTEL_C2 = np.uint64(0xDB2D)
 N_ROUNDS = 8
 MASK32 = np.uint64(0xFFFFFFFF)
 MASK24 = np.uint64(0xFFFFFF)
@@ -63,77 +63,67 @@ def round_keys(seed: int, perms: np.ndarray, lib: int = 0) -> np.ndarray:
     return np.concatenate(out, axis=-1)
 
 
-def domain_dims(n: int) -> tuple[int, int]:
-    """Mixed-radix domain A x B >= n: A = power of two ~ sqrt(n), B = ceil(n / A), both >= 16
-    (sqgr_rng.h: make_domain)."""
+def domain_dims(n: int) -> tuple[int, int, int]:
+    """Mixed-radix domain A x B >= n: A = power of two ~ sqrt(n), B = ceil(n / A), both >= 16, plus
+    Bmask = 2**ceil(log2 B) - 1 (sqgr_rng.h: make_domain)."""
     r = math.isqrt(n - 1) + 1 if n > 1 else n  # ceil(sqrt(n))
     A = 16
     while A < r:
         A <<= 1
     B = max(16, -(-n // A))
-    return A, B
+    m = 1
+    while m < B:
+        m <<= 1
+    return A, B, m - 1
 
 
-def _F(v: np.ndarray, k: np.uint64) -> np.ndarray:
-    t = (v ^ k) & MASK24
-    u = (t * FEISTEL_C1) & MASK32
-    u ^= u >> np.uint64(15)
-    w = ((u & MASK24) * FEISTEL_C2) & MASK32
-    return w >> np.uint64(16)
+MASK16 = np.uint64(0xFFFF)
 
 
-def feistel(a: np.ndarray, b: np.ndarray, A: int, B: int, rk: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
-    """One application of the keyed bijection of [0, A) x [0, B).  ``rk``: (8,) uint32."""
-    A64, B64 = np.uint64(A), np.uint64(B)
+def _F(v: np.ndarray, k: np.ndarray | np.uint64) -> np.ndarray:
+    """16-bit round function (sqgr_rng.h: feistel_F1 / feistel_F2): arithmetic modulo 2**16."""
+    x = (v ^ k) & MASK16
+    x = (x * FEISTEL_C1) & MASK16
+    x = x ^ (x >> np.uint64(7))
+    x = (x * FEISTEL_C2) & MASK16
+    return x ^ (x >> np.uint64(9))
+
+
+def _rounds(a: np.ndarray, b: np.ndarray, A: int, B: int, Bmask: int, key) -> tuple[np.ndarray, np.ndarray]:
+    """The 8 alternating additive rounds; ``key(r)`` returns the round key(s) of round r (low 16 bits are used)."""
+    A1, B64, bm = np.uint64(A - 1), np.uint64(B), np.uint64(Bmask)
     for r in range(0, N_ROUNDS, 2):
-        a = (a + _F(b, np.uint64(int(rk[r])))) & (A64 - np.uint64(1))
-        b = b + ((_F(a, np.uint64(int(rk[r + 1]))) * B64) >> np.uint64(16))
-        b = np.where(b >= B64, b - B64, b)
+        a = (a + _F(b, key(r))) & A1
+        t = b + (_F(a, key(r + 1)) & bm)
+        t = np.where(t >= B64, t - B64, t)
+        b = np.where(t >= B64, t - B64, t)
     return a, b
 
 
-def permutation(n: int, rk: np.ndarray) -> np.ndarray:
-    """pi with pi[i] = image of i under the cycle-walked bijection of [0, n); int64 (n,)."""
-    if n <= 1:
-        return np.zeros(n, dtype=np.int64)
-    A, B = domain_dims(n)
-    x = np.arange(n, dtype=np.uint64)
-    a, b = feistel(x // np.uint64(B), x % np.uint64(B), A, B, rk)
-    x = a * np.uint64(B) + b
-    bad = x >= np.uint64(n)
-    while bad.any():
-        a[bad], b[bad] = feistel(a[bad], b[bad], A, B, rk)
-        x = a * np.uint64(B) + b
-        bad = x >= np.uint64(n)
-    return x.astype(np.int64)
-
-
 def permutation_batch(n: int, rks: np.ndarray) -> np.ndarray:
-    """Same as :func:`permutation` for many key sets at once: ``rks`` (P, 8) -> (P, n) int64 (vectorised over keys)."""
+    """pi[p, i] = image of i under the cycle-walked bijection of [0, n) keyed by ``rks[p]``: (P, 8) -> (P, n) int64."""
     P = rks.shape[0]
     if n <= 1:
         return np.zeros((P, n), dtype=np.int64)
-    A, B = domain_dims(n)
-    A64, B64 = np.uint64(A), np.uint64(B)
-    keys = rks.astype(np.uint64)
-
-    def apply(a: np.ndarray, b: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
-        for r in range(0, N_ROUNDS, 2):
-            a = (a + _F(b, keys[:, r : r + 1])) & (A64 - np.uint64(1))
-            b = b + ((_F(a, keys[:, r + 1 : r + 2]) * B64) >> np.uint64(16))
-            b = np.where(b >= B64, b - B64, b)
-        return a, b
-
+    A, B, Bmask = domain_dims(n)
+    B64 = np.uint64(B)
+    keys = rks.astype(np.uint64) & MASK16
+    key = lambda r: keys[:, r : r + 1]  # noqa: E731
     x = np.tile(np.arange(n, dtype=np.uint64), (P, 1))
-    a, b = apply(x // B64, x % B64)
+    a, b = _rounds(x // B64, x % B64, A, B, Bmask, key)
     x = a * B64 + b
     bad = x >= np.uint64(n)
     while bad.any():
-        a2, b2 = apply(a, b)
+        a2, b2 = _rounds(a, b, A, B, Bmask, key)
         a, b = np.where(bad, a2, a), np.where(bad, b2, b)
         x = a * B64 + b
         bad = x >= np.uint64(n)
     return x.astype(np.int64)
+
+
+def permutation(n: int, rk: np.ndarray) -> np.ndarray:
+    """pi with pi[i] = image of i under the cycle-walked bijection of [0, n); int64 (n,)."""
+    return permutation_batch(n, np.asarray(rk)[None, :])[0]
 
 
 def shuffled_labels(

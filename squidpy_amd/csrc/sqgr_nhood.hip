@@ -83,15 +83,19 @@ __global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __re
     for (int w = 0; w < B / 4; ++w) {
         uint32_t word = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int b = w * 4 + j;
-            const uint32_t* rk = kb + ((size_t)b * n_libs + lib) * 8;  // uniform (scalar loads) when !HAS_LIBS
-            uint32_t a;
-            const uint32_t x = feistel_perm_ab(a0, b0, dom, rk, &a);
-            uint32_t lab = blk[a];
-            lab += (x >= tab[lab]) ? 1u : 0u;
-            while (x >= tab[lab]) ++lab;  // rarely iterates (sentinel UINT_MAX stops it)
-            word |= lab << (8 * j);
+        for (int j = 0; j < 4; j += 2) {  // two permutations per evaluation (packed 16-bit lanes); measured: one pair per
+                                          // chain (NP = 1) beats two interleaved chains (register pressure) on MI355X
+            const uint32_t* const rk[2] = {kb + ((size_t)(w * 4 + j) * n_libs + lib) * 8,
+                                           kb + ((size_t)(w * 4 + j + 1) * n_libs + lib) * 8};  // uniform when !HAS_LIBS
+            uint32_t x[2], hi[2];
+            feistel_perm_multi<1>(a0, b0, dom, rk, x, hi);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint32_t lab = blk[hi[h]];
+                lab += (x[h] >= tab[lab]) ? 1u : 0u;
+                while (x[h] >= tab[lab]) ++lab;  // rarely iterates (sentinel UINT_MAX stops it)
+                word |= lab << (8 * (j + h));
+            }
         }
         out[w] = word;
     }

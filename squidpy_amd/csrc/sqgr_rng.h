@@ -3,8 +3,9 @@
 //   round keys : Philox4x32-10( counter = (perm_lo, perm_hi, library, j), key = (seed_lo, seed_hi) ),
 //                j = 0,1  ->  8 x 32-bit keys per (seed, global permutation index, library)
 //   bijection  : 8-round alternating additive Feistel network on the mixed-radix domain A x B >= n
-//                (A = power of two ~ sqrt(n), B = ceil(n / A), both >= 16) whose round function uses only
-//                full-rate 24-bit multiplies (v_mul_u32_u24) and xor-shifts, cycle-walked into [0, n).
+//                (A = power of two ~ sqrt(n), B = ceil(n / A), both >= 16) in 16-bit arithmetic — two permutations
+//                per instruction on the packed-16 VALU — cycle-walked into [0, n); the low 16 bits of the Philox
+//                words are the round keys.
 //
 // oracle/devrng.py restates this file bit for bit; tests/test_devrng.py checks both the Philox
 // known-answer vectors and the statistical quality (uniformity over S_n for small n, agreement of
@@ -19,7 +20,7 @@ namespace sqgr {
 
 constexpr uint32_t PHILOX_M0 = 0xD2511F53u, PHILOX_M1 = 0xCD9E8D57u;
 constexpr uint32_t PHILOX_W0 = 0x9E3779B9u, PHILOX_W1 = 0xBB67AE85u;
-constexpr uint32_t FEISTEL_C1 = 0xD2511Fu, FEISTEL_C2 = 0xCD9E8Du;
+constexpr uint32_t FEISTEL_C1 = 0x88B5u, FEISTEL_C2 = 0xDB2Du;  // odd 16-bit multipliers of the round function
 constexpr int FEISTEL_ROUNDS = 8;
 
 __host__ __device__ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
@@ -45,22 +46,37 @@ __host__ __device__ inline void round_keys(uint64_t seed, uint64_t perm, uint32_
     }
 }
 
-// round function: two 24x24-bit multiplies (low 32 bits of each product, v_mul_u32_u24 reads only the low
-// 24 bits of its operands) with an xor-shift between; 16 well-mixed bits out.
-__device__ __forceinline__ uint32_t feistel_F(uint32_t v, uint32_t k) {
-    uint32_t u = __umul24(v ^ k, FEISTEL_C1);
-    u ^= u >> 15;
-    uint32_t w = __umul24(u, FEISTEL_C2);
-    return w >> 16;
+// 16-bit lanes: every quantity of the bijection (digits, keys, round function) is a 16-bit value, so two permutations
+// are evaluated per instruction with gfx950's packed-16 VALU ops (v_pk_mul_lo_u16, v_pk_add_u16, v_pk_lshrrev_b16,
+// v_pk_min_u16, plus plain 32-bit bitwise ops acting on both halves).
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+// round function: a two-round 16-bit multiply / xor-shift mixer of (v ^ k); arithmetic modulo 2^16
+__device__ __forceinline__ u16x2 feistel_F2(u16x2 v, u16x2 k) {
+    u16x2 x = v ^ k;
+    x *= (u16x2)(FEISTEL_C1);
+    x ^= x >> (u16x2)(7);
+    x *= (u16x2)(FEISTEL_C2);
+    x ^= x >> (u16x2)(9);
+    return x;
+}
+__host__ __device__ inline uint32_t feistel_F1(uint32_t v, uint32_t k) {  // the same function, one permutation
+    uint32_t x = (v ^ k) & 0xFFFFu;
+    x = (x * FEISTEL_C1) & 0xFFFFu;
+    x ^= x >> 7;
+    x = (x * FEISTEL_C2) & 0xFFFFu;
+    x ^= x >> 9;
+    return x;
 }
 
-// Mixed-radix domain A x B >= n, x <-> (a, b), x = a*B + b:  A = power of two ~ sqrt(n) (so the a-rounds reduce with
-// one AND and are exactly uniform), B = ceil(n / A); both >= 16 and < 2^16.  The excess A*B - n is < A, so cycle
-// walking almost never iterates (no wave divergence), unlike a power-of-two domain whose excess can approach n.
+// Mixed-radix domain A x B >= n, x <-> (a, b), x = a*B + b:  A = power of two ~ sqrt(n) (the a-rounds reduce with one
+// AND and are exactly uniform), B = ceil(n / A), Bmask = 2^ceil(log2 B) - 1; 16 <= B <= A <= 2^14 (n <= 2^27), so every
+// intermediate fits 16 bits.  The excess A*B - n is < A: cycle walking almost never iterates (no wave divergence).
 struct FeistelDomain {
-    uint32_t n;  // target domain [0, n)
-    uint32_t A;  // radix of the high digit
-    uint32_t B;  // radix of the low digit
+    uint32_t n;      // target domain [0, n)
+    uint32_t A;      // radix of the high digit (power of two)
+    uint32_t B;      // radix of the low digit
+    uint32_t Bmask;  // smallest all-ones mask >= B - 1 ... (2^ceil(log2 B) - 1)
 };
 
 __host__ __device__ inline uint32_t isqrt_ceil(uint32_t n) {
@@ -78,30 +94,97 @@ __host__ __device__ inline FeistelDomain make_domain(uint32_t n) {
     d.A = a;
     uint32_t b = (n + d.A - 1) / d.A;
     d.B = b < 16u ? 16u : b;
+    uint32_t m = 1u;
+    while (m < d.B) m <<= 1;
+    d.Bmask = m - 1u;
     return d;
 }
 
-// image of x (< n) under the cycle-walked keyed bijection of [0, n): 8 alternating additive Feistel rounds
-//   a <- (a + F(b,k_r)) mod A  (A = 2^m: one AND) ;  b <- (b + (F(a,k_r+1) * B >> 16)) mod B
-__device__ __forceinline__ uint32_t feistel_perm_ab(uint32_t a, uint32_t b, const FeistelDomain& d,
-                                                    const uint32_t* __restrict__ rk, uint32_t* hi_digit = nullptr) {
-    uint32_t x;
-    do {
+// one pass of the 8 alternating additive rounds on NP packed pairs (= 2*NP permutations) in lock-step:
+//   a <- (a + F(b, k_r)) mod A                      (A = 2^m: one AND)
+//   b <- (b + (F(a, k_r+1) & Bmask)) mod B          (sum < 3B: two conditional subtractions)
+// The round chain of one pair is strictly dependent and packed-16 results need a wait state before use; NP >= 2
+// independent chains interleave and fill those slots.   rk[2*i], rk[2*i+1]: round keys of pair i's two permutations.
+template <int NP>
+__device__ __forceinline__ void feistel_rounds(u16x2 (&a)[NP], u16x2 (&b)[NP], const FeistelDomain& d,
+                                               const uint32_t* const (&rk)[2 * NP]) {
+    const u16x2 am = (u16x2)((unsigned short)(d.A - 1u)), bm = (u16x2)((unsigned short)d.Bmask);
+    const u16x2 BB = (u16x2)((unsigned short)d.B);
 #pragma unroll
+    for (int r = 0; r < FEISTEL_ROUNDS; r += 2) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const u16x2 k0 = __builtin_bit_cast(u16x2, (rk[2 * i][r] & 0xFFFFu) | (rk[2 * i + 1][r] << 16));
+            a[i] = (a[i] + feistel_F2(b[i], k0)) & am;
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const u16x2 k1 = __builtin_bit_cast(u16x2, (rk[2 * i][r + 1] & 0xFFFFu) | (rk[2 * i + 1][r + 1] << 16));
+            u16x2 t = b[i] + (feistel_F2(a[i], k1) & bm);
+            t = __builtin_elementwise_min(t, (u16x2)(t - BB));  // unsigned wrap makes the wrong branch huge
+            b[i] = __builtin_elementwise_min(t, (u16x2)(t - BB));
+        }
+    }
+}
+
+// images of the rank (a0, b0) under the cycle-walked keyed bijections of [0, n) of 2*NP permutations;
+// x[j] is the image under permutation j, hi[j] its high digit (x == hi * d.B + low)
+template <int NP>
+__device__ __forceinline__ void feistel_perm_multi(uint32_t a0, uint32_t b0, const FeistelDomain& d,
+                                                   const uint32_t* const (&rk)[2 * NP], uint32_t (&x)[2 * NP],
+                                                   uint32_t (&hi)[2 * NP]) {
+    u16x2 a[NP], b[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        a[i] = (u16x2)((unsigned short)a0);
+        b[i] = (u16x2)((unsigned short)b0);
+    }
+    feistel_rounds<NP>(a, b, d, rk);
+    bool again = false;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        x[2 * i] = (uint32_t)a[i].x * d.B + b[i].x;
+        x[2 * i + 1] = (uint32_t)a[i].y * d.B + b[i].y;
+        again |= (x[2 * i] >= d.n) | (x[2 * i + 1] >= d.n);
+    }
+    while (again) {  // rare: re-apply the bijection only where the image left [0, n)
+        u16x2 a2[NP], b2[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            a2[i] = a[i];
+            b2[i] = b[i];
+        }
+        feistel_rounds<NP>(a2, b2, d, rk);
+        again = false;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            if (x[2 * i] >= d.n) { a[i].x = a2[i].x; b[i].x = b2[i].x; }
+            if (x[2 * i + 1] >= d.n) { a[i].y = a2[i].y; b[i].y = b2[i].y; }
+            x[2 * i] = (uint32_t)a[i].x * d.B + b[i].x;
+            x[2 * i + 1] = (uint32_t)a[i].y * d.B + b[i].y;
+            again |= (x[2 * i] >= d.n) | (x[2 * i + 1] >= d.n);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        hi[2 * i] = a[i].x;
+        hi[2 * i + 1] = a[i].y;
+    }
+}
+
+// single-permutation form (same arithmetic): image of x (< n)
+__host__ __device__ inline uint32_t feistel_perm(uint32_t x, const FeistelDomain& d, const uint32_t* rk) {
+    uint32_t a = x / d.B, b = x - a * d.B;
+    do {
         for (int r = 0; r < FEISTEL_ROUNDS; r += 2) {
-            a = (a + feistel_F(b, rk[r])) & (d.A - 1u);
-            uint32_t t = b + (__umul24(feistel_F(a, rk[r + 1]), d.B) >> 16);
-            b = min(t, t - d.B);  // t < 2B: subtract B when t >= B (unsigned wrap makes the other branch huge)
+            a = (a + feistel_F1(b, rk[r])) & (d.A - 1u);
+            uint32_t t = b + (feistel_F1(a, rk[r + 1]) & d.Bmask);
+            t = t >= d.B ? t - d.B : t;
+            b = t >= d.B ? t - d.B : t;
         }
         x = a * d.B + b;
     } while (x >= d.n);
-    if (hi_digit) *hi_digit = a;  // x == a * d.B + b
     return x;
-}
-
-__device__ __forceinline__ uint32_t feistel_perm(uint32_t x, const FeistelDomain& d, const uint32_t* __restrict__ rk) {
-    const uint32_t a = x / d.B;
-    return feistel_perm_ab(a, x - a * d.B, d, rk);
 }
 
 }  // namespace sqgr

@@ -26,7 +26,8 @@ def test_philox4x32_10_known_answers():
 
 @pytest.mark.parametrize("n", [1, 2, 15, 16, 17, 255, 256, 257, 1000, 65537, 100003])
 def test_bijection_and_domain(n):
-    A, B = D.domain_dims(n)
+    A, B, Bmask = D.domain_dims(n)
+    assert Bmask >= B - 1 and (Bmask + 1) & Bmask == 0 and Bmask < 2 * B
     assert A >= 16 and B >= 16 and A * B >= n and A < 2**16 and B < 2**16 and A & (A - 1) == 0
     if n > 512:
         assert A * B - n < A  # cycle walking almost never iterates
