@@ -213,6 +213,7 @@ def main() -> None:
     ap.add_argument("--cols", type=int, default=COLS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the Moran's I genes/sec leg")
+    ap.add_argument("--no-numpy-leg", action="store_true", help="skip the bit-compatible numpy-stream leg")
     ap.add_argument("--tune", type=str, default="", help="perms_per_pass,blocks_per_batch,batches_per_launch")
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
         print(_cpu_worker((sys.argv[2], N_CLS, int(sys.argv[3]), int(sys.argv[4]))))
@@ -360,7 +361,7 @@ def main() -> None:
         }
         if secondary is not None:
             out["secondary"] = secondary
-        if world == 1:  # bonus leg: the same test with numpy's own PCG64 streams reproduced bit for bit on the GPU
+        if world == 1 and not args.no_numpy_leg:  # bonus leg: the same test with numpy's own PCG64 streams reproduced bit for bit on the GPU
             from squidpy_amd._utils import pcg64_states
 
             n_exact = 8192

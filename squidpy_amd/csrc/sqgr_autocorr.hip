@@ -17,10 +17,12 @@
 #include "sqgr_common.h"
 #include "sqgr_rng.h"
 
+#include <cstdlib>
+
 namespace sqgr {
 
 constexpr int GT = 64;         // genes per tile
-constexpr int PERM_TILE = 16;  // permutations per block (4 per wave)
+constexpr int PERM_TILE = 32;  // permutations per block (8 per wave)
 constexpr uint32_t AUTOCORR_STREAM = 0x5A17u;  // "library" word of the Philox counter: separate stream from nhood
 
 // ---- per-gene statistics of a staged gene-major block X[gc][n]: mean and is-constant flag
@@ -164,55 +166,49 @@ __global__ __launch_bounds__(256) void k_perm_indices(uint64_t seed, int64_t per
 // ---- the hot kernel: partial sums of  S1[p][g] = sum_i z[i][g] * y[idx_p(i)][g]   (and, for Geary,
 //      S2[p][g] = sum_i z[i][g]^2 * r[idx_p(i)])  over one row chunk.
 // grid = (perm tiles, row chunks, gene tiles) — gene tile is the slowest grid dimension.
-// block = 4 waves; wave w owns permutations 4w..4w+3 of the block's 16; lane = gene.
+// block = 4 waves; wave w owns PERM_TILE/4 permutations of the block's PERM_TILE; lane = gene.
 template <bool GEARY>
 __global__ __launch_bounds__(256) void k_perm_dot(const double* __restrict__ Zt, const double* __restrict__ Yt,
                                                   const double* __restrict__ rowsum, const int32_t* __restrict__ idx, int64_t n,
                                                   int64_t nperm, int R, double* __restrict__ part1, double* __restrict__ part2) {
+    constexpr int PW = PERM_TILE / 4;  // permutations per wave: each z row read serves PW gathers
     const int gl = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
-    const int64_t p0 = (int64_t)blockIdx.x * PERM_TILE + wv * 4;
+    const int64_t p0 = (int64_t)blockIdx.x * PERM_TILE + wv * PW;
     if (p0 >= nperm) return;
     const int chunk = blockIdx.y, tile = blockIdx.z;
     const int64_t per = (n + R - 1) / R;
     const int64_t i0 = chunk * per, i1 = min(n, i0 + per);
     const double* Z = Zt + (size_t)tile * n * GT + gl;
     const double* Y = Yt + (size_t)tile * n * GT + gl;
-    // clamp: the (up to 3) surplus permutations of the last wave recompute permutation nperm-1 and are not stored
-    const int32_t* ix0 = idx + (size_t)min(p0 + 0, nperm - 1) * n;
-    const int32_t* ix1 = idx + (size_t)min(p0 + 1, nperm - 1) * n;
-    const int32_t* ix2 = idx + (size_t)min(p0 + 2, nperm - 1) * n;
-    const int32_t* ix3 = idx + (size_t)min(p0 + 3, nperm - 1) * n;
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
-#pragma unroll 4
+    // clamp: the surplus permutations of the last wave recompute permutation nperm-1 and are not stored
+    const int32_t* ix[PW];
+#pragma unroll
+    for (int k = 0; k < PW; ++k) ix[k] = idx + (size_t)min(p0 + k, nperm - 1) * n;
+    double a[PW], b[PW];
+#pragma unroll
+    for (int k = 0; k < PW; ++k) a[k] = b[k] = 0.0;
+#pragma unroll 2
     for (int64_t i = i0; i < i1; ++i) {
         const double z = Z[(size_t)i * GT];
-        const int32_t k0 = ix0[i], k1 = ix1[i], k2 = ix2[i], k3 = ix3[i];  // wave-uniform: scalar loads
-        a0 = fma(z, Y[(size_t)k0 * GT], a0);
-        a1 = fma(z, Y[(size_t)k1 * GT], a1);
-        a2 = fma(z, Y[(size_t)k2 * GT], a2);
-        a3 = fma(z, Y[(size_t)k3 * GT], a3);
-        if (GEARY) {
-            const double zz = z * z;
-            b0 = fma(zz, rowsum[k0], b0);
-            b1 = fma(zz, rowsum[k1], b1);
-            b2 = fma(zz, rowsum[k2], b2);
-            b3 = fma(zz, rowsum[k3], b3);
+        const double zz = z * z;
+#pragma unroll
+        for (int k = 0; k < PW; ++k) {
+            const int32_t row = ix[k][i];  // wave-uniform: scalar load
+            a[k] = fma(z, Y[(size_t)row * GT], a[k]);
+            if (GEARY) b[k] = fma(zz, rowsum[row], b[k]);  // (pre-gathering r[idx] into its own array measured slower)
         }
     }
     // partial layout [tile][p][chunk][gl]
     const size_t stride = (size_t)R * GT;
     double* o1 = part1 + ((size_t)tile * nperm * R + chunk) * GT + gl;
-    if (p0 + 0 < nperm) o1[(size_t)(p0 + 0) * stride] = a0;
-    if (p0 + 1 < nperm) o1[(size_t)(p0 + 1) * stride] = a1;
-    if (p0 + 2 < nperm) o1[(size_t)(p0 + 2) * stride] = a2;
-    if (p0 + 3 < nperm) o1[(size_t)(p0 + 3) * stride] = a3;
-    if (GEARY) {
-        double* o2 = part2 + ((size_t)tile * nperm * R + chunk) * GT + gl;
-        if (p0 + 0 < nperm) o2[(size_t)(p0 + 0) * stride] = b0;
-        if (p0 + 1 < nperm) o2[(size_t)(p0 + 1) * stride] = b1;
-        if (p0 + 2 < nperm) o2[(size_t)(p0 + 2) * stride] = b2;
-        if (p0 + 3 < nperm) o2[(size_t)(p0 + 3) * stride] = b3;
+    double* o2 = GEARY ? part2 + ((size_t)tile * nperm * R + chunk) * GT + gl : nullptr;
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+        if (p0 + k < nperm) {
+            o1[(size_t)(p0 + k) * stride] = a[k];
+            if (GEARY) o2[(size_t)(p0 + k) * stride] = b[k];
+        }
     }
 }
 
@@ -397,6 +393,7 @@ int sqgr_autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_idx,
     if (P == 0) return SQGR_OK;
     // permutations per pass: bound idx (4 n B each) and the partials (ntiles*R*64*8 B each, x2 for Geary) to ~1 GiB each
     int R = (int)std::min<int64_t>(64, std::max<int64_t>(1, ceil_div(2048, ceil_div(std::min<int64_t>(P, 1024), PERM_TILE) * 4)));
+    if (const char* env_r = getenv("SQGR_AUTOCORR_ROW_CHUNKS")) R = std::max(1, atoi(env_r));  // tuning knob
     R = (int)std::min<int64_t>(R, std::max<int64_t>(1, n / 256));
     const int64_t by_idx = std::max<int64_t>(PERM_TILE, ((int64_t)1 << 30) / (n * 4));
     const int64_t by_part = std::max<int64_t>(PERM_TILE, ((int64_t)1 << 30) / ((int64_t)h->ntiles * R * GT * 8));
