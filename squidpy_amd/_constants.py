@@ -39,42 +39,31 @@ class RipleyStat(ModeEnum):
     L = "L"
 
 
+def _suffixed(value: str | None, suffix: str) -> str:
+    """``None`` -> ``spatial_<suffix>``; ``"foo"`` -> ``"foo_<suffix>"``; an already suffixed key is kept."""
+    stem = "spatial" if value is None else value
+    return stem if stem.endswith("_" + suffix) else f"{stem}_{suffix}"
+
+
+class _Obsm:
+    spatial = "spatial"
+
+
+class _Obsp:
+    spatial_conn = staticmethod(lambda value=None: _suffixed(value, "connectivities"))
+    spatial_dist = staticmethod(lambda value=None: _suffixed(value, "distances"))
+
+
+class _Uns:
+    nhood_enrichment = staticmethod(lambda cluster: cluster + "_nhood_enrichment")
+    interaction_matrix = staticmethod(lambda cluster: cluster + "_interactions")
+    co_occurrence = staticmethod(lambda cluster: cluster + "_co_occurrence")
+    ripley = staticmethod(lambda cluster, mode: f"{cluster}_ripley_{mode}")
+
+
 class Key:
     """Names of the AnnData slots read / written by the hot path."""
 
-    class obsm:
-        spatial = "spatial"
-
-    class obsp:
-        @staticmethod
-        def _spatial_key(value: str | None, suffix: str) -> str:
-            if value is None:
-                return f"{Key.obsm.spatial}_{suffix}"
-            if value.endswith(f"_{suffix}"):
-                return value
-            return f"{value}_{suffix}"
-
-        @classmethod
-        def spatial_dist(cls, value: str | None = None) -> str:
-            return cls._spatial_key(value, "distances")
-
-        @classmethod
-        def spatial_conn(cls, value: str | None = None) -> str:
-            return cls._spatial_key(value, "connectivities")
-
-    class uns:
-        @classmethod
-        def nhood_enrichment(cls, cluster: str) -> str:
-            return f"{cluster}_nhood_enrichment"
-
-        @classmethod
-        def interaction_matrix(cls, cluster: str) -> str:
-            return f"{cluster}_interactions"
-
-        @classmethod
-        def co_occurrence(cls, cluster: str) -> str:
-            return f"{cluster}_co_occurrence"
-
-        @classmethod
-        def ripley(cls, cluster: str, mode: str) -> str:
-            return f"{cluster}_ripley_{mode}"
+    obsm = _Obsm
+    obsp = _Obsp
+    uns = _Uns

@@ -86,6 +86,31 @@ def _ppp(hull: Any, n_simulations: int, n_observations: int, rng: np.random.Gene
     return result.squeeze()
 
 
+class _Engine:
+    """Evaluates one Ripley statistic (F, G or L) for a point set on the GPU.
+
+    ``mode`` decides what "points" means: L -> pair counts inside the set; G -> nearest-neighbour distances from the
+    query set to the set; F -> the same with simulated query points (gr/_ripley.py:140-155, 160-177)."""
+
+    def __init__(self, ctx: Context, mode: RipleyStat, metric: str, support: np.ndarray, n_total: int, area: float):
+        self.ctx, self.mode, self.metric, self.support = ctx, mode, metric, support
+        self.n_total, self.area = n_total, area
+
+    def l_stat(self, points: np.ndarray) -> np.ndarray:
+        return _l_function(self.ctx, points, self.support, self.n_total, self.area, self.metric)[1]
+
+    def nn_stat(self, queries: np.ndarray, refs: np.ndarray, k: int) -> np.ndarray:
+        dist = knn_dist(self.ctx, queries, refs, k, self.metric)
+        return _f_g_function(dist.squeeze(), self.support)[1]
+
+
+def _tail_pvalues(obs: np.ndarray, sims: np.ndarray) -> np.ndarray:
+    """gr/_ripley.py:175-180: ``(1 + #{sim >= obs}) / (n_sim + 1)`` folded to the smaller tail."""
+    exceed = (sims[:, None, :] >= obs[None, :, :]).sum(axis=0)
+    p = (1.0 + exceed) / (sims.shape[0] + 1)
+    return np.minimum(p, 1 - p)
+
+
 def ripley(
     adata: Any,
     cluster_key: str,
@@ -105,9 +130,10 @@ def ripley(
 ) -> dict[str, Any] | None:
     """Calculate various Ripley's statistics for point processes (drop-in for ``squidpy.gr.ripley``).
 
-    Same parameters, numpy random streams (``spawn_generators(seed, n_simulations + 1)``), result keys
-    (``'{mode}_stat'``, ``'sims_stat'``, ``'bins'``, ``'pvalues'``) and ``adata.uns['{cluster_key}_ripley_{mode}']``
-    slot as the reference.  Supported metrics on the GPU: euclidean / manhattan / chebyshev (and their aliases).
+    Same parameters, numpy random streams (``spawn_generators(seed, n_simulations + 1)``: the first generator draws the
+    observed-mode Poisson patterns, the others one simulation each), result keys (``'{mode}_stat'``, ``'sims_stat'``,
+    ``'bins'``, ``'pvalues'``) and ``adata.uns['{cluster_key}_ripley_{mode}']`` slot as the reference.  Supported metrics
+    on the GPU: euclidean / manhattan / chebyshev (and their sklearn aliases).
     """
     from scipy.spatial import ConvexHull
     from sklearn.preprocessing import LabelEncoder
@@ -115,70 +141,55 @@ def ripley(
     adata = extract_adata_if_sdata(adata, table_key=table_key)
     _assert_categorical_obs(adata, key=cluster_key)
     _assert_spatial_basis(adata, key=spatial_key)
-    coordinates = np.asarray(adata.obsm[spatial_key])
-    clusters = adata.obs[cluster_key].values
-
-    mode = RipleyStat(mode)
-    if mode == RipleyStat.L and metric not in KDTREE_VALID_METRICS:
+    stat = RipleyStat(mode)
+    if stat == RipleyStat.L and metric not in KDTREE_VALID_METRICS:
         raise ValueError(f"Unsupported metric '{metric}'. Ripley's L supports {KDTREE_VALID_METRICS}")
     if metric not in METRICS:
         raise NotImplementedError(f"Metric `{metric}` is not implemented on the GPU path; use one of {sorted(METRICS)}.")
-    ctx = default_context(device)
 
-    # prepare support
-    N = coordinates.shape[0]
-    hull = ConvexHull(coordinates)
+    xy = np.asarray(adata.obsm[spatial_key])
+    xy64 = xy.astype(np.float64)
+    hull = ConvexHull(xy)
     area = hull.volume
-    if max_dist is None:
-        max_dist = (area / 2) ** 0.5
-    support = np.linspace(0, max_dist, n_steps)
+    radius_max = (area / 2) ** 0.5 if max_dist is None else max_dist
+    support = np.linspace(0, radius_max, n_steps)
+    encoder = LabelEncoder().fit(adata.obs[cluster_key].values)
+    codes = encoder.transform(adata.obs[cluster_key].values)
+    n_groups = encoder.classes_.shape[0]
+    engine = _Engine(default_context(device), stat, metric, support, xy.shape[0], area)
+    first_rng, *other_rngs = spawn_generators(seed, n_simulations + 1)
 
-    # prepare labels
-    le = LabelEncoder().fit(clusters)
-    cluster_idx = le.transform(clusters)
-    obs_arr = np.empty((le.classes_.shape[0], n_steps))
-    obs_rng, *sim_rngs = spawn_generators(seed, n_simulations + 1)
-    coords64 = coordinates.astype(np.float64)
-
-    random = None
-    bins = support
-    for i in np.arange(np.max(cluster_idx) + 1):
-        coord_c = coords64[cluster_idx == i, :]
-        if mode == RipleyStat.F:
-            random = _ppp(hull, n_simulations=1, n_observations=n_observations, rng=obs_rng)
-            distances = knn_dist(ctx, random, coord_c, n_neigh, metric)
-            bins, obs_stats = _f_g_function(distances.squeeze(), support)
-        elif mode == RipleyStat.G:
-            distances = knn_dist(ctx, coords64[cluster_idx != i, :], coord_c, n_neigh, metric)
-            bins, obs_stats = _f_g_function(distances.squeeze(), support)
+    # observed statistic per cluster (F: each cluster is probed with its own Poisson pattern drawn from `first_rng`)
+    observed = np.empty((n_groups, n_steps))
+    probe = None
+    for gidx in range(int(codes.max()) + 1):
+        members = xy64[codes == gidx]
+        if stat == RipleyStat.L:
+            observed[gidx] = engine.l_stat(members)
+        elif stat == RipleyStat.G:
+            observed[gidx] = engine.nn_stat(xy64[codes != gidx], members, n_neigh)
         else:
-            bins, obs_stats = _l_function(ctx, coord_c, support, N, area, metric)
-        obs_arr[i] = obs_stats
+            probe = _ppp(hull, n_simulations=1, n_observations=n_observations, rng=first_rng)
+            observed[gidx] = engine.nn_stat(probe, members, n_neigh)
 
-    sims = np.empty((n_simulations, len(bins)))
-    pvalues = np.ones((le.classes_.shape[0], len(bins)))
-    for i in range(n_simulations):
-        random_i = _ppp(hull, n_simulations=1, n_observations=n_observations, rng=sim_rngs[i])
-        if mode == RipleyStat.F:
-            distances_i = knn_dist(ctx, random, random_i, 1, metric)
-            _, stats_i = _f_g_function(distances_i.squeeze(), support)
-        elif mode == RipleyStat.G:
-            distances_i = knn_dist(ctx, coords64, random_i, 1, metric)
-            _, stats_i = _f_g_function(distances_i.squeeze(), support)
-        else:
-            _, stats_i = _l_function(ctx, random_i, support, N, area, metric)
-        for j in range(obs_arr.shape[0]):
-            pvalues[j] += stats_i >= obs_arr[j]
-        sims[i] = stats_i
+    # null distribution: complete spatial randomness inside the hull, one pattern per generator
+    simulated = np.empty((n_simulations, n_steps))
+    for s_idx, rng in enumerate(other_rngs):
+        pattern = _ppp(hull, n_simulations=1, n_observations=n_observations, rng=rng)
+        if stat == RipleyStat.L:
+            simulated[s_idx] = engine.l_stat(pattern)
+        elif stat == RipleyStat.G:
+            simulated[s_idx] = engine.nn_stat(xy64, pattern, 1)
+        else:  # the reference reuses the probe pattern of the LAST cluster here (gr/_ripley.py:163-165)
+            simulated[s_idx] = engine.nn_stat(probe, pattern, 1)
 
-    pvalues /= n_simulations + 1
-    pvalues = np.minimum(pvalues, 1 - pvalues)
-
-    obs_df = _reshape_res(obs_arr.T, columns=le.classes_, index=bins, var_name=cluster_key)
-    sims_df = _reshape_res(sims.T, columns=np.arange(n_simulations), index=bins, var_name="simulations")
-    res = {f"{mode}_stat": obs_df, "sims_stat": sims_df, "bins": bins, "pvalues": pvalues}
-
+    res = {
+        f"{stat}_stat": _reshape_res(observed.T, columns=encoder.classes_, index=support, var_name=cluster_key),
+        "sims_stat": _reshape_res(simulated.T, columns=np.arange(n_simulations), index=support, var_name="simulations"),
+        "bins": support,
+        "pvalues": _tail_pvalues(observed, simulated),
+    }
     if copy:
         return res
-    _save_data(adata, attr="uns", key=Key.uns.ripley(cluster_key, mode.s), data=res)
+    _save_data(adata, attr="uns", key=Key.uns.ripley(cluster_key, stat.s), data=res)
     return None
