@@ -1,0 +1,48 @@
+"""Randomised differential test of libsqgr against the CPU oracle (run on the GPU box: python tools/fuzz_gpu.py [seconds])."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import scipy.sparse as sp
+from oracle import devrng, restate as O
+from squidpy_amd import _lib as L
+from squidpy_amd._utils import pcg64_states
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+ctx = L.default_context()
+rng = np.random.default_rng(int(time.time()))
+t0 = time.time(); it = 0
+while time.time() - t0 < budget:
+    it += 1
+    n = int(rng.choice([3, 17, 64, 255, 257, 1000, 4097, 20000]))
+    k = int(rng.choice([2, 3, 7, 30, 50, 51, 64, 100, 203, 256]))
+    dens = rng.choice([0.0, 2.0, 6.0, 20.0]) / max(n, 1)
+    A = sp.random(n, n, density=min(1.0, dens), format="csr", random_state=int(rng.integers(1 << 31)))
+    if rng.random() < 0.3: A = A + sp.identity(n, format="csr")
+    A = sp.csr_matrix(A); A.data[:] = rng.random(A.nnz).astype(np.float32) + 0.5
+    labels = rng.integers(0, k, n).astype(np.int32)
+    if rng.random() < 0.3: labels[:] = rng.integers(0, max(1, k // 3), n)  # empty categories
+    g = L.Graph(ctx, A)
+    assert np.array_equal(L.nhood_counts(ctx, g, labels, k), O.nhood_counts(A.indices, A.indptr, labels, k)), ("counts", n, k)
+    use_libs = rng.random() < 0.4
+    nl = int(rng.integers(1, 5)); libs = rng.integers(0, nl, n).astype(np.int32) if use_libs else None
+    plan = L.NhoodPlan(ctx, g, labels, k, libs, nl if use_libs else 0)
+    plan.tune(int(rng.choice([16, 32])), int(rng.choice([0, 8, 256])), int(rng.choice([1, 3, 32])))
+    P = int(rng.integers(1, 70)); seed = int(rng.integers(1 << 62)); lo = int(rng.integers(0, 1 << 40))
+    s1, s2, perms = plan.run(seed, lo, lo + P, None, return_perms=True)
+    ref = O.nhood_perm_counts_philox(A.indices, A.indptr, labels, k, seed, lo, lo + P, libs, nl if use_libs else 0)
+    assert np.array_equal(perms, ref.astype(np.uint32)), ("philox", n, k, use_libs)
+    assert np.array_equal(s1, ref.astype(np.int64).sum(0))
+    if n <= 4097:
+        _, _, pp = plan.run_pcg64(pcg64_states(seed % 1000, P), return_perms=True)
+        refn = O.nhood_perm_counts_numpy(A.indices, A.indptr, labels, k, seed % 1000, P, libs, nl if use_libs else 0)
+        assert np.array_equal(pp, refn.astype(np.uint32)), ("pcg64", n, k, use_libs)
+    plan.close(); g.close()
+    # co-occurrence + ripley on small clouds
+    m = int(rng.choice([2, 50, 300, 700])); kk = int(rng.choice([1, 2, 5]))
+    x = np.round(rng.random(m) * 50, int(rng.integers(0, 3))).astype(np.float32); y = np.round(rng.random(m) * 50, 1).astype(np.float32)
+    labs = rng.integers(0, kk, m).astype(np.int32)
+    thr = np.sort(rng.random(int(rng.integers(1, 30))) * 60).astype(np.float32) ** 2
+    assert np.array_equal(L.cooccur_counts(ctx, x, y, labs, kk, thr), O.occur_count(x, y, thr, labs, kk)), ("cooc", m, kk)
+    pts = np.stack([x, y], 1).astype(np.float64); sup = np.linspace(0, 40, int(rng.integers(2, 40)))
+    assert np.array_equal(L.pair_counts(ctx, pts, sup), O.pair_counts_bruteforce(pts, sup)), ("pairs", m)
+print(f"fuzz ok: {it} iterations in {time.time()-t0:.0f}s")
