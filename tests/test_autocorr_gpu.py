@@ -192,3 +192,17 @@ def test_numpy_device_streams_equal_host_streams(L):
     a = sq.gr.spatial_autocorr(adata, mode="geary", n_perms=40, seed=5, copy=True, rng="numpy")
     b = sq.gr.spatial_autocorr(adata, mode="geary", n_perms=40, seed=5, copy=True, rng="numpy-host")
     pd.testing.assert_frame_equal(a, b)
+
+
+def test_use_raw_and_missing_raw(L):
+    """reference tests/graph/test_ppatterns.py:210-218 (`use_raw=True` reads `adata.raw`)."""
+    import squidpy_amd as sq
+
+    adata = _adata(n=300, G=12)
+    with pytest.raises(AttributeError, match="No `.raw` attribute found"):
+        sq.gr.spatial_autocorr(adata, use_raw=True, genes=["gene1"])
+    adata.raw = sq.AnnDataLite(X=adata.X * 3.0, obs=adata.obs, var=adata.var)
+    df_raw = sq.gr.spatial_autocorr(adata, use_raw=True, genes=["gene1", "gene2", "nope"], copy=True)
+    df = sq.gr.spatial_autocorr(adata, genes=["gene1", "gene2"], copy=True)
+    assert sorted(df_raw.index) == ["gene1", "gene2"]  # intersected with raw.var_names
+    np.testing.assert_allclose(df_raw.loc[df.index, "I"], df["I"], rtol=1e-9)
