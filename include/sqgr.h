@@ -175,6 +175,20 @@ int sqgr_pair_counts(sqgr_ctx* ctx, const double* xy, int64_t m, const double* t
 int sqgr_knn_dist(sqgr_ctx* ctx, const double* query, int64_t nq, const double* ref, int64_t nr, int32_t k, int32_t metric,
                   double* out);
 
+/* ------------------------------------------------------------------ spatial graph construction
+ * Exact 2-D neighbour search on a device cell list; xy: float64[n][2].
+ *
+ * sqgr_knn_self replaces `NearestNeighbors(n_neighbors=k, metric="euclidean").fit(xy).kneighbors()`
+ * (gr/neighbors.py:196-199, 402-405): for every sample its k nearest OTHER samples (self excluded by index),
+ * ascending; ties broken by the smaller index.  out_idx int32[n][k]; out_d2 float64[n][k] SQUARED distances
+ * (per-coordinate accumulation, no FMA; the caller applies sqrt).  1 <= k <= min(64, n-1). */
+int sqgr_knn_self(sqgr_ctx* ctx, const double* xy, int64_t n, int32_t k, int32_t* out_idx, double* out_d2);
+/* sqgr_radius_self replaces `NearestNeighbors(radius=r).fit(xy).radius_neighbors()` (gr/neighbors.py:252-255): all
+ * other samples with squared distance <= r*r, as CSR.  Call once with out_idx = out_d2 = NULL to obtain
+ * out_indptr int64[n+1], allocate out_indptr[n] entries, call again (capacity = allocated entries). */
+int sqgr_radius_self(sqgr_ctx* ctx, const double* xy, int64_t n, double radius, int64_t* out_indptr, int32_t* out_idx,
+                     double* out_d2, int64_t capacity);
+
 #ifdef __cplusplus
 }
 #endif

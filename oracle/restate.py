@@ -563,3 +563,96 @@ def hex_grid_graph(rows: int, cols: int) -> sparse.csr_matrix:
     g.indices = g.indices.astype(np.int32)
     g.indptr = g.indptr.astype(np.int32)
     return g
+
+
+# =========================================================================== spatial graph construction (§8f-3)
+
+
+def spatial_graph(
+    coords: np.ndarray,
+    kind: str,
+    n_neighs: int = 6,
+    radius: Any = None,
+    n_rings: int = 1,
+    set_diag: bool = False,
+    percentile: float | None = None,
+    transform: str | None = None,
+) -> tuple[sparse.csr_matrix, sparse.csr_matrix]:
+    """The reference's builders with sklearn's KD-tree exactly as they call it: KNNBuilder gr/neighbors.py:194-209,
+    RadiusBuilder :247-269, GridBuilder :366-419, post-processors :425-476, spectral transform :514-548."""
+    import warnings
+
+    from sklearn.neighbors import NearestNeighbors
+
+    N = coords.shape[0]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", sparse.SparseEfficiencyWarning)
+
+        def base_grid(diag: bool) -> sparse.csr_matrix:
+            tree = NearestNeighbors(n_neighbors=n_neighs, radius=1, metric="euclidean").fit(coords)
+            dists, cols = tree.kneighbors()
+            dists, cols = dists.reshape(-1), cols.reshape(-1)
+            rows = np.repeat(np.arange(N), n_neighs)
+            mask = dists < np.median(dists) * 1.3
+            a = sparse.csr_matrix((np.ones(mask.sum(), dtype=np.float32), (rows[mask], cols[mask])), shape=(N, N))
+            a.setdiag(1.0 if diag else a.diagonal())
+            return a
+
+        if kind == "grid":
+            if n_rings > 1:
+                adj = base_grid(True)
+                res, walk = adj, adj
+                for i in range(n_rings - 1):
+                    walk = walk @ adj
+                    walk[res.nonzero()] = 0.0
+                    walk.eliminate_zeros()
+                    walk.data[:] = i + 2.0
+                    res = res + walk
+                adj = res
+                adj.setdiag(float(set_diag))
+                adj.eliminate_zeros()
+                dst = adj.copy()
+                adj.data[:] = 1.0
+            else:
+                adj = base_grid(set_diag)
+                dst = adj.copy()
+            dst.setdiag(0.0)
+        else:
+            if kind == "knn":
+                tree = NearestNeighbors(n_neighbors=n_neighs, radius=1, metric="euclidean").fit(coords)
+                dists, cols = tree.kneighbors()
+                dists, cols = dists.reshape(-1), cols.reshape(-1)
+                rows = np.repeat(np.arange(N), n_neighs)
+            else:
+                r = radius if isinstance(radius, (int, float)) else max(radius)
+                tree = NearestNeighbors(radius=r, metric="euclidean").fit(coords)
+                dists, cols = tree.radius_neighbors()
+                rows = np.repeat(np.arange(N), [len(x) for x in cols])
+                dists, cols = np.concatenate(dists), np.concatenate(cols)
+            adj = sparse.csr_matrix((np.ones_like(rows, dtype=np.float32), (rows, cols)), shape=(N, N))
+            dst = sparse.csr_matrix((dists, (rows, cols)), shape=(N, N))
+            adj.setdiag(1.0 if set_diag else adj.diagonal())
+            dst.setdiag(0.0)
+            if kind == "radius" and isinstance(radius, tuple):
+                minn, maxx = sorted(radius)
+                mask = (dst.data < minn) | (dst.data > maxx)
+                a_diag = adj.diagonal()
+                dst.data[mask] = 0.0
+                adj.data[mask] = 0.0
+                adj.setdiag(a_diag)
+            if percentile is not None:
+                threshold = np.percentile(dst.data, percentile)
+                adj[dst > threshold] = 0.0
+                dst[dst > threshold] = 0.0
+        adj.eliminate_zeros()
+        dst.eliminate_zeros()
+        if transform == "spectral" and adj.nnz:
+            with np.errstate(divide="ignore"):
+                deg = np.squeeze(np.array(np.sqrt(1.0 / adj.sum(axis=0))))
+            rows = np.repeat(np.arange(N), np.diff(adj.indptr))
+            adj = sparse.csr_matrix(((deg[rows] * deg[adj.indices] * adj.data).astype(np.float32), adj.indices, adj.indptr), shape=adj.shape)
+        elif transform == "cosine":
+            from sklearn.metrics.pairwise import cosine_similarity
+
+            adj = cosine_similarity(adj, dense_output=False)
+    return sparse.csr_matrix(adj), sparse.csr_matrix(dst)

@@ -56,6 +56,8 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "sqgr_autocorr_perm_indices": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_int64, C.c_int64, c_i32p]),
     "sqgr_pair_counts": (C.c_int, [C.c_void_p, c_f64p, C.c_int64, c_f64p, C.c_int32, C.c_int32, c_i64p]),
     "sqgr_knn_dist": (C.c_int, [C.c_void_p, c_f64p, C.c_int64, c_f64p, C.c_int64, C.c_int32, C.c_int32, c_f64p]),
+    "sqgr_knn_self": (C.c_int, [C.c_void_p, c_f64p, C.c_int64, C.c_int32, c_i32p, c_f64p]),
+    "sqgr_radius_self": (C.c_int, [C.c_void_p, c_f64p, C.c_int64, C.c_double, c_i64p, c_i32p, c_f64p, C.c_int64]),
     "sqgr_cooccur_counts": (
         C.c_int,
         [C.c_void_p, c_f32p, c_f32p, c_i32p, C.c_int64, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_i64p],
@@ -485,3 +487,33 @@ def pcg64_permutations(ctx: Context, n: int, states: np.ndarray) -> np.ndarray:
     out = np.zeros((states.shape[0], n), dtype=np.int32)
     _check(ctx.lib, ctx.lib.sqgr_pcg64_permutations(ctx.h, n, _ptr(states, c_u64p), states.shape[0], _ptr(out, c_i32p)))
     return out
+
+
+def knn_self(ctx: Context, xy: np.ndarray, k: int) -> tuple[np.ndarray, np.ndarray]:
+    """k nearest other samples of every sample -> (dist float64 (n, k) ascending, idx int32 (n, k)); what
+    ``NearestNeighbors(n_neighbors=k).fit(xy).kneighbors()`` returns."""
+    xy = _as(xy, np.float64)
+    n = xy.shape[0]
+    if xy.ndim != 2 or xy.shape[1] != 2:
+        raise ValueError(f"Expected 2-D coordinates of shape (n, 2), found {xy.shape}.")
+    if k + 1 > n:
+        raise ValueError(f"Expected n_neighbors <= n_samples_fit, but n_neighbors = {k + 1}, n_samples_fit = {n}, n_samples = {n}")
+    idx = np.zeros((n, k), dtype=np.int32)
+    d2 = np.zeros((n, k), dtype=np.float64)
+    _check(ctx.lib, ctx.lib.sqgr_knn_self(ctx.h, _ptr(xy, c_f64p), n, k, _ptr(idx, c_i32p), _ptr(d2, c_f64p)))
+    return np.sqrt(d2), idx
+
+
+def radius_self(ctx: Context, xy: np.ndarray, radius: float) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """all other samples within ``radius`` of every sample -> CSR (indptr int64 (n+1,), idx int32, dist float64)."""
+    xy = _as(xy, np.float64)
+    n = xy.shape[0]
+    if xy.ndim != 2 or xy.shape[1] != 2:
+        raise ValueError(f"Expected 2-D coordinates of shape (n, 2), found {xy.shape}.")
+    indptr = np.zeros(n + 1, dtype=np.int64)
+    _check(ctx.lib, ctx.lib.sqgr_radius_self(ctx.h, _ptr(xy, c_f64p), n, float(radius), _ptr(indptr, c_i64p), None, None, 0))
+    nnz = int(indptr[-1])
+    idx = np.zeros(max(nnz, 1), dtype=np.int32)
+    d2 = np.zeros(max(nnz, 1), dtype=np.float64)
+    _check(ctx.lib, ctx.lib.sqgr_radius_self(ctx.h, _ptr(xy, c_f64p), n, float(radius), _ptr(indptr, c_i64p), _ptr(idx, c_i32p), _ptr(d2, c_f64p), max(nnz, 1)))
+    return indptr, idx[:nnz], np.sqrt(d2[:nnz])

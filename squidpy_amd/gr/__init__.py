@@ -1,7 +1,15 @@
 """``squidpy_amd.gr`` — the MI355X-native ``sq.gr`` spatial-statistics hot path."""
 
+from ._build import (
+    SpatialNeighborsResult,
+    spatial_neighbors,
+    spatial_neighbors_grid,
+    spatial_neighbors_knn,
+    spatial_neighbors_radius,
+)
 from ._nhood import NhoodEnrichmentResult, interaction_matrix, nhood_enrichment
 from ._ppatterns import co_occurrence, spatial_autocorr
 from ._ripley import ripley
 
-__all__ = ["nhood_enrichment", "interaction_matrix", "NhoodEnrichmentResult", "co_occurrence", "spatial_autocorr", "ripley"]
+__all__ = ["nhood_enrichment", "interaction_matrix", "NhoodEnrichmentResult", "co_occurrence", "spatial_autocorr", "ripley", "spatial_neighbors",
+           "spatial_neighbors_knn", "spatial_neighbors_radius", "spatial_neighbors_grid", "SpatialNeighborsResult"]
