@@ -13,13 +13,14 @@ import numpy as np
 
 
 def is_distributed() -> bool:
-    if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+    force = os.environ.get("SQGR_DIST_FORCE") == "1"  # exercise the collective path with a single rank (tests)
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1 and not force:
         return False
     try:
         import torch.distributed as dist
     except ImportError:  # pragma: no cover
         return False
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force)
 
 
 def world() -> tuple[int, int]:
