@@ -189,6 +189,32 @@ int sqgr_knn_self(sqgr_ctx* ctx, const double* xy, int64_t n, int32_t k, int32_t
 int sqgr_radius_self(sqgr_ctx* ctx, const double* xy, int64_t n, double radius, int64_t* out_indptr, int32_t* out_idx,
                      double* out_d2, int64_t capacity);
 
+/* ---- ligand-receptor permutation test -------------------------------------------------------------------------------
+ * sqgr_ligrec_counts replaces the numba kernel `_score_permutations` (gr/_ligrec.py:616-673) that `_analysis`
+ * (gr/_ligrec.py:677-775) calls once for all permutations:
+ *     for every permutation p in [perm_begin, perm_end):
+ *         perm        = shuffle(clustering)
+ *         groups[k,g] = (sum over cells with perm[cell] == k of data[cell,g], cells in index order) * inv_counts[k]
+ *         out_counts[i,j] += valid[i,j] && groups[a_j,rec_i] + groups[b_j,lig_i] > obs[i,j]
+ * with (rec_i, lig_i) = interactions[i], (a_j, b_j) = cpairs[j] and obs[i,j] = mean_obs[a_j,rec_i] + mean_obs[b_j,lig_i]
+ * (formed by the caller in float64, the same IEEE addition the reference performs per comparison).
+ *   data: the (n_cells x n_genes) float64 matrix as CSC columns of its stored entries (colptr int64[n_genes+1],
+ *         rowidx int32 ascending inside a column, values) — zeros need not be stored, they do not change a sum.
+ *   clustering int32[n_cells] in [0,K), 2 <= K <= 256; inv_counts float64[K].
+ *   pcg_states == NULL: device generator keyed by (seed, global permutation index) — the result for a permutation
+ *         range does not depend on how ranges are split over calls or GPUs.
+ *   pcg_states != NULL: numpy streams; (perm_end-perm_begin) rows [state_hi,state_lo,inc_hi,inc_lo] of the PCG64
+ *         generators `spawn_generators(seed, n_perms)[perm_begin:perm_end]` (_utils.py:240-241); permutation p is then
+ *         bit-for-bit `generators[p].shuffle(clustering.copy())`; `seed` is ignored.
+ *   out_counts int64[n_inter*n_cp] (row-major, overwritten).  out_means_perm0 (may be NULL): float64[K*n_genes], the
+ *         `groups` matrix of the first permutation of the range (for parity checks).
+ * Group sums are accumulated in the reference's order (cell index), so they are bit-identical to the CPU loop. */
+int sqgr_ligrec_counts(sqgr_ctx* ctx, int64_t n_cells, int32_t n_genes, int32_t K, const int64_t* colptr, const int32_t* rowidx,
+                       const double* values, const int32_t* clustering, const double* inv_counts, const int32_t* interactions,
+                       int64_t n_inter, const int32_t* cpairs, int32_t n_cp, const double* obs, const uint8_t* valid,
+                       uint64_t seed, const uint64_t* pcg_states, int64_t perm_begin, int64_t perm_end, int64_t* out_counts,
+                       double* out_means_perm0);
+
 #ifdef __cplusplus
 }
 #endif

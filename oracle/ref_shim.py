@@ -24,12 +24,14 @@ Reference symbols exposed (file:line in /root/reference/src/squidpy):
   gr/_ppatterns.py:283-358 ``_occur_count``/``_co_occurrence_helper``
   gr/_ppatterns.py:431-559 ``_find_min_max``/``_p_value_calc``/``_analytic_pval``/``_g_moments``
   gr/_ripley.py:197-271    ``_reshape_res``/``_f_g_function``/``_l_function``/``_ppp``
+  gr/_ligrec.py:616-775    ``_score_permutations``/``_analysis``
 """
 
 from __future__ import annotations
 
 import ast
 import os
+import re
 import sys
 import types
 from contextlib import contextmanager
@@ -114,7 +116,10 @@ class _Strip(ast.NodeTransformer):
 def _extract(relpath: str, names: list[str], namespace: dict[str, Any]) -> dict[str, Any]:
     path = os.path.join(REF_SRC, relpath)
     with open(path) as fh:
-        tree = ast.parse(fh.read(), filename=path)
+        src = fh.read()
+    # PEP 695 `type X = ...` aliases do not parse on this interpreter (3.10): blank them, keeping line numbers
+    src = re.sub(r"(?m)^type\s+\w+(\[[^\]]*\])?\s*=.*$", "pass", src)
+    tree = ast.parse(src, filename=path)
     keep: list[ast.stmt] = []
     for node in tree.body:
         if isinstance(node, ast.FunctionDef) and node.name in names:
@@ -269,4 +274,49 @@ def ripley() -> dict[str, Any]:
     }
     _extract("gr/_ripley.py", ["_reshape_res", "_f_g_function", "_l_function", "_ppp"], ns)
     _cache["ripley"] = ns
+    return ns
+
+
+class _NullProgress:
+    """Stands in for ``numba_progress.ProgressBar`` (context manager with ``update``)."""
+
+    def __init__(self, *_a: Any, **_k: Any):
+        pass
+
+    def __enter__(self) -> "_NullProgress":
+        return self
+
+    def __exit__(self, *_a: Any) -> None:
+        return None
+
+    def update(self, _n: int) -> None:
+        return None
+
+
+@contextmanager
+def _null_threads(_n: Any):
+    yield
+
+
+def ligrec() -> dict[str, Any]:
+    """Namespace with the reference's ligrec permutation kernel and its driver (gr/_ligrec.py:616-775)."""
+    if "ligrec" in _cache:
+        return _cache["ligrec"]
+    from collections import namedtuple
+
+    import pandas as pd
+
+    ns: dict[str, Any] = {
+        "np": np,
+        "pd": pd,
+        "njit": _njit,
+        "prange": range,
+        "List": list,
+        "ProgressBar": _NullProgress,
+        "numba_threads": _null_threads,
+        "TempResult": namedtuple("TempResult", ["means", "pvalues"]),
+        "spawn_generators": utils()["spawn_generators"],
+    }
+    _extract("gr/_ligrec.py", ["_score_permutations", "_analysis"], ns)
+    _cache["ligrec"] = ns
     return ns

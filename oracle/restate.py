@@ -656,3 +656,102 @@ def spatial_graph(
 
             adj = cosine_similarity(adj, dense_output=False)
     return sparse.csr_matrix(adj), sparse.csr_matrix(dst)
+
+
+# ----------------------------------------------------------------------------------------------- ligrec (§8(f) row 4)
+def ligrec_group_means(data: np.ndarray, perm: np.ndarray, inv_counts: np.ndarray) -> np.ndarray:
+    """`groups` of one permutation (gr/_ligrec.py:647-655): per cluster the sum of the rows in cell order, then
+    multiplied by the reciprocal cluster size.  ``np.add.at`` is unbuffered and visits the rows in index order, i.e.
+    every (cluster, gene) cell is accumulated in exactly the sequence of the reference's double loop."""
+    groups = np.zeros((len(inv_counts), data.shape[1]), dtype=np.float64)
+    np.add.at(groups, np.asarray(perm, dtype=np.int64), data)
+    return groups * np.asarray(inv_counts, dtype=np.float64)[:, None]
+
+
+def ligrec_perm_labels_numpy(clustering: np.ndarray, seed: int | None, n_perms: int) -> np.ndarray:
+    """Label vectors of all permutations under numpy streams: one generator per permutation, each shuffling a fresh
+    copy of the clustering (gr/_ligrec.py:643-646, 748)."""
+    out = np.empty((n_perms, len(clustering)), dtype=np.int32)
+    for p, rs in enumerate(spawn_generators(seed, n_perms)):
+        perm = np.array(clustering, dtype=np.int32, copy=True)
+        rs.shuffle(perm)
+        out[p] = perm
+    return out
+
+
+def ligrec_perm_labels_philox(clustering: np.ndarray, seed: int, perm_begin: int, perm_end: int) -> np.ndarray:
+    """Label vectors of the device generator (oracle/devrng.py), permutations [perm_begin, perm_end)."""
+    from oracle import devrng
+
+    return np.stack([devrng.shuffled_labels(np.asarray(clustering), seed, p) for p in range(perm_begin, perm_end)]).astype(np.int32)
+
+
+def ligrec_score_permutations(
+    data: np.ndarray,
+    perm_labels: np.ndarray,
+    inv_counts: np.ndarray,
+    mean_obs: np.ndarray,
+    interactions: np.ndarray,
+    interaction_clusters: np.ndarray,
+    valid: np.ndarray,
+) -> np.ndarray:
+    """``_score_permutations`` (gr/_ligrec.py:616-673) for the given shuffled label vectors (n_perms, n_cells):
+    counts[i, j] = #{p : valid[i, j] and groups_p[a_j, rec_i] + groups_p[b_j, lig_i] > mean_obs[a_j, rec_i] + mean_obs[b_j, lig_i]}."""
+    rec, lig = interactions[:, 0], interactions[:, 1]
+    a, b = interaction_clusters[:, 0], interaction_clusters[:, 1]
+    obs = mean_obs[a][:, rec].T + mean_obs[b][:, lig].T  # (n_inter, n_cpairs), float64 add as in :665
+    counts = np.zeros(obs.shape, dtype=np.int64)
+    for perm in perm_labels:
+        groups = ligrec_group_means(data, perm, inv_counts)
+        shuf = groups[a][:, rec].T + groups[b][:, lig].T
+        counts += (valid & (shuf > obs)).astype(np.int64)
+    return counts
+
+
+def ligrec_prepare(
+    data: np.ndarray, clustering: np.ndarray, interactions: np.ndarray, interaction_clusters: np.ndarray, threshold: float
+) -> dict[str, np.ndarray]:
+    """Host part of ``_analysis`` before the kernel call (gr/_ligrec.py:712-745): observed cluster means (pandas
+    groupby mean, as the reference), expression-fraction mask, reciprocal cluster sizes, `valid` and `means`."""
+    import pandas as pd
+
+    df = pd.DataFrame(np.asarray(data, dtype=np.float64))
+    groups = df.groupby(np.asarray(clustering), observed=True)
+    mean_obs = groups.mean().values
+    n_cls = mean_obs.shape[0]
+    sizes = np.bincount(np.asarray(clustering), minlength=n_cls).astype(np.float64)
+    frac = np.stack([(np.asarray(data)[np.asarray(clustering) == k] > 0).astype(np.int64).sum(axis=0) / sizes[k] for k in range(n_cls)])
+    mask = frac >= threshold
+    inv_counts = 1.0 / np.maximum(sizes, 1)
+    rec, lig = interactions[:, 0], interactions[:, 1]
+    c1, c2 = interaction_clusters[:, 0], interaction_clusters[:, 1]
+    m_rec = mean_obs[c1, :][:, rec].T
+    m_lig = mean_obs[c2, :][:, lig].T
+    nonzero = (m_rec > 0) & (m_lig > 0)
+    valid = nonzero & mask[c1, :][:, rec].T & mask[c2, :][:, lig].T
+    means = np.where(nonzero, (m_rec + m_lig) / 2.0, 0.0)
+    return {"mean_obs": mean_obs, "mask": mask, "inv_counts": inv_counts, "valid": valid, "means": means, "obs": m_rec + m_lig}
+
+
+def ligrec_analysis(
+    data: np.ndarray,
+    clustering: np.ndarray,
+    interactions: np.ndarray,
+    interaction_clusters: np.ndarray,
+    threshold: float = 0.1,
+    n_perms: int = 1000,
+    seed: int | None = None,
+    perm_labels: np.ndarray | None = None,
+) -> tuple[np.ndarray, np.ndarray]:
+    """``_analysis`` (gr/_ligrec.py:677-775): (means, pvalues).  ``perm_labels`` overrides the numpy streams."""
+    interactions = np.asarray(interactions, dtype=np.int32)
+    interaction_clusters = np.asarray(interaction_clusters, dtype=np.int32)
+    pre = ligrec_prepare(data, clustering, interactions, interaction_clusters, threshold)
+    if perm_labels is None:
+        perm_labels = ligrec_perm_labels_numpy(clustering, seed, n_perms)
+    counts = ligrec_score_permutations(
+        np.asarray(data, dtype=np.float64), perm_labels, pre["inv_counts"], pre["mean_obs"], interactions, interaction_clusters, pre["valid"]
+    )
+    pvalues = counts.astype(np.float64) / len(perm_labels)
+    pvalues[~pre["valid"]] = np.nan
+    return pre["means"], pvalues

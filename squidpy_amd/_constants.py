@@ -39,6 +39,20 @@ class RipleyStat(ModeEnum):
     L = "L"
 
 
+class CorrAxis(ModeEnum):
+    """Axis of the FDR correction in ``ligrec`` (_constants/_constants.py:21-23)."""
+
+    INTERACTIONS = "interactions"
+    CLUSTERS = "clusters"
+
+
+class ComplexPolicy(ModeEnum):
+    """Treatment of protein complexes in ``ligrec`` (_constants/_constants.py:27-29)."""
+
+    MIN = "min"
+    ALL = "all"
+
+
 def _suffixed(value: str | None, suffix: str) -> str:
     """``None`` -> ``spatial_<suffix>``; ``"foo"`` -> ``"foo_<suffix>"``; an already suffixed key is kept."""
     stem = "spatial" if value is None else value
@@ -59,6 +73,7 @@ class _Uns:
     interaction_matrix = staticmethod(lambda cluster: cluster + "_interactions")
     co_occurrence = staticmethod(lambda cluster: cluster + "_co_occurrence")
     ripley = staticmethod(lambda cluster, mode: f"{cluster}_ripley_{mode}")
+    ligrec = staticmethod(lambda cluster, value=None: f"{cluster}_ligrec" if value is None else value)
 
 
 class Key:

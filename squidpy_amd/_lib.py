@@ -58,6 +58,11 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "sqgr_knn_dist": (C.c_int, [C.c_void_p, c_f64p, C.c_int64, c_f64p, C.c_int64, C.c_int32, C.c_int32, c_f64p]),
     "sqgr_knn_self": (C.c_int, [C.c_void_p, c_f64p, C.c_int64, C.c_int32, c_i32p, c_f64p]),
     "sqgr_radius_self": (C.c_int, [C.c_void_p, c_f64p, C.c_int64, C.c_double, c_i64p, c_i32p, c_f64p, C.c_int64]),
+    "sqgr_ligrec_counts": (
+        C.c_int,
+        [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, c_i64p, c_i32p, c_f64p, c_i32p, c_f64p, c_i32p, C.c_int64, c_i32p, C.c_int32,
+         c_f64p, c_u8p, C.c_uint64, c_u64p, C.c_int64, C.c_int64, c_i64p, c_f64p],
+    ),
     "sqgr_cooccur_counts": (
         C.c_int,
         [C.c_void_p, c_f32p, c_f32p, c_i32p, C.c_int64, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_i64p],
@@ -517,3 +522,63 @@ def radius_self(ctx: Context, xy: np.ndarray, radius: float) -> tuple[np.ndarray
     d2 = np.zeros(max(nnz, 1), dtype=np.float64)
     _check(ctx.lib, ctx.lib.sqgr_radius_self(ctx.h, _ptr(xy, c_f64p), n, float(radius), _ptr(indptr, c_i64p), _ptr(idx, c_i32p), _ptr(d2, c_f64p), max(nnz, 1)))
     return indptr, idx[:nnz], np.sqrt(d2[:nnz])
+
+
+def ligrec_counts(
+    ctx: Context,
+    data_csc: Any,
+    clustering: np.ndarray,
+    n_cls: int,
+    inv_counts: np.ndarray,
+    interactions: np.ndarray,
+    cluster_pairs: np.ndarray,
+    obs: np.ndarray,
+    valid: np.ndarray,
+    *,
+    seed: int = 0,
+    pcg_states: np.ndarray | None = None,
+    perm_begin: int = 0,
+    perm_end: int = 0,
+    return_first_groups: bool = False,
+) -> np.ndarray | tuple[np.ndarray, np.ndarray]:
+    """Permutation counts of the ligand-receptor test (``_score_permutations``, gr/_ligrec.py:616-673).
+
+    ``data_csc``: scipy CSC matrix (n_cells, n_genes), float64.  Returns int64 (n_interactions, n_cluster_pairs);
+    with ``return_first_groups`` also the (n_cls, n_genes) group means of the first permutation of the range."""
+    from scipy import sparse
+
+    m = sparse.csc_matrix(data_csc)
+    if not m.has_sorted_indices:
+        m = m.sorted_indices()
+    n_cells, n_genes = m.shape
+    colptr = _as(m.indptr, np.int64)
+    rowidx = _as(m.indices, np.int32)
+    values = _as(m.data, np.float64)
+    clustering = _as(clustering, np.int32)
+    if clustering.shape != (n_cells,):
+        raise ValueError(f"Expected `{n_cells}` cluster labels, found `{clustering.shape}`.")
+    inv_counts = _as(inv_counts, np.float64)
+    interactions = _as(interactions, np.int32).reshape(-1, 2)
+    cluster_pairs = _as(cluster_pairs, np.int32).reshape(-1, 2)
+    n_inter, n_cp = interactions.shape[0], cluster_pairs.shape[0]
+    obs = _as(obs, np.float64)
+    valid = _as(valid, np.uint8)
+    if obs.shape != (n_inter, n_cp) or valid.shape != (n_inter, n_cp) or inv_counts.shape != (n_cls,):
+        raise ValueError("`obs`/`valid` must have shape (n_interactions, n_cluster_pairs) and `inv_counts` (n_cls,).")
+    states = None
+    if pcg_states is not None:
+        states = _as(pcg_states, np.uint64).reshape(-1, 4)
+        if states.shape[0] != perm_end - perm_begin:
+            raise ValueError("`pcg_states` must hold one row per permutation of the range.")
+    out = np.zeros((n_inter, n_cp), dtype=np.int64)
+    groups = np.zeros((n_cls, n_genes), dtype=np.float64) if return_first_groups else None
+    _check(
+        ctx.lib,
+        ctx.lib.sqgr_ligrec_counts(
+            ctx.h, n_cells, n_genes, n_cls, _ptr(colptr, c_i64p), _ptr(rowidx, c_i32p), _ptr(values, c_f64p),
+            _ptr(clustering, c_i32p), _ptr(inv_counts, c_f64p), _ptr(interactions, c_i32p), n_inter, _ptr(cluster_pairs, c_i32p),
+            n_cp, _ptr(obs, c_f64p), _ptr(valid, c_u8p), C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), _ptr(states, c_u64p),
+            int(perm_begin), int(perm_end), _ptr(out, c_i64p), _ptr(groups, c_f64p),
+        ),
+    )
+    return (out, groups) if return_first_groups else out

@@ -16,6 +16,7 @@
 //               accumulates d=count-shift and d*d in 64-bit integers (order independent, deterministic).
 #include "sqgr_common.h"
 #include "sqgr_rng.h"
+#include "sqgr_shuffle.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -675,19 +676,20 @@ int sqgr_interaction_matrix(sqgr_ctx* ctx, const sqgr_graph* g, const int32_t* l
     return SQGR_OK;
 }
 
-int sqgr_nhood_create(sqgr_ctx* ctx, const sqgr_graph* g, const int32_t* labels, int32_t K, const int32_t* lib_ids,
-                      int32_t n_libs, sqgr_nhood** out_plan) {
-    SQGR_REQUIRE(ctx && g && out_plan, "ctx/graph/out_plan is NULL");
+// Builds the label tables of a plan.  `g` may be NULL (label shuffling only: the ligrec path), then `n` is the number of
+// labelled items.
+static int nhood_build(sqgr_ctx* ctx, const sqgr_graph* g, int64_t n, const int32_t* labels, int32_t K, const int32_t* lib_ids,
+                       int32_t n_libs, sqgr_nhood** out_plan) {
+    SQGR_REQUIRE(ctx && out_plan, "ctx/out_plan is NULL");
     *out_plan = nullptr;
-    SQGR_REQUIRE(g->ctx == ctx, "graph belongs to a different context");
+    SQGR_REQUIRE(!g || g->ctx == ctx, "graph belongs to a different context");
     SQGR_REQUIRE(K >= 2, "Expected at least `2` clusters, found `%d`.", K);
     if (K > 256) {
         set_error("K=%d > 256 clusters is not supported by the uint8 label slab", K);
         return SQGR_ERR_UNSUPPORTED;
     }
-    const int64_t n = g->n;
-    if (n > (int64_t)1 << 27 || g->nnz > (int64_t)0xFFF00000u) {
-        set_error("graph too large for 32-bit slab offsets (n=%lld, nnz=%lld)", (long long)n, (long long)g->nnz);
+    if (n > (int64_t)1 << 27 || (g && g->nnz > (int64_t)0xFFF00000u)) {
+        set_error("graph too large for 32-bit slab offsets (n=%lld, nnz=%lld)", (long long)n, (long long)(g ? g->nnz : 0));
         return SQGR_ERR_UNSUPPORTED;
     }
     if (labels) SQGR_TRY(check_labels(labels, n, K, false));
@@ -801,6 +803,12 @@ int sqgr_nhood_create(sqgr_ctx* ctx, const sqgr_graph* g, const int32_t* labels,
     return SQGR_OK;
 }
 
+int sqgr_nhood_create(sqgr_ctx* ctx, const sqgr_graph* g, const int32_t* labels, int32_t K, const int32_t* lib_ids,
+                      int32_t n_libs, sqgr_nhood** out_plan) {
+    SQGR_REQUIRE(ctx && g && out_plan, "ctx/graph/out_plan is NULL");
+    return nhood_build(ctx, g, g->n, labels, K, lib_ids, n_libs, out_plan);
+}
+
 int sqgr_nhood_destroy(sqgr_nhood* plan) {
     if (!plan) return SQGR_OK;
     (void)hipSetDevice(plan->ctx->device);
@@ -821,18 +829,16 @@ int sqgr_nhood_tune(sqgr_nhood* plan, int32_t perms_per_pass, int32_t blocks_per
     return SQGR_OK;
 }
 
-static int launch_shuffle(sqgr_nhood* p, int nb, int buf, hipStream_t st) {
+static int launch_shuffle_raw(sqgr_nhood* p, int B, int nb, const uint32_t* keys, uint8_t* slab, hipStream_t st) {
     unsigned gx = (unsigned)ceil_div(p->n, 256);
     const char* env_blocks = getenv("SQGR_SHUFFLE_BLOCKS_PER_CU");  // throttle (only useful with SQGR_NHOOD_STREAMS=2)
     if (env_blocks && atoi(env_blocks) > 0) gx = std::min<unsigned>(gx, (unsigned)(atoi(env_blocks) * p->ctx->cu_count) / (unsigned)nb + 1);
     LaunchTimer t(p->ctx, "nhood_shuffle", st);
     const size_t lds = (size_t)p->n_libs * p->kpad * 4 + (size_t)((p->blk_bytes + 3) / 4) * 4;
-    const uint32_t* keys = p->keys.p + (size_t)buf * p->keys_stride();
-    uint8_t* slab = p->slab.p + (size_t)buf * p->slab_stride();
 #define SQGR_SHUFFLE(BB, LIBS)                                                                                  \
     k_shuffle<BB, LIBS><<<dim3(gx, nb), 256, lds, st>>>(p->n, p->cum.p, p->kpad, p->blk_bytes, keys, p->dom0, p->n_libs, p->lib_of.p, \
                                                         p->rank_of.p, p->libs.p, slab)
-    if (p->B == 32) {
+    if (B == 32) {
         if (p->has_libs) SQGR_SHUFFLE(32, true); else SQGR_SHUFFLE(32, false);
     } else {
         if (p->has_libs) SQGR_SHUFFLE(16, true); else SQGR_SHUFFLE(16, false);
@@ -840,6 +846,10 @@ static int launch_shuffle(sqgr_nhood* p, int nb, int buf, hipStream_t st) {
 #undef SQGR_SHUFFLE
     SQGR_HIP(hipGetLastError());
     return SQGR_OK;
+}
+
+static int launch_shuffle(sqgr_nhood* p, int nb, int buf, hipStream_t st) {
+    return launch_shuffle_raw(p, p->B, nb, p->keys.p + (size_t)buf * p->keys_stride(), p->slab.p + (size_t)buf * p->slab_stride(), st);
 }
 
 int sqgr_nhood_run(sqgr_nhood* plan, uint64_t seed, int64_t perm_begin, int64_t perm_end, const int64_t* shift,
@@ -1068,3 +1078,43 @@ int sqgr_pcg64_permutations(sqgr_ctx* ctx, int64_t n, const uint64_t* pcg_states
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------- label shuffler (sqgr_shuffle.h)
+// The two label generators of this file without a graph behind them: other permutation tests over cluster labels
+// (ligrec) draw their shuffled label vectors here, so a given (seed, permutation index) means the same arrangement
+// of the label multiset in every sq.gr function.
+namespace sqgr {
+
+int label_shuffler_create(sqgr_ctx* ctx, int64_t n, const int32_t* labels, int K, LabelShuffler** out) {
+    SQGR_REQUIRE(ctx && labels && out && n > 0, "ctx/labels/out is NULL or n <= 0");
+    SQGR_HIP(hipSetDevice(ctx->device));
+    sqgr_nhood* plan = nullptr;
+    SQGR_TRY(nhood_build(ctx, nullptr, n, labels, K, nullptr, 0, &plan));
+    *out = reinterpret_cast<LabelShuffler*>(plan);
+    return SQGR_OK;
+}
+
+void label_shuffler_destroy(LabelShuffler* s) { delete reinterpret_cast<sqgr_nhood*>(s); }
+
+int label_shuffler_philox(LabelShuffler* s, uint64_t seed, int64_t perm0, int nb, uint32_t* keys_ws, uint8_t* slab,
+                          hipStream_t st) {
+    sqgr_nhood* p = reinterpret_cast<sqgr_nhood*>(s);
+    {
+        LaunchTimer t(p->ctx, "ligrec_keygen", st);
+        const int64_t nk = (int64_t)nb * 32;
+        k_keygen<<<(unsigned)ceil_div(nk, 256), 256, 0, st>>>(seed, perm0, nk, 1, keys_ws);
+        SQGR_HIP(hipGetLastError());
+    }
+    return launch_shuffle_raw(p, 32, nb, keys_ws, slab, st);
+}
+
+int label_shuffler_pcg64(LabelShuffler* s, const uint64_t* states_dev, int64_t pc, int64_t stride, uint8_t* W, hipStream_t st) {
+    sqgr_nhood* p = reinterpret_cast<sqgr_nhood*>(s);
+    LaunchTimer t(p->ctx, "ligrec_pcg64_shuffle", st);
+    k_pcg_shuffle<uint8_t, false><<<(unsigned)ceil_div(pc, 64), 64, 0, st>>>(p->n, 1, p->lib_off.p, p->base_pos.p, states_dev, pc,
+                                                                            stride, W);
+    SQGR_HIP(hipGetLastError());
+    return SQGR_OK;
+}
+
+}  // namespace sqgr

@@ -7,9 +7,10 @@ from ._build import (
     spatial_neighbors_knn,
     spatial_neighbors_radius,
 )
+from ._ligrec import PermutationTest, ligrec
 from ._nhood import NhoodEnrichmentResult, interaction_matrix, nhood_enrichment
 from ._ppatterns import co_occurrence, spatial_autocorr
 from ._ripley import ripley
 
-__all__ = ["nhood_enrichment", "interaction_matrix", "NhoodEnrichmentResult", "co_occurrence", "spatial_autocorr", "ripley", "spatial_neighbors",
+__all__ = ["nhood_enrichment", "interaction_matrix", "NhoodEnrichmentResult", "co_occurrence", "spatial_autocorr", "ripley", "ligrec", "PermutationTest", "spatial_neighbors",
            "spatial_neighbors_knn", "spatial_neighbors_radius", "spatial_neighbors_grid", "SpatialNeighborsResult"]
