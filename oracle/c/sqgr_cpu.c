@@ -9,6 +9,8 @@
  *   sq_nenrich      /root/reference/src/squidpy/gr/_nhood.py:54-141   (res[N,K] uint32 scratch, row scan with
  *                   label gathers, then per-row accumulation into the row label's K-vector)
  *   sq_occur_count  /root/reference/src/squidpy/gr/_ppatterns.py:283-310 (per-point int32[L*K*K] rows, summed)
+ *   sq_ligrec_score /root/reference/src/squidpy/gr/_ligrec.py:616-673 (dense groups[K,G] per permutation from the
+ *                   shuffled label vector, then the (interaction, cluster pair) indicator loop)
  *   sq_morans_i / sq_gearys_c  scanpy.metrics (third-party; formulas in oracle/restate.py) per-gene loops
  *
  * `parallel` mirrors numba's prange -> `omp parallel for` (the reference default is numba_parallel=False).
@@ -113,4 +115,44 @@ int sq_gearys_c(const double* data, const int32_t* indices, const int32_t* indpt
         out[g] = ((double)(n - 1) * total) / (2.0 * W * den);
     }
     return 0;
+}
+
+/* `_score_permutations` without the shuffle: perm_labels[n_perms][n_cells] are the shuffled clusterings (drawn by the
+ * caller with the same numpy generators).  `parallel` mirrors the prange over permutations. */
+int sq_ligrec_score(const double* data, int64_t n_cells, int n_genes, const int32_t* perm_labels, int64_t n_perms, int n_cls,
+                    const double* inv_counts, const double* mean_obs, const int32_t* interactions, int64_t n_inter,
+                    const int32_t* cpairs, int n_cp, const uint8_t* valid, int64_t* counts, int parallel) {
+    memset(counts, 0, (size_t)n_inter * n_cp * sizeof(int64_t));
+    int failed = 0;
+#pragma omp parallel for if (parallel) schedule(static)
+    for (int64_t p = 0; p < n_perms; ++p) {
+        const int32_t* perm = perm_labels + p * n_cells;
+        double* groups = (double*)calloc((size_t)n_cls * n_genes, sizeof(double));
+        if (!groups) {
+            failed = 1;
+            continue;
+        }
+        for (int64_t cell = 0; cell < n_cells; ++cell) {
+            double* g = groups + (size_t)perm[cell] * n_genes;
+            const double* d = data + cell * n_genes;
+            for (int j = 0; j < n_genes; ++j) g[j] += d[j];
+        }
+        for (int k = 0; k < n_cls; ++k)
+            for (int j = 0; j < n_genes; ++j) groups[(size_t)k * n_genes + j] *= inv_counts[k];
+        for (int64_t i = 0; i < n_inter; ++i) {
+            const int rec = interactions[2 * i], lig = interactions[2 * i + 1];
+            for (int j = 0; j < n_cp; ++j) {
+                if (!valid[i * n_cp + j]) continue;
+                const int a = cpairs[2 * j], b = cpairs[2 * j + 1];
+                const double shuf = groups[(size_t)a * n_genes + rec] + groups[(size_t)b * n_genes + lig];
+                const double obs = mean_obs[(size_t)a * n_genes + rec] + mean_obs[(size_t)b * n_genes + lig];
+                if (shuf > obs) {
+#pragma omp atomic
+                    counts[i * n_cp + j] += 1;
+                }
+            }
+        }
+        free(groups);
+    }
+    return failed ? -1 : 0;
 }

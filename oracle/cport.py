@@ -94,3 +94,25 @@ def morans_i(g, vals, parallel: bool = False, native: bool = False) -> np.ndarra
 
 def gearys_c(g, vals, parallel: bool = False, native: bool = False) -> np.ndarray:
     return _autocorr("sq_gearys_c", g, vals, parallel, native)
+
+
+def ligrec_score(data, perm_labels, inv_counts, mean_obs, interactions, cpairs, valid, parallel: bool = False, native: bool = False) -> np.ndarray:
+    """gr/_ligrec.py:616-673 for given shuffled label vectors (n_perms, n_cells) -> int64 (n_inter, n_cpairs)."""
+    data = np.ascontiguousarray(data, dtype=np.float64)
+    perm_labels = np.ascontiguousarray(perm_labels, dtype=np.int32)
+    inv_counts = np.ascontiguousarray(inv_counts, dtype=np.float64)
+    mean_obs = np.ascontiguousarray(mean_obs, dtype=np.float64)
+    interactions = np.ascontiguousarray(interactions, dtype=np.int32)
+    cpairs = np.ascontiguousarray(cpairs, dtype=np.int32)
+    valid = np.ascontiguousarray(valid, dtype=np.uint8)
+    n_cells, n_genes = data.shape
+    out = np.zeros((len(interactions), len(cpairs)), dtype=np.int64)
+    rc = lib(native).sq_ligrec_score(
+        _p(data, C.c_double), C.c_int64(n_cells), C.c_int(n_genes), _p(perm_labels, C.c_int32), C.c_int64(len(perm_labels)),
+        C.c_int(len(inv_counts)), _p(inv_counts, C.c_double), _p(mean_obs, C.c_double), _p(interactions, C.c_int32),
+        C.c_int64(len(interactions)), _p(cpairs, C.c_int32), C.c_int(len(cpairs)), _p(valid, C.c_uint8), _p(out, C.c_int64),
+        C.c_int(int(parallel)),
+    )
+    if rc != 0:
+        raise MemoryError("sq_ligrec_score scratch allocation failed")
+    return out

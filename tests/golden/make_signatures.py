@@ -4,12 +4,13 @@ import ast, json, os, re
 
 REF = "/root/reference/src/squidpy/gr"
 HERE = os.path.dirname(os.path.abspath(__file__))
-WANT = {"_nhood.py": ["nhood_enrichment", "interaction_matrix"], "_ppatterns.py": ["spatial_autocorr", "co_occurrence"], "_ripley.py": ["ripley"],
+WANT = {"_nhood.py": ["nhood_enrichment", "interaction_matrix"], "_ppatterns.py": ["spatial_autocorr", "co_occurrence"], "_ripley.py": ["ripley"], "_ligrec.py": ["ligrec"],
         "_build.py": ["spatial_neighbors", "spatial_neighbors_knn", "spatial_neighbors_radius", "spatial_neighbors_grid"]}
 out = {}
 for fn, names in WANT.items():
     src = open(os.path.join(REF, fn)).read()
     src = re.sub(r"^(class|def) (\w+)\[[^\]]*\]\(", r"\1 \2(", src, flags=re.M)  # PEP 695 generics: py3.10 cannot parse them
+    src = re.sub(r"(?m)^type\s+\w+(\[[^\]]*\])?\s*=.*$", "pass", src)  # PEP 695 type aliases
     tree = ast.parse(src)
     for node in tree.body:
         if isinstance(node, ast.FunctionDef) and node.name in names:

@@ -8,6 +8,8 @@ import inspect
 import json
 import os
 
+from types import MappingProxyType
+
 import pytest
 
 import squidpy_amd as sq
@@ -16,7 +18,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REF = json.load(open(os.path.join(HERE, "golden", "reference_signatures.json")))
 EXTRA = {"rng", "device", "fma", "gene_block"}
 # defaults the reference spells through its constants
-SPECIAL = {"Key.obsp.spatial_conn()": "spatial_connectivities", "Key.obsm.spatial": "spatial"}
+SPECIAL = {
+    "Key.obsp.spatial_conn()": "spatial_connectivities",
+    "Key.obsm.spatial": "spatial",
+    "ComplexPolicy.MIN.v": "min",
+    "CorrAxis.CLUSTERS.v": "clusters",
+}
 
 
 def _norm(default_src: str | None):
@@ -24,7 +31,7 @@ def _norm(default_src: str | None):
         return inspect.Parameter.empty
     if default_src in SPECIAL:
         return SPECIAL[default_src]
-    return eval(default_src, {})  # literals only: numbers, strings, None, True/False
+    return eval(default_src, {"MappingProxyType": MappingProxyType})  # literals only: numbers, strings, None, True/False
 
 
 @pytest.mark.parametrize("name", sorted(REF))
