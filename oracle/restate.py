@@ -577,9 +577,12 @@ def spatial_graph(
     set_diag: bool = False,
     percentile: float | None = None,
     transform: str | None = None,
+    delaunay: bool = False,
 ) -> tuple[sparse.csr_matrix, sparse.csr_matrix]:
     """The reference's builders with sklearn's KD-tree exactly as they call it: KNNBuilder gr/neighbors.py:194-209,
-    RadiusBuilder :247-269, GridBuilder :366-419, post-processors :425-476, spectral transform :514-548."""
+    RadiusBuilder :247-269, DelaunayBuilder :319-331 (kind "delaunay"; a scalar radius means (0, r), :296-300),
+    GridBuilder :366-419 (``delaunay``: base connectivity from the triangulation, :395-398), post-processors :425-476,
+    spectral transform :514-548."""
     import warnings
 
     from sklearn.neighbors import NearestNeighbors
@@ -589,6 +592,13 @@ def spatial_graph(
         warnings.simplefilter("ignore", sparse.SparseEfficiencyWarning)
 
         def base_grid(diag: bool) -> sparse.csr_matrix:
+            if delaunay:
+                from scipy.spatial import Delaunay
+
+                indptr, indices = Delaunay(coords).vertex_neighbor_vertices
+                a = sparse.csr_matrix((np.ones_like(indices, dtype=np.float32), indices, indptr), shape=(N, N))
+                a.setdiag(1.0 if diag else a.diagonal())
+                return a
             tree = NearestNeighbors(n_neighbors=n_neighs, radius=1, metric="euclidean").fit(coords)
             dists, cols = tree.kneighbors()
             dists, cols = dists.reshape(-1), cols.reshape(-1)
@@ -623,6 +633,14 @@ def spatial_graph(
                 dists, cols = tree.kneighbors()
                 dists, cols = dists.reshape(-1), cols.reshape(-1)
                 rows = np.repeat(np.arange(N), n_neighs)
+            elif kind == "delaunay":
+                from scipy.spatial import Delaunay
+
+                indptr, cols = Delaunay(coords).vertex_neighbor_vertices
+                rows = np.repeat(np.arange(N), np.diff(indptr))
+                dists = np.linalg.norm(coords[rows] - coords[cols], axis=1)
+                if isinstance(radius, (int, float)):
+                    radius = (0.0, float(radius))
             else:
                 r = radius if isinstance(radius, (int, float)) else max(radius)
                 tree = NearestNeighbors(radius=r, metric="euclidean").fit(coords)
@@ -633,7 +651,7 @@ def spatial_graph(
             dst = sparse.csr_matrix((dists, (rows, cols)), shape=(N, N))
             adj.setdiag(1.0 if set_diag else adj.diagonal())
             dst.setdiag(0.0)
-            if kind == "radius" and isinstance(radius, tuple):
+            if kind in ("radius", "delaunay") and isinstance(radius, tuple):
                 minn, maxx = sorted(radius)
                 mask = (dst.data < minn) | (dst.data > maxx)
                 a_diag = adj.diagonal()

@@ -3,6 +3,7 @@
 from ._build import (
     SpatialNeighborsResult,
     spatial_neighbors,
+    spatial_neighbors_delaunay,
     spatial_neighbors_grid,
     spatial_neighbors_knn,
     spatial_neighbors_radius,
@@ -13,4 +14,4 @@ from ._ppatterns import co_occurrence, spatial_autocorr
 from ._ripley import ripley
 
 __all__ = ["nhood_enrichment", "interaction_matrix", "NhoodEnrichmentResult", "co_occurrence", "spatial_autocorr", "ripley", "ligrec", "PermutationTest", "spatial_neighbors",
-           "spatial_neighbors_knn", "spatial_neighbors_radius", "spatial_neighbors_grid", "SpatialNeighborsResult"]
+           "spatial_neighbors_knn", "spatial_neighbors_delaunay", "spatial_neighbors_radius", "spatial_neighbors_grid", "SpatialNeighborsResult"]

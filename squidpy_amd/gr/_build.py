@@ -7,7 +7,9 @@ builders gr/neighbors.py:157-269, 335-419; post-processing gr/neighbors.py:441-4
 The k-nearest-neighbour and fixed-radius searches — the part that dominates at 1e6 spots — run in ``libsqgr.so`` on a
 device cell list (``csrc/sqgr_neighbors.hip``); the O(nnz) CSR assembly, ring expansion, percentile / interval pruning
 and the optional spectral / cosine transforms stay on the host with scipy, written to give the reference's matrices.
-Delaunay graphs (scipy.spatial on the host in the reference) are not part of the GPU path and raise NotImplementedError.
+Delaunay graphs take their triangulation from ``scipy.spatial.Delaunay`` (Qhull) on the host exactly as the reference does
+(gr/neighbors.py:319-331, 395-398) — there is no device kernel behind them; edge lengths, pruning and transforms share
+the code of the other builders.
 """
 
 from __future__ import annotations
@@ -27,6 +29,7 @@ __all__ = [
     "spatial_neighbors_knn",
     "spatial_neighbors_radius",
     "spatial_neighbors_grid",
+    "spatial_neighbors_delaunay",
     "SpatialNeighborsResult",
 ]
 
@@ -42,7 +45,7 @@ class SpatialNeighborsResult(NamedTuple):
 
 @dataclass
 class _Spec:
-    """What to build.  ``kind``: "knn" | "radius" | "grid"."""
+    """What to build.  ``kind``: "knn" | "radius" | "grid" | "delaunay"."""
 
     kind: str
     n_neighs: int = 6
@@ -51,12 +54,13 @@ class _Spec:
     transform: str | None = None
     set_diag: bool = False
     percentile: float | None = None
+    delaunay: bool = False  # grid kind: base connectivity from the triangulation instead of the kNN candidates
 
     def uns_params(self) -> dict[str, Any]:
         if self.kind == "grid":
-            return {"coord_type": "grid", "n_neighbors": self.n_neighs, "n_rings": self.n_rings, "delaunay": False,
+            return {"coord_type": "grid", "n_neighbors": self.n_neighs, "n_rings": self.n_rings, "delaunay": self.delaunay,
                     "transform": self.transform}
-        if self.kind == "radius":
+        if self.kind in ("radius", "delaunay"):
             rad = list(self.radius) if isinstance(self.radius, tuple) else self.radius
             return {"coord_type": "generic", "radius": rad, "transform": self.transform}
         return {"coord_type": "generic", "n_neighbors": self.n_neighs, "transform": self.transform}
@@ -88,11 +92,20 @@ def _knn_edges(ctx: Context, coords: np.ndarray, k: int) -> tuple[np.ndarray, np
     return np.repeat(np.arange(n), k), idx.reshape(-1).astype(np.int64), dist.reshape(-1)
 
 
-def _build_one(ctx: Context, coords: np.ndarray, spec: _Spec) -> tuple[sparse.csr_matrix, sparse.csr_matrix]:
+def _delaunay_edges(coords: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+    """(row, col) of the vertex adjacency of Qhull's Delaunay triangulation — host code, as in the reference."""
+    from scipy.spatial import Delaunay
+
+    indptr, indices = Delaunay(coords).vertex_neighbor_vertices
+    return np.repeat(np.arange(coords.shape[0]), np.diff(indptr)), np.asarray(indices, dtype=np.int64)
+
+
+def _build_one(ctx: Context | None, coords: np.ndarray, spec: _Spec) -> tuple[sparse.csr_matrix, sparse.csr_matrix]:
     """One library: the builder's edges, then its post-processing chain (gr/neighbors.py:74-78), done on flat edge
     arrays (row, col, length, alive) and assembled into CSR once at the end."""
     coords = np.asarray(coords, dtype=np.float64)
-    if coords.ndim != 2 or coords.shape[1] != 2:
+    uses_device = spec.kind in ("knn", "radius") or (spec.kind == "grid" and not spec.delaunay)
+    if uses_device and (coords.ndim != 2 or coords.shape[1] != 2):
         raise NotImplementedError(f"The GPU neighbour search handles 2-D coordinates, found shape `{coords.shape}`.")
     n = coords.shape[0]
     if spec.kind == "grid":
@@ -100,14 +113,22 @@ def _build_one(ctx: Context, coords: np.ndarray, spec: _Spec) -> tuple[sparse.cs
     else:
         if spec.kind == "knn":
             rows, cols, length = _knn_edges(ctx, coords, spec.n_neighs)
+        elif spec.kind == "delaunay":
+            rows, cols = _delaunay_edges(coords)
+            length = np.linalg.norm(coords[rows] - coords[cols], axis=1)
         else:
             r = spec.radius if isinstance(spec.radius, (int, float)) else max(spec.radius)
             indptr, cols, length = radius_self(ctx, coords, float(r))
             rows, cols = np.repeat(np.arange(n), np.diff(indptr)), cols.astype(np.int64)
         length = length.copy()
         alive = np.ones(len(rows), dtype=bool)
-        if spec.kind == "radius" and isinstance(spec.radius, tuple):  # interval pruning (gr/neighbors.py:425-438)
-            lo, hi = sorted(spec.radius)
+        interval = None
+        if spec.kind == "radius" and isinstance(spec.radius, tuple):
+            interval = spec.radius
+        elif spec.kind == "delaunay" and spec.radius is not None:  # a scalar r is shorthand for (0, r) (gr/neighbors.py:296-300)
+            interval = spec.radius if isinstance(spec.radius, tuple) else (0.0, float(spec.radius))
+        if interval is not None:  # interval pruning (gr/neighbors.py:425-438)
+            lo, hi = sorted(interval)
             out = (length < lo) | (length > hi)
             length[out] = 0.0
             alive &= ~out
@@ -136,19 +157,23 @@ def _build_one(ctx: Context, coords: np.ndarray, spec: _Spec) -> tuple[sparse.cs
     return adj, dst
 
 
-def _grid_base(ctx: Context, coords: np.ndarray, n_neighs: int, diag: float | None) -> sparse.csr_matrix:
+def _grid_base(ctx: Context | None, coords: np.ndarray, n_neighs: int, diag: float | None, delaunay: bool = False) -> sparse.csr_matrix:
     """kNN candidates pruned at 1.3 x the median candidate distance (gr/neighbors.py:389-419)."""
     n = coords.shape[0]
-    rows, cols, dists = _knn_edges(ctx, coords, n_neighs)
-    keep = dists < np.median(dists) * 1.3
+    if delaunay:
+        rows, cols = _delaunay_edges(coords)
+        keep = np.ones(len(rows), dtype=bool)
+    else:
+        rows, cols, dists = _knn_edges(ctx, coords, n_neighs)
+        keep = dists < np.median(dists) * 1.3
     adj = sparse.csr_matrix((np.ones(int(keep.sum()), dtype=np.float32), (rows[keep], cols[keep])), shape=(n, n))
     return _with_diagonal(adj, diag)
 
 
-def _grid_graph(ctx: Context, coords: np.ndarray, spec: _Spec) -> tuple[sparse.csr_matrix, sparse.csr_matrix]:
+def _grid_graph(ctx: Context | None, coords: np.ndarray, spec: _Spec) -> tuple[sparse.csr_matrix, sparse.csr_matrix]:
     """Ring distances by repeated sparse products (gr/neighbors.py:366-387)."""
     if spec.n_rings > 1:
-        base = _grid_base(ctx, coords, spec.n_neighs, 1.0)
+        base = _grid_base(ctx, coords, spec.n_neighs, 1.0, spec.delaunay)
         reached, walk = base, base
         for ring in range(2, spec.n_rings + 1):
             walk = sparse.csr_matrix(walk @ base)
@@ -164,7 +189,7 @@ def _grid_graph(ctx: Context, coords: np.ndarray, spec: _Spec) -> tuple[sparse.c
         adj = ringed.copy()
         adj.data[:] = 1.0
     else:
-        adj = _grid_base(ctx, coords, spec.n_neighs, 1.0 if spec.set_diag else None)
+        adj = _grid_base(ctx, coords, spec.n_neighs, 1.0 if spec.set_diag else None, spec.delaunay)
         dst = adj.copy()
     dst = _with_diagonal(dst, 0.0)
     return adj, dst
@@ -184,7 +209,8 @@ def _spectral(adj: sparse.csr_matrix) -> sparse.csr_matrix:
 def _run(adata: Any, spec: _Spec, *, spatial_key: str, library_key: str | None, key_added: str, copy: bool,
          device: int | None) -> SpatialNeighborsResult | None:
     """gr/_build.py:789-849: per-library graphs, block-diagonal combination, slot writes."""
-    ctx = default_context(device)
+    host_only = spec.kind == "delaunay" or (spec.kind == "grid" and spec.delaunay)  # Qhull on the host, nothing to launch
+    ctx = None if host_only else default_context(device)
     coords = np.asarray(adata.obsm[spatial_key])
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", sparse.SparseEfficiencyWarning)
@@ -270,6 +296,31 @@ def spatial_neighbors_radius(
     return _run(adata, spec, spatial_key=spatial_key, library_key=library_key, key_added=key_added, copy=copy, device=device)
 
 
+def spatial_neighbors_delaunay(
+    data: Any,
+    *,
+    spatial_key: str = "spatial",
+    elements_to_coordinate_systems: dict[str, str] | None = None,
+    table_key: str | None = None,
+    library_key: str | None = None,
+    radius: float | tuple[float, float] | None = None,
+    percentile: float | None = None,
+    transform: str | None = None,
+    set_diag: bool = False,
+    key_added: str = "spatial",
+    copy: bool = False,
+    n_jobs: int = 1,
+    device: int | None = None,
+) -> SpatialNeighborsResult | None:
+    """Create a Delaunay triangulation graph from spatial coordinates (drop-in for ``squidpy.gr.spatial_neighbors_delaunay``,
+    gr/_build.py:625-697).  The triangulation is Qhull's (``scipy.spatial.Delaunay`` on the host, as in the reference);
+    ``radius`` only prunes the finished edges: ``(min, max)`` keeps lengths inside the interval, a scalar ``r`` means
+    ``(0, r)``."""
+    spec = _Spec("delaunay", radius=radius, transform=_check_transform(transform), set_diag=set_diag, percentile=percentile)
+    adata = _resolve_input(data, spatial_key, elements_to_coordinate_systems, table_key)
+    return _run(adata, spec, spatial_key=spatial_key, library_key=library_key, key_added=key_added, copy=copy, device=device)
+
+
 def spatial_neighbors_grid(
     data: Any,
     *,
@@ -291,9 +342,8 @@ def spatial_neighbors_grid(
     gr/_build.py:701-786): kNN candidates pruned at 1.3 x the median distance, ``n_rings`` expansion."""
     assert_positive(n_neighs, name="n_neighs")
     assert_positive(n_rings, name="n_rings")
-    if delaunay:
-        raise NotImplementedError("`delaunay=True` (scipy.spatial.Delaunay on the host) is not part of the GPU path.")
-    spec = _Spec("grid", n_neighs=n_neighs, n_rings=n_rings, transform=_check_transform(transform), set_diag=set_diag)
+    spec = _Spec("grid", n_neighs=n_neighs, n_rings=n_rings, transform=_check_transform(transform), set_diag=set_diag,
+                 delaunay=bool(delaunay))
     adata = _resolve_input(data, spatial_key, elements_to_coordinate_systems, table_key)
     return _run(adata, spec, spatial_key=spatial_key, library_key=library_key, key_added=key_added, copy=copy, device=device)
 
@@ -343,11 +393,13 @@ def spatial_neighbors(
     if mode == "grid":
         if percentile is not None:
             raise ValueError("`percentile` is not supported for grid coordinates. It only applies to generic (non-grid) graphs.")
-        if delaunay:
-            raise NotImplementedError("`delaunay=True` (scipy.spatial.Delaunay on the host) is not part of the GPU path.")
-        spec = _Spec("grid", n_neighs=k, n_rings=rings, transform=tr, set_diag=bool(set_diag))
+        spec = _Spec("grid", n_neighs=k, n_rings=rings, transform=tr, set_diag=bool(set_diag), delaunay=bool(delaunay))
     elif delaunay:
-        raise NotImplementedError("`delaunay=True` (scipy.spatial.Delaunay on the host) is not part of the GPU path.")
+        if n_neighs is not None:
+            warnings.warn("Parameter `n_neighs` is ignored when `delaunay=True` use `spatial_neighbors_delaunay` instead.", FutureWarning, stacklevel=2)
+        # legacy contract (gr/_build.py:111-117): a scalar `radius` is ignored here, only a tuple prunes
+        spec = _Spec("delaunay", radius=radius if isinstance(radius, tuple) else None, transform=tr, set_diag=bool(set_diag),
+                     percentile=percentile)
     elif radius is not None:
         if n_neighs is not None:
             warnings.warn("Parameter `n_neighs` is ignored when `radius` is set use `spatial_neighbors_radius` instead.", FutureWarning, stacklevel=2)
