@@ -378,12 +378,26 @@ __device__ __forceinline__ uint32_t pcg64_next32(Pcg64& g) {
     return (uint32_t)v;
 }
 
+constexpr int PCG_UNROLL = 8;   // swaps replayed in registers per trip (2*PCG_UNROLL loads in flight)
+constexpr int PCG_BLOCK = 32;   // steps whose draws are generated together (multiple of PCG_UNROLL)
+
 // W[pos * stride + p]: column p = the array numpy would shuffle for permutation p (positions grouped by library,
 // libraries in category order == the order `_shuffle_group` visits them, gr/_utils.py:207-212).
+//
+// Two things keep the lanes of a wave busy although every lane runs its own sequential Fisher-Yates:
+//  * rejection sampling is decoupled from the steps: the draws j of PCG_BLOCK consecutive steps are produced in one
+//    per-lane loop (a lane that needs fewer draws idles only until the slowest lane of the wave has its PCG_BLOCK
+//    draws, instead of after every single step) and parked in LDS;
+//  * the draws depend on the generator only, so the 2*PCG_UNROLL loads of a trip are issued before any swap is
+//    applied and the swaps are replayed in registers.  Step t exchanges positions i-t and j_t; i-t is above
+//    everything later steps touch, so its value is final after step t; a j position may recur (j_e == j_t, or
+//    j_e == i-t for e < t) and then takes the value the earlier step left there instead of the stale load.
 template <typename T, bool ARANGE>
 __global__ __launch_bounds__(64) void k_pcg_shuffle(int64_t n, int n_libs, const uint32_t* __restrict__ lib_off,
                                                     const T* __restrict__ base_pos, const uint64_t* __restrict__ states,
                                                     int64_t P, int64_t stride, T* __restrict__ W) {
+    __shared__ uint32_t s_j[PCG_BLOCK][64];
+    const int lane = threadIdx.x;
     const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (p >= P) return;
     Pcg64 g;
@@ -402,7 +416,82 @@ __global__ __launch_bounds__(64) void k_pcg_shuffle(int64_t n, int n_libs, const
         T* sub = col + (int64_t)off * stride;
         uint32_t mask = m - 1;  // smallest all-ones mask >= i, maintained as i decreases
         mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-        for (uint32_t i = m - 1; i >= 1; --i) {
+        uint32_t i = m - 1;
+        while (i >= (uint32_t)PCG_BLOCK) {
+            // ---- draws of steps i, i-1, ..., i-PCG_BLOCK+1 (numpy: `while ((v = next_uint32() & mask) > max);`)
+            {
+                int t = 0;
+                uint32_t it = i;
+                if ((mask >> 1) >= it) mask >>= 1;
+                if (g.has) {  // high half left over from the previous block
+                    g.has = false;
+                    const uint32_t c = g.buf & mask;
+                    if (c <= it) {
+                        s_j[t][lane] = c;
+                        ++t;
+                        --it;
+                        if ((mask >> 1) >= it) mask >>= 1;
+                    }
+                }
+                while (t < PCG_BLOCK) {
+                    const uint64_t v = pcg64_next64(g);
+                    const uint32_t c0 = (uint32_t)v & mask;
+                    if (c0 <= it) {
+                        s_j[t][lane] = c0;
+                        ++t;
+                        --it;
+                        if ((mask >> 1) >= it) mask >>= 1;
+                    }
+                    if (t < PCG_BLOCK) {
+                        const uint32_t c1 = (uint32_t)(v >> 32) & mask;
+                        if (c1 <= it) {
+                            s_j[t][lane] = c1;
+                            ++t;
+                            --it;
+                            if ((mask >> 1) >= it) mask >>= 1;
+                        }
+                    } else {  // the block is complete after the low half: numpy keeps the high half buffered
+                        g.has = true;
+                        g.buf = (uint32_t)(v >> 32);
+                    }
+                }
+            }
+            // ---- apply: PCG_UNROLL swaps per trip
+            constexpr int U = PCG_UNROLL;
+#pragma unroll 1
+            for (int t0 = 0; t0 < PCG_BLOCK; t0 += U) {
+                const uint32_t ib = i - t0;
+                uint32_t j[U];
+                T vi[U], vj[U];
+#pragma unroll
+                for (int t = 0; t < U; ++t) j[t] = s_j[t0 + t][lane];
+#pragma unroll
+                for (int t = 0; t < U; ++t) {
+                    vi[t] = sub[(int64_t)(ib - t) * stride];
+                    vj[t] = sub[(int64_t)j[t] * stride];
+                }
+                T at_i[U], at_j[U];  // values left at position ib-t resp. j_t by step t
+#pragma unroll
+                for (int t = 0; t < U; ++t) {
+                    T cur_i = vi[t], cur_j = vj[t];
+#pragma unroll
+                    for (int e = 0; e < t; ++e) {  // a later e overrides an earlier one
+                        cur_i = (j[e] == ib - t) ? at_j[e] : cur_i;
+                        cur_j = (j[e] == j[t]) ? at_j[e] : cur_j;
+                    }
+                    at_i[t] = cur_j;
+                    at_j[t] = cur_i;
+                }
+                // j stores in step order (a recurring position keeps the last one), then the final i stores on top
+#pragma unroll
+                for (int t = 0; t < U; ++t) sub[(int64_t)j[t] * stride] = at_j[t];
+#pragma unroll
+                for (int t = 0; t < U; ++t) sub[(int64_t)(ib - t) * stride] = at_i[t];
+            }
+            i -= PCG_BLOCK;
+            // the mask was advanced to step i-PCG_BLOCK's bound already (idempotent update at the top of the next block)
+        }
+        for (; i >= 1; --i) {
             if ((mask >> 1) >= i) mask >>= 1;
             uint32_t j;
             do {
@@ -413,6 +502,217 @@ __global__ __launch_bounds__(64) void k_pcg_shuffle(int64_t n, int n_libs, const
             sub[(int64_t)j * stride] = a;
         }
     }
+}
+
+// ---- one WAVE per permutation ------------------------------------------------------------------------------------
+// The sequential chain of Fisher-Yates is only apparent: (1) the raw generator outputs are a pure function of the stream
+// position (LCG jump-ahead: state_k = A_k*state + G_k*inc with A_k = M^k, G_k = 1 + M + ... + M^(k-1) mod 2^128), so
+// the 64 lanes produce the next 64 raw 32-bit draws at once; (2) whether draw d is accepted depends on earlier draws
+// only through the NUMBER of earlier acceptances (< 64), which matters only for candidates within 64 of the bound;
+// (3) the accepted swaps of a chunk touch disjoint positions unless two draws coincide.  The fast path therefore handles
+// ~64*p steps per trip fully in parallel when  no candidate lies in (i-64, i]  and  all accepted j are distinct and
+// below i-64  (probability ~1 - 64*64/i per trip); otherwise the slow path replays the chunk exactly: sequential
+// acceptance over the 64 raw draws (wave-uniform scalar code), parallel loads, the swaps replayed by one lane on an
+// LDS image of the touched positions, parallel stores.  Both paths consume the identical draw sequence as numpy
+// (32-bit halves, low first; a library that ends mid-chunk leaves the remaining draws to the next one).
+// Layout: R[p][row_stride] (a permutation's array is contiguous: the i side of a trip is one coalesced line).
+struct U128 {
+    uint64_t hi, lo;
+};
+__device__ __forceinline__ U128 mul128_lo(U128 a, U128 b) {
+    U128 r;
+    r.lo = a.lo * b.lo;
+    r.hi = __umul64hi(a.lo, b.lo) + a.lo * b.hi + a.hi * b.lo;
+    return r;
+}
+__device__ __forceinline__ U128 add128(U128 a, U128 b) {
+    U128 r;
+    r.lo = a.lo + b.lo;
+    r.hi = a.hi + b.hi + (r.lo < a.lo ? 1ull : 0ull);
+    return r;
+}
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int src) {
+    const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, src);
+    const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+constexpr int PCGW_TAB = 34;      // jump distances 0..33 (64 halves starting at an odd half reach output 33)
+constexpr int PCGW_HASH = 2048;   // duplicate filter of the fast path
+
+template <typename T, bool ARANGE>
+__global__ __launch_bounds__(64) void k_pcg_shuffle_wave(int64_t n, int64_t row_stride, int n_libs,
+                                                         const uint32_t* __restrict__ lib_off, const T* __restrict__ base_pos,
+                                                         const uint64_t* __restrict__ states, const uint64_t* __restrict__ jump,
+                                                         T* __restrict__ R, int force_slow) {
+    __shared__ uint64_t sA[PCGW_TAB][2], sD[PCGW_TAB][2];
+    __shared__ uint32_t sJ[64], sVI[64], sVJ[64], sCanon[64];
+    __shared__ uint32_t sH[PCGW_HASH];
+    const int lane = threadIdx.x;
+    const int64_t p = blockIdx.x;
+    U128 s, inc;
+    s.hi = states[4 * p + 0];
+    s.lo = states[4 * p + 1];
+    inc.hi = states[4 * p + 2];
+    inc.lo = states[4 * p + 3];
+    if (lane < PCGW_TAB) {
+        U128 a, g;
+        a.hi = jump[4 * lane + 0];
+        a.lo = jump[4 * lane + 1];
+        g.hi = jump[4 * lane + 2];
+        g.lo = jump[4 * lane + 3];
+        const U128 d = mul128_lo(g, inc);
+        sA[lane][0] = a.hi;
+        sA[lane][1] = a.lo;
+        sD[lane][0] = d.hi;
+        sD[lane][1] = d.lo;
+    }
+    for (int h = lane; h < PCGW_HASH; h += 64) sH[h] = 0;
+    T* row = R + p * row_stride;
+    for (int64_t e = lane; e < n; e += 64) row[e] = ARANGE ? (T)e : base_pos[e];
+    uint32_t half = 0;   // 1: the next draw is the high half of the 64-bit output after `s`
+    uint32_t epoch = 0;
+    for (int l = 0; l < n_libs; ++l) {
+        const uint32_t off = lib_off[l];
+        const uint32_t m = lib_off[l + 1] - off;
+        if (m < 2) continue;
+        T* sub = row + off;
+        uint32_t mask = m - 1;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        uint32_t i = m - 1;
+        while (i >= 1) {
+            // ---- the next 64 raw 32-bit draws, one per lane
+            const uint32_t hl = half + (uint32_t)lane;
+            const int kk = 1 + (int)(hl >> 1);
+            U128 a, d;
+            a.hi = sA[kk][0];
+            a.lo = sA[kk][1];
+            d.hi = sD[kk][0];
+            d.lo = sD[kk][1];
+            const U128 sk = add128(mul128_lo(a, s), d);
+            const uint64_t x = sk.hi ^ sk.lo;
+            const unsigned rot = (unsigned)(sk.hi >> 58);
+            const uint64_t out = (x >> rot) | (x << ((64u - rot) & 63u));
+            const uint32_t raw = (hl & 1u) ? (uint32_t)(out >> 32) : (uint32_t)out;
+            uint32_t used = 64;
+            bool fast = !force_slow && i >= 192u && (mask >> 1) < i - 64u;
+            if (fast) {
+                const uint32_t c = raw & mask;
+                const bool acc = c <= i - 64u;
+                const bool amb = !acc && c <= i;
+                if (__ballot(amb) != 0ull) {
+                    fast = false;
+                } else {
+                    const uint64_t am = __ballot(acc);
+                    const uint32_t t = __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
+                    const uint32_t nacc = (uint32_t)__popcll(am);
+                    ++epoch;
+                    const uint32_t tag = (epoch << 6) | (uint32_t)lane;
+                    const uint32_t h = (c * 2654435761u) >> 21;
+                    // volatile: the read-back must observe OTHER lanes' writes to the bucket, not be forwarded from this
+                    // lane's own store
+                    volatile uint32_t* vH = sH;
+                    if (acc) vH[h] = tag;
+                    const bool clash = acc && vH[h] != tag;
+                    if (__ballot(clash) != 0ull) {  // same bucket: verify exactly
+                        bool dup = false;
+                        for (int e = 0; e < 64; ++e) {
+                            const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)c, e);
+                            if (((am >> e) & 1ull) && acc && e < lane && ce == c) dup = true;
+                        }
+                        if (__ballot(dup) != 0ull) fast = false;
+                    }
+                    if (fast) {
+                        if (acc) {
+                            const T va = sub[i - t], vb = sub[c];
+                            sub[i - t] = vb;
+                            sub[c] = va;
+                        }
+                        i -= nacc;
+                    }
+                }
+            }
+            if (!fast) {
+                // ---- exact replay of the chunk.  Acceptance is sequential but wave-uniform.
+                uint32_t it = i, t = 0;
+                for (int dd = 0; dd < 64; ++dd) {
+                    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)raw, dd) & mask;
+                    if (c <= it) {
+                        sJ[t] = c;
+                        ++t;
+                        --it;
+                        if ((mask >> 1) >= it) mask >>= 1;
+                        if (it == 0u) {
+                            used = (uint32_t)dd + 1u;
+                            break;
+                        }
+                    }
+                }
+                const uint32_t nacc = t;
+                if (nacc > 0u) {
+                    const bool live = (uint32_t)lane < nacc;
+                    const uint32_t j = live ? sJ[lane] : 0u;
+                    if (live) {
+                        sVI[lane] = (uint32_t)sub[i - (uint32_t)lane];
+                        sVJ[lane] = (uint32_t)sub[j];
+                    }
+                    // slot of position j_t: 64 + t' if it is the i-side position of step t', else the first step with that j
+                    uint32_t canon = (uint32_t)lane;
+                    const uint32_t ilow = i - (nacc - 1u);
+                    if (live && j >= ilow) {
+                        canon = 64u + (i - j);
+                    } else {
+                        for (uint32_t e = 0; e < nacc; ++e) {
+                            const uint32_t je = sJ[e];
+                            if (live && e < (uint32_t)lane && je == j && canon == (uint32_t)lane) canon = e;
+                        }
+                    }
+                    if (live) sCanon[lane] = canon;
+                    if (lane == 0) {
+                        for (uint32_t q = 0; q < nacc; ++q) {
+                            const uint32_t va = sVI[q];
+                            const uint32_t slot = sCanon[q];
+                            if (slot >= 64u) {
+                                const uint32_t vb = sVI[slot - 64u];
+                                sVI[q] = vb;
+                                sVI[slot - 64u] = va;
+                            } else {
+                                const uint32_t vb = sVJ[slot];
+                                sVI[q] = vb;
+                                sVJ[slot] = va;
+                            }
+                        }
+                    }
+                    if (live) {
+                        sub[i - (uint32_t)lane] = (T)sVI[lane];
+                        if (canon == (uint32_t)lane) sub[j] = (T)sVJ[lane];
+                    }
+                }
+                i = it;
+            }
+            // ---- advance the stream by `used` 32-bit draws
+            const uint32_t hu = half + used;
+            const uint32_t dq = hu >> 1;
+            if (dq > 0u) {
+                const int src = (int)(2u * dq - 1u - half);
+                s.hi = readlane64(sk.hi, src);
+                s.lo = readlane64(sk.lo, src);
+            }
+            half = hu & 1u;
+        }
+    }
+}
+
+// rows R[q][row_stride] (bytes) -> columns W[pos * stride + q]
+__global__ __launch_bounds__(256) void k_rows_to_columns_u8(int64_t n, int64_t row_stride, const uint8_t* __restrict__ R, int64_t P,
+                                                            int64_t stride, uint8_t* __restrict__ W) {
+    __shared__ uint8_t tile[64][65];
+    const int64_t e0 = (int64_t)blockIdx.x * 64, q0 = (int64_t)blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) tile[r][tx] = (q0 + r < P && e0 + tx < n) ? R[(q0 + r) * row_stride + e0 + tx] : (uint8_t)0;
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4)
+        if (e0 + r < n && q0 + tx < P) W[(e0 + r) * stride + q0 + tx] = tile[tx][r];
 }
 
 // columns of W -> slab rows of the batched count kernel: slab[(batch*n + i)*B + b] = W[pos(i)][p0 + batch*B + b]
@@ -479,6 +779,8 @@ struct sqgr_nhood {
     DevBuf<uint32_t> lib_off;   // [n_libs + 1] first position of every library
     DevBuf<uint8_t> wcol;       // [position][stride] column workspace of the numpy-compatible shuffle
     DevBuf<uint64_t> pcg_states;
+    DevBuf<uint64_t> pcg_jump;  // [PCGW_TAB][4] jump-ahead table of the wave-per-permutation shuffle
+    DevBuf<uint8_t> rows;       // [permutation][n_pad] row workspace of the wave-per-permutation shuffle
     bool has_labels = false;
     // tuning
     int B = 16;
@@ -516,6 +818,56 @@ struct sqgr_nhood {
     int count_batches(int nb, int buf);  // slab[buf] -> partial for nb batches
     int reduce_batches(int nb, int64_t perm_batch0, int64_t perm_begin, int64_t perm_end, uint32_t* perms_out_dev);
 };
+
+// A_k = M^k and G_k = 1 + M + ... + M^(k-1) (mod 2^128) of PCG64's LCG, k = 0..PCGW_TAB-1, as [A_hi, A_lo, G_hi, G_lo]
+static int ensure_pcg_jump(DevBuf<uint64_t>& buf) {
+    if (buf.p) return SQGR_OK;
+    std::vector<uint64_t> t((size_t)PCGW_TAB * 4);
+    const unsigned __int128 M = ((unsigned __int128)0x2360ED051FC65DA4ull << 64) | (unsigned __int128)0x4385DF649FCCF645ull;
+    unsigned __int128 A = 1, G = 0;
+    for (int k = 0; k < PCGW_TAB; ++k) {
+        t[4 * k + 0] = (uint64_t)(A >> 64);
+        t[4 * k + 1] = (uint64_t)A;
+        t[4 * k + 2] = (uint64_t)(G >> 64);
+        t[4 * k + 3] = (uint64_t)G;
+        G = G * M + 1;
+        A = A * M;
+    }
+    SQGR_TRY(buf.alloc(t.size()));
+    SQGR_HIP(hipMemcpy(buf.p, t.data(), t.size() * 8, hipMemcpyHostToDevice));
+    return SQGR_OK;
+}
+
+static bool pcg_lane_kernel() {  // SQGR_PCG_KERNEL=lane selects the one-thread-per-permutation kernel (comparison runs)
+    const char* e = getenv("SQGR_PCG_KERNEL");
+    return e && strcmp(e, "lane") == 0;
+}
+static int pcg_force_slow() {
+    const char* e = getenv("SQGR_PCG_FORCE_SLOW");
+    return (e && atoi(e) == 1) ? 1 : 0;
+}
+
+// W[pos * stride + q] = array numpy's generator q leaves behind (q < pc); base labels in position order
+static int pcg_shuffle_labels(sqgr_nhood* p, const uint64_t* states_dev, int64_t pc, int64_t stride, uint8_t* W, hipStream_t st,
+                              const char* timer_name) {
+    const int64_t n = p->n;
+    LaunchTimer t(p->ctx, timer_name, st);
+    if (pcg_lane_kernel()) {
+        k_pcg_shuffle<uint8_t, false><<<(unsigned)ceil_div(pc, 64), 64, 0, st>>>(n, p->n_libs, p->lib_off.p, p->base_pos.p, states_dev,
+                                                                                pc, stride, W);
+        SQGR_HIP(hipGetLastError());
+        return SQGR_OK;
+    }
+    const int64_t n_pad = ceil_div(n, 64) * 64;
+    SQGR_TRY(ensure_pcg_jump(p->pcg_jump));
+    SQGR_TRY(p->rows.ensure((size_t)pc * n_pad));
+    k_pcg_shuffle_wave<uint8_t, false><<<(unsigned)pc, 64, 0, st>>>(n, n_pad, p->n_libs, p->lib_off.p, p->base_pos.p, states_dev,
+                                                                    p->pcg_jump.p, p->rows.p, pcg_force_slow());
+    SQGR_HIP(hipGetLastError());
+    k_rows_to_columns_u8<<<dim3((unsigned)ceil_div(n, 64), (unsigned)ceil_div(pc, 64)), 256, 0, st>>>(n, n_pad, p->rows.p, pc, stride, W);
+    SQGR_HIP(hipGetLastError());
+    return SQGR_OK;
+}
 
 int sqgr_nhood::resolve_tuning() {
     if (B == 32 && (size_t)K2 * 32 * 4 > LDS_BUDGET) B = 16;
@@ -1010,12 +1362,7 @@ int sqgr_nhood_run_pcg64(sqgr_nhood* plan, const uint64_t* pcg_states, int64_t n
     for (int64_t c0 = 0; c0 < n_perms; c0 += chunk) {
         const int64_t pc = std::min(chunk, n_perms - c0);
         SQGR_HIP(hipMemcpyAsync(p->pcg_states.p, pcg_states + (size_t)c0 * 4, (size_t)pc * 32, hipMemcpyHostToDevice, st));
-        {
-            LaunchTimer t(ctx, "nhood_pcg64_shuffle");
-            k_pcg_shuffle<uint8_t, false><<<(unsigned)ceil_div(pc, 64), 64, 0, st>>>(n, p->n_libs, p->lib_off.p, p->base_pos.p,
-                                                                                    p->pcg_states.p, pc, stride, p->wcol.p);
-            SQGR_HIP(hipGetLastError());
-        }
+        SQGR_TRY(pcg_shuffle_labels(p, p->pcg_states.p, pc, stride, p->wcol.p, st, "nhood_pcg64_shuffle"));
         for (int64_t q0 = 0; q0 < pc; q0 += per_launch) {
             const int64_t todo = std::min(per_launch, pc - q0);
             const int nb = (int)ceil_div(todo, B);
@@ -1053,10 +1400,14 @@ int sqgr_pcg64_permutations(sqgr_ctx* ctx, int64_t n, const uint64_t* pcg_states
     SQGR_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const int64_t chunk = std::max<int64_t>(64, std::min<int64_t>(ceil_div(n_perms, 64) * 64, (((int64_t)8 << 30) / (n * 4)) / 64 * 64));
+    const bool lane_kernel = pcg_lane_kernel();
     DevBuf<int32_t> W, idx;
-    DevBuf<uint64_t> states;
+    DevBuf<uint64_t> states, jump;
     DevBuf<uint32_t> off;
-    SQGR_TRY(W.alloc((size_t)n * chunk));
+    if (lane_kernel)
+        SQGR_TRY(W.alloc((size_t)n * chunk));
+    else
+        SQGR_TRY(ensure_pcg_jump(jump));
     SQGR_TRY(idx.alloc((size_t)chunk * n));
     SQGR_TRY(states.alloc((size_t)chunk * 4));
     SQGR_TRY(off.alloc(2));
@@ -1067,8 +1418,13 @@ int sqgr_pcg64_permutations(sqgr_ctx* ctx, int64_t n, const uint64_t* pcg_states
         SQGR_HIP(hipMemcpyAsync(states.p, pcg_states + (size_t)c0 * 4, (size_t)pc * 32, hipMemcpyHostToDevice, st));
         {
             LaunchTimer t(ctx, "autocorr_pcg64_permutation");
-            k_pcg_shuffle<int32_t, true><<<(unsigned)ceil_div(pc, 64), 64, 0, st>>>(n, 1, off.p, nullptr, states.p, pc, chunk, W.p);
-            k_columns_to_rows_i32<<<dim3((unsigned)ceil_div(n, 32), (unsigned)ceil_div(pc, 32)), 256, 0, st>>>(n, chunk, W.p, pc, idx.p);
+            if (lane_kernel) {
+                k_pcg_shuffle<int32_t, true><<<(unsigned)ceil_div(pc, 64), 64, 0, st>>>(n, 1, off.p, nullptr, states.p, pc, chunk, W.p);
+                k_columns_to_rows_i32<<<dim3((unsigned)ceil_div(n, 32), (unsigned)ceil_div(pc, 32)), 256, 0, st>>>(n, chunk, W.p, pc, idx.p);
+            } else {  // rows are the wanted output already: idx[q][i]
+                k_pcg_shuffle_wave<int32_t, true><<<(unsigned)pc, 64, 0, st>>>(n, n, 1, off.p, nullptr, states.p, jump.p, idx.p,
+                                                                               pcg_force_slow());
+            }
             SQGR_HIP(hipGetLastError());
         }
         SQGR_HIP(hipMemcpyAsync(out_idx + (size_t)c0 * n, idx.p, (size_t)pc * n * 4, hipMemcpyDeviceToHost, st));
@@ -1109,12 +1465,7 @@ int label_shuffler_philox(LabelShuffler* s, uint64_t seed, int64_t perm0, int nb
 }
 
 int label_shuffler_pcg64(LabelShuffler* s, const uint64_t* states_dev, int64_t pc, int64_t stride, uint8_t* W, hipStream_t st) {
-    sqgr_nhood* p = reinterpret_cast<sqgr_nhood*>(s);
-    LaunchTimer t(p->ctx, "ligrec_pcg64_shuffle", st);
-    k_pcg_shuffle<uint8_t, false><<<(unsigned)ceil_div(pc, 64), 64, 0, st>>>(p->n, 1, p->lib_off.p, p->base_pos.p, states_dev, pc,
-                                                                            stride, W);
-    SQGR_HIP(hipGetLastError());
-    return SQGR_OK;
+    return pcg_shuffle_labels(reinterpret_cast<sqgr_nhood*>(s), states_dev, pc, stride, W, st, "ligrec_pcg64_shuffle");
 }
 
 }  // namespace sqgr

@@ -163,8 +163,6 @@ def test_reference_known_answers(L):
         sq.gr.spatial_neighbors_grid  # noqa: B018
         with pytest.warns(FutureWarning):
             sq.gr.spatial_neighbors(ad, coord_type="grid", percentile=50.0)
-    with pytest.raises(NotImplementedError, match="delaunay"):
-        sq.gr.spatial_neighbors_grid(ad, delaunay=True)
     with pytest.raises(ValueError, match="Invalid option `foo` for `Transform`"):
         sq.gr.spatial_neighbors_knn(ad, n_neighs=2, transform="foo")
 

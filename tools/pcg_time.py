@@ -5,7 +5,7 @@ from squidpy_amd import _lib as L
 from squidpy_amd._synthetic import hex_grid_graph
 from squidpy_amd._utils import pcg64_states
 ctx = L.default_context()
-for rows, cols, P in ((250, 400, 16384), (1000, 1000, 16384), (1000, 1000, 65536)):
+for rows, cols, P in ((250, 400, 1000), (250, 400, 16384), (1000, 1000, 1000), (1000, 1000, 16384), (1000, 1000, 65536)):
     n = rows * cols
     adj = hex_grid_graph(rows, cols)
     labels = np.random.default_rng(0).integers(0, 30, n).astype(np.int32)
