@@ -539,17 +539,58 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int src) {
 
 constexpr int PCGW_TAB = 34;      // jump distances 0..33 (64 halves starting at an odd half reach output 33)
 constexpr int PCGW_HASH = 2048;   // duplicate filter of the fast path
+constexpr uint32_t PCGW_MIN_SPAN = 192;  // positions below i that must be in the LDS window before a trip
+
+// lane's raw 32-bit draw number `lane` after stream position (s, half); sk = the LCG state it was taken from
+__device__ __forceinline__ uint32_t pcgw_draw(const U128& s, uint32_t half, int lane, const uint64_t (*sA)[2],
+                                              const uint64_t (*sD)[2], U128& sk) {
+    const uint32_t hl = half + (uint32_t)lane;
+    const int kk = 1 + (int)(hl >> 1);
+    U128 a, d;
+    a.hi = sA[kk][0];
+    a.lo = sA[kk][1];
+    d.hi = sD[kk][0];
+    d.lo = sD[kk][1];
+    sk = add128(mul128_lo(a, s), d);
+    const uint64_t x = sk.hi ^ sk.lo;
+    const unsigned rot = (unsigned)(sk.hi >> 58);
+    const uint64_t out = (x >> rot) | (x << ((64u - rot) & 63u));
+    return (hl & 1u) ? (uint32_t)(out >> 32) : (uint32_t)out;
+}
+
+// consume `used` of the 64 draws: (s, half) move on; sk = the per-lane states pcgw_draw returned for the old position
+__device__ __forceinline__ void pcgw_advance(U128& s, uint32_t& half, const U128& sk, uint32_t used) {
+    const uint32_t hu = half + used;
+    const uint32_t dq = hu >> 1;
+    if (dq > 0u) {
+        const int src = (int)(2u * dq - 1u - half);
+        s.hi = readlane64(sk.hi, src);
+        s.lo = readlane64(sk.lo, src);
+    }
+    half = hu & 1u;
+}
 
 template <typename T, bool ARANGE>
 __global__ __launch_bounds__(64) void k_pcg_shuffle_wave(int64_t n, int64_t row_stride, int n_libs,
                                                          const uint32_t* __restrict__ lib_off, const T* __restrict__ base_pos,
                                                          const uint64_t* __restrict__ states, const uint64_t* __restrict__ jump,
-                                                         T* __restrict__ R, int force_slow) {
+                                                         int64_t P, T* __restrict__ R, int force_slow, uint32_t WS) {
+    // Window: the top WS positions [wlo, i] of the array being shuffled live in LDS (ring, index pos & (WS-1)); positions
+    // are finalised (written to R) when they are the i side of a step, everything else they see stays in LDS.  An
+    // array of <= WS elements is resident as a whole.  This takes the read-after-write on the line just stored off the
+    // critical path of every trip.
+    extern __shared__ unsigned char s_window[];
+    T* win = reinterpret_cast<T*>(s_window);
+    const uint32_t WM = WS - 1u;
     __shared__ uint64_t sA[PCGW_TAB][2], sD[PCGW_TAB][2];
-    __shared__ uint32_t sJ[64], sVI[64], sVJ[64], sCanon[64];
+    __shared__ uint32_t sJ[64];
     __shared__ uint32_t sH[PCGW_HASH];
     const int lane = threadIdx.x;
-    const int64_t p = blockIdx.x;
+    for (int h = lane; h < PCGW_HASH; h += 64) sH[h] = 0;
+    uint32_t epoch = 0;
+    // a block walks permutations blockIdx.x, blockIdx.x + gridDim.x, ... (the grid may be capped so that the rows being
+    // shuffled at any one time stay cache resident)
+    for (int64_t p = blockIdx.x; p < P; p += gridDim.x) {
     U128 s, inc;
     s.hi = states[4 * p + 0];
     s.lo = states[4 * p + 1];
@@ -567,11 +608,11 @@ __global__ __launch_bounds__(64) void k_pcg_shuffle_wave(int64_t n, int64_t row_
         sD[lane][0] = d.hi;
         sD[lane][1] = d.lo;
     }
-    for (int h = lane; h < PCGW_HASH; h += 64) sH[h] = 0;
     T* row = R + p * row_stride;
     for (int64_t e = lane; e < n; e += 64) row[e] = ARANGE ? (T)e : base_pos[e];
     uint32_t half = 0;   // 1: the next draw is the high half of the 64-bit output after `s`
-    uint32_t epoch = 0;
+    U128 sk;             // per lane: generator state behind this lane's draw
+    uint32_t raw = pcgw_draw(s, half, lane, sA, sD, sk);  // the next 64 raw 32-bit draws, one per lane
     for (int l = 0; l < n_libs; ++l) {
         const uint32_t off = lib_off[l];
         const uint32_t m = lib_off[l + 1] - off;
@@ -580,61 +621,82 @@ __global__ __launch_bounds__(64) void k_pcg_shuffle_wave(int64_t n, int64_t row_
         uint32_t mask = m - 1;
         mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
         uint32_t i = m - 1;
+        uint32_t wlo = m;  // window = positions [wlo, i], empty at first
         while (i >= 1) {
-            // ---- the next 64 raw 32-bit draws, one per lane
-            const uint32_t hl = half + (uint32_t)lane;
-            const int kk = 1 + (int)(hl >> 1);
-            U128 a, d;
-            a.hi = sA[kk][0];
-            a.lo = sA[kk][1];
-            d.hi = sD[kk][0];
-            d.lo = sD[kk][1];
-            const U128 sk = add128(mul128_lo(a, s), d);
-            const uint64_t x = sk.hi ^ sk.lo;
-            const unsigned rot = (unsigned)(sk.hi >> 58);
-            const uint64_t out = (x >> rot) | (x << ((64u - rot) & 63u));
-            const uint32_t raw = (hl & 1u) ? (uint32_t)(out >> 32) : (uint32_t)out;
-            uint32_t used = 64;
-            bool fast = !force_slow && i >= 192u && (mask >> 1) < i - 64u;
-            if (fast) {
+            asm volatile("" ::: "memory");  // LDS is shared by the lanes: nothing read in an earlier trip may be reused
+            if (wlo > 0u && i + 1u - wlo < PCGW_MIN_SPAN) {  // refill to capacity: positions [lo2, wlo)
+                const uint32_t lo2 = (i + 1u > WS) ? i + 1u - WS : 0u;
+                for (uint32_t q = lo2 + (uint32_t)lane; q < wlo; q += 64u) win[q & WM] = sub[q];
+                wlo = lo2;
+            }
+            uint32_t used = 64, nacc = 0, it = i;
+            const bool general = force_slow || i < 192u || (mask >> 1) >= i - 64u;
+            if (!general) {
+                // the bound stays above i-64 and the mask cannot change: a candidate <= i-64 is accepted, one > i rejected
+                // whatever happened before it; the few in between are decided in order from the running count
                 const uint32_t c = raw & mask;
-                const bool acc = c <= i - 64u;
-                const bool amb = !acc && c <= i;
-                if (__ballot(amb) != 0ull) {
-                    fast = false;
-                } else {
-                    const uint64_t am = __ballot(acc);
-                    const uint32_t t = __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
-                    const uint32_t nacc = (uint32_t)__popcll(am);
+                const bool sure = c <= i - 64u;
+                const uint64_t ambm = __ballot(!sure && c <= i);
+                uint64_t accm = __ballot(sure);
+                for (uint64_t rem = ambm; rem != 0ull; rem &= rem - 1ull) {
+                    const int dd = __builtin_ctzll(rem);
+                    const uint32_t cd = (uint32_t)__builtin_amdgcn_readlane((int)c, dd);
+                    const uint32_t before = (uint32_t)__popcll(accm & ((1ull << dd) - 1ull));
+                    if (cd <= i - before) accm |= 1ull << dd;
+                }
+                const bool acc = (accm >> lane) & 1ull;
+                const uint32_t t = __builtin_amdgcn_mbcnt_hi((uint32_t)(accm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)accm, 0u));
+                nacc = (uint32_t)__popcll(accm);
+                it = i - nacc;
+                bool conflict = (ambm & accm) != 0ull;  // such a j may be the i side of a step of this very trip
+                if (!conflict) {
+                    // coinciding draws: every accepted lane tags its bucket; a lane that reads back another lane's tag shares
+                    // the bucket with it.  With a single such lane the only possible twin is the bucket's winner.
                     ++epoch;
                     const uint32_t tag = (epoch << 6) | (uint32_t)lane;
                     const uint32_t h = (c * 2654435761u) >> 21;
-                    // volatile: the read-back must observe OTHER lanes' writes to the bucket, not be forwarded from this
-                    // lane's own store
-                    volatile uint32_t* vH = sH;
-                    if (acc) vH[h] = tag;
-                    const bool clash = acc && vH[h] != tag;
-                    if (__ballot(clash) != 0ull) {  // same bucket: verify exactly
+                    if (acc) sH[h] = tag;
+                    asm volatile("" ::: "memory");  // the read-back must see the other lanes' stores, not be forwarded
+                    const uint32_t got = acc ? sH[h] : tag;
+                    const uint64_t cm = __ballot(got != tag);
+                    if (cm != 0ull) {
                         bool dup = false;
-                        for (int e = 0; e < 64; ++e) {
-                            const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)c, e);
-                            if (((am >> e) & 1ull) && acc && e < lane && ce == c) dup = true;
+                        if ((cm & (cm - 1ull)) == 0ull) {
+                            const uint32_t cw = (uint32_t)__shfl((int)c, (int)(got & 63u));
+                            dup = got != tag && cw == c;
+                        } else {
+                            for (int e = 0; e < 64; ++e) {
+                                const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)c, e);
+                                if (((accm >> e) & 1ull) && acc && e < lane && ce == c) dup = true;
+                            }
                         }
-                        if (__ballot(dup) != 0ull) fast = false;
-                    }
-                    if (fast) {
-                        if (acc) {
-                            const T va = sub[i - t], vb = sub[c];
-                            sub[i - t] = vb;
-                            sub[c] = va;
-                        }
-                        i -= nacc;
+                        conflict = __ballot(dup) != 0ull;
                     }
                 }
-            }
-            if (!fast) {
-                // ---- exact replay of the chunk.  Acceptance is sequential but wave-uniform.
-                uint32_t it = i, t = 0;
+                if (!conflict) {
+                    // ---- all swaps of the trip are independent.  The next chunk's draws are computed while the loads fly.
+                    T va = 0, vb = 0;
+                    if (acc) {
+                        va = win[(i - t) & WM];
+                        vb = (c >= wlo) ? win[c & WM] : sub[c];
+                    }
+                    pcgw_advance(s, half, sk, 64u);
+                    U128 sk2;
+                    const uint32_t raw2 = pcgw_draw(s, half, lane, sA, sD, sk2);
+                    if (acc) {
+                        sub[i - t] = vb;  // final
+                        if (c >= wlo) win[c & WM] = va; else sub[c] = va;
+                    }
+                    i = it;
+                    raw = raw2;
+                    sk = sk2;
+                    continue;
+                }
+                if (acc) sJ[t] = c;  // step-indexed list for the replay
+            } else {
+                // ---- sequential acceptance over the 64 raw draws (wave-uniform scalar code): mask changes, the last
+                // steps of a library, tiny arrays
+                uint32_t t = 0;
                 for (int dd = 0; dd < 64; ++dd) {
                     const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)raw, dd) & mask;
                     if (c <= it) {
@@ -648,58 +710,68 @@ __global__ __launch_bounds__(64) void k_pcg_shuffle_wave(int64_t n, int64_t row_
                         }
                     }
                 }
-                const uint32_t nacc = t;
-                if (nacc > 0u) {
-                    const bool live = (uint32_t)lane < nacc;
-                    const uint32_t j = live ? sJ[lane] : 0u;
-                    if (live) {
-                        sVI[lane] = (uint32_t)sub[i - (uint32_t)lane];
-                        sVJ[lane] = (uint32_t)sub[j];
-                    }
-                    // slot of position j_t: 64 + t' if it is the i-side position of step t', else the first step with that j
-                    uint32_t canon = (uint32_t)lane;
-                    const uint32_t ilow = i - (nacc - 1u);
-                    if (live && j >= ilow) {
-                        canon = 64u + (i - j);
+                nacc = t;
+            }
+            // ---- exact replay of steps 0..nacc-1 (step q: positions i-q and sJ[q]) on a register image: lane q holds the
+            // value at i-q (vI) and at its j (vJ)
+            if (nacc > 0u) {
+                asm volatile("" ::: "memory");
+                const bool live = (uint32_t)lane < nacc;
+                const uint32_t j = live ? sJ[lane] : 0xFFFFFFFFu;
+                uint32_t vI = 0, vJ = 0;
+                if (live) {
+                    vI = (uint32_t)win[(i - (uint32_t)lane) & WM];
+                    vJ = (uint32_t)((j >= wlo) ? win[j & WM] : sub[j]);
+                }
+                // slot of position j_q: 64 + q' if it is the i side of step q', else the first step with that j
+                uint32_t canon = (uint32_t)lane;
+                const uint32_t ilow = i - (nacc - 1u);
+                const bool in_i = live && j >= ilow;
+                if (in_i) canon = 64u + (i - j);
+                for (uint32_t e = 0; e + 1u < nacc; ++e) {
+                    const uint32_t je = (uint32_t)__builtin_amdgcn_readlane((int)j, (int)e);
+                    if (live && !in_i && e < (uint32_t)lane && je == j && canon == (uint32_t)lane) canon = e;
+                }
+                // steps that share a slot with another step run in order; all others are plain exchanges
+                const uint64_t refm = __ballot(live && canon != (uint32_t)lane);
+                uint64_t inv = refm;
+                for (uint64_t rem = refm; rem != 0ull; rem &= rem - 1ull) {
+                    const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)canon, __builtin_ctzll(rem));
+                    inv |= 1ull << (slot >= 64u ? slot - 64u : slot);
+                }
+                if (live && !((inv >> lane) & 1ull)) {
+                    const uint32_t tmp = vI;
+                    vI = vJ;
+                    vJ = tmp;
+                }
+                for (uint64_t rem = inv; rem != 0ull; rem &= rem - 1ull) {
+                    const int q = __builtin_ctzll(rem);
+                    const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)canon, q);
+                    const uint32_t va = (uint32_t)__builtin_amdgcn_readlane((int)vI, q);
+                    if (slot >= 64u) {
+                        const int q2 = (int)(slot - 64u);
+                        const uint32_t vb = (uint32_t)__builtin_amdgcn_readlane((int)vI, q2);
+                        vI = (lane == q) ? vb : vI;
+                        vI = (lane == q2) ? va : vI;
                     } else {
-                        for (uint32_t e = 0; e < nacc; ++e) {
-                            const uint32_t je = sJ[e];
-                            if (live && e < (uint32_t)lane && je == j && canon == (uint32_t)lane) canon = e;
-                        }
-                    }
-                    if (live) sCanon[lane] = canon;
-                    if (lane == 0) {
-                        for (uint32_t q = 0; q < nacc; ++q) {
-                            const uint32_t va = sVI[q];
-                            const uint32_t slot = sCanon[q];
-                            if (slot >= 64u) {
-                                const uint32_t vb = sVI[slot - 64u];
-                                sVI[q] = vb;
-                                sVI[slot - 64u] = va;
-                            } else {
-                                const uint32_t vb = sVJ[slot];
-                                sVI[q] = vb;
-                                sVJ[slot] = va;
-                            }
-                        }
-                    }
-                    if (live) {
-                        sub[i - (uint32_t)lane] = (T)sVI[lane];
-                        if (canon == (uint32_t)lane) sub[j] = (T)sVJ[lane];
+                        const uint32_t vb = (uint32_t)__builtin_amdgcn_readlane((int)vJ, (int)slot);
+                        vI = (lane == q) ? vb : vI;
+                        vJ = (lane == (int)slot) ? va : vJ;
                     }
                 }
-                i = it;
+                if (live) {
+                    sub[i - (uint32_t)lane] = (T)vI;  // final
+                    if (canon == (uint32_t)lane) {
+                        if (j >= wlo) win[j & WM] = (T)vJ; else sub[j] = (T)vJ;
+                    }
+                }
             }
-            // ---- advance the stream by `used` 32-bit draws
-            const uint32_t hu = half + used;
-            const uint32_t dq = hu >> 1;
-            if (dq > 0u) {
-                const int src = (int)(2u * dq - 1u - half);
-                s.hi = readlane64(sk.hi, src);
-                s.lo = readlane64(sk.lo, src);
-            }
-            half = hu & 1u;
+            i = it;
+            pcgw_advance(s, half, sk, used);
+            raw = pcgw_draw(s, half, lane, sA, sD, sk);
         }
+        if (lane == 0) sub[0] = win[0];  // position 0 is never the i side of a step: its last value is still in LDS
+    }
     }
 }
 
@@ -842,6 +914,25 @@ static bool pcg_lane_kernel() {  // SQGR_PCG_KERNEL=lane selects the one-thread-
     const char* e = getenv("SQGR_PCG_KERNEL");
     return e && strcmp(e, "lane") == 0;
 }
+static unsigned pcg_grid(int64_t pc) {  // SQGR_PCG_WAVES caps the number of permutations in flight (tuning runs)
+    const char* e = getenv("SQGR_PCG_WAVES");
+    const int64_t cap = (e && atoll(e) > 0) ? atoll(e) : pc;
+    return (unsigned)std::min<int64_t>(pc, cap);
+}
+// LDS window (elements, power of two).  Measured on MI355X: a larger window (up to the whole array) buys nothing — the
+// trips are bound by their own instruction stream, not by the i-side loads — and costs occupancy.
+static uint32_t pcg_window(int64_t n_max, int64_t pc, int cu_count, size_t elem) {
+    (void)pc; (void)cu_count; (void)elem;
+    uint32_t ws = 1024;
+    while ((int64_t)ws < n_max && ws < 4096u) ws <<= 1;
+    return ws;
+}
+template <typename KernelT>
+static int pcg_allow_lds(KernelT kernel, size_t bytes) {
+    if (bytes + 16 * 1024 <= 64 * 1024) return SQGR_OK;
+    SQGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return SQGR_OK;
+}
 static int pcg_force_slow() {
     const char* e = getenv("SQGR_PCG_FORCE_SLOW");
     return (e && atoi(e) == 1) ? 1 : 0;
@@ -861,8 +952,10 @@ static int pcg_shuffle_labels(sqgr_nhood* p, const uint64_t* states_dev, int64_t
     const int64_t n_pad = ceil_div(n, 64) * 64;
     SQGR_TRY(ensure_pcg_jump(p->pcg_jump));
     SQGR_TRY(p->rows.ensure((size_t)pc * n_pad));
-    k_pcg_shuffle_wave<uint8_t, false><<<(unsigned)pc, 64, 0, st>>>(n, n_pad, p->n_libs, p->lib_off.p, p->base_pos.p, states_dev,
-                                                                    p->pcg_jump.p, p->rows.p, pcg_force_slow());
+    const uint32_t ws = pcg_window(n, pc, p->ctx->cu_count, 1);
+    SQGR_TRY(pcg_allow_lds(k_pcg_shuffle_wave<uint8_t, false>, (size_t)ws));
+    k_pcg_shuffle_wave<uint8_t, false><<<pcg_grid(pc), 64, (size_t)ws, st>>>(n, n_pad, p->n_libs, p->lib_off.p, p->base_pos.p, states_dev,
+                                                                             p->pcg_jump.p, pc, p->rows.p, pcg_force_slow(), ws);
     SQGR_HIP(hipGetLastError());
     k_rows_to_columns_u8<<<dim3((unsigned)ceil_div(n, 64), (unsigned)ceil_div(pc, 64)), 256, 0, st>>>(n, n_pad, p->rows.p, pc, stride, W);
     SQGR_HIP(hipGetLastError());
@@ -1422,8 +1515,10 @@ int sqgr_pcg64_permutations(sqgr_ctx* ctx, int64_t n, const uint64_t* pcg_states
                 k_pcg_shuffle<int32_t, true><<<(unsigned)ceil_div(pc, 64), 64, 0, st>>>(n, 1, off.p, nullptr, states.p, pc, chunk, W.p);
                 k_columns_to_rows_i32<<<dim3((unsigned)ceil_div(n, 32), (unsigned)ceil_div(pc, 32)), 256, 0, st>>>(n, chunk, W.p, pc, idx.p);
             } else {  // rows are the wanted output already: idx[q][i]
-                k_pcg_shuffle_wave<int32_t, true><<<(unsigned)pc, 64, 0, st>>>(n, n, 1, off.p, nullptr, states.p, jump.p, idx.p,
-                                                                               pcg_force_slow());
+                const uint32_t ws = pcg_window(n, pc, ctx->cu_count, 4);
+                SQGR_TRY(pcg_allow_lds(k_pcg_shuffle_wave<int32_t, true>, (size_t)ws * 4));
+                k_pcg_shuffle_wave<int32_t, true><<<pcg_grid(pc), 64, (size_t)ws * 4, st>>>(n, n, 1, off.p, nullptr, states.p, jump.p, pc,
+                                                                                            idx.p, pcg_force_slow(), ws);
             }
             SQGR_HIP(hipGetLastError());
         }

@@ -276,3 +276,38 @@ def test_numpy_permutation_streams_on_device(L, ctx, n):
 
 def g_identity_indices(n):
     return np.arange(n)
+
+
+@pytest.mark.parametrize("variant", ["wave", "wave-slow-path-only", "lane"])
+def test_numpy_shuffle_kernel_variants_agree_with_numpy(L, ctx, variant, monkeypatch):
+    """The wave-per-permutation shuffle (jump-ahead draws, parallel swaps, exact replay where a chunk has coinciding
+    draws / borderline candidates / a mask change / a library end), the same kernel forced onto its replay path, and
+    the one-thread-per-permutation kernel must all reproduce numpy bit for bit — sizes around the 64-draw chunk and
+    the 192-element fast-path limit, and libraries that end in the middle of a chunk."""
+    from squidpy_amd._utils import pcg64_states
+
+    if variant == "wave-slow-path-only":
+        monkeypatch.setenv("SQGR_PCG_FORCE_SLOW", "1")
+    elif variant == "lane":
+        monkeypatch.setenv("SQGR_PCG_KERNEL", "lane")
+    for n in (2, 3, 63, 64, 65, 128, 191, 192, 193, 257, 1000, 4097, 33000):
+        P = 66
+        got = L.pcg64_permutations(ctx, n, pcg64_states(n, P))
+        want = np.stack([np.random.default_rng(s).permutation(n) for s in np.random.SeedSequence(n).spawn(P)])
+        np.testing.assert_array_equal(got, want, err_msg=f"n={n}")
+    # label shuffles per library (`_shuffle_group`: one generator walks the libraries in category order)
+    rng = np.random.default_rng(5)
+    n, k, n_libs, P = 6000, 9, 7, 40
+    labels = rng.integers(0, k, n).astype(np.int32)
+    libs = rng.integers(0, n_libs, n).astype(np.int32)
+    libs[:300] = 3  # one library is much larger than the others, one (6) may stay tiny
+    libs[libs == 6] = np.where(rng.random((libs == 6).sum()) < 0.01, 6, 0)
+    ring = sp.csr_matrix((np.ones(n, np.float32), (np.arange(n), (np.arange(n) + 1) % n)), shape=(n, n))  # i -> i+1
+    g = L.Graph(ctx, ring)
+    plan = L.NhoodPlan(ctx, g, labels, k, libs, n_libs)
+    _, _, perms = plan.run_pcg64(pcg64_states(21, P), return_perms=True)
+    want = np.stack([
+        O.nhood_counts(ring.indices, ring.indptr, O.shuffle_group(labels, libs, n_libs, rs), k) for rs in O.spawn_generators(21, P)
+    ])
+    np.testing.assert_array_equal(perms, want.astype(np.uint32))
+    assert len({w.tobytes() for w in want}) == P  # the counts do depend on the arrangement
