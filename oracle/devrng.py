@@ -80,21 +80,22 @@ def domain_dims(n: int) -> tuple[int, int, int]:
 MASK16 = np.uint64(0xFFFF)
 
 
-def _F(v: np.ndarray, k: np.ndarray | np.uint64) -> np.ndarray:
-    """16-bit round function (sqgr_rng.h: feistel_F1 / feistel_F2): arithmetic modulo 2**16."""
-    x = (v ^ k) & MASK16
-    x = (x * FEISTEL_C1) & MASK16
+def _F(v: np.ndarray, k: np.ndarray | np.uint64, bits: int) -> np.ndarray:
+    """16-bit round function (sqgr_rng.h: feistel_F1 / feistel_F2), arithmetic modulo 2**16: multiply-add, xor-shift,
+    multiply; the top ``bits`` bits are the result."""
+    x = (v * FEISTEL_C1 + (k & MASK16)) & MASK16
     x = x ^ (x >> np.uint64(7))
     x = (x * FEISTEL_C2) & MASK16
-    return x ^ (x >> np.uint64(9))
+    return x >> np.uint64(16 - bits)
 
 
 def _rounds(a: np.ndarray, b: np.ndarray, A: int, B: int, Bmask: int, key) -> tuple[np.ndarray, np.ndarray]:
     """The 8 alternating additive rounds; ``key(r)`` returns the round key(s) of round r (low 16 bits are used)."""
-    A1, B64, bm = np.uint64(A - 1), np.uint64(B), np.uint64(Bmask)
+    A1, B64 = np.uint64(A - 1), np.uint64(B)
+    abits, bbits = int(A).bit_length() - 1, int(Bmask + 1).bit_length() - 1
     for r in range(0, N_ROUNDS, 2):
-        a = (a + _F(b, key(r))) & A1
-        t = b + (_F(a, key(r + 1)) & bm)
+        a = (a + _F(b, key(r), abits)) & A1
+        t = b + _F(a, key(r + 1), bbits)
         t = np.where(t >= B64, t - B64, t)
         b = np.where(t >= B64, t - B64, t)
     return a, b

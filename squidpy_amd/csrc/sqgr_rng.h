@@ -51,22 +51,20 @@ __host__ __device__ inline void round_keys(uint64_t seed, uint64_t perm, uint32_
 // v_pk_min_u16, plus plain 32-bit bitwise ops acting on both halves).
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
-// round function: a two-round 16-bit multiply / xor-shift mixer of (v ^ k); arithmetic modulo 2^16
-__device__ __forceinline__ u16x2 feistel_F2(u16x2 v, u16x2 k) {
-    u16x2 x = v ^ k;
-    x *= (u16x2)(FEISTEL_C1);
+// round function: 16-bit multiply-add / xor-shift / multiply, of which the TOP `16 - sh` bits are returned (the best mixed
+// ones, and already reduced to the digit's power-of-two range: no mask afterwards); arithmetic modulo 2^16.
+// 5 packed ops: v_pk_mad_u16, v_pk_lshrrev_b16, v_xor_b32, v_pk_mul_lo_u16, v_pk_lshrrev_b16.
+__device__ __forceinline__ u16x2 feistel_F2(u16x2 v, u16x2 k, u16x2 sh) {
+    u16x2 x = v * (u16x2)(FEISTEL_C1) + k;
     x ^= x >> (u16x2)(7);
     x *= (u16x2)(FEISTEL_C2);
-    x ^= x >> (u16x2)(9);
-    return x;
+    return x >> sh;
 }
-__host__ __device__ inline uint32_t feistel_F1(uint32_t v, uint32_t k) {  // the same function, one permutation
-    uint32_t x = (v ^ k) & 0xFFFFu;
-    x = (x * FEISTEL_C1) & 0xFFFFu;
+__host__ __device__ inline uint32_t feistel_F1(uint32_t v, uint32_t k, uint32_t sh) {  // the same function, one permutation
+    uint32_t x = (v * FEISTEL_C1 + (k & 0xFFFFu)) & 0xFFFFu;
     x ^= x >> 7;
     x = (x * FEISTEL_C2) & 0xFFFFu;
-    x ^= x >> 9;
-    return x;
+    return x >> sh;
 }
 
 // Mixed-radix domain A x B >= n, x <-> (a, b), x = a*B + b:  A = power of two ~ sqrt(n) (the a-rounds reduce with one
@@ -77,6 +75,8 @@ struct FeistelDomain {
     uint32_t A;      // radix of the high digit (power of two)
     uint32_t B;      // radix of the low digit
     uint32_t Bmask;  // smallest all-ones mask >= B - 1 ... (2^ceil(log2 B) - 1)
+    uint32_t ash;    // 16 - log2(A): the round function's shift for the high digit
+    uint32_t bsh;    // 16 - log2(Bmask + 1): ... for the low digit
 };
 
 __host__ __device__ inline uint32_t isqrt_ceil(uint32_t n) {
@@ -97,30 +97,35 @@ __host__ __device__ inline FeistelDomain make_domain(uint32_t n) {
     uint32_t m = 1u;
     while (m < d.B) m <<= 1;
     d.Bmask = m - 1u;
+    d.ash = 16u;
+    for (uint32_t t = d.A; t > 1u; t >>= 1) --d.ash;
+    d.bsh = 16u;
+    for (uint32_t t = m; t > 1u; t >>= 1) --d.bsh;
     return d;
 }
 
 // one pass of the 8 alternating additive rounds on NP packed pairs (= 2*NP permutations) in lock-step:
-//   a <- (a + F(b, k_r)) mod A                      (A = 2^m: one AND)
-//   b <- (b + (F(a, k_r+1) & Bmask)) mod B          (sum < 3B: two conditional subtractions)
+//   a <- (a + F_A(b, k_r)) mod A                    (A = 2^m: one AND; F_A < A)
+//   b <- (b + F_B(a, k_r+1)) mod B                  (F_B <= Bmask < 2B, sum < 3B: two conditional subtractions)
 // The round chain of one pair is strictly dependent and packed-16 results need a wait state before use; NP >= 2
 // independent chains interleave and fill those slots.   rk[2*i], rk[2*i+1]: round keys of pair i's two permutations.
 template <int NP>
 __device__ __forceinline__ void feistel_rounds(u16x2 (&a)[NP], u16x2 (&b)[NP], const FeistelDomain& d,
                                                const uint32_t* const (&rk)[2 * NP]) {
-    const u16x2 am = (u16x2)((unsigned short)(d.A - 1u)), bm = (u16x2)((unsigned short)d.Bmask);
+    const u16x2 am = (u16x2)((unsigned short)(d.A - 1u));
+    const u16x2 ash = (u16x2)((unsigned short)d.ash), bsh = (u16x2)((unsigned short)d.bsh);
     const u16x2 BB = (u16x2)((unsigned short)d.B);
 #pragma unroll
     for (int r = 0; r < FEISTEL_ROUNDS; r += 2) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const u16x2 k0 = __builtin_bit_cast(u16x2, (rk[2 * i][r] & 0xFFFFu) | (rk[2 * i + 1][r] << 16));
-            a[i] = (a[i] + feistel_F2(b[i], k0)) & am;
+            a[i] = (a[i] + feistel_F2(b[i], k0, ash)) & am;
         }
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const u16x2 k1 = __builtin_bit_cast(u16x2, (rk[2 * i][r + 1] & 0xFFFFu) | (rk[2 * i + 1][r + 1] << 16));
-            u16x2 t = b[i] + (feistel_F2(a[i], k1) & bm);
+            u16x2 t = b[i] + feistel_F2(a[i], k1, bsh);
             t = __builtin_elementwise_min(t, (u16x2)(t - BB));  // unsigned wrap makes the wrong branch huge
             b[i] = __builtin_elementwise_min(t, (u16x2)(t - BB));
         }
@@ -177,8 +182,8 @@ __host__ __device__ inline uint32_t feistel_perm(uint32_t x, const FeistelDomain
     uint32_t a = x / d.B, b = x - a * d.B;
     do {
         for (int r = 0; r < FEISTEL_ROUNDS; r += 2) {
-            a = (a + feistel_F1(b, rk[r])) & (d.A - 1u);
-            uint32_t t = b + (feistel_F1(a, rk[r + 1]) & d.Bmask);
+            a = (a + feistel_F1(b, rk[r], d.ash)) & (d.A - 1u);
+            uint32_t t = b + feistel_F1(a, rk[r + 1], d.bsh);
             t = t >= d.B ? t - d.B : t;
             b = t >= d.B ? t - d.B : t;
         }
