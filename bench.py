@@ -211,6 +211,9 @@ def main() -> None:
     ap.add_argument("--perms-per-step", type=int, default=PERMS_PER_STEP)
     ap.add_argument("--rows", type=int, default=ROWS)
     ap.add_argument("--cols", type=int, default=COLS)
+    ap.add_argument("--label-dist", choices=["uniform", "dirichlet"], default="uniform",
+                    help="cluster sizes: uniform (the headline workload) or Dirichlet(0.5) proportions (SURVEY §8d: skewed variant "
+                    "that concentrates the LDS-atomic traffic of the count kernel on few counters)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the Moran's I genes/sec leg")
     ap.add_argument("--no-numpy-leg", action="store_true", help="skip the bit-compatible numpy-stream leg")
@@ -244,7 +247,11 @@ def main() -> None:
     ctx = _lib.default_context(local_rank % max(_lib.device_count(), 1))
     adj = hex_grid_graph(args.rows, args.cols)
     n, nnz = adj.shape[0], int(adj.nnz)
-    labels = np.random.default_rng(0).integers(0, N_CLS, n).astype(np.int32)
+    lab_rng = np.random.default_rng(0)
+    if args.label_dist == "dirichlet":
+        labels = lab_rng.choice(N_CLS, size=n, p=lab_rng.dirichlet(np.full(N_CLS, 0.5))).astype(np.int32)
+    else:
+        labels = lab_rng.integers(0, N_CLS, n).astype(np.int32)
     graph = _lib.Graph(ctx, adj, with_data=False)          # resident in HBM from here on
     plan = _lib.NhoodPlan(ctx, graph, labels, N_CLS)
     if args.tune:
@@ -330,7 +337,9 @@ def main() -> None:
             "data": "synthetic",
             "config": {
                 "workload": f"nhood_enrichment: {n} spots ({args.rows}x{args.cols} hex grid, nnz={nnz}), {N_CLS} clusters, "
-                f"{P} permutations per step per GPU, on-device Philox/Feistel shuffles",
+                f"{P} permutations per step per GPU, on-device Philox/Feistel shuffles"
+                + ("" if args.label_dist == "uniform" else ", Dirichlet(0.5) cluster proportions"),
+                "label_dist": args.label_dist,
                 "perms_per_step_per_gpu": P,
                 "parallelism": f"permutation ranges over {world} rank(s), all-reduce of int64 moments",
             },

@@ -311,3 +311,29 @@ def test_numpy_shuffle_kernel_variants_agree_with_numpy(L, ctx, variant, monkeyp
     ])
     np.testing.assert_array_equal(perms, want.astype(np.uint32))
     assert len({w.tobytes() for w in want}) == P  # the counts do depend on the arrangement
+
+
+def test_skewed_cluster_sizes(L, ctx):
+    """SURVEY §8d skewed variant: Dirichlet(0.5) cluster proportions (a few huge clusters, some almost empty, one
+    empty) concentrate the count kernel's LDS atomics on few counters and make label boundaries fall inside single
+    rank blocks of the shuffle's lookup table.  Counts and permutation counts stay bit-exact."""
+    import squidpy_amd as sq
+
+    rng = np.random.default_rng(3)
+    k = 12
+    adata = hex_adata(60, 80, k, seed=4)
+    n = adata.n_obs
+    prop = rng.dirichlet(np.full(k - 1, 0.5))
+    lab = rng.choice(k - 1, size=n, p=prop).astype(np.int32)  # category k-1 stays empty
+    adata.obs["cluster"] = pd.Categorical.from_codes(lab, [f"c{i}" for i in range(k)])
+    adj = adata.obsp["spatial_connectivities"]
+    g = L.Graph(ctx, adj)
+    np.testing.assert_array_equal(L.nhood_counts(ctx, g, lab, k), O.nhood_counts(adj.indices, adj.indptr, lab, k))
+    plan = L.NhoodPlan(ctx, g, lab, k)
+    _, _, perms = plan.run(17, 0, 48, None, return_perms=True)
+    np.testing.assert_array_equal(perms, O.nhood_perm_counts_philox(adj.indices, adj.indptr, lab, k, 17, 0, 48).astype(np.uint32))
+    res = sq.gr.nhood_enrichment(adata, "cluster", n_perms=48, seed=17, copy=True)
+    ref = O.nhood_zscore(res.counts, perms.astype(np.float64))
+    ok = np.isfinite(ref)
+    np.testing.assert_allclose(res.zscore[ok], ref[ok], rtol=1e-9)
+    assert np.isnan(res.zscore[k - 1]).all() and np.isnan(ref[k - 1]).all()  # empty category: 0/0 as in the reference
