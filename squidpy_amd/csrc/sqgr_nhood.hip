@@ -861,7 +861,7 @@ struct sqgr_nhood {
     // tuning
     int B = 16;
     int nblk = 0;
-    int nbatch = 32;
+    int nbatch = 0;  // batches per launch group; 0: automatic (resolve_tuning)
     // workspace
     DevBuf<uint32_t> keys;   // 2 buffers (ping-pong between the shuffle and the count stream)
     DevBuf<uint8_t> slab;    // 2 buffers
@@ -888,7 +888,22 @@ struct sqgr_nhood {
             if ((size_t)K2 * b * 4 <= LDS_BUDGET) return b;
         return 0;
     }
-    int partial_blocks() const { return (B == 16 && be() == 0) ? 1 : nblk; }
+    // 1024-thread blocks per batch of a launch with `nb` batches.  nblk > 0: fixed by sqgr_nhood_tune.  Auto: ~8 blocks
+    // per CU over the whole launch, at least 32 per batch — measured on MI355X (tools/tune_sweep.sh): with 64 batches in
+    // flight 32-48 blocks per batch beat one block per CU by 15 % (fewer partial histograms to write and re-read:
+    // blocks * K*K*B*4 bytes per batch; longer edge runs per block).
+    int blocks_for(int nb) const {
+        if (nblk > 0) return nblk;
+        const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
+        return (int)std::max<int64_t>(32, std::min<int64_t>(cus, ceil_div((int64_t)8 * cus, std::max(nb, 1))));
+    }
+    int nblk_launch = 0;  // blocks per batch of the launch in flight (count -> reduce)
+    int partial_blocks(int nb) const { return (B == 16 && be() == 0) ? 1 : blocks_for(nb); }
+    size_t partial_words() const {  // largest nb * blocks_for(nb) * hist_words over the launches this plan can issue
+        size_t m = 0;
+        for (int nb = 1; nb <= nbatch; ++nb) m = std::max(m, (size_t)nb * partial_blocks(nb));
+        return m * (size_t)hist_words();
+    }
     int resolve_tuning();
     int ensure_workspace(bool need_perms);
     int count_batches(int nb, int buf);  // slab[buf] -> partial for nb batches
@@ -970,12 +985,17 @@ int sqgr_nhood::resolve_tuning() {
     if (B == 32 && (size_t)K2 * 32 * 4 > LDS_BUDGET) B = 16;
     if (B != 16 && B != 32) B = 16;
     const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
-    if (nblk <= 0) {
-        // one 1024-thread block per CU: measured best on MI355X (sweep in profiles/nhood_sweep_r01.txt) — more blocks
-        // only add partial-histogram traffic (nblk * K*K*B*4 bytes written and re-read per batch)
-        nblk = cus;
+    (void)cus;
+    if (nbatch <= 0) {
+        // 64 batches (1024 permutations) per launch group, fewer when two slab buffers of that size would not fit a
+        // quarter of the free HBM (n up to 2^27 spots)
+        size_t free_b = 0, total_b = 0;
+        nbatch = 64;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && n > 0) {
+            const int64_t fit = (int64_t)(free_b / 4) / (2 * n * B);
+            nbatch = (int)std::max<int64_t>(1, std::min<int64_t>(64, fit));
+        }
     }
-    if (nbatch <= 0) nbatch = 32;
     return SQGR_OK;
 }
 
@@ -988,7 +1008,8 @@ int sqgr_nhood::ensure_workspace(bool need_perms) {
         if (!ev_shuffled[i]) SQGR_HIP(hipEventCreateWithFlags(&ev_shuffled[i], hipEventDisableTiming));
         if (!ev_counted[i]) SQGR_HIP(hipEventCreateWithFlags(&ev_counted[i], hipEventDisableTiming));
     }
-    SQGR_TRY(partial.ensure((size_t)nbatch * partial_blocks() * hw));
+    (void)hw;
+    SQGR_TRY(partial.ensure(partial_words()));
     SQGR_TRY(acc_sum.ensure((size_t)nbatch * hw));
     SQGR_TRY(acc_sq.ensure((size_t)nbatch * hw));
     SQGR_TRY(shift.ensure((size_t)K2));
@@ -1003,8 +1024,10 @@ int sqgr_nhood::count_batches(int nb, int buf) {
     const int64_t nnz = g->nnz;
     hipStream_t st = ctx->stream;
     const int hw = hist_words();
+    const int nblk = blocks_for(nb);  // shadows the tuning member on purpose: everything below is per launch
+    nblk_launch = partial_blocks(nb);
     if (nnz == 0) {  // no edges: every count is zero
-        SQGR_HIP(hipMemsetAsync(partial.p, 0, (size_t)nb * partial_blocks() * hw * 4, st));
+        SQGR_HIP(hipMemsetAsync(partial.p, 0, (size_t)nb * nblk_launch * hw * 4, st));
         return SQGR_OK;
     }
     if (B == 32) {
@@ -1049,7 +1072,7 @@ int sqgr_nhood::count_batches(int nb, int buf) {
 int sqgr_nhood::reduce_batches(int nb, int64_t perm_batch0, int64_t perm_begin, int64_t perm_end, uint32_t* perms_out_dev) {
     const int hw = hist_words();
     LaunchTimer t(ctx, "nhood_reduce");
-    k_reduce<<<dim3((unsigned)ceil_div(hw, 64), nb), 256, 0, ctx->stream>>>(partial.p, partial_blocks(), hw, B, K2, shift.p,
+    k_reduce<<<dim3((unsigned)ceil_div(hw, 64), nb), 256, 0, ctx->stream>>>(partial.p, nblk_launch, hw, B, K2, shift.p,
                                                                             perm_batch0, perm_begin, perm_end, acc_sum.p,
                                                                             acc_sq.p, perms_out_dev);
     SQGR_HIP(hipGetLastError());
@@ -1272,7 +1295,7 @@ int sqgr_nhood_tune(sqgr_nhood* plan, int32_t perms_per_pass, int32_t blocks_per
                  "tuning value out of range");
     plan->B = perms_per_pass ? perms_per_pass : 16;
     plan->nblk = blocks_per_batch;
-    plan->nbatch = batches_per_launch ? batches_per_launch : 32;
+    plan->nbatch = batches_per_launch;  // 0: automatic (resolve_tuning)
     // force re-allocation with the new geometry
     plan->keys.release(); plan->slab.release(); plan->partial.release(); plan->acc_sum.release(); plan->acc_sq.release();
     return SQGR_OK;
