@@ -23,6 +23,7 @@ from .._utils import (
     category_codes,
     extract_adata_if_sdata,
     get_n_processes,
+    logg,
     pcg64_states,
     resolve_seed,
     spawn_generators,
@@ -127,7 +128,9 @@ def nhood_enrichment(
     graph = Graph(ctx, adj, with_data=False)
     try:
         count = nhood_counts(ctx, graph, int_clust, n_cls)
-        if rng == "numpy-host":
+        if n_cls > MAX_DEVICE_SHUFFLE_CLUSTERS:
+            zscore = _zscore_many_clusters(ctx, graph, int_clust, n_cls, lib_codes, n_libs, seed, n_perms, count)
+        elif rng == "numpy-host":
             zscore = _zscore_numpy_streams(ctx, graph, int_clust, n_cls, lib_codes, n_libs, seed, n_perms, count)
         elif rng == "numpy":
             rank, world = _dist.world()
@@ -169,6 +172,47 @@ def _broadcast_seed(key: int) -> int:
         return key
     arr = np.array([key if _dist.world()[0] == 0 else 0], dtype=np.uint64)
     return int(_dist.allreduce_sum_([arr])[0][0])
+
+
+MAX_DEVICE_SHUFFLE_CLUSTERS = 256  # the batched permutation kernels keep labels as uint8
+
+
+def _zscore_many_clusters(
+    ctx: Context,
+    graph: Graph,
+    int_clust: np.ndarray,
+    n_cls: int,
+    lib_codes: np.ndarray | None,
+    n_libs: int,
+    seed: int | None,
+    n_perms: int,
+    count: np.ndarray,
+) -> np.ndarray:
+    """More than 256 clusters: the batched device shuffle does not apply (uint8 labels, K*K*16 counters per pass), so each
+    permutation is drawn with the reference's own numpy stream on the host (gr/_nhood.py:213, 530-539) and counted by the
+    general edge-pair kernel (`sqgr_nhood_counts`, any K) — Squidpy's z-scores for the seed, at ~1 ms per permutation
+    plus the shuffle.  Permutation ranges are split over ranks like the other paths."""
+    logg.info("`%s` clusters > %s: label shuffles are drawn with numpy on the host for this call", n_cls, MAX_DEVICE_SHUFFLE_CLUSTERS)
+    if seed is None:
+        seed = _broadcast_seed(resolve_seed(None))
+    rank, world = _dist.world()
+    lo, hi = _dist.shard_range(n_perms, rank, world)
+    gens = spawn_generators(seed, n_perms)[lo:hi]
+    lib_idx = [np.where(lib_codes == c)[0] for c in range(n_libs)] if lib_codes is not None else None
+    perms = np.empty((hi - lo, n_cls, n_cls), dtype=np.float64)
+    for q, rs in enumerate(gens):
+        lab = int_clust.copy()
+        if lib_idx is None:
+            rs.shuffle(lab)
+        else:  # gr/_utils.py:185-213
+            for idx in lib_idx:
+                grp = int_clust[idx].copy()
+                rs.shuffle(grp)
+                lab[idx] = grp
+        perms[q] = nhood_counts(ctx, graph, lab, n_cls)
+    perms = np.concatenate(_dist.allgather_object(perms), axis=0)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return (count - perms.mean(axis=0)) / perms.std(axis=0)
 
 
 def _zscore_numpy_streams(

@@ -337,3 +337,26 @@ def test_skewed_cluster_sizes(L, ctx):
     ok = np.isfinite(ref)
     np.testing.assert_allclose(res.zscore[ok], ref[ok], rtol=1e-9)
     assert np.isnan(res.zscore[k - 1]).all() and np.isnan(ref[k - 1]).all()  # empty category: 0/0 as in the reference
+
+
+def test_more_than_256_clusters_use_the_general_path(L, ctx):
+    """K > 256 (uint8 labels do not apply): numpy streams on the host + the any-K edge-pair kernel; equals the oracle's
+    numpy-stream result (i.e. Squidpy's z-scores for the seed) for either `rng` spelling."""
+    import squidpy_amd as sq
+
+    k = 300
+    adata = hex_adata(30, 40, 6, seed=8)
+    n = adata.n_obs
+    lab = np.random.default_rng(8).integers(0, k, n).astype(np.int32)
+    lab[:k] = np.arange(k)
+    adata.obs["cluster"] = pd.Categorical.from_codes(lab, [f"c{i:03d}" for i in range(k)])
+    adj = adata.obsp["spatial_connectivities"]
+    res = sq.gr.nhood_enrichment(adata, "cluster", n_perms=12, seed=3, copy=True)
+    ref_perms = O.nhood_perm_counts_numpy(adj.indices, adj.indptr, lab, k, 3, 12)
+    np.testing.assert_array_equal(res.counts, O.nhood_counts(adj.indices, adj.indptr, lab, k))
+    want = O.nhood_zscore(res.counts, ref_perms)
+    np.testing.assert_array_equal(np.isnan(res.zscore), np.isnan(want))
+    ok = np.isfinite(want)
+    np.testing.assert_array_equal(res.zscore[ok], want[ok])
+    res2 = sq.gr.nhood_enrichment(adata, "cluster", n_perms=12, seed=3, copy=True, rng="numpy")
+    np.testing.assert_array_equal(res2.zscore[ok], want[ok])
