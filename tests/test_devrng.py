@@ -99,3 +99,19 @@ def test_library_shuffle_preserves_multisets():
     for c in range(3):
         assert np.array_equal(np.sort(out[libs == c]), np.sort(labels[libs == c]))
     assert not np.array_equal(out, labels)
+
+
+def test_large_domain_difference_statistics():
+    """n = 1e5 (domain 512 x 196): images of neighbouring ranks (x, x+1: same high digit) and of ranks one low-digit
+    period apart (x, x+B: same low digit) must differ by a uniformly distributed amount.  This is the statistic that
+    exposes too few rounds / a too weak round function first (a 6-round variant with a half-range low-digit term scores
+    z ~ 20 here while passing every small-n test)."""
+    n, P, g = 100000, 120, 1000
+    pis = D.permutation_batch(n, D.round_keys(99, np.arange(P)))
+    _, B, _ = D.domain_dims(n)
+    for lag in (1, B):
+        d = ((pis[:, lag:] - pis[:, :-lag]) % n).ravel()
+        cnt = np.bincount(d * g // n, minlength=g).astype(float)
+        e = cnt.sum() / g
+        z = (((cnt - e) ** 2 / e).sum() - (g - 1)) / math.sqrt(2 * (g - 1))
+        assert abs(z) < 4.5, (lag, z)
