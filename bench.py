@@ -366,6 +366,9 @@ def main() -> None:
                 "frac_of_hbm_peak": b_perm * args.steps * P / (gpu_ms * 1e-3) / HBM_PEAK if gpu_ms > 0 else None,
                 "wall_frac_of_hbm_peak": b_perm * (total_perms / world) / elapsed / HBM_PEAK,
                 "avg_kernel_ms": kern_ms,
+                "time_share": {k: round(v[1] / gpu_ms, 3) for k, v in kernels.items() if v[0] > 0 and gpu_ms > 0},
+                "note": "nhood_shuffle (label generation, VALU-bound: ~45 packed-16 ops per spot and permutation, no HBM "
+                "roofline applies) and nhood_count (the CSR gather the roofline object prices) share the step",
             },
         }
         if secondary is not None:
