@@ -90,12 +90,19 @@ class AnnDataLite:
             osel = osel.to_numpy() if isinstance(osel, pd.Series) else np.asarray(osel)
             oidx = np.where(osel)[0] if osel.dtype == bool else osel.astype(np.int64)
 
+        all_obs = len(oidx) == self.n_obs and bool(np.array_equal(oidx, np.arange(self.n_obs)))
+        v_range = len(vidx) > 0 and bool(np.array_equal(vidx, np.arange(vidx[0], vidx[0] + len(vidx))))
+
         def sub(m: Any) -> Any:
             if m is None:
                 return None
             if sparse.issparse(m):
-                return m.tocsr()[oidx, :][:, vidx]
-            return np.asarray(m)[np.ix_(oidx, vidx)]
+                m = m.tocsr()
+                return m[:, vidx] if all_obs else m[oidx, :][:, vidx]
+            m = np.asarray(m)
+            if all_obs:  # like AnnData views: no copy for a contiguous run of variables (e.g. all genes)
+                return m[:, vidx[0] : vidx[0] + len(vidx)] if v_range else m[:, vidx]
+            return m[np.ix_(oidx, vidx)]
 
         return AnnDataLite(
             X=sub(self.X),

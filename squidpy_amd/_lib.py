@@ -50,6 +50,7 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "sqgr_nhood_tune": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "sqgr_interaction_matrix": (C.c_int, [C.c_void_p, C.c_void_p, c_i32p, C.c_int32, C.c_int32, c_f64p]),
     "sqgr_autocorr_create": (C.c_int, [C.c_void_p, C.c_void_p, c_f64p, C.c_int64, C.POINTER(C.c_void_p)]),
+    "sqgr_autocorr_create_cm": (C.c_int, [C.c_void_p, C.c_void_p, c_f64p, C.c_int64, C.POINTER(C.c_void_p)]),
     "sqgr_autocorr_destroy": (C.c_int, [C.c_void_p]),
     "sqgr_autocorr_scores": (C.c_int, [C.c_void_p, C.c_int32, c_f64p]),
     "sqgr_autocorr_perms": (C.c_int, [C.c_void_p, C.c_int32, c_i32p, C.c_uint64, C.c_int64, C.c_int64, c_f64p]),
@@ -386,12 +387,19 @@ class AutocorrPlan:
     MODES = {"moran": 0, "geary": 1}
 
     def __init__(self, ctx: Context, g: Graph, vals: np.ndarray):
-        vals = _as(vals, np.float64)
+        vals = np.asarray(vals, dtype=np.float64)
         if vals.ndim != 2 or vals.shape[1] != g.n:
             raise ValueError(f"Expected vals of shape (n_features, {g.n}), found {vals.shape}.")
         self.ctx, self.g, self.G = ctx, g, vals.shape[0]
         h = C.c_void_p()
-        _check(ctx.lib, ctx.lib.sqgr_autocorr_create(ctx.h, g.h, _ptr(vals, c_f64p), self.G, C.byref(h)))
+        if not vals.flags.c_contiguous and vals.T.strides[1] == vals.itemsize and vals.shape[0] > 1:
+            # a slice of a transposed cell-major matrix (`adata.X[:, genes].T`): hand it over cell-major instead of
+            # materialising the transpose on the host
+            cm = np.ascontiguousarray(vals.T)
+            _check(ctx.lib, ctx.lib.sqgr_autocorr_create_cm(ctx.h, g.h, _ptr(cm, c_f64p), self.G, C.byref(h)))
+        else:
+            vals = _as(vals, np.float64)
+            _check(ctx.lib, ctx.lib.sqgr_autocorr_create(ctx.h, g.h, _ptr(vals, c_f64p), self.G, C.byref(h)))
         self.h = h
 
     def scores(self, mode: str) -> np.ndarray:

@@ -56,6 +56,24 @@ __global__ __launch_bounds__(256) void k_gene_stats(const double* __restrict__ X
     }
 }
 
+// ---- cell-major input D[i][G_all] (what AnnData's X is) -> the staged gene-major block X[gl][i] of genes g0..g0+gc
+__global__ __launch_bounds__(256) void k_cells_to_genes(const double* __restrict__ D, int64_t ld, int64_t n, int64_t g0, int gc,
+                                                        double* __restrict__ X) {
+    __shared__ double tile[GT][GT + 1];
+    const int64_t i0 = (int64_t)blockIdx.x * GT;
+    const int gb = blockIdx.y * GT;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < GT; r += 4) {  // r: spot inside tile, tx: gene
+        const int64_t i = i0 + r;
+        tile[r][tx] = (i < n && gb + tx < gc) ? D[(size_t)i * ld + g0 + gb + tx] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < GT; r += 4) {  // r: gene inside tile, tx: spot
+        const int64_t i = i0 + tx;
+        if (gb + r < gc && i < n) X[(size_t)(gb + r) * n + i] = tile[tx][r];
+    }
+}
+
 // ---- Zt[tile][i][gl] = X[g][i] - mean[g]   (64 x 64 tile transpose through LDS; gc is a multiple of 64 or the tail)
 __global__ __launch_bounds__(256) void k_center_transpose(const double* __restrict__ X, int64_t n, int gc, int64_t g0,
                                                           const double* __restrict__ mean, double* __restrict__ Zt) {
@@ -283,9 +301,7 @@ static int column_sum(sqgr_autocorr* h, int mode, const double* A, const double*
     return SQGR_OK;
 }
 
-extern "C" {
-
-int sqgr_autocorr_create(sqgr_ctx* ctx, const sqgr_graph* g, const double* vals, int64_t G, sqgr_autocorr** out) {
+static int autocorr_create(sqgr_ctx* ctx, const sqgr_graph* g, const double* vals, int64_t G, bool cell_major, sqgr_autocorr** out) {
     SQGR_REQUIRE(ctx && g && vals && out, "null argument");
     *out = nullptr;
     SQGR_REQUIRE(g->ctx == ctx, "graph belongs to a different context");
@@ -313,12 +329,21 @@ int sqgr_autocorr_create(sqgr_ctx* ctx, const sqgr_graph* g, const double* vals,
         return fail(rc);
     // stage the gene-major input in blocks of <= 256 genes (and <= ~256 MB)
     int64_t gc_max = std::max<int64_t>(GT, std::min<int64_t>(256, ((int64_t)1 << 28) / (n * 8) / GT * GT));
-    DevBuf<double> X;
+    DevBuf<double> X, D;
     if ((rc = X.alloc((size_t)gc_max * n))) return fail(rc);
     hipError_t e = hipSuccess;
+    if (cell_major) {  // one contiguous upload of vals[n][G]; the gene blocks are cut out of it on the device
+        if ((rc = D.alloc((size_t)n * G))) return fail(rc);
+        e = hipMemcpyAsync(D.p, vals, (size_t)n * G * 8, hipMemcpyHostToDevice, st);
+    }
     for (int64_t g0 = 0; g0 < G && e == hipSuccess; g0 += gc_max) {
         const int gc = (int)std::min<int64_t>(gc_max, G - g0);
-        e = hipMemcpyAsync(X.p, vals + (size_t)g0 * n, (size_t)gc * n * 8, hipMemcpyHostToDevice, st);
+        if (cell_major) {
+            k_cells_to_genes<<<dim3((unsigned)ceil_div(n, GT), (unsigned)ceil_div(gc, GT)), 256, 0, st>>>(D.p, G, n, g0, gc, X.p);
+            e = hipGetLastError();
+        } else {
+            e = hipMemcpyAsync(X.p, vals + (size_t)g0 * n, (size_t)gc * n * 8, hipMemcpyHostToDevice, st);
+        }
         if (e != hipSuccess) break;
         {
             LaunchTimer t(ctx, "autocorr_prepare");
@@ -354,6 +379,16 @@ int sqgr_autocorr_create(sqgr_ctx* ctx, const sqgr_graph* g, const double* vals,
     h->W = W;
     *out = h;
     return SQGR_OK;
+}
+
+extern "C" {
+
+int sqgr_autocorr_create(sqgr_ctx* ctx, const sqgr_graph* g, const double* vals, int64_t G, sqgr_autocorr** out) {
+    return autocorr_create(ctx, g, vals, G, false, out);
+}
+
+int sqgr_autocorr_create_cm(sqgr_ctx* ctx, const sqgr_graph* g, const double* vals, int64_t G, sqgr_autocorr** out) {
+    return autocorr_create(ctx, g, vals, G, true, out);
 }
 
 int sqgr_autocorr_destroy(sqgr_autocorr* h) {
