@@ -1,0 +1,595 @@
+// libsqgr: numpy-compatible permutation streams on the device.
+//
+// Reference semantics: `spawn_generators(seed, n)` (_utils.py:240-241) gives every permutation its own PCG64 generator;
+// the label test shuffles with `Generator.shuffle` (gr/_nhood.py:533-538, gr/_utils.py:207-212, gr/_ligrec.py:643-646), the
+// autocorrelation test draws `Generator.permutation(N)` (gr/_ppatterns.py:270-271).  Both are the same reverse Fisher-Yates
+// with masked rejection sampling over buffered 32-bit halves of the 64-bit outputs.
+#include "sqgr_pcg.h"
+
+#include <algorithm>
+#include <cstdlib>
+
+namespace sqgr {
+
+// Bit-for-bit numpy on the device ("next" row f-1 of SURVEY.md §8): permutation p is shuffled by numpy's own
+// algorithm — PCG64 (128-bit LCG, XSL-RR output, 32-bit halves buffered low first) driving the reverse
+// Fisher-Yates of Generator.shuffle with masked rejection sampling — from the generator state that
+// `np.random.default_rng(SeedSequence(seed).spawn(n)[p])` starts in (computed by numpy on the host, 32 bytes per
+// permutation).  Two kernels: k_pcg_shuffle_wave (default, one WAVE per permutation, further down) and the simpler
+// k_pcg_shuffle (SQGR_PCG_KERNEL=lane: ONE THREAD PER PERMUTATION, each on its own column of a [position][permutation]
+// matrix; the access to row i is coalesced across threads, the access to row j is the scattered one) — kept as an
+// independent implementation the tests compare against.
+struct Pcg64 {
+    uint64_t lo, hi, inc_lo, inc_hi;
+    uint32_t buf;
+    bool has;
+};
+
+__device__ __forceinline__ uint64_t pcg64_next64(Pcg64& g) {
+    const uint64_t ML = 0x4385DF649FCCF645ull, MH = 0x2360ED051FC65DA4ull;  // PCG_DEFAULT_MULTIPLIER_128
+    const uint64_t plo = g.lo * ML;
+    const uint64_t phi = __umul64hi(g.lo, ML) + g.lo * MH + g.hi * ML;
+    const uint64_t nlo = plo + g.inc_lo;
+    const uint64_t nhi = phi + g.inc_hi + (nlo < plo ? 1ull : 0ull);
+    g.lo = nlo;
+    g.hi = nhi;
+    const uint64_t x = nhi ^ nlo;
+    const unsigned rot = (unsigned)(nhi >> 58);
+    return (x >> rot) | (x << ((64u - rot) & 63u));
+}
+
+__device__ __forceinline__ uint32_t pcg64_next32(Pcg64& g) {
+    if (g.has) {
+        g.has = false;
+        return g.buf;
+    }
+    const uint64_t v = pcg64_next64(g);
+    g.has = true;
+    g.buf = (uint32_t)(v >> 32);
+    return (uint32_t)v;
+}
+
+constexpr int PCG_UNROLL = 8;   // swaps replayed in registers per trip (2*PCG_UNROLL loads in flight)
+constexpr int PCG_BLOCK = 32;   // steps whose draws are generated together (multiple of PCG_UNROLL)
+
+// W[pos * stride + p]: column p = the array numpy would shuffle for permutation p (positions grouped by library,
+// libraries in category order == the order `_shuffle_group` visits them, gr/_utils.py:207-212).
+//
+// Two things keep the lanes of a wave busy although every lane runs its own sequential Fisher-Yates:
+//  * rejection sampling is decoupled from the steps: the draws j of PCG_BLOCK consecutive steps are produced in one
+//    per-lane loop (a lane that needs fewer draws idles only until the slowest lane of the wave has its PCG_BLOCK
+//    draws, instead of after every single step) and parked in LDS;
+//  * the draws depend on the generator only, so the 2*PCG_UNROLL loads of a trip are issued before any swap is
+//    applied and the swaps are replayed in registers.  Step t exchanges positions i-t and j_t; i-t is above
+//    everything later steps touch, so its value is final after step t; a j position may recur (j_e == j_t, or
+//    j_e == i-t for e < t) and then takes the value the earlier step left there instead of the stale load.
+template <typename T, bool ARANGE>
+__global__ __launch_bounds__(64) void k_pcg_shuffle(int64_t n, int n_libs, const uint32_t* __restrict__ lib_off,
+                                                    const T* __restrict__ base_pos, const uint64_t* __restrict__ states,
+                                                    int64_t P, int64_t stride, T* __restrict__ W) {
+    __shared__ uint32_t s_j[PCG_BLOCK][64];
+    const int lane = threadIdx.x;
+    const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    Pcg64 g;
+    g.hi = states[4 * p + 0];
+    g.lo = states[4 * p + 1];
+    g.inc_hi = states[4 * p + 2];
+    g.inc_lo = states[4 * p + 3];
+    g.has = false;
+    g.buf = 0;
+    T* col = W + p;
+    for (int64_t e = 0; e < n; ++e) col[e * stride] = ARANGE ? (T)e : base_pos[e];
+    for (int l = 0; l < n_libs; ++l) {
+        const uint32_t off = lib_off[l];
+        const uint32_t m = lib_off[l + 1] - off;
+        if (m < 2) continue;
+        T* sub = col + (int64_t)off * stride;
+        uint32_t mask = m - 1;  // smallest all-ones mask >= i, maintained as i decreases
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        uint32_t i = m - 1;
+        while (i >= (uint32_t)PCG_BLOCK) {
+            // ---- draws of steps i, i-1, ..., i-PCG_BLOCK+1 (numpy: `while ((v = next_uint32() & mask) > max);`)
+            {
+                int t = 0;
+                uint32_t it = i;
+                if ((mask >> 1) >= it) mask >>= 1;
+                if (g.has) {  // high half left over from the previous block
+                    g.has = false;
+                    const uint32_t c = g.buf & mask;
+                    if (c <= it) {
+                        s_j[t][lane] = c;
+                        ++t;
+                        --it;
+                        if ((mask >> 1) >= it) mask >>= 1;
+                    }
+                }
+                while (t < PCG_BLOCK) {
+                    const uint64_t v = pcg64_next64(g);
+                    const uint32_t c0 = (uint32_t)v & mask;
+                    if (c0 <= it) {
+                        s_j[t][lane] = c0;
+                        ++t;
+                        --it;
+                        if ((mask >> 1) >= it) mask >>= 1;
+                    }
+                    if (t < PCG_BLOCK) {
+                        const uint32_t c1 = (uint32_t)(v >> 32) & mask;
+                        if (c1 <= it) {
+                            s_j[t][lane] = c1;
+                            ++t;
+                            --it;
+                            if ((mask >> 1) >= it) mask >>= 1;
+                        }
+                    } else {  // the block is complete after the low half: numpy keeps the high half buffered
+                        g.has = true;
+                        g.buf = (uint32_t)(v >> 32);
+                    }
+                }
+            }
+            // ---- apply: PCG_UNROLL swaps per trip
+            constexpr int U = PCG_UNROLL;
+#pragma unroll 1
+            for (int t0 = 0; t0 < PCG_BLOCK; t0 += U) {
+                const uint32_t ib = i - t0;
+                uint32_t j[U];
+                T vi[U], vj[U];
+#pragma unroll
+                for (int t = 0; t < U; ++t) j[t] = s_j[t0 + t][lane];
+#pragma unroll
+                for (int t = 0; t < U; ++t) {
+                    vi[t] = sub[(int64_t)(ib - t) * stride];
+                    vj[t] = sub[(int64_t)j[t] * stride];
+                }
+                T at_i[U], at_j[U];  // values left at position ib-t resp. j_t by step t
+#pragma unroll
+                for (int t = 0; t < U; ++t) {
+                    T cur_i = vi[t], cur_j = vj[t];
+#pragma unroll
+                    for (int e = 0; e < t; ++e) {  // a later e overrides an earlier one
+                        cur_i = (j[e] == ib - t) ? at_j[e] : cur_i;
+                        cur_j = (j[e] == j[t]) ? at_j[e] : cur_j;
+                    }
+                    at_i[t] = cur_j;
+                    at_j[t] = cur_i;
+                }
+                // j stores in step order (a recurring position keeps the last one), then the final i stores on top
+#pragma unroll
+                for (int t = 0; t < U; ++t) sub[(int64_t)j[t] * stride] = at_j[t];
+#pragma unroll
+                for (int t = 0; t < U; ++t) sub[(int64_t)(ib - t) * stride] = at_i[t];
+            }
+            i -= PCG_BLOCK;
+            // the mask was advanced to step i-PCG_BLOCK's bound already (idempotent update at the top of the next block)
+        }
+        for (; i >= 1; --i) {
+            if ((mask >> 1) >= i) mask >>= 1;
+            uint32_t j;
+            do {
+                j = pcg64_next32(g) & mask;
+            } while (j > i);
+            const T a = sub[(int64_t)i * stride], b = sub[(int64_t)j * stride];
+            sub[(int64_t)i * stride] = b;
+            sub[(int64_t)j * stride] = a;
+        }
+    }
+}
+
+// ---- one WAVE per permutation ------------------------------------------------------------------------------------
+// The sequential chain of Fisher-Yates is only apparent:
+//  (1) the raw generator outputs are a pure function of the stream position (LCG jump-ahead: state_k = A_k*state +
+//      G_k*inc with A_k = M^k, G_k = 1 + M + ... + M^(k-1) mod 2^128), so the 64 lanes produce the next 64 raw 32-bit
+//      draws at once;
+//  (2) whether draw d is accepted depends on earlier draws only through the NUMBER of earlier acceptances (< 64): a
+//      candidate <= i-64 is accepted and one > i rejected regardless; the few in between are decided in order;
+//  (3) the accepted swaps of a trip touch disjoint positions unless two draws coincide or a draw hits the i side of a
+//      step of the same trip.  Then (probability ~ 64*64/i per trip) the steps that share a position are replayed in
+//      order on a register image of the touched positions (lane q: values at i-q and at j_q), all others stay plain
+//      exchanges.
+// Both paths consume the identical draw sequence as numpy (32-bit halves, low first; a library that ends mid-chunk leaves
+// the remaining draws to the next one; a mask change or the last 192 steps take the draws one by one).
+// Layout: R[p][row_stride] (a permutation's array is contiguous).  ~45 steps per trip; measured 12x the
+// one-thread-per-permutation kernel at Squidpy's default n_perms = 1000 (1e5 spots: 4.0 ms vs 48 ms).
+struct U128 {
+    uint64_t hi, lo;
+};
+__device__ __forceinline__ U128 mul128_lo(U128 a, U128 b) {
+    U128 r;
+    r.lo = a.lo * b.lo;
+    r.hi = __umul64hi(a.lo, b.lo) + a.lo * b.hi + a.hi * b.lo;
+    return r;
+}
+__device__ __forceinline__ U128 add128(U128 a, U128 b) {
+    U128 r;
+    r.lo = a.lo + b.lo;
+    r.hi = a.hi + b.hi + (r.lo < a.lo ? 1ull : 0ull);
+    return r;
+}
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int src) {
+    const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, src);
+    const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+constexpr int PCGW_TAB = 34;      // jump distances 0..33 (64 halves starting at an odd half reach output 33)
+constexpr int PCGW_HASH = 2048;   // duplicate filter of the fast path
+constexpr uint32_t PCGW_MIN_SPAN = 192;  // positions below i that must be in the LDS window before a trip
+
+// lane's raw 32-bit draw number `lane` after stream position (s, half); sk = the LCG state it was taken from
+__device__ __forceinline__ uint32_t pcgw_draw(const U128& s, uint32_t half, int lane, const uint64_t (*sA)[2],
+                                              const uint64_t (*sD)[2], U128& sk) {
+    const uint32_t hl = half + (uint32_t)lane;
+    const int kk = 1 + (int)(hl >> 1);
+    U128 a, d;
+    a.hi = sA[kk][0];
+    a.lo = sA[kk][1];
+    d.hi = sD[kk][0];
+    d.lo = sD[kk][1];
+    sk = add128(mul128_lo(a, s), d);
+    const uint64_t x = sk.hi ^ sk.lo;
+    const unsigned rot = (unsigned)(sk.hi >> 58);
+    const uint64_t out = (x >> rot) | (x << ((64u - rot) & 63u));
+    return (hl & 1u) ? (uint32_t)(out >> 32) : (uint32_t)out;
+}
+
+// consume `used` of the 64 draws: (s, half) move on; sk = the per-lane states pcgw_draw returned for the old position
+__device__ __forceinline__ void pcgw_advance(U128& s, uint32_t& half, const U128& sk, uint32_t used) {
+    const uint32_t hu = half + used;
+    const uint32_t dq = hu >> 1;
+    if (dq > 0u) {
+        const int src = (int)(2u * dq - 1u - half);
+        s.hi = readlane64(sk.hi, src);
+        s.lo = readlane64(sk.lo, src);
+    }
+    half = hu & 1u;
+}
+
+template <typename T, bool ARANGE>
+__global__ __launch_bounds__(64) void k_pcg_shuffle_wave(int64_t n, int64_t row_stride, int n_libs,
+                                                         const uint32_t* __restrict__ lib_off, const T* __restrict__ base_pos,
+                                                         const uint64_t* __restrict__ states, const uint64_t* __restrict__ jump,
+                                                         int64_t P, T* __restrict__ R, int force_slow, uint32_t WS) {
+    // Window: the top WS positions [wlo, i] of the array being shuffled live in LDS (ring, index pos & (WS-1)); positions
+    // are finalised (written to R) when they are the i side of a step, everything else they see stays in LDS.  An
+    // array of <= WS elements is resident as a whole.  This takes the read-after-write on the line just stored off the
+    // critical path of every trip.
+    extern __shared__ unsigned char s_window[];
+    T* win = reinterpret_cast<T*>(s_window);
+    const uint32_t WM = WS - 1u;
+    __shared__ uint64_t sA[PCGW_TAB][2], sD[PCGW_TAB][2];
+    __shared__ uint32_t sJ[64];
+    __shared__ uint32_t sH[PCGW_HASH];
+    const int lane = threadIdx.x;
+    for (int h = lane; h < PCGW_HASH; h += 64) sH[h] = 0;
+    uint32_t epoch = 0;
+    // a block walks permutations blockIdx.x, blockIdx.x + gridDim.x, ... (the grid may be capped so that the rows being
+    // shuffled at any one time stay cache resident)
+    for (int64_t p = blockIdx.x; p < P; p += gridDim.x) {
+    U128 s, inc;
+    s.hi = states[4 * p + 0];
+    s.lo = states[4 * p + 1];
+    inc.hi = states[4 * p + 2];
+    inc.lo = states[4 * p + 3];
+    if (lane < PCGW_TAB) {
+        U128 a, g;
+        a.hi = jump[4 * lane + 0];
+        a.lo = jump[4 * lane + 1];
+        g.hi = jump[4 * lane + 2];
+        g.lo = jump[4 * lane + 3];
+        const U128 d = mul128_lo(g, inc);
+        sA[lane][0] = a.hi;
+        sA[lane][1] = a.lo;
+        sD[lane][0] = d.hi;
+        sD[lane][1] = d.lo;
+    }
+    T* row = R + p * row_stride;
+    for (int64_t e = lane; e < n; e += 64) row[e] = ARANGE ? (T)e : base_pos[e];
+    uint32_t half = 0;   // 1: the next draw is the high half of the 64-bit output after `s`
+    U128 sk;             // per lane: generator state behind this lane's draw
+    uint32_t raw = pcgw_draw(s, half, lane, sA, sD, sk);  // the next 64 raw 32-bit draws, one per lane
+    for (int l = 0; l < n_libs; ++l) {
+        const uint32_t off = lib_off[l];
+        const uint32_t m = lib_off[l + 1] - off;
+        if (m < 2) continue;
+        T* sub = row + off;
+        uint32_t mask = m - 1;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        uint32_t i = m - 1;
+        uint32_t wlo = m;  // window = positions [wlo, i], empty at first
+        while (i >= 1) {
+            asm volatile("" ::: "memory");  // LDS is shared by the lanes: nothing read in an earlier trip may be reused
+            if (wlo > 0u && i + 1u - wlo < PCGW_MIN_SPAN) {  // refill to capacity: positions [lo2, wlo)
+                const uint32_t lo2 = (i + 1u > WS) ? i + 1u - WS : 0u;
+                for (uint32_t q = lo2 + (uint32_t)lane; q < wlo; q += 64u) win[q & WM] = sub[q];
+                wlo = lo2;
+            }
+            uint32_t used = 64, nacc = 0, it = i;
+            const bool general = force_slow || i < 192u || (mask >> 1) >= i - 64u;
+            if (!general) {
+                // the bound stays above i-64 and the mask cannot change: a candidate <= i-64 is accepted, one > i rejected
+                // whatever happened before it; the few in between are decided in order from the running count
+                const uint32_t c = raw & mask;
+                const bool sure = c <= i - 64u;
+                const uint64_t ambm = __ballot(!sure && c <= i);
+                uint64_t accm = __ballot(sure);
+                for (uint64_t rem = ambm; rem != 0ull; rem &= rem - 1ull) {
+                    const int dd = __builtin_ctzll(rem);
+                    const uint32_t cd = (uint32_t)__builtin_amdgcn_readlane((int)c, dd);
+                    const uint32_t before = (uint32_t)__popcll(accm & ((1ull << dd) - 1ull));
+                    if (cd <= i - before) accm |= 1ull << dd;
+                }
+                const bool acc = (accm >> lane) & 1ull;
+                const uint32_t t = __builtin_amdgcn_mbcnt_hi((uint32_t)(accm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)accm, 0u));
+                nacc = (uint32_t)__popcll(accm);
+                it = i - nacc;
+                bool conflict = (ambm & accm) != 0ull;  // such a j may be the i side of a step of this very trip
+                if (!conflict) {
+                    // coinciding draws: every accepted lane tags its bucket; a lane that reads back another lane's tag shares
+                    // the bucket with it.  With a single such lane the only possible twin is the bucket's winner.
+                    ++epoch;
+                    const uint32_t tag = (epoch << 6) | (uint32_t)lane;
+                    const uint32_t h = (c * 2654435761u) >> 21;
+                    if (acc) sH[h] = tag;
+                    asm volatile("" ::: "memory");  // the read-back must see the other lanes' stores, not be forwarded
+                    const uint32_t got = acc ? sH[h] : tag;
+                    const uint64_t cm = __ballot(got != tag);
+                    if (cm != 0ull) {
+                        bool dup = false;
+                        if ((cm & (cm - 1ull)) == 0ull) {
+                            const uint32_t cw = (uint32_t)__shfl((int)c, (int)(got & 63u));
+                            dup = got != tag && cw == c;
+                        } else {
+                            for (int e = 0; e < 64; ++e) {
+                                const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)c, e);
+                                if (((accm >> e) & 1ull) && acc && e < lane && ce == c) dup = true;
+                            }
+                        }
+                        conflict = __ballot(dup) != 0ull;
+                    }
+                }
+                if (!conflict) {
+                    // ---- all swaps of the trip are independent.  The next chunk's draws are computed while the loads fly.
+                    T va = 0, vb = 0;
+                    if (acc) {
+                        va = win[(i - t) & WM];
+                        vb = (c >= wlo) ? win[c & WM] : sub[c];
+                    }
+                    pcgw_advance(s, half, sk, 64u);
+                    U128 sk2;
+                    const uint32_t raw2 = pcgw_draw(s, half, lane, sA, sD, sk2);
+                    if (acc) {
+                        sub[i - t] = vb;  // final
+                        if (c >= wlo) win[c & WM] = va; else sub[c] = va;
+                    }
+                    i = it;
+                    raw = raw2;
+                    sk = sk2;
+                    continue;
+                }
+                if (acc) sJ[t] = c;  // step-indexed list for the replay
+            } else {
+                // ---- sequential acceptance over the 64 raw draws (wave-uniform scalar code): mask changes, the last
+                // steps of a library, tiny arrays
+                uint32_t t = 0;
+                for (int dd = 0; dd < 64; ++dd) {
+                    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)raw, dd) & mask;
+                    if (c <= it) {
+                        sJ[t] = c;
+                        ++t;
+                        --it;
+                        if ((mask >> 1) >= it) mask >>= 1;
+                        if (it == 0u) {
+                            used = (uint32_t)dd + 1u;
+                            break;
+                        }
+                    }
+                }
+                nacc = t;
+            }
+            // ---- exact replay of steps 0..nacc-1 (step q: positions i-q and sJ[q]) on a register image: lane q holds the
+            // value at i-q (vI) and at its j (vJ)
+            if (nacc > 0u) {
+                asm volatile("" ::: "memory");
+                const bool live = (uint32_t)lane < nacc;
+                const uint32_t j = live ? sJ[lane] : 0xFFFFFFFFu;
+                uint32_t vI = 0, vJ = 0;
+                if (live) {
+                    vI = (uint32_t)win[(i - (uint32_t)lane) & WM];
+                    vJ = (uint32_t)((j >= wlo) ? win[j & WM] : sub[j]);
+                }
+                // slot of position j_q: 64 + q' if it is the i side of step q', else the first step with that j
+                uint32_t canon = (uint32_t)lane;
+                const uint32_t ilow = i - (nacc - 1u);
+                const bool in_i = live && j >= ilow;
+                if (in_i) canon = 64u + (i - j);
+                for (uint32_t e = 0; e + 1u < nacc; ++e) {
+                    const uint32_t je = (uint32_t)__builtin_amdgcn_readlane((int)j, (int)e);
+                    if (live && !in_i && e < (uint32_t)lane && je == j && canon == (uint32_t)lane) canon = e;
+                }
+                // steps that share a slot with another step run in order; all others are plain exchanges
+                const uint64_t refm = __ballot(live && canon != (uint32_t)lane);
+                uint64_t inv = refm;
+                for (uint64_t rem = refm; rem != 0ull; rem &= rem - 1ull) {
+                    const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)canon, __builtin_ctzll(rem));
+                    inv |= 1ull << (slot >= 64u ? slot - 64u : slot);
+                }
+                if (live && !((inv >> lane) & 1ull)) {
+                    const uint32_t tmp = vI;
+                    vI = vJ;
+                    vJ = tmp;
+                }
+                for (uint64_t rem = inv; rem != 0ull; rem &= rem - 1ull) {
+                    const int q = __builtin_ctzll(rem);
+                    const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)canon, q);
+                    const uint32_t va = (uint32_t)__builtin_amdgcn_readlane((int)vI, q);
+                    if (slot >= 64u) {
+                        const int q2 = (int)(slot - 64u);
+                        const uint32_t vb = (uint32_t)__builtin_amdgcn_readlane((int)vI, q2);
+                        vI = (lane == q) ? vb : vI;
+                        vI = (lane == q2) ? va : vI;
+                    } else {
+                        const uint32_t vb = (uint32_t)__builtin_amdgcn_readlane((int)vJ, (int)slot);
+                        vI = (lane == q) ? vb : vI;
+                        vJ = (lane == (int)slot) ? va : vJ;
+                    }
+                }
+                if (live) {
+                    sub[i - (uint32_t)lane] = (T)vI;  // final
+                    if (canon == (uint32_t)lane) {
+                        if (j >= wlo) win[j & WM] = (T)vJ; else sub[j] = (T)vJ;
+                    }
+                }
+            }
+            i = it;
+            pcgw_advance(s, half, sk, used);
+            raw = pcgw_draw(s, half, lane, sA, sD, sk);
+        }
+        if (lane == 0) sub[0] = win[0];  // position 0 is never the i side of a step: its last value is still in LDS
+    }
+    }
+}
+
+// rows R[q][row_stride] (bytes) -> columns W[pos * stride + q]
+__global__ __launch_bounds__(256) void k_rows_to_columns_u8(int64_t n, int64_t row_stride, const uint8_t* __restrict__ R, int64_t P,
+                                                            int64_t stride, uint8_t* __restrict__ W) {
+    __shared__ uint8_t tile[64][65];
+    const int64_t e0 = (int64_t)blockIdx.x * 64, q0 = (int64_t)blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) tile[r][tx] = (q0 + r < P && e0 + tx < n) ? R[(q0 + r) * row_stride + e0 + tx] : (uint8_t)0;
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4)
+        if (e0 + r < n && q0 + tx < P) W[(e0 + r) * stride + q0 + tx] = tile[tx][r];
+}
+
+// idx[p][i] = W[i][p]  (autocorr row permutations)
+__global__ __launch_bounds__(256) void k_columns_to_rows_i32(int64_t n, int64_t stride, const int32_t* __restrict__ W, int64_t P,
+                                                             int32_t* __restrict__ idx) {
+    __shared__ int32_t tile[32][33];
+    const int64_t i0 = (int64_t)blockIdx.x * 32, q0 = (int64_t)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8)
+        tile[r][tx] = (i0 + r < n && q0 + tx < P) ? W[(i0 + r) * stride + q0 + tx] : 0;
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (q0 + r < P && i0 + tx < n) idx[(size_t)(q0 + r) * n + i0 + tx] = tile[tx][r];
+}
+
+}  // namespace sqgr
+
+using namespace sqgr;
+
+// A_k = M^k and G_k = 1 + M + ... + M^(k-1) (mod 2^128) of PCG64's LCG, k = 0..PCGW_TAB-1, as [A_hi, A_lo, G_hi, G_lo]
+static int ensure_pcg_jump(DevBuf<uint64_t>& buf) {
+    if (buf.p) return SQGR_OK;
+    std::vector<uint64_t> t((size_t)PCGW_TAB * 4);
+    const unsigned __int128 M = ((unsigned __int128)0x2360ED051FC65DA4ull << 64) | (unsigned __int128)0x4385DF649FCCF645ull;
+    unsigned __int128 A = 1, G = 0;
+    for (int k = 0; k < PCGW_TAB; ++k) {
+        t[4 * k + 0] = (uint64_t)(A >> 64);
+        t[4 * k + 1] = (uint64_t)A;
+        t[4 * k + 2] = (uint64_t)(G >> 64);
+        t[4 * k + 3] = (uint64_t)G;
+        G = G * M + 1;
+        A = A * M;
+    }
+    SQGR_TRY(buf.alloc(t.size()));
+    SQGR_HIP(hipMemcpy(buf.p, t.data(), t.size() * 8, hipMemcpyHostToDevice));
+    return SQGR_OK;
+}
+
+static bool pcg_lane_kernel() {  // SQGR_PCG_KERNEL=lane selects the one-thread-per-permutation kernel (comparison runs)
+    const char* e = getenv("SQGR_PCG_KERNEL");
+    return e && strcmp(e, "lane") == 0;
+}
+static unsigned pcg_grid(int64_t pc) {  // SQGR_PCG_WAVES caps the number of permutations in flight (tuning runs)
+    const char* e = getenv("SQGR_PCG_WAVES");
+    const int64_t cap = (e && atoll(e) > 0) ? atoll(e) : pc;
+    return (unsigned)std::min<int64_t>(pc, cap);
+}
+// LDS window (elements, power of two).  Measured on MI355X: a larger window (up to the whole array) buys nothing — the
+// trips are bound by their own instruction stream, not by the i-side loads — and costs occupancy.
+static uint32_t pcg_window(int64_t n_max) {
+    uint32_t ws = 1024;
+    while ((int64_t)ws < n_max && ws < 4096u) ws <<= 1;
+    return ws;
+}
+template <typename KernelT>
+static int pcg_allow_lds(KernelT kernel, size_t bytes) {
+    if (bytes + 16 * 1024 <= 64 * 1024) return SQGR_OK;
+    SQGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return SQGR_OK;
+}
+static int pcg_force_slow() {
+    const char* e = getenv("SQGR_PCG_FORCE_SLOW");
+    return (e && atoi(e) == 1) ? 1 : 0;
+}
+
+namespace sqgr {
+
+int pcg_shuffle_labels(sqgr_ctx* ctx, PcgWorkspace& ws, int64_t n, int n_libs, const uint32_t* lib_off_dev, const uint8_t* base_pos_dev,
+                       const uint64_t* states_dev, int64_t pc, int64_t stride, uint8_t* W, hipStream_t st, const char* timer_name) {
+    LaunchTimer t(ctx, timer_name, st);
+    if (pcg_lane_kernel()) {
+        k_pcg_shuffle<uint8_t, false><<<(unsigned)ceil_div(pc, 64), 64, 0, st>>>(n, n_libs, lib_off_dev, base_pos_dev, states_dev, pc, stride, W);
+        SQGR_HIP(hipGetLastError());
+        return SQGR_OK;
+    }
+    const int64_t n_pad = ceil_div(n, 64) * 64;
+    SQGR_TRY(ensure_pcg_jump(ws.jump));
+    SQGR_TRY(ws.rows.ensure((size_t)pc * n_pad));
+    const uint32_t wsz = pcg_window(n);
+    SQGR_TRY(pcg_allow_lds(k_pcg_shuffle_wave<uint8_t, false>, (size_t)wsz));
+    k_pcg_shuffle_wave<uint8_t, false><<<pcg_grid(pc), 64, (size_t)wsz, st>>>(n, n_pad, n_libs, lib_off_dev, base_pos_dev, states_dev,
+                                                                              ws.jump.p, pc, ws.rows.p, pcg_force_slow(), wsz);
+    SQGR_HIP(hipGetLastError());
+    k_rows_to_columns_u8<<<dim3((unsigned)ceil_div(n, 64), (unsigned)ceil_div(pc, 64)), 256, 0, st>>>(n, n_pad, ws.rows.p, pc, stride, W);
+    SQGR_HIP(hipGetLastError());
+    return SQGR_OK;
+}
+
+}  // namespace sqgr
+
+extern "C" {
+
+int sqgr_pcg64_permutations(sqgr_ctx* ctx, int64_t n, const uint64_t* pcg_states, int64_t n_perms, int32_t* out_idx) {
+    SQGR_REQUIRE(ctx && pcg_states && out_idx && n > 0 && n < (int64_t)0x7fffffff && n_perms >= 0, "bad argument");
+    if (n_perms == 0) return SQGR_OK;
+    SQGR_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int64_t chunk = std::max<int64_t>(64, std::min<int64_t>(ceil_div(n_perms, 64) * 64, (((int64_t)8 << 30) / (n * 4)) / 64 * 64));
+    const bool lane_kernel = pcg_lane_kernel();
+    DevBuf<int32_t> W, idx;
+    DevBuf<uint64_t> states, jump;
+    DevBuf<uint32_t> off;
+    if (lane_kernel)
+        SQGR_TRY(W.alloc((size_t)n * chunk));
+    else
+        SQGR_TRY(ensure_pcg_jump(jump));
+    SQGR_TRY(idx.alloc((size_t)chunk * n));
+    SQGR_TRY(states.alloc((size_t)chunk * 4));
+    SQGR_TRY(off.alloc(2));
+    const uint32_t off_h[2] = {0u, (uint32_t)n};
+    SQGR_HIP(hipMemcpyAsync(off.p, off_h, 8, hipMemcpyHostToDevice, st));
+    for (int64_t c0 = 0; c0 < n_perms; c0 += chunk) {
+        const int64_t pc = std::min(chunk, n_perms - c0);
+        SQGR_HIP(hipMemcpyAsync(states.p, pcg_states + (size_t)c0 * 4, (size_t)pc * 32, hipMemcpyHostToDevice, st));
+        {
+            LaunchTimer t(ctx, "autocorr_pcg64_permutation");
+            if (lane_kernel) {
+                k_pcg_shuffle<int32_t, true><<<(unsigned)ceil_div(pc, 64), 64, 0, st>>>(n, 1, off.p, nullptr, states.p, pc, chunk, W.p);
+                k_columns_to_rows_i32<<<dim3((unsigned)ceil_div(n, 32), (unsigned)ceil_div(pc, 32)), 256, 0, st>>>(n, chunk, W.p, pc, idx.p);
+            } else {  // rows are the wanted output already: idx[q][i]
+                const uint32_t ws = pcg_window(n);
+                SQGR_TRY(pcg_allow_lds(k_pcg_shuffle_wave<int32_t, true>, (size_t)ws * 4));
+                k_pcg_shuffle_wave<int32_t, true><<<pcg_grid(pc), 64, (size_t)ws * 4, st>>>(n, n, 1, off.p, nullptr, states.p, jump.p, pc,
+                                                                                            idx.p, pcg_force_slow(), ws);
+            }
+            SQGR_HIP(hipGetLastError());
+        }
+        SQGR_HIP(hipMemcpyAsync(out_idx + (size_t)c0 * n, idx.p, (size_t)pc * n * 4, hipMemcpyDeviceToHost, st));
+        SQGR_HIP(hipStreamSynchronize(st));
+    }
+    return SQGR_OK;
+}
+
+}  // extern "C"
