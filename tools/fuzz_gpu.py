@@ -45,4 +45,25 @@ while time.time() - t0 < budget:
     assert np.array_equal(L.cooccur_counts(ctx, x, y, labs, kk, thr), O.occur_count(x, y, thr, labs, kk)), ("cooc", m, kk)
     pts = np.stack([x, y], 1).astype(np.float64); sup = np.linspace(0, 40, int(rng.integers(2, 40)))
     assert np.array_equal(L.pair_counts(ctx, pts, sup), O.pair_counts_bruteforce(pts, sup)), ("pairs", m)
+    # numpy permutation streams at a random size
+    nn = int(rng.integers(2, 9000)); Pn = int(rng.integers(1, 40)); sd = int(rng.integers(1 << 30))
+    assert np.array_equal(L.pcg64_permutations(ctx, nn, pcg64_states(sd, Pn)), O.autocorr_perm_indices(nn, sd, Pn)), ("perm", nn, sd)
+    # ligrec: random sparse expression, both generators
+    nc = int(rng.choice([40, 333, 2000])); ng = int(rng.integers(2, 30)); kc = int(rng.choice([2, 3, 9, 40, 90]))
+    data = (rng.random((nc, ng)) < rng.choice([0.05, 0.3, 1.0])) * (np.rint(rng.gamma(2, 2, (nc, ng))) if rng.random() < 0.5 else rng.gamma(2, 1, (nc, ng)))
+    kc = min(kc, nc)
+    cl = rng.integers(0, kc, nc).astype(np.int32); cl[:kc] = np.arange(kc)  # every cluster populated
+    inter = rng.integers(0, ng, (int(rng.integers(1, 60)), 2)).astype(np.int32)
+    cp = rng.integers(0, kc, (int(rng.integers(1, 300)), 2)).astype(np.int32)
+    pre = O.ligrec_prepare(data, cl, inter, cp, float(rng.choice([0.0, 0.1, 0.5])))
+    Pl = int(rng.integers(1, 80)); sd = int(rng.integers(1 << 30))
+    got = L.ligrec_counts(ctx, sp.csc_matrix(data), cl, kc, pre["inv_counts"], inter, cp, pre["obs"], pre["valid"].astype(np.uint8),
+                          pcg_states=pcg64_states(sd, Pl), perm_begin=0, perm_end=Pl)
+    want = O.ligrec_score_permutations(data, O.ligrec_perm_labels_numpy(cl, sd, Pl), pre["inv_counts"], pre["mean_obs"], inter, cp, pre["valid"])
+    assert np.array_equal(got, want), ("ligrec numpy", nc, ng, kc)
+    lo = int(rng.integers(0, 1000))
+    got = L.ligrec_counts(ctx, sp.csc_matrix(data), cl, kc, pre["inv_counts"], inter, cp, pre["obs"], pre["valid"].astype(np.uint8),
+                          seed=sd, perm_begin=lo, perm_end=lo + Pl)
+    want = O.ligrec_score_permutations(data, O.ligrec_perm_labels_philox(cl, sd, lo, lo + Pl), pre["inv_counts"], pre["mean_obs"], inter, cp, pre["valid"])
+    assert np.array_equal(got, want), ("ligrec philox", nc, ng, kc)
 print(f"fuzz ok: {it} iterations in {time.time()-t0:.0f}s")
