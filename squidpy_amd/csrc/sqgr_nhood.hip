@@ -29,15 +29,19 @@ constexpr int COUNT_THREADS = 1024;
 constexpr size_t LDS_BUDGET = 160 * 1024;
 
 // ---------------------------------------------------------------------------------------------- key generation
+// keys[(q * n_libs + lib) * 8 + r] = round-r keys of permutations perm0 + 2q (low 16 bits) and perm0 + 2q + 1 (high 16
+// bits) for library `lib`: the label shuffle evaluates two permutations per packed-16 instruction and reads one word
+// per round.  nperm is even.
 __global__ void k_keygen(uint64_t seed, int64_t perm0, int64_t nperm, int n_libs, uint32_t* __restrict__ keys) {
     int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (t >= nperm * n_libs) return;
-    int64_t p = t / n_libs;
+    if (t >= (nperm / 2) * n_libs) return;
+    int64_t q = t / n_libs;
     uint32_t lib = (uint32_t)(t % n_libs);
-    uint32_t rk[8];
-    round_keys(seed, (uint64_t)(perm0 + p), lib, rk);
+    uint32_t ra[8], rb[8];
+    round_keys(seed, (uint64_t)(perm0 + 2 * q), lib, ra);
+    round_keys(seed, (uint64_t)(perm0 + 2 * q + 1), lib, rb);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) keys[t * 8 + i] = rk[i];
+    for (int i = 0; i < 8; ++i) keys[t * 8 + i] = (ra[i] & 0xFFFFu) | (rb[i] << 16);
 }
 
 // ---------------------------------------------------------------------------------------------- label shuffle
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __re
     for (int t = threadIdx.x; t < blk_bytes; t += 256) s_blk[t] = g_blk[t];
     __syncthreads();
     const int batch = blockIdx.y;
-    const uint32_t* kb = keys + (size_t)batch * B * n_libs * 8;
+    const uint32_t* kb = keys + (size_t)batch * (B / 2) * n_libs * 8;
     // grid-stride over spots: the launch may be throttled to a few blocks per CU so that the (LDS-atomic bound) count
     // kernel of the previous launch group can share the CUs (SQGR_NHOOD_STREAMS=2)
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -87,8 +91,7 @@ __global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __re
 #pragma unroll
         for (int j = 0; j < 4; j += 2) {  // two permutations per evaluation (packed 16-bit lanes); measured: one pair per
                                           // chain (NP = 1) beats two interleaved chains (register pressure) on MI355X
-            const uint32_t* const rk[2] = {kb + ((size_t)(w * 4 + j) * n_libs + lib) * 8,
-                                           kb + ((size_t)(w * 4 + j + 1) * n_libs + lib) * 8};  // uniform when !HAS_LIBS
+            const uint32_t* const rk[1] = {kb + ((size_t)(w * 2 + j / 2) * n_libs + lib) * 8};  // uniform when !HAS_LIBS
             uint32_t x[2], hi[2];
             feistel_perm_multi<1>(a0, b0, dom, rk, x, hi);
 #pragma unroll

@@ -108,10 +108,11 @@ __host__ __device__ inline FeistelDomain make_domain(uint32_t n) {
 //   a <- (a + F_A(b, k_r)) mod A                    (A = 2^m: one AND; F_A < A)
 //   b <- (b + F_B(a, k_r+1)) mod B                  (F_B <= Bmask < 2B, sum < 3B: two conditional subtractions)
 // The round chain of one pair is strictly dependent and packed-16 results need a wait state before use; NP >= 2
-// independent chains interleave and fill those slots.   rk[2*i], rk[2*i+1]: round keys of pair i's two permutations.
+// independent chains interleave and fill those slots.   pk[i][r]: round-r keys of pair i's two permutations, packed
+// (low half: first permutation) — see k_keygen.
 template <int NP>
 __device__ __forceinline__ void feistel_rounds(u16x2 (&a)[NP], u16x2 (&b)[NP], const FeistelDomain& d,
-                                               const uint32_t* const (&rk)[2 * NP]) {
+                                               const uint32_t* const (&pk)[NP]) {
     const u16x2 am = (u16x2)((unsigned short)(d.A - 1u));
     const u16x2 ash = (u16x2)((unsigned short)d.ash), bsh = (u16x2)((unsigned short)d.bsh);
     const u16x2 BB = (u16x2)((unsigned short)d.B);
@@ -119,12 +120,12 @@ __device__ __forceinline__ void feistel_rounds(u16x2 (&a)[NP], u16x2 (&b)[NP], c
     for (int r = 0; r < FEISTEL_ROUNDS; r += 2) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            const u16x2 k0 = __builtin_bit_cast(u16x2, (rk[2 * i][r] & 0xFFFFu) | (rk[2 * i + 1][r] << 16));
+            const u16x2 k0 = __builtin_bit_cast(u16x2, pk[i][r]);
             a[i] = (a[i] + feistel_F2(b[i], k0, ash)) & am;
         }
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            const u16x2 k1 = __builtin_bit_cast(u16x2, (rk[2 * i][r + 1] & 0xFFFFu) | (rk[2 * i + 1][r + 1] << 16));
+            const u16x2 k1 = __builtin_bit_cast(u16x2, pk[i][r + 1]);
             u16x2 t = b[i] + feistel_F2(a[i], k1, bsh);
             t = __builtin_elementwise_min(t, (u16x2)(t - BB));  // unsigned wrap makes the wrong branch huge
             b[i] = __builtin_elementwise_min(t, (u16x2)(t - BB));
@@ -136,7 +137,7 @@ __device__ __forceinline__ void feistel_rounds(u16x2 (&a)[NP], u16x2 (&b)[NP], c
 // x[j] is the image under permutation j, hi[j] its high digit (x == hi * d.B + low)
 template <int NP>
 __device__ __forceinline__ void feistel_perm_multi(uint32_t a0, uint32_t b0, const FeistelDomain& d,
-                                                   const uint32_t* const (&rk)[2 * NP], uint32_t (&x)[2 * NP],
+                                                   const uint32_t* const (&pk)[NP], uint32_t (&x)[2 * NP],
                                                    uint32_t (&hi)[2 * NP]) {
     u16x2 a[NP], b[NP];
 #pragma unroll
@@ -144,7 +145,7 @@ __device__ __forceinline__ void feistel_perm_multi(uint32_t a0, uint32_t b0, con
         a[i] = (u16x2)((unsigned short)a0);
         b[i] = (u16x2)((unsigned short)b0);
     }
-    feistel_rounds<NP>(a, b, d, rk);
+    feistel_rounds<NP>(a, b, d, pk);
     bool again = false;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
@@ -159,7 +160,7 @@ __device__ __forceinline__ void feistel_perm_multi(uint32_t a0, uint32_t b0, con
             a2[i] = a[i];
             b2[i] = b[i];
         }
-        feistel_rounds<NP>(a2, b2, d, rk);
+        feistel_rounds<NP>(a2, b2, d, pk);
         again = false;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
