@@ -48,30 +48,30 @@ __global__ void k_keygen(uint64_t seed, int64_t perm0, int64_t nperm, int n_libs
 // A uniformly random arrangement of the label multiset does not depend on the order of the base vector, so
 // the base is taken *sorted by label* (inside each library): the label at sorted rank x is
 //   #{k >= 1 : cum[k] <= x},   cum[k] = number of spots with label < k   (cum[K] = UINT_MAX sentinel).
-// No memory gather: rank x = a*B + b arrives with its high digit a, an LDS byte table gives the label of the first
-// rank of block a, and one compare against the next boundary finishes it (a loop only if a block of B ranks holds
-// several boundaries, i.e. clusters smaller than ~sqrt(n) spots).
+// No memory gather: rank x = a*B + b arrives as its two digits; one LDS word per high digit a (block table, see
+// nhood_build) holds the label of the block's first rank and the low digit where the next label starts, so the label is
+// `lab0 + (b >= next)`.  Blocks flagged BLK_EXACT (several label starts, skipped empty categories, or ranks >= n — the
+// cycle-walking case) take the exact route: x = a*B + b against the boundary table, and a re-walk where x >= n.
 //   slab[(batch*n + i)*B + b] = label_at_rank( pi_{perm,lib}(rank_i) )
+constexpr uint32_t BLK_EXACT = 0x100u;
+
 struct LibDom {
     FeistelDomain dom;
-    uint32_t aoff;  // offset of this library's block-start table
+    uint32_t aoff;  // offset of this library's block table
 };
 
 template <int B, bool HAS_LIBS>
-__global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __restrict__ cum, int kpad, int blk_bytes,
+__global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __restrict__ cum, int kpad, int blk_words,
                                                  const uint32_t* __restrict__ keys, LibDom dom0, int n_libs,
                                                  const int32_t* __restrict__ lib_of, const int32_t* __restrict__ rank_of,
                                                  const LibDom* __restrict__ libdoms, uint8_t* __restrict__ slab_all) {
-    extern __shared__ uint32_t s_cum[];                                          // [n_libs][kpad]
-    uint8_t* s_blk = reinterpret_cast<uint8_t*>(s_cum + n_libs * kpad);          // [blk_bytes] label of rank a*B
-    const uint8_t* g_blk = reinterpret_cast<const uint8_t*>(cum + n_libs * kpad);
-    for (int t = threadIdx.x; t < n_libs * kpad; t += 256) s_cum[t] = cum[t];
-    for (int t = threadIdx.x; t < blk_bytes; t += 256) s_blk[t] = g_blk[t];
+    extern __shared__ uint32_t s_cum[];               // [n_libs][kpad] boundaries, then [blk_words] block table
+    uint32_t* s_blk = s_cum + n_libs * kpad;
+    for (int t = threadIdx.x; t < n_libs * kpad + blk_words; t += 256) s_cum[t] = cum[t];
     __syncthreads();
     const int batch = blockIdx.y;
     const uint32_t* kb = keys + (size_t)batch * (B / 2) * n_libs * 8;
-    // grid-stride over spots: the launch may be throttled to a few blocks per CU so that the (LDS-atomic bound) count
-    // kernel of the previous launch group can share the CUs (SQGR_NHOOD_STREAMS=2)
+    // grid-stride over spots (launch_shuffle_raw caps the grid)
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     uint32_t out[B / 4];
     LibDom ld = dom0;
@@ -83,24 +83,46 @@ __global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __re
     }
     const FeistelDomain dom = ld.dom;
     const uint32_t* tab = s_cum + lib * kpad + 1;  // tab[k] = cum[k + 1]
-    const uint8_t* blk = s_blk + ld.aoff;
+    const uint32_t* blk = s_blk + ld.aoff;
     const uint32_t a0 = x0 / dom.B, b0 = x0 - a0 * dom.B;  // one division per spot, shared by all B permutations
 #pragma unroll
     for (int w = 0; w < B / 4; ++w) {
         uint32_t word = 0;
 #pragma unroll
         for (int j = 0; j < 4; j += 2) {  // two permutations per evaluation (packed 16-bit lanes); measured: one pair per
-                                          // chain (NP = 1) beats two interleaved chains (register pressure) on MI355X
-            const uint32_t* const rk[1] = {kb + ((size_t)(w * 2 + j / 2) * n_libs + lib) * 8};  // uniform when !HAS_LIBS
-            uint32_t x[2], hi[2];
-            feistel_perm_multi<1>(a0, b0, dom, rk, x, hi);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                uint32_t lab = blk[hi[h]];
-                lab += (x[h] >= tab[lab]) ? 1u : 0u;
-                while (x[h] >= tab[lab]) ++lab;  // rarely iterates (sentinel UINT_MAX stops it)
-                word |= lab << (8 * (j + h));
-            }
+                                          // chain beats two interleaved chains (register pressure) on MI355X
+            const uint32_t* const pk[1] = {kb + ((size_t)(w * 2 + j / 2) * n_libs + lib) * 8};  // uniform when !HAS_LIBS
+            u16x2 a[1] = {(u16x2)((unsigned short)a0)}, b[1] = {(u16x2)((unsigned short)b0)};
+            feistel_rounds<1>(a, b, dom, pk);
+            uint32_t l0, l1;
+            bool again;
+            do {
+                const uint32_t ax = a[0].x, ay = a[0].y, bx = b[0].x, by = b[0].y;
+                const uint32_t e0 = blk[ax], e1 = blk[ay];
+                l0 = (e0 & 0xFFu) + (bx >= (e0 >> 16) ? 1u : 0u);
+                l1 = (e1 & 0xFFu) + (by >= (e1 >> 16) ? 1u : 0u);
+                again = false;
+                if ((e0 | e1) & BLK_EXACT) {
+                    const uint32_t xx0 = __umul24(ax, dom.B) + bx, xx1 = __umul24(ay, dom.B) + by;  // digits < 2^14
+                    const bool w0 = xx0 >= dom.n, w1 = xx1 >= dom.n;
+                    if (!w0) {
+                        l0 = e0 & 0xFFu;
+                        while (xx0 >= tab[l0]) ++l0;  // sentinel UINT_MAX stops it
+                    }
+                    if (!w1) {
+                        l1 = e1 & 0xFFu;
+                        while (xx1 >= tab[l1]) ++l1;
+                    }
+                    again = w0 | w1;
+                    if (again) {  // cycle walk: re-apply the bijection where the image left [0, n)
+                        u16x2 a2[1] = {a[0]}, b2[1] = {b[0]};
+                        feistel_rounds<1>(a2, b2, dom, pk);
+                        if (w0) { a[0].x = a2[0].x; b[0].x = b2[0].x; }
+                        if (w1) { a[0].y = a2[0].y; b[0].y = b2[0].y; }
+                    }
+                }
+            } while (again);
+            word |= (l0 << (8 * j)) | (l1 << (8 * (j + 1)));
         }
         out[w] = word;
     }
@@ -386,7 +408,7 @@ struct sqgr_nhood {
     int n_libs = 1;
     bool has_libs = false;
     LibDom dom0{};
-    int blk_bytes = 0;
+    int blk_bytes = 0;  // words of the block table (one per high digit and library)
     DevBuf<uint32_t> cum;  // [n_libs][kpad] label boundaries of the label-sorted base
     int kpad = 0;
     DevBuf<int32_t> lib_of, rank_of;
@@ -682,26 +704,47 @@ static int nhood_build(sqgr_ctx* ctx, const sqgr_graph* g, int64_t n, const int3
             blk_total += doms[l].dom.A;
         }
         p->blk_bytes = (int)blk_total;
-        if ((size_t)p->n_libs * p->kpad * 4 + blk_total > 150 * 1024) {
+        if ((size_t)p->n_libs * p->kpad * 4 + blk_total * 4 > 150 * 1024) {
             set_error("library/label tables (%zu bytes) exceed the LDS budget of the shuffle kernel",
-                      (size_t)p->n_libs * p->kpad * 4 + blk_total);
+                      (size_t)p->n_libs * p->kpad * 4 + blk_total * 4);
             rc = SQGR_ERR_UNSUPPORTED;
             break;
         }
-        // block-start table: label of sorted rank a*B for every high digit a (appended to the boundary table)
-        std::vector<uint8_t> blk(blk_total + 4, 0);
+        // block table (appended to the boundary table): one word per high digit a describing the ranks [a*B, (a+1)*B) of
+        // the label-sorted base — bits 0-7 the label of rank a*B, bits 16-31 the low digit at which the NEXT label starts
+        // (0xFFFF: none), bit 8 set when that is not the whole story (several label starts inside the block, empty
+        // categories skipped, or the block reaches past the library's last rank) and the exact search must run.
+        std::vector<uint32_t> blk(blk_total, 0);
         for (int l = 0; l < p->n_libs; ++l) {
             const uint32_t* c = &cum[(size_t)l * p->kpad];
+            const uint64_t n_l = (uint64_t)cnt[l];
             uint32_t lab = 0;
             for (uint32_t a = 0; a < doms[l].dom.A; ++a) {
-                const uint64_t x = (uint64_t)a * doms[l].dom.B;
-                while (lab + 1 < (uint32_t)K && c[lab + 1] <= x) ++lab;
-                blk[doms[l].aoff + a] = (uint8_t)lab;
+                const uint64_t lo = (uint64_t)a * doms[l].dom.B, hi = lo + doms[l].dom.B;
+                uint32_t word;
+                if (lo >= n_l) {
+                    word = BLK_EXACT | (0xFFFFu << 16);
+                } else {
+                    while (lab + 1 < (uint32_t)K && c[lab + 1] <= lo) ++lab;
+                    uint32_t starts = 0, first_k = 0;
+                    for (uint32_t k2 = lab + 1; k2 < (uint32_t)K && c[k2] < hi; ++k2) {  // labels starting inside (lo, hi)
+                        if (starts == 0) first_k = k2;
+                        ++starts;
+                    }
+                    if (starts == 0)
+                        word = lab | (0xFFFFu << 16);
+                    else if (starts == 1 && first_k == lab + 1)
+                        word = lab | ((uint32_t)(c[first_k] - lo) << 16);
+                    else
+                        word = lab | BLK_EXACT | (0xFFFFu << 16);
+                    if (hi > n_l) word |= BLK_EXACT;
+                }
+                blk[doms[l].aoff + a] = word;
             }
         }
         const size_t cum_words = cum.size();
-        cum.resize(cum_words + (blk.size() + 3) / 4);
-        memcpy(cum.data() + cum_words, blk.data(), blk.size());
+        cum.insert(cum.end(), blk.begin(), blk.end());
+        (void)cum_words;
         if (!libs_on) p->dom0 = doms[0];
         {   // numpy-compatible mode: labels in library-grouped position order + library offsets
             std::vector<uint32_t> off((size_t)p->n_libs + 1, 0);
@@ -778,7 +821,7 @@ static int launch_shuffle_raw(sqgr_nhood* p, int B, int nb, const uint32_t* keys
     if (env_blocks && atoi(env_blocks) > 0) per_cu = atoi(env_blocks);
     gx = std::min<unsigned>(gx, (unsigned)(per_cu * std::max(p->ctx->cu_count, 1)) / (unsigned)std::max(nb, 1) + 1);
     LaunchTimer t(p->ctx, "nhood_shuffle", st);
-    const size_t lds = (size_t)p->n_libs * p->kpad * 4 + (size_t)((p->blk_bytes + 3) / 4) * 4;
+    const size_t lds = (size_t)p->n_libs * p->kpad * 4 + (size_t)p->blk_bytes * 4;
 #define SQGR_SHUFFLE(BB, LIBS)                                                                                  \
     k_shuffle<BB, LIBS><<<dim3(gx, nb), 256, lds, st>>>(p->n, p->cum.p, p->kpad, p->blk_bytes, keys, p->dom0, p->n_libs, p->lib_of.p, \
                                                         p->rank_of.p, p->libs.p, slab)

@@ -133,51 +133,6 @@ __device__ __forceinline__ void feistel_rounds(u16x2 (&a)[NP], u16x2 (&b)[NP], c
     }
 }
 
-// images of the rank (a0, b0) under the cycle-walked keyed bijections of [0, n) of 2*NP permutations;
-// x[j] is the image under permutation j, hi[j] its high digit (x == hi * d.B + low)
-template <int NP>
-__device__ __forceinline__ void feistel_perm_multi(uint32_t a0, uint32_t b0, const FeistelDomain& d,
-                                                   const uint32_t* const (&pk)[NP], uint32_t (&x)[2 * NP],
-                                                   uint32_t (&hi)[2 * NP]) {
-    u16x2 a[NP], b[NP];
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        a[i] = (u16x2)((unsigned short)a0);
-        b[i] = (u16x2)((unsigned short)b0);
-    }
-    feistel_rounds<NP>(a, b, d, pk);
-    bool again = false;
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        x[2 * i] = (uint32_t)a[i].x * d.B + b[i].x;
-        x[2 * i + 1] = (uint32_t)a[i].y * d.B + b[i].y;
-        again |= (x[2 * i] >= d.n) | (x[2 * i + 1] >= d.n);
-    }
-    while (again) {  // rare: re-apply the bijection only where the image left [0, n)
-        u16x2 a2[NP], b2[NP];
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            a2[i] = a[i];
-            b2[i] = b[i];
-        }
-        feistel_rounds<NP>(a2, b2, d, pk);
-        again = false;
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            if (x[2 * i] >= d.n) { a[i].x = a2[i].x; b[i].x = b2[i].x; }
-            if (x[2 * i + 1] >= d.n) { a[i].y = a2[i].y; b[i].y = b2[i].y; }
-            x[2 * i] = (uint32_t)a[i].x * d.B + b[i].x;
-            x[2 * i + 1] = (uint32_t)a[i].y * d.B + b[i].y;
-            again |= (x[2 * i] >= d.n) | (x[2 * i + 1] >= d.n);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        hi[2 * i] = a[i].x;
-        hi[2 * i + 1] = a[i].y;
-    }
-}
-
 // single-permutation form (same arithmetic): image of x (< n)
 __host__ __device__ inline uint32_t feistel_perm(uint32_t x, const FeistelDomain& d, const uint32_t* rk) {
     uint32_t a = x / d.B, b = x - a * d.B;
