@@ -160,6 +160,26 @@ __device__ __forceinline__ int xcd_chunk(int b, int nblk) {
 // Step s of lane (edge slot el, q) handles byte (s + el) mod B/4, so the 32 lanes of a DS lane group touch
 // B distinct banks (conflict-free for B = 32).  The stagger costs nothing per step: the label words are rotated
 // once per edge (v_alignbit) so that byte extraction is static, and the per-step bank offsets are loop invariant.
+// pair = byte<BYTE>(la) * K + byte<BYTE>(lb) in two instructions: gfx9 sub-dword addressing folds the byte extraction
+// into the 24-bit multiply and into the add (the compiler emits v_bfe_u32 x2 + v_mad_u32_u24 otherwise).
+#define SQGR_PAIR_SDWA(BYTE)                                                                                              \
+    asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_" #BYTE " src1_sel:DWORD"       \
+        : "=v"(t)                                                                                                         \
+        : "v"(la), "v"(K));                                                                                               \
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_" #BYTE " src1_sel:DWORD"           \
+        : "=v"(p)                                                                                                         \
+        : "v"(lb), "v"(t));
+template <int BYTE>
+__device__ __forceinline__ uint32_t pair_index(uint32_t la, uint32_t lb, uint32_t K) {
+    uint32_t t, p;
+    if constexpr (BYTE == 0) { SQGR_PAIR_SDWA(0) }
+    else if constexpr (BYTE == 1) { SQGR_PAIR_SDWA(1) }
+    else if constexpr (BYTE == 2) { SQGR_PAIR_SDWA(2) }
+    else { SQGR_PAIR_SDWA(3) }
+    return p;
+}
+#undef SQGR_PAIR_SDWA
+
 template <int B, int MIN_WAVES>
 __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz, const int2* __restrict__ coo,
                                                                     const uint8_t* __restrict__ slab_all, int64_t n, int K,
@@ -239,12 +259,20 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
                 lb[0] = __builtin_amdgcn_alignbit(bhi, blo, rot);
                 lb[1] = __builtin_amdgcn_alignbit(blo, bhi, rot);
             }
-#pragma unroll
-            for (int s = 0; s < BPL; ++s) {
-                const uint32_t va = (la[s >> 2] >> (8 * (s & 3))) & 0xffu;  // static byte extraction
-                const uint32_t vb = (lb[s >> 2] >> (8 * (s & 3))) & 0xffu;
-                const uint32_t pair = __umul24(va, (uint32_t)K) + vb;
+            auto bump = [&](auto s_tag) {
+                constexpr int s = decltype(s_tag)::value;
+                const uint32_t pair = pair_index<(s & 3)>(la[s >> 2], lb[s >> 2], (uint32_t)K);
                 atomicAdd(reinterpret_cast<uint32_t*>(hist_bytes + ((pair << LOGW) + bank_ofs[s])), inc);
+            };
+            bump(std::integral_constant<int, 0>{});
+            bump(std::integral_constant<int, 1>{});
+            bump(std::integral_constant<int, 2>{});
+            bump(std::integral_constant<int, 3>{});
+            if constexpr (BPL == 8) {
+                bump(std::integral_constant<int, 4>{});
+                bump(std::integral_constant<int, 5>{});
+                bump(std::integral_constant<int, 6>{});
+                bump(std::integral_constant<int, 7>{});
             }
         }
 #pragma unroll
