@@ -221,39 +221,32 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
     const uint32_t last = nnz - 1;
     auto gather_rows = [&](const int2 mine, Row (&ra)[U], Row (&rb)[U]) {
         uint32_t r[U], c[U];
-        r[0] = (uint32_t)__builtin_amdgcn_update_dpp(0, mine.x, 0x00, 0xF, 0xF, false);  // quad_perm:[0,0,0,0]
-        c[0] = (uint32_t)__builtin_amdgcn_update_dpp(0, mine.y, 0x00, 0xF, 0xF, false);
-        r[1] = (uint32_t)__builtin_amdgcn_update_dpp(0, mine.x, 0x55, 0xF, 0xF, false);  // quad_perm:[1,1,1,1]
-        c[1] = (uint32_t)__builtin_amdgcn_update_dpp(0, mine.y, 0x55, 0xF, 0xF, false);
-        r[2] = (uint32_t)__builtin_amdgcn_update_dpp(0, mine.x, 0xAA, 0xF, 0xF, false);  // quad_perm:[2,2,2,2]
-        c[2] = (uint32_t)__builtin_amdgcn_update_dpp(0, mine.y, 0xAA, 0xF, 0xF, false);
-        r[3] = (uint32_t)__builtin_amdgcn_update_dpp(0, mine.x, 0xFF, 0xF, 0xF, false);  // quad_perm:[3,3,3,3]
-        c[3] = (uint32_t)__builtin_amdgcn_update_dpp(0, mine.y, 0xFF, 0xF, 0xF, false);
+        r[0] = (uint32_t)__builtin_amdgcn_update_dpp(mine.x, mine.x, 0x00, 0xF, 0xF, false);  // quad_perm:[0,0,0,0]
+        c[0] = (uint32_t)__builtin_amdgcn_update_dpp(mine.y, mine.y, 0x00, 0xF, 0xF, false);
+        r[1] = (uint32_t)__builtin_amdgcn_update_dpp(mine.x, mine.x, 0x55, 0xF, 0xF, false);  // quad_perm:[1,1,1,1]
+        c[1] = (uint32_t)__builtin_amdgcn_update_dpp(mine.y, mine.y, 0x55, 0xF, 0xF, false);
+        r[2] = (uint32_t)__builtin_amdgcn_update_dpp(mine.x, mine.x, 0xAA, 0xF, 0xF, false);  // quad_perm:[2,2,2,2]
+        c[2] = (uint32_t)__builtin_amdgcn_update_dpp(mine.y, mine.y, 0xAA, 0xF, 0xF, false);
+        r[3] = (uint32_t)__builtin_amdgcn_update_dpp(mine.x, mine.x, 0xFF, 0xF, 0xF, false);  // quad_perm:[3,3,3,3]
+        c[3] = (uint32_t)__builtin_amdgcn_update_dpp(mine.y, mine.y, 0xFF, 0xF, 0xF, false);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             ra[u] = *reinterpret_cast<const Row*>(slab + (r[u] * B + qoff));
             rb[u] = *reinterpret_cast<const Row*>(slab + (c[u] * B + qoff));
         }
     };
-    uint32_t e = e0 + el * U;
-    Row cur_a[U], cur_b[U];
-    gather_rows(coo[min(e + q, last)], cur_a, cur_b);                     // rows of iteration 0
-    int2 nxt_rc = coo[min(e + STEP + q, last)];                           // pairs of iteration 1 (clamped: in bounds)
-    for (; e < e1; e += STEP) {
-        Row nxt_a[U], nxt_b[U];
-        gather_rows(nxt_rc, nxt_a, nxt_b);                                // rows of iteration k+1
-        nxt_rc = coo[min(e + 2 * STEP + q, last)];                        // pairs of iteration k+2
+    auto histogram = [&](const Row (&row_a)[U], const Row (&row_b)[U], uint32_t eb) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint32_t inc = (e + u < e1) ? 1u : 0u;  // branch-free tail: out-of-range edges add 0
+            const uint32_t inc = (eb + u < e1) ? 1u : 0u;  // branch-free tail: out-of-range edges add 0
             uint32_t la[2], lb[2];
             if constexpr (B == 16) {
-                la[0] = __builtin_amdgcn_alignbit(cur_a[u], cur_a[u], rot);
-                lb[0] = __builtin_amdgcn_alignbit(cur_b[u], cur_b[u], rot);
+                la[0] = __builtin_amdgcn_alignbit(row_a[u], row_a[u], rot);
+                lb[0] = __builtin_amdgcn_alignbit(row_b[u], row_b[u], rot);
             } else {
                 const bool sw = (rot & 32) != 0;
-                const uint32_t alo = sw ? cur_a[u].y : cur_a[u].x, ahi = sw ? cur_a[u].x : cur_a[u].y;
-                const uint32_t blo = sw ? cur_b[u].y : cur_b[u].x, bhi = sw ? cur_b[u].x : cur_b[u].y;
+                const uint32_t alo = sw ? row_a[u].y : row_a[u].x, ahi = sw ? row_a[u].x : row_a[u].y;
+                const uint32_t blo = sw ? row_b[u].y : row_b[u].x, bhi = sw ? row_b[u].x : row_b[u].y;
                 la[0] = __builtin_amdgcn_alignbit(ahi, alo, rot);
                 la[1] = __builtin_amdgcn_alignbit(alo, ahi, rot);
                 lb[0] = __builtin_amdgcn_alignbit(bhi, blo, rot);
@@ -275,11 +268,21 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
                 bump(std::integral_constant<int, 7>{});
             }
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            cur_a[u] = nxt_a[u];
-            cur_b[u] = nxt_b[u];
-        }
+    };
+    uint32_t e = e0 + el * U;
+    Row p_a[U], p_b[U], q_a[U], q_b[U];  // ping-pong row buffers: no register rotation at the end of an iteration
+    gather_rows(coo[min(e + q, last)], p_a, p_b);                         // rows of iteration 0
+    int2 nxt_rc = coo[min(e + STEP + q, last)];                           // pairs of iteration 1 (clamped: in bounds)
+    while (e < e1) {
+        gather_rows(nxt_rc, q_a, q_b);                                    // rows of iteration k+1
+        nxt_rc = coo[min(e + 2 * STEP + q, last)];                        // pairs of iteration k+2
+        histogram(p_a, p_b, e);
+        e += STEP;
+        if (e >= e1) break;
+        gather_rows(nxt_rc, p_a, p_b);
+        nxt_rc = coo[min(e + 2 * STEP + q, last)];
+        histogram(q_a, q_b, e);
+        e += STEP;
     }
     __syncthreads();
     uint32_t* dst = partial_all + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * hist_words;
