@@ -161,6 +161,12 @@ int sqgr_autocorr_scores(sqgr_autocorr* h, int32_t mode, double* out_scores);
  * permutation index => independent of how the range is split).  out_sims: float64[P][G], P = perm_end-perm_begin. */
 int sqgr_autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_idx, uint64_t seed, int64_t perm_begin,
                         int64_t perm_end, double* out_sims);
+/* sqgr_autocorr_perms with the reference's own numpy streams generated ON THE DEVICE: pcg_states holds n_perms rows
+ * [state_hi, state_lo, inc_hi, inc_lo] of `spawn_generators(seed, n_perms)` (_utils.py:240-241); permutation p of the
+ * rows is bit for bit `generators[p].permutation(n)` (gr/_ppatterns.py:270-271).  Nothing but 32 bytes per permutation
+ * crosses PCIe (injecting the same permutations through sqgr_autocorr_perms costs 4*n bytes each, per feature block). */
+int sqgr_autocorr_perms_pcg64(sqgr_autocorr* h, int32_t mode, const uint64_t* pcg_states, int64_t n_perms, double* out_sims);
+
 /* parity hook: the device generator's permutations, int32[perm_end-perm_begin][n] (<= 32768 per call) */
 int sqgr_autocorr_perm_indices(sqgr_ctx* ctx, int64_t n, uint64_t seed, int64_t perm_begin, int64_t perm_end,
                                int32_t* out_idx);

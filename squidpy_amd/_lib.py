@@ -54,6 +54,7 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "sqgr_autocorr_destroy": (C.c_int, [C.c_void_p]),
     "sqgr_autocorr_scores": (C.c_int, [C.c_void_p, C.c_int32, c_f64p]),
     "sqgr_autocorr_perms": (C.c_int, [C.c_void_p, C.c_int32, c_i32p, C.c_uint64, C.c_int64, C.c_int64, c_f64p]),
+    "sqgr_autocorr_perms_pcg64": (C.c_int, [C.c_void_p, C.c_int32, c_u64p, C.c_int64, c_f64p]),
     "sqgr_autocorr_perm_indices": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_int64, C.c_int64, c_i32p]),
     "sqgr_pair_counts": (C.c_int, [C.c_void_p, c_f64p, C.c_int64, c_f64p, C.c_int32, C.c_int32, c_i64p]),
     "sqgr_knn_dist": (C.c_int, [C.c_void_p, c_f64p, C.c_int64, c_f64p, C.c_int64, C.c_int32, C.c_int32, c_f64p]),
@@ -420,6 +421,17 @@ class AutocorrPlan:
                 self.h, self.MODES[mode], _ptr(perm_idx, c_i32p), C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF),
                 int(perm_begin), int(perm_end), _ptr(out, c_f64p),
             ),
+        )
+        return out
+
+    def perms_pcg64(self, mode: str, pcg_states: np.ndarray) -> np.ndarray:
+        """Permutation scores under numpy's own streams, drawn on the device (``sqgr_autocorr_perms_pcg64``);
+        ``pcg_states``: (n_perms, 4) uint64 from :func:`squidpy_amd._utils.pcg64_states`."""
+        states = _as(pcg_states, np.uint64).reshape(-1, 4)
+        out = np.zeros((states.shape[0], self.G), dtype=np.float64)
+        _check(
+            self.ctx.lib,
+            self.ctx.lib.sqgr_autocorr_perms_pcg64(self.h, self.MODES[mode], _ptr(states, c_u64p), states.shape[0], _ptr(out, c_f64p)),
         )
         return out
 

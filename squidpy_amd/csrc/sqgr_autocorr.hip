@@ -16,6 +16,7 @@
 // All reductions are two-stage with a fixed order => bit-reproducible run to run.
 #include "sqgr_common.h"
 #include "sqgr_rng.h"
+#include "sqgr_pcg.h"
 
 #include <cstdlib>
 
@@ -278,6 +279,8 @@ struct sqgr_autocorr {
     // permutation workspace
     DevBuf<int32_t> idx;
     DevBuf<double> part1, part2, sims;
+    PcgWorkspace pcg_ws;          // numpy-stream permutations generated in place (sqgr_autocorr_perms_pcg64)
+    DevBuf<uint64_t> pcg_states;
 };
 
 static int column_sum(sqgr_autocorr* h, int mode, const double* A, const double* B, double* out_dev) {
@@ -416,8 +419,10 @@ int sqgr_autocorr_scores(sqgr_autocorr* h, int32_t mode, double* out_scores) {
     return SQGR_OK;
 }
 
-int sqgr_autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_idx, uint64_t seed, int64_t perm_begin,
-                        int64_t perm_end, double* out_sims) {
+// permutation scores for permutations [perm_begin, perm_end): row permutations injected from the host (perm_idx), drawn
+// from numpy's streams on the device (pcg_states, one row per permutation of the range) or from the device generator
+static int autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_idx, const uint64_t* pcg_states, uint64_t seed,
+                          int64_t perm_begin, int64_t perm_end, double* out_sims) {
     SQGR_REQUIRE(h && out_sims, "null argument");
     SQGR_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (moran) or 1 (geary)");
     SQGR_REQUIRE(perm_begin >= 0 && perm_end >= perm_begin, "bad permutation range");
@@ -437,6 +442,7 @@ int sqgr_autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_idx,
     SQGR_TRY(h->part1.ensure((size_t)h->ntiles * chunk * R * GT));
     if (mode == 1) SQGR_TRY(h->part2.ensure((size_t)h->ntiles * chunk * R * GT));
     SQGR_TRY(h->sims.ensure((size_t)chunk * G));
+    if (pcg_states) SQGR_TRY(h->pcg_states.ensure((size_t)chunk * 4));
     if (perm_idx)
         for (int64_t t = 0; t < P * n; ++t)
             SQGR_REQUIRE(perm_idx[t] >= 0 && perm_idx[t] < n, "perm_idx[%lld]=%d outside [0,%lld)", (long long)t, perm_idx[t], (long long)n);
@@ -445,6 +451,9 @@ int sqgr_autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_idx,
         const int64_t pc = std::min(chunk, P - c0);
         if (perm_idx) {
             SQGR_HIP(hipMemcpyAsync(h->idx.p, perm_idx + (size_t)c0 * n, (size_t)pc * n * 4, hipMemcpyHostToDevice, st));
+        } else if (pcg_states) {
+            SQGR_HIP(hipMemcpyAsync(h->pcg_states.p, pcg_states + (size_t)c0 * 4, (size_t)pc * 32, hipMemcpyHostToDevice, st));
+            SQGR_TRY(pcg_permutations_dev(ctx, h->pcg_ws, n, h->pcg_states.p, pc, h->idx.p, st));
         } else {
             LaunchTimer t(ctx, "autocorr_perm_indices");
             k_perm_indices<<<dim3((unsigned)ceil_div(n, 256), (unsigned)pc), 256, 0, st>>>(seed, perm_begin + c0, n, dom, h->idx.p);
@@ -472,6 +481,16 @@ int sqgr_autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_idx,
         SQGR_HIP(hipStreamSynchronize(st));
     }
     return SQGR_OK;
+}
+
+int sqgr_autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_idx, uint64_t seed, int64_t perm_begin,
+                        int64_t perm_end, double* out_sims) {
+    return autocorr_perms(h, mode, perm_idx, nullptr, seed, perm_begin, perm_end, out_sims);
+}
+
+int sqgr_autocorr_perms_pcg64(sqgr_autocorr* h, int32_t mode, const uint64_t* pcg_states, int64_t n_perms, double* out_sims) {
+    SQGR_REQUIRE(pcg_states && n_perms >= 0, "pcg_states is NULL or n_perms < 0");
+    return autocorr_perms(h, mode, nullptr, pcg_states, 0, 0, n_perms, out_sims);
 }
 
 /* the device generator's permutation indices (parity hook): int32[(perm_end-perm_begin)][n] */

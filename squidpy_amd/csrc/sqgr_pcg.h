@@ -8,11 +8,17 @@ namespace sqgr {
 struct PcgWorkspace {
     DevBuf<uint64_t> jump;  // [34][4] LCG jump-ahead table of the wave-per-permutation kernel
     DevBuf<uint8_t> rows;   // [permutation][n_pad] row-major shuffle workspace
+    DevBuf<uint32_t> span;  // {0, n}: the single "library" of a plain permutation
+    DevBuf<int32_t> cols;   // column workspace of the one-thread-per-permutation kernel (SQGR_PCG_KERNEL=lane)
 };
 
 // W[pos * stride + q] = element `pos` of the byte array numpy's generator q (states_dev row q: state_hi, state_lo, inc_hi,
 // inc_lo) leaves behind after shuffling base_pos library by library (lib_off_dev: n_libs + 1 position offsets), q < pc.
 int pcg_shuffle_labels(sqgr_ctx* ctx, PcgWorkspace& ws, int64_t n, int n_libs, const uint32_t* lib_off_dev, const uint8_t* base_pos_dev,
                        const uint64_t* states_dev, int64_t pc, int64_t stride, uint8_t* W, hipStream_t st, const char* timer_name);
+
+// idx_dev[q * n + i] = element i of `Generator.permutation(n)` drawn by generator q (states_dev row q), q < pc.
+int pcg_permutations_dev(sqgr_ctx* ctx, PcgWorkspace& ws, int64_t n, const uint64_t* states_dev, int64_t pc, int32_t* idx_dev,
+                         hipStream_t st);
 
 }  // namespace sqgr

@@ -547,6 +547,30 @@ int pcg_shuffle_labels(sqgr_ctx* ctx, PcgWorkspace& ws, int64_t n, int n_libs, c
     return SQGR_OK;
 }
 
+int pcg_permutations_dev(sqgr_ctx* ctx, PcgWorkspace& ws, int64_t n, const uint64_t* states_dev, int64_t pc, int32_t* idx_dev,
+                         hipStream_t st) {
+    if (!ws.span.p) {
+        SQGR_TRY(ws.span.alloc(2));
+        const uint32_t span_h[2] = {0u, (uint32_t)n};
+        SQGR_HIP(hipMemcpy(ws.span.p, span_h, 8, hipMemcpyHostToDevice));
+    }
+    LaunchTimer t(ctx, "autocorr_pcg64_permutation", st);
+    if (pcg_lane_kernel()) {
+        const int64_t stride = ceil_div(pc, 64) * 64;
+        SQGR_TRY(ws.cols.ensure((size_t)n * stride));
+        k_pcg_shuffle<int32_t, true><<<(unsigned)ceil_div(pc, 64), 64, 0, st>>>(n, 1, ws.span.p, nullptr, states_dev, pc, stride, ws.cols.p);
+        k_columns_to_rows_i32<<<dim3((unsigned)ceil_div(n, 32), (unsigned)ceil_div(pc, 32)), 256, 0, st>>>(n, stride, ws.cols.p, pc, idx_dev);
+    } else {  // rows are the wanted output already: idx[q][i]
+        SQGR_TRY(ensure_pcg_jump(ws.jump));
+        const uint32_t wsz = pcg_window(n);
+        SQGR_TRY(pcg_allow_lds(k_pcg_shuffle_wave<int32_t, true>, (size_t)wsz * 4));
+        k_pcg_shuffle_wave<int32_t, true><<<pcg_grid(pc), 64, (size_t)wsz * 4, st>>>(n, n, 1, ws.span.p, nullptr, states_dev, ws.jump.p, pc,
+                                                                                     idx_dev, pcg_force_slow(), wsz);
+    }
+    SQGR_HIP(hipGetLastError());
+    return SQGR_OK;
+}
+
 }  // namespace sqgr
 
 extern "C" {
@@ -557,35 +581,15 @@ int sqgr_pcg64_permutations(sqgr_ctx* ctx, int64_t n, const uint64_t* pcg_states
     SQGR_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const int64_t chunk = std::max<int64_t>(64, std::min<int64_t>(ceil_div(n_perms, 64) * 64, (((int64_t)8 << 30) / (n * 4)) / 64 * 64));
-    const bool lane_kernel = pcg_lane_kernel();
-    DevBuf<int32_t> W, idx;
-    DevBuf<uint64_t> states, jump;
-    DevBuf<uint32_t> off;
-    if (lane_kernel)
-        SQGR_TRY(W.alloc((size_t)n * chunk));
-    else
-        SQGR_TRY(ensure_pcg_jump(jump));
+    PcgWorkspace ws;
+    DevBuf<int32_t> idx;
+    DevBuf<uint64_t> states;
     SQGR_TRY(idx.alloc((size_t)chunk * n));
     SQGR_TRY(states.alloc((size_t)chunk * 4));
-    SQGR_TRY(off.alloc(2));
-    const uint32_t off_h[2] = {0u, (uint32_t)n};
-    SQGR_HIP(hipMemcpyAsync(off.p, off_h, 8, hipMemcpyHostToDevice, st));
     for (int64_t c0 = 0; c0 < n_perms; c0 += chunk) {
         const int64_t pc = std::min(chunk, n_perms - c0);
         SQGR_HIP(hipMemcpyAsync(states.p, pcg_states + (size_t)c0 * 4, (size_t)pc * 32, hipMemcpyHostToDevice, st));
-        {
-            LaunchTimer t(ctx, "autocorr_pcg64_permutation");
-            if (lane_kernel) {
-                k_pcg_shuffle<int32_t, true><<<(unsigned)ceil_div(pc, 64), 64, 0, st>>>(n, 1, off.p, nullptr, states.p, pc, chunk, W.p);
-                k_columns_to_rows_i32<<<dim3((unsigned)ceil_div(n, 32), (unsigned)ceil_div(pc, 32)), 256, 0, st>>>(n, chunk, W.p, pc, idx.p);
-            } else {  // rows are the wanted output already: idx[q][i]
-                const uint32_t ws = pcg_window(n);
-                SQGR_TRY(pcg_allow_lds(k_pcg_shuffle_wave<int32_t, true>, (size_t)ws * 4));
-                k_pcg_shuffle_wave<int32_t, true><<<pcg_grid(pc), 64, (size_t)ws * 4, st>>>(n, n, 1, off.p, nullptr, states.p, jump.p, pc,
-                                                                                            idx.p, pcg_force_slow(), ws);
-            }
-            SQGR_HIP(hipGetLastError());
-        }
+        SQGR_TRY(pcg_permutations_dev(ctx, ws, n, states.p, pc, idx.p, st));
         SQGR_HIP(hipMemcpyAsync(out_idx + (size_t)c0 * n, idx.p, (size_t)pc * n * 4, hipMemcpyDeviceToHost, st));
         SQGR_HIP(hipStreamSynchronize(st));
     }

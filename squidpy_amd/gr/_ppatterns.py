@@ -17,7 +17,7 @@ import pandas as pd
 from scipy import sparse
 
 from .._constants import SpatialAutocorr
-from .._lib import AutocorrPlan, Graph, cooccur_counts, default_context, pcg64_permutations
+from .._lib import AutocorrPlan, Graph, cooccur_counts, default_context
 from .._stats import multipletests_pvals, p_value_calc
 from .._utils import (
     _assert_categorical_obs,
@@ -226,13 +226,14 @@ def spatial_autocorr(
     n = g.shape[0]
     n_feat = vals.shape[0]
     perm_idx = None
+    states = None
     key = resolve_seed(seed)
     ctx = default_context(device)
     if n_perms is not None and rng == "numpy-host":
         gens = spawn_generators(seed, n_perms)
         perm_idx = np.stack([gens[p].permutation(n) for p in range(n_perms)]).astype(np.int32)
-    elif n_perms is not None and rng == "numpy":  # numpy's `rng.permutation(N)` streams reproduced on the device
-        perm_idx = pcg64_permutations(ctx, n, pcg64_states(seed if seed is not None else key, n_perms))
+    elif n_perms is not None and rng == "numpy":  # numpy's `rng.permutation(N)` streams, reproduced on the device per block
+        states = pcg64_states(seed if seed is not None else key, n_perms)
 
     graph = Graph(ctx, g, with_data=True)
     rank, world = _dist.world()
@@ -248,7 +249,9 @@ def spatial_autocorr(
             plan = AutocorrPlan(ctx, graph, blk)
             try:
                 score[b0:b1] = plan.scores(mode.s)
-                if n_perms is not None:
+                if n_perms is not None and states is not None:
+                    sims[:, b0:b1] = plan.perms_pcg64(mode.s, states)
+                elif n_perms is not None:
                     sims[:, b0:b1] = plan.perms(mode.s, perm_idx=perm_idx, seed=key, perm_begin=0, perm_end=n_perms)
             finally:
                 plan.close()
