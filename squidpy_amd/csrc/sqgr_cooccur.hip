@@ -27,12 +27,14 @@ constexpr int CO_CELLS_MAX = 32768;
 constexpr int CO_LMAX = 120;          // thresholds per sweep: (L+?)*1 KiB of private histogram columns must fit LDS
 constexpr int CO_BATCH = 8;           // pairs in flight per thread in the branch-free kernel
 constexpr int CO_CHUNK_TILES = 64;
+constexpr int CO_TRASH = 3;           // overflow rows behind the L bins of the branch-free kernel (bin <= L + 2)
 
 struct CoParams {
     float inv_cell;
     int ncells;
     int T, L, K;
     int shard_index, shard_count;
+    int finite;               // all coordinates are finite: full foreign batches may skip the per-pair checks
     unsigned long long* out;  // [K][K][L] per-bin (non cumulative) ordered pair counts
 };
 
@@ -135,8 +137,8 @@ __global__ __launch_bounds__(CO_TILE) void k_cooccur_fast(const float* __restric
                                                           const uint16_t* __restrict__ cell, CoParams p) {
     extern __shared__ uint32_t smem[];
     const int L = p.L;
-    uint32_t* hist = smem;                                          // [L][256]
-    float* s_thr = reinterpret_cast<float*>(smem + L * CO_TILE);    // [L + 2], two +inf sentinels
+    uint32_t* hist = smem;                                          // [L + CO_TRASH][256]: bins, then write-only overflow rows
+    float* s_thr = reinterpret_cast<float*>(smem + (L + CO_TRASH) * CO_TILE);  // [L + 2], two +inf sentinels
     uint16_t* s_cell = reinterpret_cast<uint16_t*>(s_thr + L + 2);  // [ncells]
     const int t = threadIdx.x;
 
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(CO_TILE) void k_cooccur_fast(const float* __restric
     const int tj1 = min(p.T, ((int)blockIdx.y + 1) * CO_CHUNK_TILES);
     if (tj0 >= tj1) return;
 
-    for (int i = t; i < L * CO_TILE; i += CO_TILE) hist[i] = 0;
+    for (int i = t; i < (L + CO_TRASH) * CO_TILE; i += CO_TILE) hist[i] = 0;
     for (int i = t; i < L + 2; i += CO_TILE) s_thr[i] = i < L ? thr[i] : __builtin_inff();
     for (int i = t; i < p.ncells; i += CO_TILE) s_cell[i] = cell[i];
     __syncthreads();
@@ -170,25 +172,41 @@ __global__ __launch_bounds__(CO_TILE) void k_cooccur_fast(const float* __restric
         const float* __restrict__ xj = xs + (size_t)tj * CO_TILE;  // wave-uniform addresses: scalar loads; the tile is
         const float* __restrict__ yj = ys + (size_t)tj * CO_TILE;  // zero-padded to 256 so reading past vj is safe
         const int self = (tj == ti) ? t : -1;
-        if (active) {
-            for (int j0 = 0; j0 < vj; j0 += CO_BATCH) {
-                float d2[CO_BATCH];
-                int g[CO_BATCH];
+        // One batch of CO_BATCH points of tile tj against this thread's point.  CHECKED: the general form (tail batch
+        // of a tile, diagonal tile: j < vj, j != self, NaN, bin < L tested and folded into the increment).  Unchecked:
+        // a full batch of a foreign tile with finite coordinates needs none of it — a pair beyond the last threshold
+        // lands in one of the CO_TRASH overflow rows (bin <= L + 2 by construction of the cell table) that are never read.
+        auto batch = [&](int j0, auto checked_tag) {
+            constexpr bool CHECKED = decltype(checked_tag)::value;
+            float d2[CO_BATCH];
+            int g[CO_BATCH];
 #pragma unroll
-                for (int u = 0; u < CO_BATCH; ++u) {
-                    d2[u] = dist2<FMA>(xi, yi, xj[j0 + u], yj[j0 + u]);
-                    int cellv = (int)(d2[u] * inv_cell);  // v_cvt_i32_f32 saturates; NaN -> 0
-                    g[u] = s_cell[min(max(cellv, 0), cmax)];
-                }
+            for (int u = 0; u < CO_BATCH; ++u) {
+                d2[u] = dist2<FMA>(xi, yi, xj[j0 + u], yj[j0 + u]);
+                int cellv = (int)(d2[u] * inv_cell);  // v_cvt_i32_f32 saturates; NaN -> 0
+                g[u] = s_cell[min(max(cellv, 0), cmax)];
+            }
 #pragma unroll
-                for (int u = 0; u < CO_BATCH; ++u) {
-                    const float t0 = s_thr[g[u]], t1 = s_thr[g[u] + 1];  // adjacent: one ds_read2_b32
-                    // thresholds ascend, so !(d2 <= t1) implies !(d2 <= t0): bin = g + c0 + c1 (no branches)
-                    const int c0 = !(d2[u] <= t0), c1 = !(d2[u] <= t1);
-                    const int gg = g[u] + c0 + c1;
+            for (int u = 0; u < CO_BATCH; ++u) {
+                const float t0 = s_thr[g[u]], t1 = s_thr[g[u] + 1];  // adjacent: one ds_read2_b32
+                // thresholds ascend, so !(d2 <= t1) implies !(d2 <= t0): bin = g + c0 + c1 (no branches)
+                const int c0 = !(d2[u] <= t0), c1 = !(d2[u] <= t1);
+                const int gg = g[u] + c0 + c1;
+                if constexpr (CHECKED) {
                     const int ok = (int)(gg < L) & (int)(j0 + u < vj) & (int)(j0 + u != self) & (int)(d2[u] == d2[u]);
                     atomicAdd(my + min(gg, L - 1) * CO_TILE, (uint32_t)ok);
+                } else {
+                    atomicAdd(my + gg * CO_TILE, 1u);
                 }
+            }
+        };
+        if (active) {
+            if (tj == ti || !p.finite) {
+                for (int j0 = 0; j0 < vj; j0 += CO_BATCH) batch(j0, std::true_type{});
+            } else {
+                const int jfull = vj & ~(CO_BATCH - 1);
+                for (int j0 = 0; j0 < jfull; j0 += CO_BATCH) batch(j0, std::false_type{});
+                if (jfull < vj) batch(jfull, std::true_type{});
             }
         }
         if (tj == ti) co_flush(hist, L, p.K, a, a, false, p.out);  // diagonal tile: ordered pairs complete, credit (a,a) once
@@ -224,11 +242,13 @@ extern "C" int sqgr_cooccur_counts(sqgr_ctx* ctx, const float* x, const float* y
     std::vector<float> xs((size_t)T * CO_TILE, 0.f), ys((size_t)T * CO_TILE, 0.f);
     std::vector<int32_t> tile_label((size_t)T), tile_valid((size_t)T);
     std::vector<int64_t> fill((size_t)K, 0);
+    bool all_finite = true;
     for (int64_t i = 0; i < n; ++i) {
         const int k = labels[i];
         const int64_t pos = tile0[k] * CO_TILE + fill[k]++;
         xs[pos] = x[i];
         ys[pos] = y[i];
+        all_finite = all_finite && std::isfinite(x[i]) && std::isfinite(y[i]);
     }
     for (int k = 0; k < K; ++k)
         for (int64_t tt = tile0[k]; tt < tile0[k + 1]; ++tt) {
@@ -263,7 +283,7 @@ extern "C" int sqgr_cooccur_counts(sqgr_ctx* ctx, const float* x, const float* y
         for (int g = 0; g < L_eff; ++g)
             if (std::isfinite(thr_s[g])) tmax = std::max(tmax, thr_s[g]);
         const bool table_ok = tmax > 0.f;
-        const size_t lds_fixed = (size_t)L_eff * CO_TILE * 4 + (size_t)(L_eff + 2) * 4;
+        const size_t lds_fixed = (size_t)(L_eff + CO_TRASH) * CO_TILE * 4 + (size_t)(L_eff + 2) * 4;
         int ncells = CO_CELLS_MIN;
         float inv_cell = 0.f;
         std::vector<uint16_t> cell;
@@ -321,7 +341,7 @@ extern "C" int sqgr_cooccur_counts(sqgr_ctx* ctx, const float* x, const float* y
         SQGR_HIP(hipMemcpyAsync(d_tv.p, tile_valid.data(), (size_t)T * 4, hipMemcpyHostToDevice, st));
         SQGR_HIP(hipMemcpyAsync(d_cell.p, cell.data(), (size_t)ncells * 2, hipMemcpyHostToDevice, st));
         SQGR_HIP(hipMemsetAsync(d_out.p, 0, (size_t)K * K * L_eff * 8, st));
-        CoParams p{inv_cell, ncells, (int)T, L_eff, K, shard_index, shard_count, d_out.p};
+        CoParams p{inv_cell, ncells, (int)T, L_eff, K, shard_index, shard_count, all_finite ? 1 : 0, d_out.p};
         const size_t lds_eff = lds_fixed + (size_t)ncells * 2;
         dim3 grid((unsigned)ceil_div(T, shard_count), (unsigned)ceil_div(T, CO_CHUNK_TILES));
         {
