@@ -184,13 +184,21 @@ __global__ __launch_bounds__(CO_TILE) void k_cooccur_fast(const float* __restric
             for (int u = 0; u < CO_BATCH; ++u) {
                 d2[u] = dist2<FMA>(xi, yi, xj[j0 + u], yj[j0 + u]);
                 int cellv = (int)(d2[u] * inv_cell);  // v_cvt_i32_f32 saturates; NaN -> 0
-                g[u] = s_cell[min(max(cellv, 0), cmax)];
+                if constexpr (CHECKED) cellv = max(cellv, 0);  // finite d2 >= 0 cannot go negative
+                g[u] = s_cell[min(cellv, cmax)];
+            }
+            // all threshold pairs are fetched before the first histogram update: the compiler may not move an LDS read
+            // across an LDS atomic, so one loop would pay the LDS latency once per pair instead of once per batch
+            float t0[CO_BATCH], t1[CO_BATCH];
+#pragma unroll
+            for (int u = 0; u < CO_BATCH; ++u) {
+                t0[u] = s_thr[g[u]];  // adjacent: one ds_read2_b32
+                t1[u] = s_thr[g[u] + 1];
             }
 #pragma unroll
             for (int u = 0; u < CO_BATCH; ++u) {
-                const float t0 = s_thr[g[u]], t1 = s_thr[g[u] + 1];  // adjacent: one ds_read2_b32
                 // thresholds ascend, so !(d2 <= t1) implies !(d2 <= t0): bin = g + c0 + c1 (no branches)
-                const int c0 = !(d2[u] <= t0), c1 = !(d2[u] <= t1);
+                const int c0 = !(d2[u] <= t0[u]), c1 = !(d2[u] <= t1[u]);
                 const int gg = g[u] + c0 + c1;
                 if constexpr (CHECKED) {
                     const int ok = (int)(gg < L) & (int)(j0 + u < vj) & (int)(j0 + u != self) & (int)(d2[u] == d2[u]);
