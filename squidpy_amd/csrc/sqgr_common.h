@@ -61,6 +61,12 @@ struct sqgr_ctx {
     std::vector<int64_t> timer_count;
     std::vector<hipEvent_t> event_pool;
 
+    // small reusable device buffers for entry points that are called in tight host loops (Ripley: one call per cluster
+    // and per simulation): hipMalloc/hipFree per call cost more than the kernels.  Slot s holds at least the bytes last
+    // asked for; valid until the next request for the same slot.  Single stream, calls are synchronous: no aliasing.
+    std::vector<std::pair<void*, size_t>> scratch;
+    int scratch_get(int slot, size_t bytes, void** out);
+
     int timer_id(const char* name);
     int begin_launch(const char* name, sqgr::TimedLaunch* tl, hipStream_t st);
     int end_launch(const sqgr::TimedLaunch& tl);

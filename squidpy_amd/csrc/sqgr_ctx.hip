@@ -127,6 +127,26 @@ int sqgr_ctx_create(int device, sqgr_ctx** out_ctx) {
     return SQGR_OK;
 }
 
+int sqgr_ctx::scratch_get(int slot, size_t bytes, void** out) {
+    if ((size_t)slot >= scratch.size()) scratch.resize((size_t)slot + 1, {nullptr, 0});
+    auto& sc = scratch[(size_t)slot];
+    if (bytes == 0) bytes = 8;
+    if (sc.second < bytes) {
+        if (sc.first) (void)hipFree(sc.first);
+        sc = {nullptr, 0};
+        const size_t want = bytes + bytes / 4;  // head-room: point counts of successive calls vary a little
+        hipError_t e = hipMalloc(&sc.first, want);
+        if (e != hipSuccess) {
+            sc.first = nullptr;
+            sqgr::set_error("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+            return SQGR_ERR_NOMEM;
+        }
+        sc.second = want;
+    }
+    *out = sc.first;
+    return SQGR_OK;
+}
+
 int sqgr_ctx_destroy(sqgr_ctx* ctx) {
     if (!ctx) return SQGR_OK;
     (void)hipSetDevice(ctx->device);
@@ -137,6 +157,8 @@ int sqgr_ctx_destroy(sqgr_ctx* ctx) {
         (void)hipEventDestroy(tl.stop);
     }
     for (auto ev : ctx->event_pool) (void)hipEventDestroy(ev);
+    for (auto& sc : ctx->scratch)
+        if (sc.first) (void)hipFree(sc.first);
     (void)hipStreamDestroy(ctx->stream);
     (void)hipStreamDestroy(ctx->stream2);
     delete ctx;

@@ -76,6 +76,91 @@ __global__ __launch_bounds__(RP_TILE) void k_pair_hist(const double* __restrict_
     }
 }
 
+// Branch-free variant (same scheme as k_cooccur_fast): a lookup table over the metric value gives a lower bound g of the
+// bin with true bin <= g + 2; two compares against the adjacent thresholds finish it.  Full batches of off-diagonal
+// tiles with finite coordinates skip all validity tests (out-of-range pairs land in RP_TRASH write-only rows).
+constexpr int RP_BATCH = 8;
+constexpr int RP_TRASH = 3;
+constexpr int RP_CELLS_MIN = 1024;
+constexpr int RP_CELLS_MAX = 32768;
+
+template <int METRIC>
+__global__ __launch_bounds__(RP_TILE) void k_pair_hist_fast(const double* __restrict__ xs, const double* __restrict__ ys, int64_t m,
+                                                            const double* __restrict__ thr, int S, int T,
+                                                            const uint16_t* __restrict__ cell, int ncells, double inv_cell,
+                                                            int finite, unsigned long long* __restrict__ out) {
+    extern __shared__ unsigned char smem_raw[];
+    double* s_thr = reinterpret_cast<double*>(smem_raw);                       // [S + 2], two +inf sentinels
+    uint32_t* hist = reinterpret_cast<uint32_t*>(s_thr + S + 2);               // [S + RP_TRASH][256]
+    uint16_t* s_cell = reinterpret_cast<uint16_t*>(hist + (S + RP_TRASH) * RP_TILE);  // [ncells]
+    const int t = threadIdx.x;
+    const int ti = blockIdx.x;
+    const int tj0 = max(ti, (int)blockIdx.y * RP_CHUNK);
+    const int tj1 = min(T, ((int)blockIdx.y + 1) * RP_CHUNK);
+    if (tj0 >= tj1) return;
+    for (int i = t; i < S + 2; i += RP_TILE) s_thr[i] = i < S ? thr[i] : __builtin_inf();
+    for (int i = t; i < (S + RP_TRASH) * RP_TILE; i += RP_TILE) hist[i] = 0;
+    for (int i = t; i < ncells; i += RP_TILE) s_cell[i] = cell[i];
+    __syncthreads();
+    const int64_t gi = (int64_t)ti * RP_TILE + t;
+    const bool active = gi < m;
+    const double xi = active ? xs[gi] : 0.0, yi = active ? ys[gi] : 0.0;
+    const int cmax = ncells - 1;
+    uint32_t* my = hist + t;
+    for (int tj = tj0; tj < tj1; ++tj) {
+        const int64_t j0g = (int64_t)tj * RP_TILE;
+        const int vj = (int)min<int64_t>(RP_TILE, m - j0g);
+        const double* __restrict__ xj = xs + j0g;  // wave-uniform: scalar loads (arrays are padded to whole tiles)
+        const double* __restrict__ yj = ys + j0g;
+        const bool diag = (tj == ti);
+        const uint32_t w = diag ? 1u : 2u;  // a diagonal tile yields each ordered pair once, an off-diagonal tile pair twice
+        auto batch = [&](int j0, auto checked_tag) {
+            constexpr bool CHECKED = decltype(checked_tag)::value;
+            double d[RP_BATCH];
+            int g[RP_BATCH];
+#pragma unroll
+            for (int u = 0; u < RP_BATCH; ++u) {
+                d[u] = metric_dist<METRIC>(xi, yi, xj[j0 + u], yj[j0 + u]);
+                int cellv = (int)(d[u] * inv_cell);  // saturating conversion; NaN -> 0
+                if constexpr (CHECKED) cellv = max(cellv, 0);
+                g[u] = s_cell[min(cellv, cmax)];
+            }
+            double t0[RP_BATCH], t1[RP_BATCH];  // fetched before the first LDS atomic (reads cannot move across it)
+#pragma unroll
+            for (int u = 0; u < RP_BATCH; ++u) {
+                t0[u] = s_thr[g[u]];
+                t1[u] = s_thr[g[u] + 1];
+            }
+#pragma unroll
+            for (int u = 0; u < RP_BATCH; ++u) {
+                const int c0 = !(d[u] <= t0[u]), c1 = !(d[u] <= t1[u]);
+                const int gg = g[u] + c0 + c1;
+                if constexpr (CHECKED) {
+                    const bool ok = (gg < S) & (j0 + u < vj) & !(diag && j0 + u == t) & (d[u] == d[u]);
+                    atomicAdd(my + min(gg, S - 1) * RP_TILE, ok ? w : 0u);
+                } else {
+                    atomicAdd(my + gg * RP_TILE, w);
+                }
+            }
+        };
+        if (active) {
+            if (diag || !finite) {
+                for (int j0 = 0; j0 < vj; j0 += RP_BATCH) batch(j0, std::true_type{});
+            } else {
+                const int jfull = vj & ~(RP_BATCH - 1);
+                for (int j0 = 0; j0 < jfull; j0 += RP_BATCH) batch(j0, std::false_type{});
+                if (jfull < vj) batch(jfull, std::true_type{});
+            }
+        }
+    }
+    __syncthreads();
+    for (int g = t; g < S; g += RP_TILE) {
+        unsigned long long s = 0;
+        for (int k = 0; k < RP_TILE; ++k) s += hist[g * RP_TILE + ((k + t) & (RP_TILE - 1))];
+        if (s) atomicAdd(&out[g], s);
+    }
+}
+
 // k smallest metric distances (euclidean: squared) of every query to the reference set, ascending.
 template <int METRIC, int KMAX>
 __global__ __launch_bounds__(256) void k_knn(const double* __restrict__ qx, const double* __restrict__ qy, int64_t nq,
@@ -120,8 +205,9 @@ static int launch_knn(sqgr_ctx* ctx, const double* qx, const double* qy, int64_t
 }
 
 static int split_xy(const double* xy, int64_t m, std::vector<double>& x, std::vector<double>& y) {
-    x.resize((size_t)std::max<int64_t>(m, 1));
-    y.resize((size_t)std::max<int64_t>(m, 1));
+    const size_t padded = (size_t)ceil_div(std::max<int64_t>(m, 1), RP_TILE) * RP_TILE;  // whole tiles, zero padded
+    x.assign(padded, 0.0);
+    y.assign(padded, 0.0);
     for (int64_t i = 0; i < m; ++i) {
         x[i] = xy[2 * i];
         y[i] = xy[2 * i + 1];
@@ -150,20 +236,72 @@ int sqgr_pair_counts(sqgr_ctx* ctx, const double* xy, int64_t m, const double* t
     SQGR_HIP(hipSetDevice(ctx->device));
     std::vector<double> x, y;
     split_xy(xy, m, x, y);
-    DevBuf<double> dx, dy, dthr;
-    DevBuf<unsigned long long> dout;
-    SQGR_TRY(dx.alloc((size_t)m));
-    SQGR_TRY(dy.alloc((size_t)m));
-    SQGR_TRY(dthr.alloc((size_t)S));
-    SQGR_TRY(dout.alloc((size_t)S));
+    bool finite = true;
+    for (int64_t i = 0; i < 2 * m; ++i) finite = finite && std::isfinite(xy[i]);
+    const size_t mp = x.size();  // padded length
+    // lookup table over the metric value for the branch-free kernel: cell c -> lower bound of the bin of every value in it
+    double tmax = 0.0;
+    for (int s2 = 0; s2 < S; ++s2)
+        if (std::isfinite(thr[s2])) tmax = std::max(tmax, thr[s2]);
+    std::vector<uint16_t> cell;
+    int ncells = RP_CELLS_MIN;
+    double inv_cell = 0.0;
+    bool fast = false;
+    const size_t lds_fast_fixed = (size_t)(S + 2) * 8 + (size_t)(S + RP_TRASH) * RP_TILE * 4;
+    if (tmax > 0.0 && S < 65000) {
+        for (;; ncells *= 2) {
+            inv_cell = (double)ncells / tmax;
+            if (!std::isfinite(inv_cell) || lds_fast_fixed + (size_t)ncells * 2 > 160 * 1024) break;
+            cell.assign((size_t)ncells, 0);
+            int worst = 0;
+            for (int c = 0; c < ncells; ++c) {
+                // every value landing in cell c lies in [(c-1)/inv_cell, (c+2)/inv_cell): a full cell of slack on both sides
+                // absorbs the rounding of value * inv_cell
+                const double lo = (c >= 1) ? ((double)(c - 1) / inv_cell) * (1.0 - 1e-9) : -1.0;
+                const double hi = (c == ncells - 1) ? (double)INFINITY : ((double)(c + 2) / inv_cell) * (1.0 + 1e-9);
+                int g = 0;
+                while (g < S && thr[g] < lo) ++g;
+                int gh = g;
+                while (gh < S && thr[gh] < hi) ++gh;
+                cell[c] = (uint16_t)g;
+                worst = std::max(worst, gh - g);
+            }
+            if (worst <= 2) {
+                fast = true;
+                break;
+            }
+            if (ncells * 2 > RP_CELLS_MAX) break;
+        }
+    }
+    struct { double* p; } dx, dy, dthr;  // context scratch: this entry point runs once per cluster and per simulation
+    struct { unsigned long long* p; } dout;
+    struct { uint16_t* p; } dcell;
+    SQGR_TRY(ctx->scratch_get(0, mp * 8, reinterpret_cast<void**>(&dx.p)));
+    SQGR_TRY(ctx->scratch_get(1, mp * 8, reinterpret_cast<void**>(&dy.p)));
+    SQGR_TRY(ctx->scratch_get(4, (size_t)RP_CELLS_MAX * 2, reinterpret_cast<void**>(&dcell.p)));
+    SQGR_TRY(ctx->scratch_get(2, (size_t)S * 8, reinterpret_cast<void**>(&dthr.p)));
+    SQGR_TRY(ctx->scratch_get(3, (size_t)S * 8, reinterpret_cast<void**>(&dout.p)));
     hipStream_t st = ctx->stream;
-    SQGR_HIP(hipMemcpyAsync(dx.p, x.data(), (size_t)m * 8, hipMemcpyHostToDevice, st));
-    SQGR_HIP(hipMemcpyAsync(dy.p, y.data(), (size_t)m * 8, hipMemcpyHostToDevice, st));
+    SQGR_HIP(hipMemcpyAsync(dx.p, x.data(), mp * 8, hipMemcpyHostToDevice, st));
+    SQGR_HIP(hipMemcpyAsync(dy.p, y.data(), mp * 8, hipMemcpyHostToDevice, st));
     SQGR_HIP(hipMemcpyAsync(dthr.p, thr, (size_t)S * 8, hipMemcpyHostToDevice, st));
+    if (fast) SQGR_HIP(hipMemcpyAsync(dcell.p, cell.data(), (size_t)ncells * 2, hipMemcpyHostToDevice, st));
     SQGR_HIP(hipMemsetAsync(dout.p, 0, (size_t)S * 8, st));
     const int T = (int)ceil_div(m, RP_TILE);
     dim3 grid((unsigned)T, (unsigned)ceil_div(T, RP_CHUNK));
-    {
+    if (fast) {
+        LaunchTimer t(ctx, "ripley_pair_hist_fast");
+        const size_t lds_fast = lds_fast_fixed + (size_t)ncells * 2;
+#define SQGR_PHF(M)                                                                                                        \
+    do {                                                                                                                    \
+        if (lds_fast > 64 * 1024)                                                                                           \
+            SQGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_hist_fast<M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast)); \
+        k_pair_hist_fast<M><<<grid, RP_TILE, lds_fast, st>>>(dx.p, dy.p, m, dthr.p, S, T, dcell.p, ncells, inv_cell, finite ? 1 : 0, dout.p); \
+    } while (0)
+        if (metric == 0) SQGR_PHF(0); else if (metric == 1) SQGR_PHF(1); else SQGR_PHF(2);
+#undef SQGR_PHF
+        SQGR_HIP(hipGetLastError());
+    } else {
         LaunchTimer t(ctx, "ripley_pair_hist");
 #define SQGR_PH(M)                                                                                                         \
     do {                                                                                                                    \
@@ -201,12 +339,12 @@ int sqgr_knn_dist(sqgr_ctx* ctx, const double* query, int64_t nq, const double* 
     std::vector<double> qx, qy, rx, ry;
     split_xy(query, nq, qx, qy);
     split_xy(ref, nr, rx, ry);
-    DevBuf<double> dqx, dqy, drx, dry, dout;
-    SQGR_TRY(dqx.alloc((size_t)nq));
-    SQGR_TRY(dqy.alloc((size_t)nq));
-    SQGR_TRY(drx.alloc((size_t)nr));
-    SQGR_TRY(dry.alloc((size_t)nr));
-    SQGR_TRY(dout.alloc((size_t)nq * k));
+    struct { double* p; } dqx, dqy, drx, dry, dout;  // context scratch (see sqgr_pair_counts)
+    SQGR_TRY(ctx->scratch_get(0, (size_t)nq * 8, reinterpret_cast<void**>(&dqx.p)));
+    SQGR_TRY(ctx->scratch_get(1, (size_t)nq * 8, reinterpret_cast<void**>(&dqy.p)));
+    SQGR_TRY(ctx->scratch_get(2, (size_t)nr * 8, reinterpret_cast<void**>(&drx.p)));
+    SQGR_TRY(ctx->scratch_get(3, (size_t)nr * 8, reinterpret_cast<void**>(&dry.p)));
+    SQGR_TRY(ctx->scratch_get(4, (size_t)nq * k * 8, reinterpret_cast<void**>(&dout.p)));
     hipStream_t st = ctx->stream;
     SQGR_HIP(hipMemcpyAsync(dqx.p, qx.data(), (size_t)nq * 8, hipMemcpyHostToDevice, st));
     SQGR_HIP(hipMemcpyAsync(dqy.p, qy.data(), (size_t)nq * 8, hipMemcpyHostToDevice, st));
