@@ -172,8 +172,7 @@ __global__ __launch_bounds__(256) void k_knn(const double* __restrict__ qx, cons
     double best[KMAX];
 #pragma unroll
     for (int s = 0; s < KMAX; ++s) best[s] = __builtin_inf();
-    for (int64_t j = 0; j < nr; ++j) {
-        double d = metric_dist<METRIC>(xi, yi, rx[j], ry[j]);  // rx[j]: wave-uniform scalar load
+    auto offer = [&](double d) {
         if (d < best[KMAX - 1]) {
 #pragma unroll
             for (int s = 0; s < KMAX; ++s) {  // sorted insertion by compare-exchange down the register list
@@ -182,7 +181,19 @@ __global__ __launch_bounds__(256) void k_knn(const double* __restrict__ qx, cons
                 d = hi;
             }
         }
+    };
+    // references arrive through wave-uniform scalar loads; batches of 8 so that one s_load_dwordx16 pair feeds eight
+    // distance evaluations instead of one load (and one SMEM latency) per reference
+    constexpr int KB = 8;
+    const int64_t nr_full = nr & ~(int64_t)(KB - 1);
+    for (int64_t j = 0; j < nr_full; j += KB) {
+        double d[KB];
+#pragma unroll
+        for (int u = 0; u < KB; ++u) d[u] = metric_dist<METRIC>(xi, yi, rx[j + u], ry[j + u]);
+#pragma unroll
+        for (int u = 0; u < KB; ++u) offer(d[u]);
     }
+    for (int64_t j = nr_full; j < nr; ++j) offer(metric_dist<METRIC>(xi, yi, rx[j], ry[j]));
     if (active) {
 #pragma unroll
         for (int s = 0; s < KMAX; ++s)
