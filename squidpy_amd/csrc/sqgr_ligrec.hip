@@ -59,16 +59,18 @@ __global__ __launch_bounds__(64 * WAVES) void k_ligrec_sums(int G, int K, const 
         const double my_val = in ? vals[e0 + lane] : 0.0;
         const int my_lo = __double2loint(my_val), my_hi = __double2hiint(my_val);
         const int cnt = (int)((e_end - e0 < 64) ? e_end - e0 : 64);
-        const int cnt8 = (cnt + 7) & ~7;
-        for (int j0 = 0; j0 < cnt8; j0 += 8) {
-            uint32_t lab[8];
+        constexpr int GU = 16;  // label rows in flight per wave: the kernel runs at 8 waves per CU (LDS), latency is hidden
+                                // by memory-level parallelism inside the wave
+        const int cntu = (cnt + GU - 1) & ~(GU - 1);
+        for (int j0 = 0; j0 < cntu; j0 += GU) {
+            uint32_t lab[GU];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < GU; ++u) {
                 const int cell = __builtin_amdgcn_readlane(my_cell, j0 + u);
                 lab[u] = lab_lane[(int64_t)cell * lv.row_stride];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < GU; ++u) {
                 const double v = __hiloint2double(__builtin_amdgcn_readlane(my_hi, j0 + u), __builtin_amdgcn_readlane(my_lo, j0 + u));
                 // entries past `cnt` were padded with +0.0: the add is a no-op
                 __hip_atomic_fetch_add(&acc[lab[u] * 64 + lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
