@@ -297,7 +297,11 @@ __global__ __launch_bounds__(64) void k_pcg_shuffle_wave(int64_t n, int64_t row_
         uint32_t i = m - 1;
         uint32_t wlo = m;  // window = positions [wlo, i], empty at first
         while (i >= 1) {
-            asm volatile("" ::: "memory");  // LDS is shared by the lanes: nothing read in an earlier trip may be reused
+            // Lanes of this wave exchange data through LDS and through the row in global memory (a position stored by one
+            // lane in trip k is loaded by another lane in trip k+1).  A wavefront executes its memory instructions in
+            // order, so wavefront-scope ordering costs no instruction; the fence states the requirement and keeps the
+            // compiler from carrying values across trips.
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             if (wlo > 0u && i + 1u - wlo < PCGW_MIN_SPAN) {  // refill to capacity: positions [lo2, wlo)
                 const uint32_t lo2 = (i + 1u > WS) ? i + 1u - WS : 0u;
                 for (uint32_t q = lo2 + (uint32_t)lane; q < wlo; q += 64u) win[q & WM] = sub[q];
