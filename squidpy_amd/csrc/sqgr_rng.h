@@ -21,7 +21,10 @@ namespace sqgr {
 constexpr uint32_t PHILOX_M0 = 0xD2511F53u, PHILOX_M1 = 0xCD9E8D57u;
 constexpr uint32_t PHILOX_W0 = 0x9E3779B9u, PHILOX_W1 = 0xBB67AE85u;
 constexpr uint32_t FEISTEL_C1 = 0x88B5u, FEISTEL_C2 = 0xDB2Du;  // odd 16-bit multipliers of the round function
-constexpr int FEISTEL_ROUNDS = 8;
+#ifndef SQGR_FEISTEL_ROUNDS
+#define SQGR_FEISTEL_ROUNDS 8  // overridable only for the round-count study of tools/null_moments.py
+#endif
+constexpr int FEISTEL_ROUNDS = SQGR_FEISTEL_ROUNDS;
 
 __host__ __device__ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
 #pragma unroll
