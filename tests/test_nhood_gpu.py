@@ -360,3 +360,32 @@ def test_more_than_256_clusters_use_the_general_path(L, ctx):
     np.testing.assert_array_equal(res.zscore[ok], want[ok])
     res2 = sq.gr.nhood_enrichment(adata, "cluster", n_perms=12, seed=3, copy=True, rng="numpy")
     np.testing.assert_array_equal(res2.zscore[ok], want[ok])
+
+
+def test_null_distribution_matches_numpy_streams_at_high_power(L, ctx):
+    """The statistic the permutation test is about: mean and variance of every count cell under the device generator vs
+    under numpy's own shuffles, 30 000 permutations each on a 1e5-spot hex grid with 20 clusters (BASELINE config C2's
+    shape) — a bias of ~1 % of sigma in any of the 400 cells would fail (tools/null_moments.py runs the 2e5-permutation,
+    1e6-spot version)."""
+    from squidpy_amd._utils import pcg64_states
+
+    P, k = 30_000, 20
+    adj = O.hex_grid_graph(250, 400)
+    labels = np.random.default_rng(2).integers(0, k, adj.shape[0]).astype(np.int32)
+    g = L.Graph(ctx, adj, with_data=False)
+    plan = L.NhoodPlan(ctx, g, labels, k)
+    freq = np.bincount(labels, minlength=k) / adj.shape[0]
+    shift = np.rint(adj.nnz * np.outer(freq, freq)).astype(np.int64)
+
+    def moments(s1, s2):
+        mean = s1.astype(np.float64) / P
+        return mean, s2.astype(np.float64) / P - mean * mean
+
+    s1, s2, _ = plan.run(99, 0, P, shift)
+    m_dev, v_dev = moments(s1, s2)
+    s1, s2, _ = plan.run_pcg64(pcg64_states(3, P), shift)
+    m_np, v_np = moments(s1, s2)
+    z_mean = (m_dev - m_np) / np.sqrt((v_dev + v_np) / P)
+    z_var = (v_dev - v_np) / (0.5 * (v_dev + v_np) * np.sqrt(4.0 / P))
+    assert np.abs(z_mean).max() < 5.0 and np.abs(z_var).max() < 5.0, (np.abs(z_mean).max(), np.abs(z_var).max())
+    assert 0.7 < np.sqrt((z_mean**2).mean()) < 1.3 and 0.7 < np.sqrt((z_var**2).mean()) < 1.3
