@@ -150,6 +150,13 @@ int sqgr_autocorr_create(sqgr_ctx* ctx, const sqgr_graph* g, const double* vals,
  * transposes it (gr/_ppatterns.py:168) — so the host never has to materialise the transpose (a strided 8-byte gather,
  * ~0.1 GB/s in numpy: 13 s for 1e5 cells x 2048 genes).  Results are bit-identical to sqgr_autocorr_create. */
 int sqgr_autocorr_create_cm(sqgr_ctx* ctx, const sqgr_graph* g, const double* vals, int64_t G, sqgr_autocorr** out);
+/* The whole expression matrix resident on the device: x float64[n_rows][n_cols] row-major (`adata.X` as it lies in
+ * memory), uploaded once; feature blocks are then columns [col0, col0 + G) of it — no host-side slicing or transposing
+ * per block at all (gr/_ppatterns.py:154-185 builds `vals = adata[:, genes].X.T` on the host). */
+typedef struct sqgr_matrix sqgr_matrix;
+int sqgr_matrix_create(sqgr_ctx* ctx, const double* x, int64_t n_rows, int64_t n_cols, sqgr_matrix** out);
+int sqgr_matrix_destroy(sqgr_matrix* m);
+int sqgr_autocorr_create_cols(sqgr_ctx* ctx, const sqgr_graph* g, const sqgr_matrix* m, int64_t col0, int64_t G, sqgr_autocorr** out);
 int sqgr_autocorr_destroy(sqgr_autocorr* h);
 /* observed statistic: replaces `score = func(g, vals)` (gr/_ppatterns.py:216; scanpy.metrics.morans_i/gearys_c);
  * constant features -> NaN.  out_scores: float64[G]. */

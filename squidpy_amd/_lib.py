@@ -51,6 +51,9 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "sqgr_interaction_matrix": (C.c_int, [C.c_void_p, C.c_void_p, c_i32p, C.c_int32, C.c_int32, c_f64p]),
     "sqgr_autocorr_create": (C.c_int, [C.c_void_p, C.c_void_p, c_f64p, C.c_int64, C.POINTER(C.c_void_p)]),
     "sqgr_autocorr_create_cm": (C.c_int, [C.c_void_p, C.c_void_p, c_f64p, C.c_int64, C.POINTER(C.c_void_p)]),
+    "sqgr_matrix_create": (C.c_int, [C.c_void_p, c_f64p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p)]),
+    "sqgr_matrix_destroy": (C.c_int, [C.c_void_p]),
+    "sqgr_autocorr_create_cols": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p)]),
     "sqgr_autocorr_destroy": (C.c_int, [C.c_void_p]),
     "sqgr_autocorr_scores": (C.c_int, [C.c_void_p, C.c_int32, c_f64p]),
     "sqgr_autocorr_perms": (C.c_int, [C.c_void_p, C.c_int32, c_i32p, C.c_uint64, C.c_int64, C.c_int64, c_f64p]),
@@ -382,10 +385,44 @@ def cooccur_counts(
     return out
 
 
+class DeviceMatrix:
+    """A dense row-major float64 matrix resident on the device (``sqgr_matrix``): ``adata.X`` uploaded once."""
+
+    def __init__(self, ctx: Context, x: np.ndarray):
+        x = np.asarray(x)
+        if x.ndim != 2 or x.dtype != np.float64 or not x.flags.c_contiguous:
+            raise ValueError("DeviceMatrix needs a C-contiguous 2-D float64 array.")
+        self.ctx, self.shape = ctx, x.shape
+        h = C.c_void_p()
+        _check(ctx.lib, ctx.lib.sqgr_matrix_create(ctx.h, _ptr(x, c_f64p), x.shape[0], x.shape[1], C.byref(h)))
+        self.h = h
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.ctx.lib.sqgr_matrix_destroy(self.h)
+            self.h = None
+
+    def __del__(self) -> None:  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class AutocorrPlan:
     """Resident feature block for Moran's I / Geary's C (``sqgr_autocorr``).  ``vals``: (G, N) float64."""
 
     MODES = {"moran": 0, "geary": 1}
+
+    @classmethod
+    def from_columns(cls, ctx: Context, g: Graph, matrix: "DeviceMatrix", col0: int, n_features: int) -> "AutocorrPlan":
+        """Features = columns ``[col0, col0 + n_features)`` of a device-resident (cells x genes) matrix."""
+        self = cls.__new__(cls)
+        self.ctx, self.g, self.G = ctx, g, int(n_features)
+        h = C.c_void_p()
+        _check(ctx.lib, ctx.lib.sqgr_autocorr_create_cols(ctx.h, g.h, matrix.h, int(col0), int(n_features), C.byref(h)))
+        self.h = h
+        return self
 
     def __init__(self, ctx: Context, g: Graph, vals: np.ndarray):
         vals = np.asarray(vals, dtype=np.float64)

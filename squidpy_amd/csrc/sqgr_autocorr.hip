@@ -268,6 +268,12 @@ __global__ void k_scores(int mode, int64_t G, int64_t n, double W, const double*
 
 using namespace sqgr;
 
+struct sqgr_matrix {  // a dense row-major float64 matrix resident on the device (the expression matrix, uploaded once)
+    sqgr_ctx* ctx = nullptr;
+    int64_t n_rows = 0, n_cols = 0;
+    DevBuf<double> data;
+};
+
 struct sqgr_autocorr {
     sqgr_ctx* ctx = nullptr;
     const sqgr_graph* g = nullptr;
@@ -304,8 +310,11 @@ static int column_sum(sqgr_autocorr* h, int mode, const double* A, const double*
     return SQGR_OK;
 }
 
-static int autocorr_create(sqgr_ctx* ctx, const sqgr_graph* g, const double* vals, int64_t G, bool cell_major, sqgr_autocorr** out) {
-    SQGR_REQUIRE(ctx && g && vals && out, "null argument");
+// vals: host block (gene-major, or cell-major when `cell_major`), or NULL when the features are columns
+// [dev_col0, dev_col0 + G) of a matrix already resident on the device (dev_x[i * dev_ld + col])
+static int autocorr_create(sqgr_ctx* ctx, const sqgr_graph* g, const double* vals, int64_t G, bool cell_major, sqgr_autocorr** out,
+                           const double* dev_x = nullptr, int64_t dev_ld = 0, int64_t dev_col0 = 0) {
+    SQGR_REQUIRE(ctx && g && (vals || dev_x) && out, "null argument");
     *out = nullptr;
     SQGR_REQUIRE(g->ctx == ctx, "graph belongs to a different context");
     SQGR_REQUIRE(g->has_data, "graph was uploaded without edge weights");
@@ -335,14 +344,17 @@ static int autocorr_create(sqgr_ctx* ctx, const sqgr_graph* g, const double* val
     DevBuf<double> X, D;
     if ((rc = X.alloc((size_t)gc_max * n))) return fail(rc);
     hipError_t e = hipSuccess;
-    if (cell_major) {  // one contiguous upload of vals[n][G]; the gene blocks are cut out of it on the device
+    const double* cm_src = dev_x ? dev_x + dev_col0 : nullptr;  // cell-major source on the device and its row pitch
+    int64_t cm_ld = dev_x ? dev_ld : G;
+    if (cell_major && !dev_x) {  // one contiguous upload of vals[n][G]; the gene blocks are cut out of it on the device
         if ((rc = D.alloc((size_t)n * G))) return fail(rc);
         e = hipMemcpyAsync(D.p, vals, (size_t)n * G * 8, hipMemcpyHostToDevice, st);
+        cm_src = D.p;
     }
     for (int64_t g0 = 0; g0 < G && e == hipSuccess; g0 += gc_max) {
         const int gc = (int)std::min<int64_t>(gc_max, G - g0);
-        if (cell_major) {
-            k_cells_to_genes<<<dim3((unsigned)ceil_div(n, GT), (unsigned)ceil_div(gc, GT)), 256, 0, st>>>(D.p, G, n, g0, gc, X.p);
+        if (cm_src) {
+            k_cells_to_genes<<<dim3((unsigned)ceil_div(n, GT), (unsigned)ceil_div(gc, GT)), 256, 0, st>>>(cm_src, cm_ld, n, g0, gc, X.p);
             e = hipGetLastError();
         } else {
             e = hipMemcpyAsync(X.p, vals + (size_t)g0 * n, (size_t)gc * n * 8, hipMemcpyHostToDevice, st);
@@ -392,6 +404,46 @@ int sqgr_autocorr_create(sqgr_ctx* ctx, const sqgr_graph* g, const double* vals,
 
 int sqgr_autocorr_create_cm(sqgr_ctx* ctx, const sqgr_graph* g, const double* vals, int64_t G, sqgr_autocorr** out) {
     return autocorr_create(ctx, g, vals, G, true, out);
+}
+
+int sqgr_matrix_create(sqgr_ctx* ctx, const double* x, int64_t n_rows, int64_t n_cols, sqgr_matrix** out) {
+    SQGR_REQUIRE(ctx && x && out && n_rows > 0 && n_cols > 0, "null argument or empty matrix");
+    *out = nullptr;
+    SQGR_HIP(hipSetDevice(ctx->device));
+    sqgr_matrix* m = new sqgr_matrix();
+    m->ctx = ctx;
+    m->n_rows = n_rows;
+    m->n_cols = n_cols;
+    int rc = m->data.alloc((size_t)n_rows * n_cols);
+    if (rc != SQGR_OK) {
+        delete m;
+        return rc;
+    }
+    hipError_t e = hipMemcpyAsync(m->data.p, x, (size_t)n_rows * n_cols * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        set_error("matrix upload failed: %s", hipGetErrorString(e));
+        delete m;
+        return SQGR_ERR_HIP;
+    }
+    *out = m;
+    return SQGR_OK;
+}
+
+int sqgr_matrix_destroy(sqgr_matrix* m) {
+    if (!m) return SQGR_OK;
+    (void)hipSetDevice(m->ctx->device);
+    delete m;
+    return SQGR_OK;
+}
+
+int sqgr_autocorr_create_cols(sqgr_ctx* ctx, const sqgr_graph* g, const sqgr_matrix* m, int64_t col0, int64_t G, sqgr_autocorr** out) {
+    SQGR_REQUIRE(ctx && g && m && out, "null argument");
+    SQGR_REQUIRE(m->ctx == ctx, "matrix belongs to a different context");
+    SQGR_REQUIRE(m->n_rows == g->n, "matrix has %lld rows, the graph %lld", (long long)m->n_rows, (long long)g->n);
+    SQGR_REQUIRE(col0 >= 0 && G >= 1 && col0 + G <= m->n_cols, "columns [%lld, %lld) outside the matrix (%lld columns)", (long long)col0,
+                 (long long)(col0 + G), (long long)m->n_cols);
+    return autocorr_create(ctx, g, nullptr, G, true, out, m->data.p, m->n_cols, col0);
 }
 
 int sqgr_autocorr_destroy(sqgr_autocorr* h) {

@@ -17,7 +17,7 @@ import pandas as pd
 from scipy import sparse
 
 from .._constants import SpatialAutocorr
-from .._lib import AutocorrPlan, Graph, cooccur_counts, default_context
+from .._lib import AutocorrPlan, DeviceMatrix, Graph, cooccur_counts, default_context
 from .._stats import multipletests_pvals, p_value_calc
 from .._utils import (
     _assert_categorical_obs,
@@ -240,13 +240,23 @@ def spatial_autocorr(
     blocks = [(b0, min(n_feat, b0 + gene_block)) for b0 in range(0, n_feat, max(int(gene_block), 1))]
     score = np.full(n_feat, np.nan)
     sims = np.full((n_perms, n_feat), np.nan) if n_perms is not None else None
+    # `vals` is usually the transposed view of a cell-major array (`adata.X[:, genes].T`): upload that array once and take
+    # the feature blocks as its columns on the device — no slicing / transposing copy on the host per block
+    resident = None
+    base = vals.T if isinstance(vals, np.ndarray) and vals.ndim == 2 else None
+    if base is not None and base.dtype == np.float64 and base.flags.c_contiguous and n_feat > 1 and world == 1:
+        if base.nbytes <= ctx.device_info()["hbm_bytes"] // 4:
+            resident = DeviceMatrix(ctx, base)
     try:
         for bi, (b0, b1) in enumerate(blocks):
             if bi % world != rank:
                 continue
-            blk = vals[b0:b1]
-            blk = np.asarray(blk.toarray() if sparse.issparse(blk) else blk, dtype=np.float64)
-            plan = AutocorrPlan(ctx, graph, blk)
+            if resident is not None:
+                plan = AutocorrPlan.from_columns(ctx, graph, resident, b0, b1 - b0)
+            else:
+                blk = vals[b0:b1]
+                blk = np.asarray(blk.toarray() if sparse.issparse(blk) else blk, dtype=np.float64)
+                plan = AutocorrPlan(ctx, graph, blk)
             try:
                 score[b0:b1] = plan.scores(mode.s)
                 if n_perms is not None and states is not None:
@@ -256,6 +266,8 @@ def spatial_autocorr(
             finally:
                 plan.close()
     finally:
+        if resident is not None:
+            resident.close()
         graph.close()
     if world > 1:
         score = _merge_blocks(score, blocks, world, axis=0)
