@@ -461,8 +461,10 @@ __global__ __launch_bounds__(256) void k_rows_to_columns_u8(int64_t n, int64_t r
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int r = ty; r < 64; r += 4) tile[r][tx] = (q0 + r < P && e0 + tx < n) ? R[(q0 + r) * row_stride + e0 + tx] : (uint8_t)0;
     __syncthreads();
+    // columns P .. stride-1 of the last tile are written too (as label 0): consumers read whole batches of columns and
+    // must never see stale bytes there (a stale value >= K would index outside the count kernel's counters)
     for (int r = ty; r < 64; r += 4)
-        if (e0 + r < n && q0 + tx < P) W[(e0 + r) * stride + q0 + tx] = tile[tx][r];
+        if (e0 + r < n && q0 + tx < stride) W[(e0 + r) * stride + q0 + tx] = tile[tx][r];
 }
 
 // idx[p][i] = W[i][p]  (autocorr row permutations)
@@ -534,6 +536,9 @@ int pcg_shuffle_labels(sqgr_ctx* ctx, PcgWorkspace& ws, int64_t n, int n_libs, c
                        const uint64_t* states_dev, int64_t pc, int64_t stride, uint8_t* W, hipStream_t st, const char* timer_name) {
     LaunchTimer t(ctx, timer_name, st);
     if (pcg_lane_kernel()) {
+        const int64_t pc64 = std::min<int64_t>(stride, ceil_div(pc, 64) * 64);
+        if (pc64 > pc)  // columns past pc that whole-batch consumers still read: label 0 instead of stale bytes
+            SQGR_HIP(hipMemset2DAsync(W + pc, (size_t)stride, 0, (size_t)(pc64 - pc), (size_t)n, st));
         k_pcg_shuffle<uint8_t, false><<<(unsigned)ceil_div(pc, 64), 64, 0, st>>>(n, n_libs, lib_off_dev, base_pos_dev, states_dev, pc, stride, W);
         SQGR_HIP(hipGetLastError());
         return SQGR_OK;

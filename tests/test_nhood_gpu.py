@@ -389,3 +389,24 @@ def test_null_distribution_matches_numpy_streams_at_high_power(L, ctx):
     z_var = (v_dev - v_np) / (0.5 * (v_dev + v_np) * np.sqrt(4.0 / P))
     assert np.abs(z_mean).max() < 5.0 and np.abs(z_var).max() < 5.0, (np.abs(z_mean).max(), np.abs(z_var).max())
     assert 0.7 < np.sqrt((z_mean**2).mean()) < 1.3 and 0.7 < np.sqrt((z_var**2).mean()) < 1.3
+
+
+def test_numpy_streams_partial_last_batch_with_device_scope_counters(L, ctx):
+    """Regression (found by tools/fuzz_gpu.py): K = 203 counts through device-scope atomics straight into global memory;
+    with numpy streams the label columns past the last permutation of a partly filled batch must hold valid labels, or
+    the count kernel indexes outside its counters (a GPU memory fault, not a wrong number)."""
+    from squidpy_amd._utils import pcg64_states
+
+    rng = np.random.default_rng(1)
+    n, k, P = 255, 203, 38
+    A = sp.csr_matrix(sp.random(n, n, density=3.0 / n, format="csr", random_state=3))
+    A.data[:] = 1.0
+    labels = rng.integers(0, k, n).astype(np.int32)
+    g = L.Graph(ctx, A)
+    for tune in ((16, 0, 3), (16, 8, 1), (16, 0, 0)):
+        plan = L.NhoodPlan(ctx, g, labels, k)
+        plan.tune(*tune)
+        _, _, perms = plan.run_pcg64(pcg64_states(1, P), return_perms=True)
+        ref = O.nhood_perm_counts_numpy(A.indices, A.indptr, labels, k, 1, P)
+        np.testing.assert_array_equal(perms, ref.astype(np.uint32))
+        plan.close()
