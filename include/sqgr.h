@@ -113,6 +113,11 @@ int sqgr_nhood_run(sqgr_nhood* plan, uint64_t seed, int64_t perm_begin, int64_t 
  * float64 `perms.mean/std` (gr/_nhood.py:231) and obtain Squidpy's z-scores for that seed exactly. */
 int sqgr_nhood_run_pcg64(sqgr_nhood* plan, const uint64_t* pcg_states, int64_t n_perms, const int64_t* shift, int64_t* out_sum,
                          uint64_t* out_sumsq, uint32_t* out_perms);
+/* The numpy-stream test reduced the way the reference reduces it (gr/_nhood.py:231): out_mean / out_std float64[K*K] are
+ * `perms.mean(axis=0)` and `perms.std(axis=0)` of the (n_perms, K, K) float64 count array, bit for bit (sequential
+ * float64 accumulation in permutation order, as numpy does over a leading axis), so that
+ * `(count - mean) / std` is Squidpy's z-score for the seed — without moving the n_perms*K*K counts to the host. */
+int sqgr_nhood_run_pcg64_stats(sqgr_nhood* plan, const uint64_t* pcg_states, int64_t n_perms, double* out_mean, double* out_std);
 
 /* numpy's `Generator.permutation(n)` for n_perms generator states (layout as above), on the device:
  * out_idx int32[n_perms][n] — the row permutations of `_score_helper` (gr/_ppatterns.py:269-271). */

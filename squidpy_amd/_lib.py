@@ -45,6 +45,7 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "sqgr_nhood_destroy": (C.c_int, [C.c_void_p]),
     "sqgr_nhood_run": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, c_i64p, c_i64p, c_u64p, c_u32p]),
     "sqgr_nhood_run_pcg64": (C.c_int, [C.c_void_p, c_u64p, C.c_int64, c_i64p, c_i64p, c_u64p, c_u32p]),
+    "sqgr_nhood_run_pcg64_stats": (C.c_int, [C.c_void_p, c_u64p, C.c_int64, c_f64p, c_f64p]),
     "sqgr_pcg64_permutations": (C.c_int, [C.c_void_p, C.c_int64, c_u64p, C.c_int64, c_i32p]),
     "sqgr_nhood_shuffled_labels": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, c_u8p]),
     "sqgr_nhood_tune": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
@@ -337,6 +338,16 @@ class NhoodPlan:
             ),
         )
         return out_sum, out_sq, perms
+
+    def run_pcg64_stats(self, states: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+        """numpy's ``perms.mean(axis=0)`` / ``perms.std(axis=0)`` of the numpy-stream permutation counts, formed on the
+        device bit for bit (``sqgr_nhood_run_pcg64_stats``)."""
+        k = self.n_cls
+        states = _as(states, np.uint64).reshape(-1, 4)
+        mean = np.zeros((k, k), dtype=np.float64)
+        std = np.zeros((k, k), dtype=np.float64)
+        _check(self.ctx.lib, self.ctx.lib.sqgr_nhood_run_pcg64_stats(self.h, _ptr(states, c_u64p), states.shape[0], _ptr(mean, c_f64p), _ptr(std, c_f64p)))
+        return mean, std
 
     def shuffled_labels(self, seed: int, perm: int) -> np.ndarray:
         out = np.zeros(self.g.n, dtype=np.uint8)

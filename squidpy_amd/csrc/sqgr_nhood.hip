@@ -412,6 +412,27 @@ __global__ __launch_bounds__(256) void k_columns_to_slab(int64_t n, int64_t stri
     for (int v = 0; v < B / 16; ++v) dst[v] = src[v];
 }
 
+// numpy's float64 `perms.mean(axis=0)` and `perms.std(axis=0)` of the (P, K, K) count array, bit for bit: a reduction over
+// the first axis of a C-contiguous array is a plain sequential accumulation per cell (one rounded add per permutation,
+// in permutation order) — `mean = sum / P`, then `sum((x - mean)**2) / P` accumulated the same way, then sqrt.  One
+// thread per cell walks the permutations in order; every operation is individually rounded (-ffp-contract=off).
+__global__ __launch_bounds__(64) void k_numpy_mean_std(const uint32_t* __restrict__ perms, int64_t P, int K2,
+                                                       double* __restrict__ mean, double* __restrict__ stdev) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= K2) return;
+    const uint32_t* col = perms + c;
+    double acc = 0.0;
+    for (int64_t q = 0; q < P; ++q) acc += (double)col[(size_t)q * K2];
+    const double m = acc / (double)P;
+    double acc2 = 0.0;
+    for (int64_t q = 0; q < P; ++q) {
+        const double d = (double)col[(size_t)q * K2] - m;
+        acc2 += d * d;
+    }
+    mean[c] = m;
+    stdev[c] = sqrt(acc2 / (double)P);
+}
+
 }  // namespace sqgr
 
 using namespace sqgr;
@@ -997,14 +1018,16 @@ int sqgr_nhood_counts_batch(sqgr_ctx* ctx, const sqgr_graph* g, const uint8_t* l
     return rc;
 }
 
-int sqgr_nhood_run_pcg64(sqgr_nhood* plan, const uint64_t* pcg_states, int64_t n_perms, const int64_t* shift, int64_t* out_sum,
-                         uint64_t* out_sumsq, uint32_t* out_perms) {
+// keep_perms: the per-permutation counts stay in plan->perms_dev (copied to out_perms when that is not NULL)
+static int run_pcg64_impl(sqgr_nhood* plan, const uint64_t* pcg_states, int64_t n_perms, const int64_t* shift, int64_t* out_sum,
+                          uint64_t* out_sumsq, uint32_t* out_perms, bool keep_perms) {
     SQGR_REQUIRE(plan && pcg_states && out_sum && out_sumsq && n_perms >= 0, "null argument or n_perms < 0");
     sqgr_nhood* p = plan;
+    keep_perms = keep_perms || out_perms != nullptr;
     SQGR_REQUIRE(p->has_labels, "plan was created without labels");
     sqgr_ctx* ctx = p->ctx;
     SQGR_HIP(hipSetDevice(ctx->device));
-    SQGR_TRY(p->ensure_workspace(out_perms != nullptr));
+    SQGR_TRY(p->ensure_workspace(keep_perms));
     hipStream_t st = ctx->stream;
     const int B = p->B, K2 = p->K2, hw = p->hist_words();
     const int64_t n = p->n;
@@ -1014,7 +1037,7 @@ int sqgr_nhood_run_pcg64(sqgr_nhood* plan, const uint64_t* pcg_states, int64_t n
         SQGR_HIP(hipMemsetAsync(p->shift.p, 0, (size_t)K2 * 8, st));
     SQGR_HIP(hipMemsetAsync(p->acc_sum.p, 0, (size_t)p->nbatch * hw * 8, st));
     SQGR_HIP(hipMemsetAsync(p->acc_sq.p, 0, (size_t)p->nbatch * hw * 8, st));
-    if (out_perms && n_perms > 0) SQGR_TRY(p->perms_dev.ensure((size_t)n_perms * K2));
+    if (keep_perms && n_perms > 0) SQGR_TRY(p->perms_dev.ensure((size_t)n_perms * K2));
     // permutations per chunk: one thread each; the column matrix takes n bytes per permutation (<= 25 % of free HBM)
     size_t free_b = 0, total_b = 0;
     SQGR_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -1044,7 +1067,7 @@ int sqgr_nhood_run_pcg64(sqgr_nhood* plan, const uint64_t* pcg_states, int64_t n
             }
             SQGR_TRY(p->count_batches(nb, 0));
             // columns past `pc` of the last batch hold stale data: reduce masks permutations >= n_perms
-            SQGR_TRY(p->reduce_batches(nb, c0 + q0, 0, c0 + pc, out_perms ? p->perms_dev.p : nullptr));
+            SQGR_TRY(p->reduce_batches(nb, c0 + q0, 0, c0 + pc, keep_perms ? p->perms_dev.p : nullptr));
         }
     }
     {
@@ -1057,6 +1080,33 @@ int sqgr_nhood_run_pcg64(sqgr_nhood* plan, const uint64_t* pcg_states, int64_t n
     SQGR_HIP(hipMemcpyAsync(out_sumsq, p->fin_sq.p, (size_t)K2 * 8, hipMemcpyDeviceToHost, st));
     if (out_perms && n_perms > 0)
         SQGR_HIP(hipMemcpyAsync(out_perms, p->perms_dev.p, (size_t)n_perms * K2 * 4, hipMemcpyDeviceToHost, st));
+    SQGR_HIP(hipStreamSynchronize(st));
+    return SQGR_OK;
+}
+
+int sqgr_nhood_run_pcg64(sqgr_nhood* plan, const uint64_t* pcg_states, int64_t n_perms, const int64_t* shift, int64_t* out_sum,
+                         uint64_t* out_sumsq, uint32_t* out_perms) {
+    return run_pcg64_impl(plan, pcg_states, n_perms, shift, out_sum, out_sumsq, out_perms, false);
+}
+
+int sqgr_nhood_run_pcg64_stats(sqgr_nhood* plan, const uint64_t* pcg_states, int64_t n_perms, double* out_mean, double* out_std) {
+    SQGR_REQUIRE(plan && out_mean && out_std && n_perms >= 1, "null argument or n_perms < 1");
+    const int K2 = plan->K2;
+    std::vector<int64_t> s1((size_t)K2);
+    std::vector<uint64_t> s2((size_t)K2);
+    SQGR_TRY(run_pcg64_impl(plan, pcg_states, n_perms, nullptr, s1.data(), s2.data(), nullptr, true));
+    sqgr_ctx* ctx = plan->ctx;
+    hipStream_t st = ctx->stream;
+    DevBuf<double> d_mean, d_std;
+    SQGR_TRY(d_mean.alloc((size_t)K2));
+    SQGR_TRY(d_std.alloc((size_t)K2));
+    {
+        LaunchTimer t(ctx, "nhood_numpy_mean_std");
+        k_numpy_mean_std<<<(unsigned)ceil_div(K2, 64), 64, 0, st>>>(plan->perms_dev.p, n_perms, K2, d_mean.p, d_std.p);
+        SQGR_HIP(hipGetLastError());
+    }
+    SQGR_HIP(hipMemcpyAsync(out_mean, d_mean.p, (size_t)K2 * 8, hipMemcpyDeviceToHost, st));
+    SQGR_HIP(hipMemcpyAsync(out_std, d_std.p, (size_t)K2 * 8, hipMemcpyDeviceToHost, st));
     SQGR_HIP(hipStreamSynchronize(st));
     return SQGR_OK;
 }

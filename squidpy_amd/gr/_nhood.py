@@ -139,12 +139,18 @@ def nhood_enrichment(
                 seed = _broadcast_seed(resolve_seed(None))
             plan = NhoodPlan(ctx, graph, int_clust, n_cls, lib_codes, n_libs)
             try:
-                _, _, perms = plan.run_pcg64(pcg64_states(seed, n_perms, lo, hi), return_perms=True)
+                if world == 1:  # the float64 mean/std of gr/_nhood.py:231 formed on the device, bit for bit
+                    mean, std = plan.run_pcg64_stats(pcg64_states(seed, n_perms))
+                    perms = None
+                else:
+                    _, _, perms = plan.run_pcg64(pcg64_states(seed, n_perms, lo, hi), return_perms=True)
             finally:
                 plan.close()
-            perms = np.concatenate(_dist.allgather_object(perms), axis=0).astype(np.float64)
+            if perms is not None:  # several ranks: the sequential float64 reduction needs all counts in permutation order
+                perms = np.concatenate(_dist.allgather_object(perms), axis=0).astype(np.float64)
+                mean, std = perms.mean(axis=0), perms.std(axis=0)
             with np.errstate(divide="ignore", invalid="ignore"):
-                zscore = (count - perms.mean(axis=0)) / perms.std(axis=0)  # gr/_nhood.py:231 verbatim
+                zscore = (count - mean) / std  # gr/_nhood.py:231
         else:
             rank, world = _dist.world()
             lo, hi = _dist.shard_range(n_perms, rank, world)
