@@ -196,6 +196,15 @@ int sqgr_pair_counts(sqgr_ctx* ctx, const double* xy, int64_t m, const double* t
  * 163-169): out float64[nq][k] ascending; for metric 0 the SQUARED distances (caller applies sqrt). 1 <= k <= 16. */
 int sqgr_knn_dist(sqgr_ctx* ctx, const double* query, int64_t nq, const double* ref, int64_t nr, int32_t k, int32_t metric,
                   double* out);
+/* Ripley's G keeps its (large) query set on the device: sqgr_points holds coordinates (+ an int32 label per point);
+ * sqgr_knn_hist finds, for every query point whose label differs from `exclude_label` (-1: all points), the k nearest of
+ * the `ref` points and returns `np.histogram(distances, bins=edges)[0]` (int64[S-1]) of all those distances — what
+ * gr/_ripley.py:163-169 + `_f_g_function` :206-209 compute with sklearn and numpy, without moving the distances. */
+typedef struct sqgr_points sqgr_points;
+int sqgr_points_create(sqgr_ctx* ctx, const double* xy, const int32_t* labels, int64_t n, sqgr_points** out);
+int sqgr_points_destroy(sqgr_points* p);
+int sqgr_knn_hist(sqgr_ctx* ctx, const sqgr_points* queries, int32_t exclude_label, const double* ref, int64_t nr, int32_t k,
+                  int32_t metric, const double* edges, int32_t S, int64_t* out_counts);
 
 /* ------------------------------------------------------------------ spatial graph construction
  * Exact 2-D neighbour search on a device cell list; xy: float64[n][2].

@@ -62,6 +62,9 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "sqgr_autocorr_perm_indices": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_int64, C.c_int64, c_i32p]),
     "sqgr_pair_counts": (C.c_int, [C.c_void_p, c_f64p, C.c_int64, c_f64p, C.c_int32, C.c_int32, c_i64p]),
     "sqgr_knn_dist": (C.c_int, [C.c_void_p, c_f64p, C.c_int64, c_f64p, C.c_int64, C.c_int32, C.c_int32, c_f64p]),
+    "sqgr_points_create": (C.c_int, [C.c_void_p, c_f64p, c_i32p, C.c_int64, C.POINTER(C.c_void_p)]),
+    "sqgr_points_destroy": (C.c_int, [C.c_void_p]),
+    "sqgr_knn_hist": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, c_f64p, C.c_int64, C.c_int32, C.c_int32, c_f64p, C.c_int32, c_i64p]),
     "sqgr_knn_self": (C.c_int, [C.c_void_p, c_f64p, C.c_int64, C.c_int32, c_i32p, c_f64p]),
     "sqgr_radius_self": (C.c_int, [C.c_void_p, c_f64p, C.c_int64, C.c_double, c_i64p, c_i32p, c_f64p, C.c_int64]),
     "sqgr_ligrec_counts": (
@@ -650,3 +653,43 @@ def ligrec_counts(
         ),
     )
     return (out, groups) if return_first_groups else out
+
+
+class DevicePoints:
+    """A 2-D point set (and an optional integer label per point) resident on the device (``sqgr_points``)."""
+
+    def __init__(self, ctx: Context, xy: np.ndarray, labels: np.ndarray | None = None):
+        xy = _as(xy, np.float64)
+        if xy.ndim != 2 or xy.shape[1] != 2:
+            raise ValueError(f"Expected 2-D coordinates of shape (n, 2), found {xy.shape}.")
+        lab = _as(labels, np.int32) if labels is not None else None
+        if lab is not None and lab.shape != (xy.shape[0],):
+            raise ValueError("`labels` must hold one entry per point.")
+        self.ctx, self.n = ctx, xy.shape[0]
+        h = C.c_void_p()
+        _check(ctx.lib, ctx.lib.sqgr_points_create(ctx.h, _ptr(xy, c_f64p), _ptr(lab, c_i32p), self.n, C.byref(h)))
+        self.h = h
+
+    def knn_hist(self, refs: np.ndarray, k: int, edges: np.ndarray, metric: str = "euclidean", exclude_label: int = -1) -> np.ndarray:
+        """``np.histogram(kneighbors(queries, k) distances, bins=edges)[0]`` for the resident points (those whose label is
+        not ``exclude_label``) against ``refs``; int64 (len(edges) - 1,)."""
+        refs = _as(refs, np.float64)
+        edges = _as(edges, np.float64)
+        out = np.zeros(len(edges) - 1, dtype=np.int64)
+        _check(
+            self.ctx.lib,
+            self.ctx.lib.sqgr_knn_hist(self.ctx.h, self.h, int(exclude_label), _ptr(refs, c_f64p), refs.shape[0], int(k), METRICS[metric],
+                                       _ptr(edges, c_f64p), len(edges), _ptr(out, c_i64p)),
+        )
+        return out
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.ctx.lib.sqgr_points_destroy(self.h)
+            self.h = None
+
+    def __del__(self) -> None:  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -201,6 +201,69 @@ __global__ __launch_bounds__(256) void k_knn(const double* __restrict__ qx, cons
     }
 }
 
+// The same sweep for query points that stay on the device, followed by numpy's histogram of the k distances
+// (`np.histogram(d, bins=edges)`: bin i counts edges[i] <= d < edges[i+1], the last bin also d == edges[S-1]; values
+// outside [edges[0], edges[S-1]] and NaN are dropped).  Queries whose label equals `exclude` do not take part (Ripley's G:
+// every point NOT in the cluster against the cluster's points, gr/_ripley.py:163-169).
+template <int METRIC, int KMAX>
+__global__ __launch_bounds__(256) void k_knn_hist(const double* __restrict__ qx, const double* __restrict__ qy,
+                                                  const int32_t* __restrict__ qlabel, int exclude, int64_t nq,
+                                                  const double* __restrict__ rx, const double* __restrict__ ry, int64_t nr, int k,
+                                                  const double* __restrict__ edges, int S, unsigned long long* __restrict__ out) {
+    extern __shared__ unsigned char knn_smem[];
+    double* s_edges = reinterpret_cast<double*>(knn_smem);             // [S]
+    uint32_t* s_hist = reinterpret_cast<uint32_t*>(s_edges + S);       // [S - 1]
+    for (int i = threadIdx.x; i < S; i += 256) s_edges[i] = edges[i];
+    for (int i = threadIdx.x; i < S - 1; i += 256) s_hist[i] = 0;
+    __syncthreads();
+    const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const bool active = q < nq && (exclude < 0 || qlabel[q] != exclude);
+    const double xi = active ? qx[q] : 0.0, yi = active ? qy[q] : 0.0;
+    double best[KMAX];
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) best[s] = __builtin_inf();
+    auto offer = [&](double d) {
+        if (d < best[KMAX - 1]) {
+#pragma unroll
+            for (int s = 0; s < KMAX; ++s) {
+                const double lo = fmin(best[s], d), hi = fmax(best[s], d);
+                best[s] = lo;
+                d = hi;
+            }
+        }
+    };
+    constexpr int KB = 8;
+    const int64_t nr_full = nr & ~(int64_t)(KB - 1);
+    for (int64_t j = 0; j < nr_full; j += KB) {
+        double d[KB];
+#pragma unroll
+        for (int u = 0; u < KB; ++u) d[u] = metric_dist<METRIC>(xi, yi, rx[j + u], ry[j + u]);
+#pragma unroll
+        for (int u = 0; u < KB; ++u) offer(d[u]);
+    }
+    for (int64_t j = nr_full; j < nr; ++j) offer(metric_dist<METRIC>(xi, yi, rx[j], ry[j]));
+    if (active) {
+        const double e_first = s_edges[0], e_last = s_edges[S - 1];
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s) {
+            if (s < k) {
+                const double v = (METRIC == 0) ? __dsqrt_rn(best[s]) : best[s];  // euclidean keeps squared distances
+                if (v >= e_first && v <= e_last) {   // false for NaN
+                    int lo = 0, hi = S - 1;          // largest i in [0, S-2] with edges[i] <= v (v == e_last -> S-2)
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (s_edges[mid] <= v) lo = mid; else hi = mid;
+                    }
+                    atomicAdd(&s_hist[lo], 1u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < S - 1; i += 256)
+        if (s_hist[i]) atomicAdd(&out[i], (unsigned long long)s_hist[i]);
+}
+
 template <int METRIC>
 static int launch_knn(sqgr_ctx* ctx, const double* qx, const double* qy, int64_t nq, const double* rx, const double* ry, int64_t nr,
                       int k, double* out) {
@@ -229,6 +292,14 @@ static int split_xy(const double* xy, int64_t m, std::vector<double>& x, std::ve
 }  // namespace sqgr
 
 using namespace sqgr;
+
+struct sqgr_points {  // a point set resident on the device (coordinates split into x / y, optional integer label per point)
+    sqgr_ctx* ctx = nullptr;
+    int64_t n = 0;
+    bool has_label = false;
+    DevBuf<double> x, y;
+    DevBuf<int32_t> label;
+};
 
 extern "C" {
 
@@ -369,6 +440,92 @@ int sqgr_knn_dist(sqgr_ctx* ctx, const double* query, int64_t nq, const double* 
     }
     SQGR_HIP(hipMemcpyAsync(out, dout.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
     SQGR_HIP(hipStreamSynchronize(st));
+    return SQGR_OK;
+}
+
+int sqgr_points_create(sqgr_ctx* ctx, const double* xy, const int32_t* labels, int64_t n, sqgr_points** out) {
+    SQGR_REQUIRE(ctx && xy && out && n > 0, "null argument or n <= 0");
+    *out = nullptr;
+    SQGR_HIP(hipSetDevice(ctx->device));
+    sqgr_points* p = new sqgr_points();
+    p->ctx = ctx;
+    p->n = n;
+    p->has_label = labels != nullptr;
+    std::vector<double> x, y;
+    split_xy(xy, n, x, y);
+    int rc = SQGR_OK;
+    if ((rc = p->x.alloc((size_t)n)) || (rc = p->y.alloc((size_t)n)) || (rc = p->label.alloc((size_t)n))) {
+        delete p;
+        return rc;
+    }
+    hipError_t e = hipMemcpy(p->x.p, x.data(), (size_t)n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p->y.p, y.data(), (size_t)n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess && labels) e = hipMemcpy(p->label.p, labels, (size_t)n * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        set_error("point upload failed: %s", hipGetErrorString(e));
+        delete p;
+        return SQGR_ERR_HIP;
+    }
+    *out = p;
+    return SQGR_OK;
+}
+
+int sqgr_points_destroy(sqgr_points* p) {
+    if (!p) return SQGR_OK;
+    (void)hipSetDevice(p->ctx->device);
+    delete p;
+    return SQGR_OK;
+}
+
+int sqgr_knn_hist(sqgr_ctx* ctx, const sqgr_points* queries, int32_t exclude_label, const double* ref, int64_t nr, int32_t k,
+                  int32_t metric, const double* edges, int32_t S, int64_t* out_counts) {
+    SQGR_REQUIRE(ctx && queries && ref && edges && out_counts, "null argument");
+    SQGR_REQUIRE(queries->ctx == ctx, "points belong to a different context");
+    SQGR_REQUIRE(S >= 2 && S <= 8192 && metric >= 0 && metric <= 2, "bad argument S=%d metric=%d", S, metric);
+    SQGR_REQUIRE(exclude_label < 0 || queries->has_label, "points were created without labels");
+    SQGR_REQUIRE(k >= 1 && k <= nr, "Expected n_neighbors <= n_samples_fit, but n_neighbors = %d, n_samples_fit = %lld, n_samples = %lld", k,
+                 (long long)nr, (long long)queries->n);
+    for (int s2 = 1; s2 < S; ++s2) SQGR_REQUIRE(edges[s2 - 1] <= edges[s2], "bin edges must be ascending");
+    if (k > 16) {
+        set_error("n_neighbors=%d > 16 is not supported by the register-resident kNN sweep", k);
+        return SQGR_ERR_UNSUPPORTED;
+    }
+    SQGR_HIP(hipSetDevice(ctx->device));
+    std::vector<double> rx, ry;
+    split_xy(ref, nr, rx, ry);
+    struct { double* p; } drx, dry, dedges;
+    struct { unsigned long long* p; } dout;
+    SQGR_TRY(ctx->scratch_get(0, (size_t)nr * 8, reinterpret_cast<void**>(&drx.p)));
+    SQGR_TRY(ctx->scratch_get(1, (size_t)nr * 8, reinterpret_cast<void**>(&dry.p)));
+    SQGR_TRY(ctx->scratch_get(2, (size_t)S * 8, reinterpret_cast<void**>(&dedges.p)));
+    SQGR_TRY(ctx->scratch_get(3, (size_t)S * 8, reinterpret_cast<void**>(&dout.p)));
+    hipStream_t st = ctx->stream;
+    SQGR_HIP(hipMemcpyAsync(drx.p, rx.data(), (size_t)nr * 8, hipMemcpyHostToDevice, st));
+    SQGR_HIP(hipMemcpyAsync(dry.p, ry.data(), (size_t)nr * 8, hipMemcpyHostToDevice, st));
+    SQGR_HIP(hipMemcpyAsync(dedges.p, edges, (size_t)S * 8, hipMemcpyHostToDevice, st));
+    SQGR_HIP(hipMemsetAsync(dout.p, 0, (size_t)S * 8, st));
+    {
+        LaunchTimer t(ctx, "ripley_knn_hist");
+        const unsigned grid = (unsigned)ceil_div(queries->n, 256);
+        const size_t lds = (size_t)S * 8 + (size_t)S * 4;
+#define SQGR_KH(M, KM) k_knn_hist<M, KM><<<grid, 256, lds, st>>>(queries->x.p, queries->y.p, queries->label.p, exclude_label, queries->n, drx.p, dry.p, nr, k, dedges.p, S, dout.p)
+#define SQGR_KHM(M)                                \
+    do {                                           \
+        if (k <= 1) SQGR_KH(M, 1);                 \
+        else if (k <= 2) SQGR_KH(M, 2);            \
+        else if (k <= 4) SQGR_KH(M, 4);            \
+        else if (k <= 8) SQGR_KH(M, 8);            \
+        else SQGR_KH(M, 16);                       \
+    } while (0)
+        if (metric == 0) SQGR_KHM(0); else if (metric == 1) SQGR_KHM(1); else SQGR_KHM(2);
+#undef SQGR_KHM
+#undef SQGR_KH
+        SQGR_HIP(hipGetLastError());
+    }
+    std::vector<unsigned long long> h((size_t)S);
+    SQGR_HIP(hipMemcpyAsync(h.data(), dout.p, (size_t)(S - 1) * 8, hipMemcpyDeviceToHost, st));
+    SQGR_HIP(hipStreamSynchronize(st));
+    for (int s2 = 0; s2 < S - 1; ++s2) out_counts[s2] = (int64_t)h[s2];
     return SQGR_OK;
 }
 

@@ -12,7 +12,7 @@ import numpy as np
 import pandas as pd
 
 from .._constants import Key, RipleyStat
-from .._lib import METRICS, Context, default_context, knn_dist, pair_counts
+from .._lib import METRICS, Context, DevicePoints, default_context, knn_dist, pair_counts
 from .._utils import _assert_categorical_obs, _assert_spatial_basis, _save_data, extract_adata_if_sdata, spawn_generators
 
 __all__ = ["ripley"]
@@ -103,6 +103,14 @@ class _Engine:
         dist = knn_dist(self.ctx, queries, refs, k, self.metric)
         return _f_g_function(dist.squeeze(), self.support)[1]
 
+    def nn_stat_resident(self, queries: DevicePoints, refs: np.ndarray, k: int, exclude_label: int = -1) -> np.ndarray:
+        """The same statistic with the query set resident on the device and the histogram of `_f_g_function` formed
+        there (Ripley's G queries ~all points per cluster and per simulation)."""
+        counts = queries.knn_hist(refs, k, self.support, self.metric, exclude_label)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            fracs = np.cumsum(counts) / counts.sum()
+        return np.concatenate((np.zeros((1,), dtype=float), fracs))
+
 
 def _tail_pvalues(obs: np.ndarray, sims: np.ndarray) -> np.ndarray:
     """gr/_ripley.py:175-180: ``(1 + #{sim >= obs}) / (n_sim + 1)`` folded to the smaller tail."""
@@ -162,12 +170,13 @@ def ripley(
     # observed statistic per cluster (F: each cluster is probed with its own Poisson pattern drawn from `first_rng`)
     observed = np.empty((n_groups, n_steps))
     probe = None
+    everyone = DevicePoints(engine.ctx, xy64, codes) if stat == RipleyStat.G else None  # G queries (nearly) all points
     for gidx in range(int(codes.max()) + 1):
         members = xy64[codes == gidx]
         if stat == RipleyStat.L:
             observed[gidx] = engine.l_stat(members)
         elif stat == RipleyStat.G:
-            observed[gidx] = engine.nn_stat(xy64[codes != gidx], members, n_neigh)
+            observed[gidx] = engine.nn_stat_resident(everyone, members, n_neigh, exclude_label=gidx)
         else:
             probe = _ppp(hull, n_simulations=1, n_observations=n_observations, rng=first_rng)
             observed[gidx] = engine.nn_stat(probe, members, n_neigh)
@@ -179,10 +188,12 @@ def ripley(
         if stat == RipleyStat.L:
             simulated[s_idx] = engine.l_stat(pattern)
         elif stat == RipleyStat.G:
-            simulated[s_idx] = engine.nn_stat(xy64, pattern, 1)
+            simulated[s_idx] = engine.nn_stat_resident(everyone, pattern, 1)
         else:  # the reference reuses the probe pattern of the LAST cluster here (gr/_ripley.py:163-165)
             simulated[s_idx] = engine.nn_stat(probe, pattern, 1)
 
+    if everyone is not None:
+        everyone.close()
     res = {
         f"{stat}_stat": _reshape_res(observed.T, columns=encoder.classes_, index=support, var_name=cluster_key),
         "sims_stat": _reshape_res(simulated.T, columns=np.arange(n_simulations), index=support, var_name="simulations"),

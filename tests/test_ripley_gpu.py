@@ -110,3 +110,27 @@ def test_ripley_structure_ported_from_reference_tests(L):
         sq.gr.ripley(adata, "cl", mode="Z")
     res = sq.gr.ripley(adata, "cl", mode="G", metric="manhattan", n_simulations=3, n_observations=50, n_steps=7, seed=0, copy=True, max_dist=100.0)
     assert res["bins"][-1] == 100.0
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "manhattan", "chebyshev"])
+def test_resident_knn_histogram_equals_numpy_histogram(metric):
+    """`DevicePoints.knn_hist` == np.histogram(knn distances, bins=edges)[0]: lattice coordinates put many distances
+    exactly on bin edges (the last edge is inclusive, everything outside the edges is dropped), one label is excluded."""
+    from squidpy_amd import _lib as L
+
+    ctx = L.default_context()
+    rng = np.random.default_rng(4)
+    q = np.round(rng.random((3000, 2)) * 40)            # integer lattice: exact ties with integer edges
+    lab = rng.integers(0, 4, len(q)).astype(np.int32)
+    refs = np.round(rng.random((500, 2)) * 40)
+    pts = L.DevicePoints(ctx, q, lab)
+    dropped = []
+    for k, edges, excl in ((1, np.arange(0.0, 6.0), -1), (2, np.linspace(1.0, 9.0, 17), 2), (3, np.array([0.0, 0.5, 0.5, 2.0, 7.0]), 0)):
+        got = pts.knn_hist(refs, k, edges, metric, exclude_label=excl)
+        keep = np.ones(len(q), bool) if excl < 0 else lab != excl
+        dist = L.knn_dist(ctx, q[keep], refs, k, metric)
+        want = np.histogram(dist.ravel(), bins=edges)[0]
+        np.testing.assert_array_equal(got, want)
+        dropped.append(int(dist.size - got.sum()))
+    assert max(dropped) > 0  # at least one setting has distances outside its edges
+    pts.close()
