@@ -4,7 +4,10 @@ CPU (numpy) restatement of the *device* permutation generator used by the HIP pa
 ``rng="philox"`` (``squidpy_amd/csrc/sqgr_rng.h``): Philox4x32-10 derives eight 32-bit round
 keys per (seed, permutation index, library), of which the low 16 bits are used; a keyed 8-round additive
 Feistel network in 16-bit arithmetic over the mixed-radix domain ``A x B >= n`` (``A`` = power of two ~ sqrt(n),
-``B = ceil(n / A)``, both >= 16) with cycle walking turns them into a bijection of ``[0, n)``.  The reference (squidpy) has no such generator — it uses numpy PCG64 shuffles
+``B = ceil(n / A)``, both >= 16) with cycle walking turns them into a bijection of ``[0, n)``.  Label shuffles are
+two-level: the 16 permutations ``16g .. 16g+15`` share the 8-round bijection of their group and differ by a keyed
+2-round network applied to its image (``label_permutations``); ``spatial_autocorr`` row permutations use one independent
+8-round bijection each (``permutation``).  The reference (squidpy) has no such generator — it uses numpy PCG64 shuffles
 (`/root/reference/src/squidpy/_utils.py:240-241`, ``gr/_nhood.py:533-538``) — so this file
 does not follow a reference file; it exists so that the GPU permutation test can be checked
 *bit for bit* (same permutations => same counts => same z-scores) and so that the statistical
@@ -43,13 +46,18 @@ def philox4x32_10(ctr: np.ndarray, key: tuple[int, int]) -> np.ndarray:
     return np.stack(c, axis=-1).astype(np.uint32)
 
 
-def round_keys(seed: int, perms: np.ndarray, lib: int = 0) -> np.ndarray:
-    """Round keys, shape (len(perms), 8) uint32, for global permutation indices ``perms``."""
+FEISTEL_GROUP = 16  # permutations 16g .. 16g+15 of a label shuffle share the group bijection pi_g
+
+
+def round_keys(seed: int, perms: np.ndarray, lib: int = 0, tags: tuple[int, ...] = (0, 1)) -> np.ndarray:
+    """Round keys, shape (len(perms), 4 * len(tags)) uint32, for global (permutation or group) indices ``perms``:
+    Philox4x32-10 of the counters (index_lo, index_hi, lib, tag) — sqgr_rng.h: round_keys_tagged.  Tags (0, 1): the
+    independent 8-round bijection of an index; (2, 3): the group bijection; (4,): the per-permutation 2-round sigma."""
     perms = np.asarray(perms, dtype=np.uint64)
     seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     key = (seed & 0xFFFFFFFF, seed >> 32)
     out = []
-    for j in (0, 1):
+    for j in tags:
         ctr = np.stack(
             [
                 (perms & MASK32).astype(np.uint32),
@@ -122,6 +130,60 @@ def permutation_batch(n: int, rks: np.ndarray) -> np.ndarray:
     return x.astype(np.int64)
 
 
+def group_keys(seed: int, groups: np.ndarray, lib: int = 0) -> np.ndarray:
+    """(len(groups), 8) keys of the group bijections pi_g (sqgr_rng.h: group_keys)."""
+    return round_keys(seed, groups, lib, tags=(2, 3))
+
+
+def sigma_keys(seed: int, perms: np.ndarray, lib: int = 0) -> np.ndarray:
+    """(len(perms), 2) keys of the per-permutation 2-round networks sigma_p (sqgr_rng.h: sigma_keys)."""
+    return round_keys(seed, perms, lib, tags=(4,))[:, :2]
+
+
+def _sigma(a: np.ndarray, b: np.ndarray, A: int, B: int, Bmask: int, sk: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+    """sigma_p: b <- (b + F_B(a, k0)) mod B, then a <- (a + F_A(b, k1)) mod A (sqgr_rng.h: sigma_rounds)."""
+    A1, B64 = np.uint64(A - 1), np.uint64(B)
+    abits, bbits = int(A).bit_length() - 1, int(Bmask + 1).bit_length() - 1
+    t = b + _F(a, sk[:, 0:1], bbits)
+    t = np.where(t >= B64, t - B64, t)
+    b = np.where(t >= B64, t - B64, t)
+    a = (a + _F(b, sk[:, 1:2], abits)) & A1
+    return a, b
+
+
+def grouped_permutation_batch(n: int, gks: np.ndarray, sks: np.ndarray) -> np.ndarray:
+    """Two-level label permutations: pi[p, i] = sigma(sks[p]) o pi(gks[p]) (i), both cycle-walked into [0, n)
+    (sqgr_rng.h: grouped_perm).  ``gks``: (P, 8) — row p holds the keys of permutation p's GROUP; ``sks``: (P, 2)."""
+    P = gks.shape[0]
+    if n <= 1:
+        return np.zeros((P, n), dtype=np.int64)
+    A, B, Bmask = domain_dims(n)
+    B64 = np.uint64(B)
+    keys = gks.astype(np.uint64) & MASK16
+    key = lambda r: keys[:, r : r + 1]  # noqa: E731
+    sk = sks.astype(np.uint64) & MASK16
+    x = np.tile(np.arange(n, dtype=np.uint64), (P, 1))
+    a, b = _rounds(x // B64, x % B64, A, B, Bmask, key)
+    bad = a * B64 + b >= np.uint64(n)
+    while bad.any():
+        a2, b2 = _rounds(a, b, A, B, Bmask, key)
+        a, b = np.where(bad, a2, a), np.where(bad, b2, b)
+        bad = a * B64 + b >= np.uint64(n)
+    a, b = _sigma(a, b, A, B, Bmask, sk)
+    bad = a * B64 + b >= np.uint64(n)
+    while bad.any():
+        a2, b2 = _sigma(a, b, A, B, Bmask, sk)
+        a, b = np.where(bad, a2, a), np.where(bad, b2, b)
+        bad = a * B64 + b >= np.uint64(n)
+    return (a * B64 + b).astype(np.int64)
+
+
+def label_permutations(n: int, seed: int, perms: np.ndarray, lib: int = 0) -> np.ndarray:
+    """(len(perms), n) label-shuffle permutations of the global permutation indices ``perms``."""
+    perms = np.asarray(perms, dtype=np.int64)
+    return grouped_permutation_batch(n, group_keys(seed, perms // FEISTEL_GROUP, lib), sigma_keys(seed, perms, lib))
+
+
 def permutation(n: int, rk: np.ndarray) -> np.ndarray:
     """pi with pi[i] = image of i under the cycle-walked bijection of [0, n); int64 (n,)."""
     return permutation_batch(n, np.asarray(rk)[None, :])[0]
@@ -137,13 +199,11 @@ def shuffled_labels(
     binary search over K boundaries instead of a memory gather:  out[i] = sort(labels)[pi(rank_i)]."""
     labels = np.asarray(labels)
     if lib_ids is None:
-        rk = round_keys(seed, np.array([perm]))[0]
-        return np.sort(labels)[permutation(len(labels), rk)]
+        return np.sort(labels)[label_permutations(len(labels), seed, np.array([perm]))[0]]
     out = np.empty_like(labels)
     for lib in range(n_libs):
         idx = np.where(lib_ids == lib)[0]
-        rk = round_keys(seed, np.array([perm]), lib=lib)[0]
-        out[idx] = np.sort(labels[idx])[permutation(len(idx), rk)]
+        out[idx] = np.sort(labels[idx])[label_permutations(len(idx), seed, np.array([perm]), lib=lib)[0]]
     return out
 
 

@@ -130,4 +130,13 @@ struct sqgr_graph {
     sqgr::DevBuf<int2> coo;         // [nnz] (row, col) pairs: one 8-byte load per edge in the nhood count kernel
     sqgr::DevBuf<float> data;       // [nnz] or empty
     bool has_data = false;
+    // Structurally symmetric graphs (every stored (r, c) has a stored (c, r); canonical CSR: rows sorted, no duplicates):
+    // the neighbourhood counts of a labelling satisfy count = h + h^T with h taken over the edges r < c only, so the
+    // permutation kernels walk `half` = [edges with r < c in CSR order | self loops] — half the gathers and LDS atomics.
+    // Built lazily on the device by ensure_half() (sqgr_ctx.hip); sym_state: 0 unknown, 1 symmetric, -1 not.
+    mutable int sym_state = 0;
+    mutable sqgr::DevBuf<int2> half;
+    mutable int64_t n_half = 0;  // edges with r < c
+    mutable int64_t n_self = 0;  // self loops, stored behind them
+    int ensure_half() const;
 };

@@ -1,6 +1,8 @@
 // libsqgr: context, error reporting, kernel timers and the device-resident CSR graph.
 #include "sqgr_common.h"
 
+#include <cstdlib>
+
 namespace sqgr {
 
 static thread_local char g_err[1024] = "";
@@ -26,9 +28,172 @@ __global__ void k_expand_rows(const int64_t* __restrict__ indptr, const int32_t*
     coo[e] = make_int2((int)lo, indices[e]);
 }
 
+// ---------------------------------------------------------------------------------------------- symmetric half list
+// flags[0]: some edge has no mirror; flags[1]: a row is not strictly increasing (unsorted or duplicate entries — the
+// binary search below is then meaningless and the graph is treated as not symmetric).
+__global__ __launch_bounds__(256) void k_sym_check(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                                   const int32_t* __restrict__ erow, int64_t nnz, int* __restrict__ flags) {
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= nnz) return;
+    const int32_t r = erow[e], c = indices[e];
+    if (e > indptr[r] && indices[e - 1] >= c) flags[1] = 1;
+    if (r == c) return;
+    int64_t lo = indptr[c], hi = indptr[c + 1];  // first position in row c with index >= r
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (indices[mid] < r) lo = mid + 1; else hi = mid;
+    }
+    if (lo >= indptr[c + 1] || indices[lo] != r) flags[0] = 1;
+}
+
+constexpr int HALF_TILE = 1024;  // edges per block of the stable compaction
+
+// pass 1: per tile, the number of edges with r < c and of self loops
+__global__ __launch_bounds__(HALF_TILE) void k_half_count(const int2* __restrict__ coo, int64_t nnz, uint32_t* __restrict__ tile_lt,
+                                                          uint32_t* __restrict__ tile_self) {
+    __shared__ uint32_t s_lt, s_self;
+    if (threadIdx.x == 0) s_lt = s_self = 0;
+    __syncthreads();
+    const int64_t e = blockIdx.x * (int64_t)HALF_TILE + threadIdx.x;
+    bool lt = false, self = false;
+    if (e < nnz) {
+        const int2 rc = coo[e];
+        lt = rc.x < rc.y;
+        self = rc.x == rc.y;
+    }
+    const uint64_t m_lt = __ballot(lt), m_self = __ballot(self);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&s_lt, (uint32_t)__popcll(m_lt));
+        atomicAdd(&s_self, (uint32_t)__popcll(m_self));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        tile_lt[blockIdx.x] = s_lt;
+        tile_self[blockIdx.x] = s_self;
+    }
+}
+
+// pass 2: exclusive scan of the tile counts in place (one block walks the tiles 1024 at a time); totals[0..1] = sums
+__global__ __launch_bounds__(1024) void k_half_scan(uint32_t* __restrict__ tile_lt, uint32_t* __restrict__ tile_self, int64_t ntiles,
+                                                    unsigned long long* __restrict__ totals) {
+    __shared__ unsigned long long s_a[1024], s_b[1024];
+    __shared__ unsigned long long carry_a, carry_b;
+    if (threadIdx.x == 0) carry_a = carry_b = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < ntiles; base += 1024) {
+        const int64_t t = base + threadIdx.x;
+        const unsigned long long va = t < ntiles ? tile_lt[t] : 0, vb = t < ntiles ? tile_self[t] : 0;
+        s_a[threadIdx.x] = va;
+        s_b[threadIdx.x] = vb;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+            unsigned long long xa = 0, xb = 0;
+            if ((int)threadIdx.x >= off) {
+                xa = s_a[threadIdx.x - off];
+                xb = s_b[threadIdx.x - off];
+            }
+            __syncthreads();
+            s_a[threadIdx.x] += xa;
+            s_b[threadIdx.x] += xb;
+            __syncthreads();
+        }
+        if (t < ntiles) {  // offsets fit 32 bits: nnz < 2^32 is required by the callers of the half list
+            tile_lt[t] = (uint32_t)(carry_a + s_a[threadIdx.x] - va);
+            tile_self[t] = (uint32_t)(carry_b + s_b[threadIdx.x] - vb);
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) {
+            carry_a += s_a[1023];
+            carry_b += s_b[1023];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        totals[0] = carry_a;
+        totals[1] = carry_b;
+    }
+}
+
+// pass 3: stable scatter — edges with r < c keep their CSR order in out[0, n_lt), self loops follow in out[n_lt, ...)
+__global__ __launch_bounds__(HALF_TILE) void k_half_scatter(const int2* __restrict__ coo, int64_t nnz, const uint32_t* __restrict__ tile_lt,
+                                                            const uint32_t* __restrict__ tile_self, uint32_t n_lt, int2* __restrict__ out) {
+    __shared__ uint32_t w_lt[HALF_TILE / 64], w_self[HALF_TILE / 64];
+    const int64_t e = blockIdx.x * (int64_t)HALF_TILE + threadIdx.x;
+    int2 rc = make_int2(0, 0);
+    bool lt = false, self = false;
+    if (e < nnz) {
+        rc = coo[e];
+        lt = rc.x < rc.y;
+        self = rc.x == rc.y;
+    }
+    const uint64_t m_lt = __ballot(lt), m_self = __ballot(self);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    if (lane == 0) {
+        w_lt[wave] = (uint32_t)__popcll(m_lt);
+        w_self[wave] = (uint32_t)__popcll(m_self);
+    }
+    __syncthreads();
+    uint32_t o_lt = tile_lt[blockIdx.x], o_self = tile_self[blockIdx.x];
+    for (int w = 0; w < wave; ++w) {
+        o_lt += w_lt[w];
+        o_self += w_self[w];
+    }
+    if (lt) out[o_lt + (uint32_t)__popcll(m_lt & below)] = rc;
+    if (self) out[(size_t)n_lt + o_self + (uint32_t)__popcll(m_self & below)] = rc;
+}
+
 }  // namespace sqgr
 
 using namespace sqgr;
+
+int sqgr_graph::ensure_half() const {
+    if (sym_state != 0) return SQGR_OK;
+    sym_state = -1;
+    if (nnz == 0 || nnz >= ((int64_t)1 << 32) || getenv("SQGR_NO_SYMMETRY")) return SQGR_OK;
+    SQGR_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int64_t ntiles = ceil_div(nnz, HALF_TILE);
+    DevBuf<int> flags;
+    DevBuf<uint32_t> t_lt, t_self;
+    DevBuf<unsigned long long> totals;
+    SQGR_TRY(flags.alloc(2));
+    SQGR_HIP(hipMemsetAsync(flags.p, 0, 8, st));
+    {
+        LaunchTimer t(ctx, "graph_sym_check");
+        k_sym_check<<<(unsigned)ceil_div(nnz, 256), 256, 0, st>>>(indptr.p, indices.p, erow.p, nnz, flags.p);
+        SQGR_HIP(hipGetLastError());
+    }
+    int h_flags[2] = {1, 1};
+    SQGR_HIP(hipMemcpyAsync(h_flags, flags.p, 8, hipMemcpyDeviceToHost, st));
+    SQGR_HIP(hipStreamSynchronize(st));
+    if (h_flags[0] || h_flags[1]) return SQGR_OK;  // not symmetric (or not canonical): the full edge list is used
+    SQGR_TRY(t_lt.alloc((size_t)ntiles));
+    SQGR_TRY(t_self.alloc((size_t)ntiles));
+    SQGR_TRY(totals.alloc(2));
+    unsigned long long h_tot[2] = {0, 0};
+    {
+        LaunchTimer t(ctx, "graph_half_list");
+        k_half_count<<<(unsigned)ntiles, HALF_TILE, 0, st>>>(coo.p, nnz, t_lt.p, t_self.p);
+        k_half_scan<<<1, 1024, 0, st>>>(t_lt.p, t_self.p, ntiles, totals.p);
+        SQGR_HIP(hipGetLastError());
+        SQGR_HIP(hipMemcpyAsync(h_tot, totals.p, 16, hipMemcpyDeviceToHost, st));
+        SQGR_HIP(hipStreamSynchronize(st));
+        if (2 * h_tot[0] + h_tot[1] != (unsigned long long)nnz) {
+            set_error("internal error: half list of a symmetric graph has %llu + %llu entries for nnz=%lld", h_tot[0], h_tot[1],
+                      (long long)nnz);
+            return SQGR_ERR_HIP;
+        }
+        SQGR_TRY(half.alloc((size_t)(h_tot[0] + h_tot[1])));
+        k_half_scatter<<<(unsigned)ntiles, HALF_TILE, 0, st>>>(coo.p, nnz, t_lt.p, t_self.p, (uint32_t)h_tot[0], half.p);
+        SQGR_HIP(hipGetLastError());
+    }
+    SQGR_HIP(hipStreamSynchronize(st));
+    n_half = (int64_t)h_tot[0];
+    n_self = (int64_t)h_tot[1];
+    sym_state = 1;
+    return SQGR_OK;
+}
 
 int sqgr_ctx::timer_id(const char* name) {
     auto it = timer_ids.find(name);

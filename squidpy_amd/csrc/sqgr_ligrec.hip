@@ -87,7 +87,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_ligrec_sums(int G, int K, const 
 __global__ __launch_bounds__(256) void k_ligrec_score(int K, int n_cp, const int32_t* __restrict__ inter,
                                                       const int32_t* __restrict__ cpairs, const double* __restrict__ obs,
                                                       const uint8_t* __restrict__ valid, const double* __restrict__ means,
-                                                      int64_t npl, int n_valid_perms, int64_t* __restrict__ counts) {
+                                                      int64_t npl, int first_valid, int n_valid_perms,
+                                                      int64_t* __restrict__ counts) {
     extern __shared__ double s_tile[];  // [2][K][SCORE_LD]
     double* s_rec = s_tile;
     double* s_lig = s_tile + (size_t)K * SCORE_LD;
@@ -111,7 +112,9 @@ __global__ __launch_bounds__(256) void k_ligrec_score(int K, int n_cp, const int
         const int np = (n_valid_perms - p0 < SCORE_TP) ? n_valid_perms - p0 : SCORE_TP;
         const double* ra = s_rec + a * SCORE_LD;
         const double* lb = s_lig + b * SCORE_LD;
-        for (int pl = 0; pl < np; ++pl) cnt += (ra[pl] + lb[pl] > o) ? 1 : 0;
+        // columns before `first_valid` belong to permutations in front of the requested range (ranges start inside a
+        // 16-permutation group of the label generator: the whole group is generated)
+        for (int pl = (first_valid > p0 ? first_valid - p0 : 0); pl < np; ++pl) cnt += (ra[pl] + lb[pl] > o) ? 1 : 0;
     }
     if (live && valid[(size_t)i * n_cp + j]) counts[(size_t)i * n_cp + j] += cnt;
 }
@@ -191,7 +194,10 @@ int sqgr_ligrec_counts(sqgr_ctx* ctx, int64_t n_cells, int32_t n_genes, int32_t 
     SQGR_HIP(hipMemsetAsync(d_counts.p, 0, n_out * 8, st));
 
     // permutations per launch group: labels take n_cells bytes, the group means G*K*8 bytes per permutation
-    const int64_t n_perms = perm_end - perm_begin;
+    // the device generator works in groups of 16 permutations (sqgr_rng.h): start at the group boundary at or below
+    // perm_begin and leave the `skip` columns in front of the range out of the scores
+    const int64_t skip = pcg_states ? 0 : (perm_begin % 16);
+    const int64_t n_perms = perm_end - perm_begin + skip;
     size_t free_b = 0, total_b = 0;
     SQGR_HIP(hipMemGetInfo(&free_b, &total_b));
     const int64_t per_perm = n_cells + (int64_t)n_genes * K * 8;
@@ -230,7 +236,7 @@ int sqgr_ligrec_counts(sqgr_ctx* ctx, int64_t n_cells, int32_t n_genes, int32_t 
             lv.seg = (int)npl;
             lv.seg_stride = 0;
         } else {
-            SQGR_TRY(label_shuffler_philox(sh.s, seed, perm_begin + c0, (int)(pc64 / 32), d_keys.p, d_labels.p, st));
+            SQGR_TRY(label_shuffler_philox(sh.s, seed, perm_begin - skip + c0, (int)(pc64 / 32), d_keys.p, d_labels.p, st));
             lv.row_stride = 32;
             lv.seg = 32;
             lv.seg_stride = n_cells * 32;
@@ -249,7 +255,7 @@ int sqgr_ligrec_counts(sqgr_ctx* ctx, int64_t n_cells, int32_t n_genes, int32_t 
         if (out_means_perm0 && c0 == 0) {
             // group means of the first permutation of the range, [K][G] like the reference's `groups` (testing hook)
             std::vector<double> col((size_t)n_genes * K);
-            SQGR_HIP(hipMemcpy2DAsync(col.data(), 8, d_means.p, (size_t)npl * 8, 8, (size_t)n_genes * K, hipMemcpyDeviceToHost, st));
+            SQGR_HIP(hipMemcpy2DAsync(col.data(), 8, d_means.p + skip, (size_t)npl * 8, 8, (size_t)n_genes * K, hipMemcpyDeviceToHost, st));
             SQGR_HIP(hipStreamSynchronize(st));
             for (int g = 0; g < n_genes; ++g)
                 for (int k = 0; k < K; ++k) out_means_perm0[(size_t)k * n_genes + g] = col[(size_t)g * K + k];
@@ -257,8 +263,8 @@ int sqgr_ligrec_counts(sqgr_ctx* ctx, int64_t n_cells, int32_t n_genes, int32_t 
         {
             LaunchTimer t(ctx, "ligrec_score");
             dim3 grid((unsigned)n_inter, (unsigned)ceil_div(n_cp, 256));
-            k_ligrec_score<<<grid, 256, lds_score, st>>>(K, n_cp, d_inter.p, d_cpairs.p, d_obs.p, d_valid.p, d_means.p, npl, (int)pc,
-                                                         d_counts.p);
+            k_ligrec_score<<<grid, 256, lds_score, st>>>(K, n_cp, d_inter.p, d_cpairs.p, d_obs.p, d_valid.p, d_means.p, npl,
+                                                         c0 == 0 ? (int)skip : 0, (int)pc, d_counts.p);
             SQGR_HIP(hipGetLastError());
         }
     }

@@ -29,19 +29,36 @@ constexpr int COUNT_THREADS = 1024;
 constexpr size_t LDS_BUDGET = 160 * 1024;
 
 // ---------------------------------------------------------------------------------------------- key generation
-// keys[(q * n_libs + lib) * 8 + r] = round-r keys of permutations perm0 + 2q (low 16 bits) and perm0 + 2q + 1 (high 16
-// bits) for library `lib`: the label shuffle evaluates two permutations per packed-16 instruction and reads one word
-// per round.  nperm is even.
-__global__ void k_keygen(uint64_t seed, int64_t perm0, int64_t nperm, int n_libs, uint32_t* __restrict__ keys) {
-    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (t >= (nperm / 2) * n_libs) return;
-    int64_t q = t / n_libs;
-    uint32_t lib = (uint32_t)(t % n_libs);
-    uint32_t ra[8], rb[8];
-    round_keys(seed, (uint64_t)(perm0 + 2 * q), lib, ra);
-    round_keys(seed, (uint64_t)(perm0 + 2 * q + 1), lib, rb);
+// Keys of one slab row (B permutations perm_row .. perm_row + B - 1, perm_row a multiple of 16) — see sqgr_rng.h for the
+// two-level construction.  Layout in 32-bit words, every word two packed 16-bit lanes (two permutations per packed-16
+// instruction of the label shuffle):
+//   group keys : [g][lib][8]   g < B/16: the 8 round keys of group perm_row/16 + g in both halves
+//   sigma keys : [t][lib][2]   t < B/2 : the 2 round keys of permutations perm_row + 2t (low half) and + 2t + 1 (high half)
+__host__ __device__ constexpr int key_words_per_row(int B, int n_libs) { return n_libs * ((B / FEISTEL_GROUP) * 8 + (B / 2) * 2); }
+
+__global__ void k_keygen(uint64_t seed, int64_t perm0, int nrows, int B, int n_libs, uint32_t* __restrict__ keys) {
+    const int items = B / FEISTEL_GROUP + B / 2;  // per (row, library)
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= (int64_t)nrows * n_libs * items) return;
+    const int item = (int)(t % items);
+    const uint32_t lib = (uint32_t)((t / items) % n_libs);
+    const int64_t row = t / ((int64_t)items * n_libs);
+    uint32_t* out = keys + row * key_words_per_row(B, n_libs);
+    const int64_t perm_row = perm0 + row * B;
+    if (item < B / FEISTEL_GROUP) {
+        uint32_t rk[8];
+        group_keys(seed, (uint64_t)(perm_row / FEISTEL_GROUP + item), lib, rk);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) keys[t * 8 + i] = (ra[i] & 0xFFFFu) | (rb[i] << 16);
+        for (int i = 0; i < 8; ++i) out[((size_t)item * n_libs + lib) * 8 + i] = (rk[i] & 0xFFFFu) * 0x10001u;
+    } else {
+        const int tt = item - B / FEISTEL_GROUP;
+        uint32_t ra[2], rb[2];
+        sigma_keys(seed, (uint64_t)(perm_row + 2 * tt), lib, ra);
+        sigma_keys(seed, (uint64_t)(perm_row + 2 * tt + 1), lib, rb);
+        uint32_t* o = out + (size_t)(B / FEISTEL_GROUP) * n_libs * 8 + ((size_t)tt * n_libs + lib) * 2;
+        o[0] = (ra[0] & 0xFFFFu) | (rb[0] << 16);
+        o[1] = (ra[1] & 0xFFFFu) | (rb[1] << 16);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- label shuffle
@@ -52,7 +69,9 @@ __global__ void k_keygen(uint64_t seed, int64_t perm0, int64_t nperm, int n_libs
 // nhood_build) holds the label of the block's first rank and the low digit where the next label starts, so the label is
 // `lab0 + (b >= next)`.  Blocks flagged BLK_EXACT (several label starts, skipped empty categories, or ranks >= n — the
 // cycle-walking case) take the exact route: x = a*B + b against the boundary table, and a re-walk where x >= n.
-//   slab[(batch*n + i)*B + b] = label_at_rank( pi_{perm,lib}(rank_i) )
+//   slab[(batch*n + i)*B + b] = label_at_rank( sigma_p( pi_g( rank_i ) ) ),  p = perm_row + b, g = p / 16
+// One evaluation of the 8-round group bijection per spot and 16 permutations; per permutation the 2-round sigma network
+// (two permutations per packed-16 instruction) and the table look-up.
 constexpr uint32_t BLK_EXACT = 0x100u;
 
 struct LibDom {
@@ -70,7 +89,9 @@ __global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __re
     for (int t = threadIdx.x; t < n_libs * kpad + blk_words; t += 256) s_cum[t] = cum[t];
     __syncthreads();
     const int batch = blockIdx.y;
-    const uint32_t* kb = keys + (size_t)batch * (B / 2) * n_libs * 8;
+    constexpr int NG = B / FEISTEL_GROUP;
+    const uint32_t* kg = keys + (size_t)batch * key_words_per_row(B, n_libs);  // group keys of this row
+    const uint32_t* ks = kg + (size_t)NG * n_libs * 8;                           // sigma keys
     // grid-stride over spots (launch_shuffle_raw caps the grid)
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     uint32_t out[B / 4];
@@ -86,45 +107,53 @@ __global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __re
     const uint32_t* blk = s_blk + ld.aoff;
     const uint32_t a0 = x0 / dom.B, b0 = x0 - a0 * dom.B;  // one division per spot, shared by all B permutations
 #pragma unroll
-    for (int w = 0; w < B / 4; ++w) {
-        uint32_t word = 0;
+    for (int g = 0; g < NG; ++g) {
+        // pi_g: the strong bijection of the group, both packed lanes carry the same value
+        u16x2 ga[1] = {(u16x2)((unsigned short)a0)}, gb[1] = {(u16x2)((unsigned short)b0)};
+        const uint32_t* const pg[1] = {kg + ((size_t)g * n_libs + lib) * 8};  // uniform when !HAS_LIBS
+        do {
+            feistel_rounds<1>(ga, gb, dom, pg);
+        } while (__umul24((uint32_t)ga[0].x, dom.B) + (uint32_t)gb[0].x >= dom.n);  // cycle walk (rare: < 1/B of the ranks)
 #pragma unroll
-        for (int j = 0; j < 4; j += 2) {  // two permutations per evaluation (packed 16-bit lanes); measured: one pair per
-                                          // chain beats two interleaved chains (register pressure) on MI355X
-            const uint32_t* const pk[1] = {kb + ((size_t)(w * 2 + j / 2) * n_libs + lib) * 8};  // uniform when !HAS_LIBS
-            u16x2 a[1] = {(u16x2)((unsigned short)a0)}, b[1] = {(u16x2)((unsigned short)b0)};
-            feistel_rounds<1>(a, b, dom, pk);
-            uint32_t l0, l1;
-            bool again;
-            do {
-                const uint32_t ax = a[0].x, ay = a[0].y, bx = b[0].x, by = b[0].y;
-                const uint32_t e0 = blk[ax], e1 = blk[ay];
-                l0 = (e0 & 0xFFu) + (bx >= (e0 >> 16) ? 1u : 0u);
-                l1 = (e1 & 0xFFu) + (by >= (e1 >> 16) ? 1u : 0u);
-                again = false;
-                if ((e0 | e1) & BLK_EXACT) {
-                    const uint32_t xx0 = __umul24(ax, dom.B) + bx, xx1 = __umul24(ay, dom.B) + by;  // digits < 2^14
-                    const bool w0 = xx0 >= dom.n, w1 = xx1 >= dom.n;
-                    if (!w0) {
-                        l0 = e0 & 0xFFu;
-                        while (xx0 >= tab[l0]) ++l0;  // sentinel UINT_MAX stops it
+        for (int w = 0; w < FEISTEL_GROUP / 4; ++w) {
+            uint32_t word = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {  // two permutations per evaluation (packed 16-bit lanes)
+                const uint32_t* const pk[1] = {ks + ((size_t)(g * (FEISTEL_GROUP / 2) + w * 2 + j / 2) * n_libs + lib) * 2};
+                u16x2 a[1] = {ga[0]}, b[1] = {gb[0]};
+                sigma_rounds<1>(a, b, dom, pk);
+                uint32_t l0, l1;
+                bool again;
+                do {
+                    const uint32_t ax = a[0].x, ay = a[0].y, bx = b[0].x, by = b[0].y;
+                    const uint32_t e0 = blk[ax], e1 = blk[ay];
+                    l0 = (e0 & 0xFFu) + (bx >= (e0 >> 16) ? 1u : 0u);
+                    l1 = (e1 & 0xFFu) + (by >= (e1 >> 16) ? 1u : 0u);
+                    again = false;
+                    if ((e0 | e1) & BLK_EXACT) {
+                        const uint32_t xx0 = __umul24(ax, dom.B) + bx, xx1 = __umul24(ay, dom.B) + by;  // digits < 2^14
+                        const bool w0 = xx0 >= dom.n, w1 = xx1 >= dom.n;
+                        if (!w0) {
+                            l0 = e0 & 0xFFu;
+                            while (xx0 >= tab[l0]) ++l0;  // sentinel UINT_MAX stops it
+                        }
+                        if (!w1) {
+                            l1 = e1 & 0xFFu;
+                            while (xx1 >= tab[l1]) ++l1;
+                        }
+                        again = w0 | w1;
+                        if (again) {  // cycle walk: re-apply sigma where the image left [0, n)
+                            u16x2 a2[1] = {a[0]}, b2[1] = {b[0]};
+                            sigma_rounds<1>(a2, b2, dom, pk);
+                            if (w0) { a[0].x = a2[0].x; b[0].x = b2[0].x; }
+                            if (w1) { a[0].y = a2[0].y; b[0].y = b2[0].y; }
+                        }
                     }
-                    if (!w1) {
-                        l1 = e1 & 0xFFu;
-                        while (xx1 >= tab[l1]) ++l1;
-                    }
-                    again = w0 | w1;
-                    if (again) {  // cycle walk: re-apply the bijection where the image left [0, n)
-                        u16x2 a2[1] = {a[0]}, b2[1] = {b[0]};
-                        feistel_rounds<1>(a2, b2, dom, pk);
-                        if (w0) { a[0].x = a2[0].x; b[0].x = b2[0].x; }
-                        if (w1) { a[0].y = a2[0].y; b[0].y = b2[0].y; }
-                    }
-                }
-            } while (again);
-            word |= (l0 << (8 * j)) | (l1 << (8 * (j + 1)));
+                } while (again);
+                word |= (l0 << (8 * j)) | (l1 << (8 * (j + 1)));
+            }
+            out[g * (FEISTEL_GROUP / 4) + w] = word;
         }
-        out[w] = word;
     }
     uint4* dst = reinterpret_cast<uint4*>(slab_all + ((size_t)batch * n + i) * B);
 #pragma unroll
@@ -180,11 +209,14 @@ __device__ __forceinline__ uint32_t pair_index(uint32_t la, uint32_t lb, uint32_
 }
 #undef SQGR_PAIR_SDWA
 
-template <int B, int MIN_WAVES>
+// The edge list is either the full COO view or, on structurally symmetric graphs, the half list of sqgr_graph (edges
+// r < c, then the self loops from `self_begin` on): k_reduce then forms count = h + h^T.  SELF (the half list has self
+// loops): half edges add 2, self loops 1 and k_reduce halves the sum — exact, every sum is even by construction.
+template <int B, int MIN_WAVES, bool SELF>
 __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz, const int2* __restrict__ coo,
                                                                     const uint8_t* __restrict__ slab_all, int64_t n, int K,
                                                                     int hist_words, uint32_t edges_per_block,
-                                                                    uint32_t* __restrict__ partial_all) {
+                                                                    uint32_t self_begin, uint32_t* __restrict__ partial_all) {
     extern __shared__ uint32_t hist[];
     // this kernel is bound by LDS-atomic throughput and needs few VALU slots; when the VALU-bound shuffle kernel of the
     // next launch group shares the CU (SQGR_NHOOD_STREAMS=2), issue priority keeps the LDS pipe fed
@@ -238,7 +270,8 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
     auto histogram = [&](const Row (&row_a)[U], const Row (&row_b)[U], uint32_t eb) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint32_t inc = (eb + u < e1) ? 1u : 0u;  // branch-free tail: out-of-range edges add 0
+            uint32_t inc = (eb + u < e1) ? 1u : 0u;  // branch-free tail: out-of-range edges add 0
+            if constexpr (SELF) inc += (eb + u < min(e1, self_begin)) ? 1u : 0u;
             uint32_t la[2], lb[2];
             if constexpr (B == 16) {
                 la[0] = __builtin_amdgcn_alignbit(row_a[u], row_a[u], rot);
@@ -338,26 +371,35 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_wide(int64_t nnz, const
 // ---------------------------------------------------------------------------------------------- reduction
 // word w = pair*B + b.  acc slots are private to (batch, w): no atomics, bit-reproducible.
 // 256 threads = 64 words x 4 slices of the block loop (combined through LDS).
+// sym: 0 the partials hold the counts; 1 they hold h over the half list: count[a,b] = h[a,b] + h[b,a];
+//      2 the same in doubled units (half lists with self loops): count = (h + h^T) / 2.
 __global__ __launch_bounds__(256) void k_reduce(const uint32_t* __restrict__ partial_all, int nblk, int hist_words, int B,
-                                                int K2, const int64_t* __restrict__ shift, int64_t perm_batch0,
+                                                int K, int sym, const int64_t* __restrict__ shift, int64_t perm_batch0,
                                                 int64_t perm_begin, int64_t perm_end, int64_t* __restrict__ acc_sum,
                                                 uint64_t* __restrict__ acc_sq, uint32_t* __restrict__ perms_out) {
     __shared__ unsigned long long part[4][64];
     const int wl = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int w = blockIdx.x * 64 + wl;
     const int batch = blockIdx.y;
+    const int K2 = K * K;
     unsigned long long c = 0;
     if (w < hist_words) {
         const uint32_t* src = partial_all + (size_t)batch * nblk * hist_words + w;
         for (int k = slice; k < nblk; k += 4) c += src[(size_t)k * hist_words];
+        if (sym) {
+            const int pair = w / B, la = pair / K, lb = pair - la * K;
+            const uint32_t* srcT = partial_all + (size_t)batch * nblk * hist_words + (size_t)(lb * K + la) * B + (w - pair * B);
+            for (int k = slice; k < nblk; k += 4) c += srcT[(size_t)k * hist_words];
+        }
     }
     part[slice][wl] = c;
     __syncthreads();
     if (slice != 0 || w >= hist_words) return;
     c = part[0][wl] + part[1][wl] + part[2][wl] + part[3][wl];
+    if (sym == 2) c >>= 1;
     const int pair = w / B, b = w % B;
     const int64_t p = perm_batch0 + (int64_t)batch * B + b;
-    if (p >= perm_end) return;
+    if (p >= perm_end || p < perm_begin) return;
     const int64_t d = (int64_t)c - shift[pair];
     const size_t slot = (size_t)batch * hist_words + w;
     acc_sum[slot] += d;
@@ -485,7 +527,7 @@ struct sqgr_nhood {
             if (ev_counted[i]) (void)hipEventDestroy(ev_counted[i]);
         }
     }
-    size_t keys_stride() const { return (size_t)nbatch * B * n_libs * 8; }
+    size_t keys_stride() const { return (size_t)nbatch * key_words_per_row(B, n_libs); }
     size_t slab_stride() const { return (size_t)nbatch * n * B; }
     DevBuf<uint32_t> partial;
     DevBuf<int64_t> acc_sum;
@@ -511,6 +553,7 @@ struct sqgr_nhood {
         return (int)std::max<int64_t>(32, std::min<int64_t>(cus, ceil_div((int64_t)8 * cus, std::max(nb, 1))));
     }
     int nblk_launch = 0;  // blocks per batch of the launch in flight (count -> reduce)
+    int sym_launch = 0;   // k_reduce mode of the launch in flight (0 full edge list, 1 half list, 2 half list with self loops)
     int partial_blocks(int nb) const { return (B == 16 && be() == 0) ? 1 : blocks_for(nb); }
     size_t partial_words() const {  // largest nb * blocks_for(nb) * hist_words over the launches this plan can issue
         size_t m = 0;
@@ -568,25 +611,47 @@ int sqgr_nhood::count_batches(int nb, int buf) {
     const int hw = hist_words();
     const int nblk = blocks_for(nb);  // shadows the tuning member on purpose: everything below is per launch
     nblk_launch = partial_blocks(nb);
+    sym_launch = 0;
     if (nnz == 0) {  // no edges: every count is zero
         SQGR_HIP(hipMemsetAsync(partial.p, 0, (size_t)nb * nblk_launch * hw * 4, st));
         return SQGR_OK;
     }
-    if (B == 32) {
-        const uint32_t epb = (uint32_t)(ceil_div(ceil_div(nnz, nblk), 256) * 256);
-        LaunchTimer t(ctx, "nhood_count_b32");
-        SQGR_TRY(allow_lds(k_count<32, 4>, (size_t)hw * 4));
-        k_count<32, 4><<<dim3(nblk, nb), COUNT_THREADS, (size_t)hw * 4, st>>>((uint32_t)nnz, g->coo.p, slab_p, n, K, hw,
-                                                                           epb, partial.p);
-    } else if (be() == 16) {
-        const uint32_t epb = (uint32_t)(ceil_div(ceil_div(nnz, nblk), 256) * 256);
-        LaunchTimer t(ctx, "nhood_count_b16");
-        if ((size_t)hw * 4 * 2 <= LDS_BUDGET)
-            k_count<16, 8><<<dim3(nblk, nb), COUNT_THREADS, (size_t)hw * 4, st>>>((uint32_t)nnz, g->coo.p, slab_p, n, K,
-                                                                               hw, epb, partial.p);
-        else if (allow_lds(k_count<16, 4>, (size_t)hw * 4) == SQGR_OK)
-            k_count<16, 4><<<dim3(nblk, nb), COUNT_THREADS, (size_t)hw * 4, st>>>((uint32_t)nnz, g->coo.p, slab_p, n, K,
-                                                                               hw, epb, partial.p);
+    if (B == 32 || be() == 16) {
+        // LDS-histogram kernels: on a structurally symmetric graph they walk the half list (see sqgr_graph::ensure_half)
+        SQGR_TRY(g->ensure_half());
+        const bool half = g->sym_state == 1;
+        const int2* list = half ? g->half.p : g->coo.p;
+        const uint32_t m = (uint32_t)(half ? g->n_half + g->n_self : nnz);
+        const uint32_t self_begin = (uint32_t)(half ? g->n_half : nnz);
+        const bool self = half && g->n_self > 0;
+        sym_launch = half ? (self ? 2 : 1) : 0;
+        const uint32_t epb = (uint32_t)(ceil_div(ceil_div((int64_t)m, nblk), 256) * 256);
+        const size_t lds = (size_t)hw * 4;
+        const dim3 grid(nblk, nb);
+#define SQGR_COUNT(BB, MW, SELF) \
+    k_count<BB, MW, SELF><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, hw, epb, self_begin, partial.p)
+        if (B == 32) {
+            LaunchTimer t(ctx, half ? "nhood_count_b32_half" : "nhood_count_b32");
+            if (self) {
+                SQGR_TRY(allow_lds(k_count<32, 4, true>, lds));
+                SQGR_COUNT(32, 4, true);
+            } else {
+                SQGR_TRY(allow_lds(k_count<32, 4, false>, lds));
+                SQGR_COUNT(32, 4, false);
+            }
+        } else {
+            LaunchTimer t(ctx, half ? "nhood_count_b16_half" : "nhood_count_b16");
+            if (lds * 2 <= LDS_BUDGET) {
+                if (self) SQGR_COUNT(16, 8, true); else SQGR_COUNT(16, 8, false);
+            } else if (self) {
+                SQGR_TRY(allow_lds(k_count<16, 4, true>, lds));
+                SQGR_COUNT(16, 4, true);
+            } else {
+                SQGR_TRY(allow_lds(k_count<16, 4, false>, lds));
+                SQGR_COUNT(16, 4, false);
+            }
+        }
+#undef SQGR_COUNT
     } else {
         const int e = be();
         const int64_t epb = ceil_div(nnz, nblk);
@@ -614,7 +679,7 @@ int sqgr_nhood::count_batches(int nb, int buf) {
 int sqgr_nhood::reduce_batches(int nb, int64_t perm_batch0, int64_t perm_begin, int64_t perm_end, uint32_t* perms_out_dev) {
     const int hw = hist_words();
     LaunchTimer t(ctx, "nhood_reduce");
-    k_reduce<<<dim3((unsigned)ceil_div(hw, 64), nb), 256, 0, ctx->stream>>>(partial.p, nblk_launch, hw, B, K2, shift.p,
+    k_reduce<<<dim3((unsigned)ceil_div(hw, 64), nb), 256, 0, ctx->stream>>>(partial.p, nblk_launch, hw, B, K, sym_launch, shift.p,
                                                                             perm_batch0, perm_begin, perm_end, acc_sum.p,
                                                                             acc_sq.p, perms_out_dev);
     SQGR_HIP(hipGetLastError());
@@ -918,16 +983,17 @@ int sqgr_nhood_run(sqgr_nhood* plan, uint64_t seed, int64_t perm_begin, int64_t 
     const char* env_streams = getenv("SQGR_NHOOD_STREAMS");
     hipStream_t sa = (env_streams && atoi(env_streams) == 2) ? ctx->stream2 : st;
     int64_t grp = 0;
-    for (int64_t p0 = perm_begin; p0 < perm_end; p0 += per_launch, ++grp) {
+    // the label generator works in groups of 16 permutations (sqgr_rng.h): rows start at multiples of 16 of the GLOBAL
+    // permutation index, permutations in front of perm_begin are generated and masked out by k_reduce
+    for (int64_t p0 = perm_begin - perm_begin % FEISTEL_GROUP; p0 < perm_end; p0 += per_launch, ++grp) {
         const int64_t todo = (perm_end - p0 < per_launch) ? perm_end - p0 : per_launch;
         const int nb = (int)ceil_div(todo, B);
         const int buf = (int)(grp & 1);
         if (grp >= 2) SQGR_HIP(hipStreamWaitEvent(sa, p->ev_counted[buf], 0));  // slab[buf] has been consumed
         {
             LaunchTimer t(ctx, "nhood_keygen", sa);
-            const int64_t nk = (int64_t)nb * B * p->n_libs;
-            k_keygen<<<(unsigned)ceil_div(nk, 256), 256, 0, sa>>>(seed, p0, (int64_t)nb * B, p->n_libs,
-                                                                 p->keys.p + (size_t)buf * p->keys_stride());
+            const int64_t nk = (int64_t)nb * p->n_libs * (B / FEISTEL_GROUP + B / 2);
+            k_keygen<<<(unsigned)ceil_div(nk, 256), 256, 0, sa>>>(seed, p0, nb, B, p->n_libs, p->keys.p + (size_t)buf * p->keys_stride());
             SQGR_HIP(hipGetLastError());
         }
         SQGR_TRY(launch_shuffle(p, nb, buf, sa));
@@ -959,13 +1025,15 @@ int sqgr_nhood_shuffled_labels(sqgr_nhood* plan, uint64_t seed, int64_t perm, ui
     SQGR_TRY(p->ensure_workspace(false));
     hipStream_t st = ctx->stream;
     const int B = p->B;
-    k_keygen<<<(unsigned)ceil_div((int64_t)B * p->n_libs, 256), 256, 0, st>>>(seed, perm, B, p->n_libs, p->keys.p);
+    const int64_t perm_row = perm - perm % FEISTEL_GROUP;  // rows start at group boundaries of the global index
+    k_keygen<<<(unsigned)ceil_div((int64_t)p->n_libs * (B / FEISTEL_GROUP + B / 2), 256), 256, 0, st>>>(seed, perm_row, 1, B, p->n_libs,
+                                                                                                       p->keys.p);
     SQGR_HIP(hipGetLastError());
     SQGR_TRY(launch_shuffle(p, 1, 0, st));
     std::vector<uint8_t> rows((size_t)p->n * B);
     SQGR_HIP(hipMemcpyAsync(rows.data(), p->slab.p, rows.size(), hipMemcpyDeviceToHost, st));
     SQGR_HIP(hipStreamSynchronize(st));
-    for (int64_t i = 0; i < p->n; ++i) out_labels[i] = rows[(size_t)i * B];
+    for (int64_t i = 0; i < p->n; ++i) out_labels[i] = rows[(size_t)i * B + (size_t)(perm - perm_row)];
     return SQGR_OK;
 }
 
@@ -1135,8 +1203,12 @@ int label_shuffler_philox(LabelShuffler* s, uint64_t seed, int64_t perm0, int nb
     sqgr_nhood* p = reinterpret_cast<sqgr_nhood*>(s);
     {
         LaunchTimer t(p->ctx, "ligrec_keygen", st);
-        const int64_t nk = (int64_t)nb * 32;
-        k_keygen<<<(unsigned)ceil_div(nk, 256), 256, 0, st>>>(seed, perm0, nk, 1, keys_ws);
+        if (perm0 % FEISTEL_GROUP != 0) {
+            set_error("label_shuffler_philox: perm0=%lld is not a multiple of %d", (long long)perm0, FEISTEL_GROUP);
+            return SQGR_ERR_INVALID;
+        }
+        const int64_t nk = (int64_t)nb * (32 / FEISTEL_GROUP + 32 / 2);
+        k_keygen<<<(unsigned)ceil_div(nk, 256), 256, 0, st>>>(seed, perm0, nb, 32, 1, keys_ws);
         SQGR_HIP(hipGetLastError());
     }
     return launch_shuffle_raw(p, 32, nb, keys_ws, slab, st);

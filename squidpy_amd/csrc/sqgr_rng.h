@@ -1,11 +1,23 @@
 // Counter-based permutation generator for the on-device label shuffles (gfx950).
 //
-//   round keys : Philox4x32-10( counter = (perm_lo, perm_hi, library, j), key = (seed_lo, seed_hi) ),
-//                j = 0,1  ->  8 x 32-bit keys per (seed, global permutation index, library)
+//   round keys : Philox4x32-10( counter = (index_lo, index_hi, library, j), key = (seed_lo, seed_hi) ),
+//                j = 0,1  ->  8 x 32-bit keys per (seed, global permutation index, library)      [feistel_perm]
+//                j = 2,3  ->  8 keys per (seed, permutation GROUP index, library)                [group bijection pi_g]
+//                j = 4    ->  2 keys per (seed, global permutation index, library)               [per-permutation sigma_p]
 //   bijection  : 8-round alternating additive Feistel network on the mixed-radix domain A x B >= n
 //                (A = power of two ~ sqrt(n), B = ceil(n / A), both >= 16) in 16-bit arithmetic — two permutations
 //                per instruction on the packed-16 VALU — cycle-walked into [0, n); the low 16 bits of the Philox
 //                words are the round keys.
+//
+// Label shuffles (nhood_enrichment, ligrec) use a TWO-LEVEL construction: the FEISTEL_GROUP = 16 permutations with
+// global indices 16g .. 16g+15 share one strong bijection pi_g (the 8-round network, keys j = 2,3 of index g) and differ
+// by a cheap 2-round network sigma_p (keys j = 4 of index p) applied to its image:  perm_p = sigma_p o pi_g, both
+// cycle-walked into [0, n).  Each perm_p is as uniform as pi_g (a fixed bijection after a uniform one is uniform); the
+// permutations of one group are dependent, which leaves every per-permutation statistic untouched and enters the
+// permutation-test moments only through the label contingency tables of (L o sigma_p, L o sigma_p') — tested to be
+// those of independent arrangements (tests/test_devrng.py, tools/null_moments.py).  One pi_g evaluation per spot serves
+// 16 label bytes: 3x fewer VALU operations per label than 16 independent 8-round evaluations.
+// Row permutations of spatial_autocorr keep one independent 8-round bijection per permutation (feistel_perm).
 //
 // oracle/devrng.py restates this file bit for bit; tests/test_devrng.py checks both the Philox
 // known-answer vectors and the statistical quality (uniformity over S_n for small n, agreement of
@@ -41,12 +53,26 @@ __host__ __device__ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
     }
 }
 
-__host__ __device__ inline void round_keys(uint64_t seed, uint64_t perm, uint32_t lib, uint32_t rk[8]) {
+__host__ __device__ inline void round_keys_tagged(uint64_t seed, uint64_t index, uint32_t lib, uint32_t tag0, uint32_t rk[8]) {
     for (uint32_t j = 0; j < 2; ++j) {
-        uint32_t c[4] = {(uint32_t)perm, (uint32_t)(perm >> 32), lib, j};
+        uint32_t c[4] = {(uint32_t)index, (uint32_t)(index >> 32), lib, tag0 + j};
         philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
         rk[4 * j + 0] = c[0]; rk[4 * j + 1] = c[1]; rk[4 * j + 2] = c[2]; rk[4 * j + 3] = c[3];
     }
+}
+__host__ __device__ inline void round_keys(uint64_t seed, uint64_t perm, uint32_t lib, uint32_t rk[8]) {
+    round_keys_tagged(seed, perm, lib, 0u, rk);
+}
+// two-level label shuffles: permutations 16g .. 16g+15 share the group bijection keyed by group_keys(g)
+constexpr int FEISTEL_GROUP = 16;
+__host__ __device__ inline void group_keys(uint64_t seed, uint64_t group, uint32_t lib, uint32_t rk[8]) {
+    round_keys_tagged(seed, group, lib, 2u, rk);
+}
+__host__ __device__ inline void sigma_keys(uint64_t seed, uint64_t perm, uint32_t lib, uint32_t rk[2]) {
+    uint32_t c[4] = {(uint32_t)perm, (uint32_t)(perm >> 32), lib, 4u};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    rk[0] = c[0];
+    rk[1] = c[1];
 }
 
 // 16-bit lanes: every quantity of the bijection (digits, keys, round function) is a 16-bit value, so two permutations
@@ -134,6 +160,50 @@ __device__ __forceinline__ void feistel_rounds(u16x2 (&a)[NP], u16x2 (&b)[NP], c
             b[i] = __builtin_elementwise_min(t, (u16x2)(t - BB));
         }
     }
+}
+
+// sigma_p: two additive rounds, low digit first —  b <- (b + F_B(a, k_0)) mod B;  a <- (a + F_A(b, k_1)) mod A.
+// (Low digit first: the label of a rank is decided by its high digit almost alone, so the shift of the high digit must
+// depend on both input digits for neighbouring ranks to part.)
+template <int NP>
+__device__ __forceinline__ void sigma_rounds(u16x2 (&a)[NP], u16x2 (&b)[NP], const FeistelDomain& d,
+                                             const uint32_t* const (&pk)[NP]) {
+    const u16x2 am = (u16x2)((unsigned short)(d.A - 1u));
+    const u16x2 ash = (u16x2)((unsigned short)d.ash), bsh = (u16x2)((unsigned short)d.bsh);
+    const u16x2 BB = (u16x2)((unsigned short)d.B);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const u16x2 k0 = __builtin_bit_cast(u16x2, pk[i][0]);
+        u16x2 t = b[i] + feistel_F2(a[i], k0, bsh);
+        t = __builtin_elementwise_min(t, (u16x2)(t - BB));
+        b[i] = __builtin_elementwise_min(t, (u16x2)(t - BB));
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const u16x2 k1 = __builtin_bit_cast(u16x2, pk[i][1]);
+        a[i] = (a[i] + feistel_F2(b[i], k1, ash)) & am;
+    }
+}
+
+// single-permutation form of the two-level label permutation (same arithmetic): image of x (< n) under
+// sigma(sk) o pi(gk), gk = group_keys(seed, perm / 16, lib), sk = sigma_keys(seed, perm, lib)
+__host__ __device__ inline uint32_t grouped_perm(uint32_t x, const FeistelDomain& d, const uint32_t* gk, const uint32_t* sk) {
+    uint32_t a = x / d.B, b = x - a * d.B;
+    do {
+        for (int r = 0; r < FEISTEL_ROUNDS; r += 2) {
+            a = (a + feistel_F1(b, gk[r], d.ash)) & (d.A - 1u);
+            uint32_t t = b + feistel_F1(a, gk[r + 1], d.bsh);
+            t = t >= d.B ? t - d.B : t;
+            b = t >= d.B ? t - d.B : t;
+        }
+    } while (a * d.B + b >= d.n);
+    do {
+        uint32_t t = b + feistel_F1(a, sk[0], d.bsh);
+        t = t >= d.B ? t - d.B : t;
+        b = t >= d.B ? t - d.B : t;
+        a = (a + feistel_F1(b, sk[1], d.ash)) & (d.A - 1u);
+    } while (a * d.B + b >= d.n);
+    return a * d.B + b;
 }
 
 // single-permutation form (same arithmetic): image of x (< n)
