@@ -1,17 +1,34 @@
 #!/usr/bin/env python
 """Benchmark of the sq.gr hot path on MI355X (contract: see the task statement / DESIGN.md §Measurement).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong --total-perms P]
 
 Workload (N=1): ``nhood_enrichment`` permutation test on the 1e6-spot hex grid x 30 clusters that BASELINE.json's
-metric is quoted on; one *step* = one pass of the hot path over one batch of PERMS_PER_STEP (10 000) permutations
-with graph and labels already resident in HBM.  N>1: one process per GPU (torch.distributed, backend nccl = RCCL),
-every rank runs its own permutation range of each step (weak scaling, no data-path collective) followed by the
-path's one real exchange: an all-reduce of the exact integer moments.
+metric is quoted on (config 5's shape); one *step* = one pass of the hot path over one batch of permutations with
+graph and labels already resident in HBM.  N>1: one process per GPU started by any launcher that exports
+RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (``python -m torch.distributed.run``); the ranks find each other through
+squidpy_amd's own socket rendezvous — torch is not imported — and every step ends with the path's one real exchange:
+the all-reduce of the exact integer moments, done ON THE DEVICE by RCCL inside libsqgr (``sqgr_nhood_set_comm``).
 
-Rank 0 prints ONE JSON line with `roofline` (HIP-event timing of the CSR-gather kernel on the library's own
-stream) and, at N=1, `cpu_baseline` (the oracle's C restatement of Squidpy's numba kernel driven by numpy's
-PCG64 shuffles, timed on this box's host cores on a bounded sample)."""
+* ``--scaling weak`` (default): every rank runs ``--perms-per-step`` (10 000) permutations per step, disjoint global
+  permutation indices per rank and step.
+* ``--scaling strong``: a step is BASELINE config 5 as specified — ``--total-perms`` (100 000) permutations split
+  1/N over the ranks.
+
+Rank 0 prints ONE JSON line.  Every ``frac`` in it is a fraction of a ceiling the kernel can actually reach:
+
+* ``roofline``            the CSR-gather kernel (``nhood_count*``): LDS-atomic issue — one ``ds_add_u32`` lane-operation
+                          per (edge of the list, permutation) against the chip's measured ``ds_add_u32`` rate
+                          (profiles/r02_ubench_ops.json, tools/ubench_ops.hip); its HBM side (algorithmic bytes,
+                          PMC traffic) is reported next to it, the ratio of the two is ``algorithmic_reuse``.
+* ``kernels``             the same for every kernel of the step (label shuffle: VALU issue; reduce: HBM).
+* ``secondary``           Moran's I genes/s on the config-3 shape, gather-bound out of L2 / Infinity Cache.
+* ``legs``                co_occurrence and Ripley L on the config-4 shape (pairs/s, VALU issue).
+* ``cpu_baseline``        the oracle's C restatement of Squidpy's numba kernel driven by numpy's PCG64 shuffles, timed
+                          on this box's host cores on a bounded sample (N=1, rank 0 only).
+PMC-derived inputs (HBM traffic, instruction counts per launch) cannot be collected inside this process; they come from
+``profiles/r02_counters.json``, written by ``tools/profile_round.sh`` from rocprofv3 ``--pmc`` passes of THIS command,
+and are used only when that file's workload (spots, permutations per launch, list length) matches the run."""
 
 from __future__ import annotations
 
@@ -30,9 +47,61 @@ if ROOT not in sys.path:
 ROWS = COLS = 1000
 N_CLS = 30
 PERMS_PER_STEP = 10_000
-HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md
+HBM_PEAK = 8.0e12   # B/s, MI355X_MICROARCH.md
+L2_PEAK = 34.5e12   # B/s aggregate L2 bandwidth, MI355X_MICROARCH.md §L2
+PROFILE_TAG = "r02"
 
 
+# --------------------------------------------------------------------------------------------- measured ceilings
+def load_ceilings() -> dict:
+    """Issue-rate ceilings measured by tools/ubench_ops.hip on an MI355X (committed: profiles/r02_ubench_ops.json)."""
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_ubench_ops.json")
+    out = {"source": os.path.relpath(path, ROOT), "valu_simple": None, "valu_complex": None, "lds_add": None, "lds_add_pattern": None}
+    try:
+        with open(path) as fh:
+            ub = json.load(fh)
+        ops = {r["op"]: r["wave_instr_per_s"] for r in ub["valu"]}
+        simple = [ops[k] for k in ("v_fma_f32", "v_add_u32", "v_sub_u32", "v_xor_b32", "v_and_b32", "v_lshrrev_b32") if k in ops]
+        cplx = [v for k, v in ops.items() if k.startswith(("v_pk_", "v_mad_u32_u24", "v_mul_u32_u24", "v_lshl_", "v_alignbit", "v_perm", "v_bfe")) or "sdwa" in k or "dpp" in k]
+        out["valu_simple"] = float(np.mean(simple))     # wave-instructions/s, whole chip: add/sub/xor/and/shift/fma class
+        out["valu_complex"] = float(np.mean(cplx))      # packed-16, VOP3, SDWA, DPP, 24-bit multiply class
+        lds = {r["pattern"]: r["wave_instr_per_s"] for r in ub["lds"]}
+        out["lds_add"] = max(v for k, v in lds.items() if "conflict-free" in k)
+        out["lds_add_pattern"] = max(v for k, v in lds.items() if "count-kernel pattern" in k and "57.6" in k)
+    except Exception as exc:  # pragma: no cover
+        out["error"] = repr(exc)
+    return out
+
+
+def load_counters() -> dict:
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_counters.json")
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+        d["_source"] = os.path.relpath(path, ROOT)
+        return d
+    except Exception:
+        return {}
+
+
+def kernel_counters(counters: dict, kernel_prefix: str, workload: dict) -> dict | None:
+    """Per-launch PMC averages of a kernel from the committed profile, only if it was taken on this workload."""
+    if not counters or counters.get("workload") != workload:
+        return None
+    for name, rec in counters.get("kernels", {}).items():
+        if kernel_prefix in name:
+            return rec
+    return None
+
+
+def valu_mix_peak(ceil: dict, frac_complex: float) -> float | None:
+    """Ceiling (wave-instructions/s) of an instruction stream with the given share of complex-class instructions."""
+    if not ceil.get("valu_simple"):
+        return None
+    return 1.0 / ((1.0 - frac_complex) / ceil["valu_simple"] + frac_complex / ceil["valu_complex"])
+
+
+# --------------------------------------------------------------------------------------------- CPU baseline legs
 def _cpu_worker(args):
     path, n_cls, first, count = args
     from oracle import cport  # checker code: cpu_baseline leg only
@@ -49,27 +118,25 @@ def _cpu_worker(args):
     return time.perf_counter() - t0
 
 
-def _cpu_baseline_all_cores(indices, indptr, base, budget_s: float) -> dict:
-    """One single-threaded worker *process* per host core (plain subprocesses of this file, hard timeout)."""
+def _cpu_baseline_all_cores(indices, indptr, base, n_cls: int, per_worker: int) -> dict:
+    """One single-threaded worker *process* per host core this process may run on (plain subprocesses, hard timeout)."""
     import subprocess
     import tempfile
 
-    ncores = len(os.sched_getaffinity(0))
-    workers = min(ncores, 64)
-    per_worker = 6
+    workers = len(os.sched_getaffinity(0))
     with tempfile.TemporaryDirectory() as tmp:
         path = os.path.join(tmp, "graph.npz")
         np.savez(path, indices=indices, indptr=indptr, base=base)
         t0 = time.perf_counter()
         procs = [
-            subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", path, str(w * per_worker), str(per_worker)],
+            subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", path, str(n_cls), str(w * per_worker), str(per_worker)],
                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
             for w in range(workers)
         ]
         busy = []
         for p in procs:
             try:
-                o, _ = p.communicate(timeout=120)
+                o, _ = p.communicate(timeout=180)
                 busy.append(float(o.strip().splitlines()[-1]))
             except Exception:
                 p.kill()
@@ -77,9 +144,9 @@ def _cpu_baseline_all_cores(indices, indptr, base, budget_s: float) -> dict:
     if len(busy) != workers:
         return {"error": f"{workers - len(busy)} of {workers} workers failed"}
     # throughput while all cores are busy: workers run concurrently, each reports the time of its own loop
-    return {"value": workers * per_worker / max(busy), "unit": "permutations/s", "cores": workers, "host_cores": ncores,
-            "mode": "n_jobs=all-cores analogue: one single-threaded worker process per core, contiguous permutation chunks",
-            "sample": f"{workers * per_worker} permutations, slowest worker loop {max(busy):.1f} s (wall incl. start-up {wall:.1f} s)"}
+    return {"value": workers * per_worker / max(busy), "unit": "permutations/s", "cores": workers,
+            "mode": "n_jobs=-1 analogue: one single-threaded worker process per core (len(os.sched_getaffinity(0))), contiguous permutation chunks",
+            "sample": f"{workers * per_worker} permutations, slowest worker loop {max(busy):.1f} s (wall incl. process start-up {wall:.1f} s)"}
 
 
 def cpu_baseline(adj, labels: np.ndarray, budget_s: float = 12.0) -> dict:
@@ -87,6 +154,7 @@ def cpu_baseline(adj, labels: np.ndarray, budget_s: float = 12.0) -> dict:
     workload: per permutation `shuffled = int_clust.copy(); rng.shuffle(shuffled); _nenrich(...)`
     (gr/_nhood.py:530-539), numba kernel restated in C (oracle/c/sqgr_cpu.c) because numba is absent."""
     from oracle import cport  # checker code: cpu_baseline leg only
+    from squidpy_amd._synthetic import hex_grid_graph
 
     cport.lib(native=True)
     indices, indptr = adj.indices.astype(np.uint32), adj.indptr.astype(np.uint32)
@@ -113,13 +181,30 @@ def cpu_baseline(adj, labels: np.ndarray, budget_s: float = 12.0) -> dict:
     # all host cores: Squidpy's n_jobs=-1 (joblib process fan-out, contiguous permutation chunks per worker,
     # _utils.py:223-231), each worker single-threaded like `_callback_wrapper` forces numba to be
     try:
-        out["all_cores"] = _cpu_baseline_all_cores(indices, indptr, base, budget_s)
+        out["all_cores"] = _cpu_baseline_all_cores(indices, indptr, base, N_CLS, per_worker=4)
     except Exception as exc:  # pragma: no cover
         out["all_cores"] = {"error": repr(exc)}
+    # BASELINE config 1 (the reference's own CPU-runnable case) in FULL: 5 000-spot hex grid, 10 clusters, n_perms = 1000
+    try:
+        g1 = hex_grid_graph(50, 100)
+        lab1 = np.random.default_rng(0).integers(0, 10, g1.shape[0]).astype(np.uint32)
+        i1, p1 = g1.indices.astype(np.uint32), g1.indptr.astype(np.uint32)
+        gens1 = [np.random.default_rng(s) for s in np.random.SeedSequence(0).spawn(1000)]
+        t1 = time.perf_counter()
+        for r in gens1:
+            sh = lab1.copy()
+            r.shuffle(sh)
+            cport.nenrich(i1, p1, sh, 10, parallel=False, native=True).astype(np.float64)
+        d1 = time.perf_counter() - t1
+        out["config1_full"] = {"value": 1000 / d1, "unit": "permutations/s", "cores": 1, "seconds": d1,
+                               "sample": "config 1 in full: 5 000-spot hex grid x 10 clusters x 1000 permutations, 1 core"}
+    except Exception as exc:  # pragma: no cover
+        out["config1_full"] = {"error": repr(exc)}
     return out
 
 
-def moran_secondary(ctx, world: int, rank: int, fence, steps: int, with_cpu: bool) -> dict:
+# --------------------------------------------------------------------------------------------- Moran's I leg
+def moran_secondary(ctx, world: int, fence, reduce_max, steps: int, with_cpu: bool, counters: dict) -> dict:
     """Second half of BASELINE.json's metric: Moran's I genes/sec on the C3 shape (1e5 spots, k=6 CSR graph,
     n_perms=1000); one step = observed score + 1000 permuted scores for a resident block of 2048 genes per GPU."""
     from sklearn.preprocessing import normalize
@@ -129,6 +214,7 @@ def moran_secondary(ctx, world: int, rank: int, fence, steps: int, with_cpu: boo
 
     rows, cols, G, P = 250, 400, 2048, 1000
     n = rows * cols
+    rank = int(os.environ.get("RANK", "0"))
     g = normalize(hex_grid_graph(rows, cols), norm="l1", axis=1)
     vals = np.random.default_rng(1 + rank).gamma(2.0, 1.0, size=(G, n))
     graph = _lib.Graph(ctx, g, with_data=True)
@@ -142,19 +228,39 @@ def moran_secondary(ctx, world: int, rank: int, fence, steps: int, with_cpu: boo
         score = plan.scores("moran")
         sims = plan.perms("moran", seed=7, perm_begin=i * P, perm_end=(i + 1) * P)
     fence()
-    elapsed = time.perf_counter() - t0
+    elapsed = reduce_max(time.perf_counter() - t0)
     kernels = ctx.timer_report()
     ctx.timer_enable(False)
     assert np.isfinite(score).all() and np.isfinite(sims).all()
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     cnt, ms = kernels.get("autocorr_perm_dot_moran", (0, 0.0))
     b_gene = (P + 1) * 8 * n
+    gather_bps = (b_gene * G * steps / (ms * 1e-3)) if ms > 0 else None
+    pmc = kernel_counters(counters.get("moran", {}), "k_perm_dot", {"spots": n, "genes": G, "perms": P})
+    roof = {
+        "kernel": "autocorr_perm_dot_moran",
+        "bound": "mall_gather",
+        "achieved": gather_bps / 1e9 if gather_bps else None,
+        "peak": L2_PEAK / 1e9,
+        "unit": "GB/s",
+        "frac": gather_bps / L2_PEAK if gather_bps else None,
+        "traffic": None,
+        "launches": cnt,
+        "avg_launch_ms": ms / max(cnt, 1),
+        "algorithmic_bytes_per_gene": b_gene,
+        "workload_key": {"spots": n, "genes": G, "perms": P},
+        "algorithmic_frac_of_hbm_peak": gather_bps / HBM_PEAK if gather_bps else None,
+        "note": "algorithmic bytes = one float64 pass over a gene's N values per evaluation (SURVEY §8d): 512-byte row gathers of "
+        "[spot][64 genes] tiles; the 51 MB working set of the tiles in flight lives in L2 / the 256 MB Infinity Cache, so the "
+        "ceiling priced is the guide's aggregate L2 bandwidth (34.5 TB/s), not HBM; HBM-side traffic and TCC hit rate from PMC below",
+    }
+    if pmc:
+        fetch, write = pmc.get("FETCH_SIZE_bytes"), pmc.get("WRITE_SIZE_bytes")
+        if fetch is not None and write is not None:
+            roof["traffic"] = 2.0 * fetch + write
+            roof["traffic_source"] = counters.get("_source")
+            roof["hbm_GBps_from_traffic"] = roof["traffic"] / (ms / max(cnt, 1) * 1e-3) / 1e9 if ms > 0 else None
+        if pmc.get("TCC_HIT_sum") is not None and pmc.get("TCC_MISS_sum") is not None:
+            roof["l2_hit_rate"] = pmc["TCC_HIT_sum"] / max(pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"], 1.0)
     out = {
         "metric": "Moran's I genes/sec (1e5 spots, CSR k=6, n_perms=1000)",
         "value": steps * G * world / elapsed,
@@ -162,19 +268,7 @@ def moran_secondary(ctx, world: int, rank: int, fence, steps: int, with_cpu: boo
         "ms_per_step": elapsed / steps * 1e3,
         "dtype": "f64",
         "config": {"workload": f"spatial_autocorr moran: {n} spots, {G} genes per GPU per step, {P} permutations, device permutations"},
-        "roofline": {
-            "kernel": "autocorr_perm_dot_moran",
-            "bound": "hbm",
-            "achieved": (b_gene * G * steps / (ms * 1e-3) / 1e9) if ms > 0 else None,
-            "peak": HBM_PEAK / 1e9,
-            "unit": "GB/s",
-            "frac": (b_gene * G * steps / (ms * 1e-3) / HBM_PEAK) if ms > 0 else None,
-            "traffic": None,
-            "launches": cnt,
-            "avg_launch_ms": ms / max(cnt, 1),
-            "algorithmic_bytes_per_gene": b_gene,
-            "note": "512-byte row gathers served mostly by the 256 MB Infinity Cache (working set per 64-gene tile = 51 MB)",
-        },
+        "roofline": roof,
     }
     if with_cpu:
         from oracle import cport  # checker code: cpu_baseline leg only
@@ -203,12 +297,102 @@ def moran_secondary(ctx, world: int, rank: int, fence, steps: int, with_cpu: boo
     return out
 
 
+# --------------------------------------------------------------------------------------------- config-4 legs
+def config4_legs(ctx, ceil: dict, with_cpu: bool) -> dict:
+    """co_occurrence and Ripley L on BASELINE config 4's shape: 1e6 points (hex grid + N(0,5) jitter), 30 clusters,
+    50 interval edges (49 thresholds) / 50 Ripley radii.  Unit of work = one ORDERED pair evaluation (SURVEY §8d);
+    both kernels are VALU-issue bound (no HBM or MFMA roofline applies): 15 VALU wave-instructions per 64 unordered
+    pairs in the branch-free inner loop, priced against the measured rate of that instruction class."""
+    from squidpy_amd import _lib
+    from squidpy_amd._synthetic import hex_grid
+    from squidpy_amd.gr._ppatterns import _find_min_max
+
+    n = ROWS * COLS
+    rng = np.random.default_rng(0)
+    xy = hex_grid(ROWS, COLS) + rng.normal(0, 5, (n, 2))
+    labels = rng.integers(0, N_CLS, n).astype(np.int32)
+    out = {}
+    # ---- co_occurrence (gr/_ppatterns.py:283-310): float32 coordinates, 49 squared thresholds
+    sp = xy.astype(np.float32)
+    lo, hi = _find_min_max(sp)
+    interval = np.linspace(lo, hi, num=50, dtype=np.float32)
+    thr2 = interval[1:] ** 2
+    _lib.cooccur_counts(ctx, sp[:4096, 0], sp[:4096, 1], labels[:4096], N_CLS, thr2)  # warm-up (module load, allocations)
+    ctx.sync()
+    ctx.timer_enable(True)
+    ctx.timer_reset()
+    t0 = time.perf_counter()
+    counts = _lib.cooccur_counts(ctx, sp[:, 0], sp[:, 1], labels, N_CLS, thr2)
+    wall = time.perf_counter() - t0
+    k = ctx.timer_report()
+    ctx.timer_enable(False)
+    kms = sum(v[1] for name, v in k.items() if name.startswith("cooccur_pairs"))
+    pairs = n * (n - 1)
+    assert int(counts[:, :, -1].sum()) <= pairs
+    valu_per_pair = 15.0 / 2.0 / 64.0   # wave-instructions per ORDERED pair (15 per 64 unordered pairs)
+    peak = valu_mix_peak(ceil, 0.5)
+    out["co_occurrence"] = {
+        "metric": "co_occurrence ordered pair evaluations/sec (1e6 points x 30 clusters x 49 thresholds)",
+        "value": pairs / wall, "unit": "pairs/s", "wall_s": wall, "kernel_ms": kms,
+        "roofline": {"kernel": "cooccur_pairs_fast", "bound": "valu_issue", "achieved": pairs * valu_per_pair / (kms * 1e-3) if kms > 0 else None,
+                     "peak": peak, "unit": "wave-instr/s", "frac": (pairs * valu_per_pair / (kms * 1e-3) / peak) if kms > 0 and peak else None,
+                     "traffic": None,
+                     "algorithmic_hbm_bytes": (n / 256.0) * n * 8.0,
+                     "note": "15 VALU + 3 LDS wave-instructions per 64 unordered pairs (branch-free loop, every unordered pair evaluated once "
+                     "and credited to (a,b) and (b,a)); HBM side negligible: (N/256)*N*8 B of tile re-reads"},
+    }
+    # ---- Ripley L (gr/_ripley.py:212-227): float64 pair counts per cluster, 50 radii
+    from scipy.spatial import ConvexHull
+
+    hull = ConvexHull(xy[:: max(n // 20000, 1)])
+    area = hull.volume
+    support = np.linspace(0, (area / 2) ** 0.5, 50)
+    by_cluster = [np.ascontiguousarray(xy[labels == c]) for c in range(N_CLS)]
+    _lib.pair_counts(ctx, by_cluster[0][:2048], support)
+    ctx.sync()
+    ctx.timer_enable(True)
+    ctx.timer_reset()
+    t0 = time.perf_counter()
+    tot = 0
+    for pts in by_cluster:
+        tot += int(_lib.pair_counts(ctx, pts, support)[-1])
+    wall = time.perf_counter() - t0
+    k = ctx.timer_report()
+    ctx.timer_enable(False)
+    kms = sum(v[1] for name, v in k.items() if name.startswith("ripley_pair_hist"))
+    rp = sum(len(p) * (len(p) - 1) for p in by_cluster)
+    out["ripley_L"] = {
+        "metric": "ripley L ordered pair evaluations/sec (1e6 points in 30 clusters, 50 radii, float64)",
+        "value": rp / wall, "unit": "pairs/s", "wall_s": wall, "kernel_ms": kms, "pairs": rp,
+        "roofline": {"kernel": "ripley_pair_hist_fast", "bound": "valu_issue",
+                     "achieved": rp / (kms * 1e-3) if kms > 0 else None, "peak": None, "unit": "pairs/s", "frac": None, "traffic": None,
+                     "note": "float64 VALU (v_fma_f64 / v_mul_f64 issue at quarter to half the f32 rate on gfx950 — not yet in tools/ubench_ops.hip), "
+                     "so no ceiling is claimed; reported as pairs/s of kernel time and of wall time"},
+    }
+    if with_cpu:
+        from oracle import cport  # checker code: cpu_baseline leg only
+
+        m = 20000
+        t0 = time.perf_counter()
+        cport.occur_count(sp[:m, 0], sp[:m, 1], thr2, labels[:m], N_CLS, parallel=False, native=True)
+        dt = time.perf_counter() - t0
+        out["co_occurrence"]["cpu_baseline"] = {"value": m * (m - 1) / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
+                                                "sample": f"C restatement of _occur_count on the first {m} points ({dt:.1f} s, 1 core); cost scales with N^2"}
+    return out
+
+
+# --------------------------------------------------------------------------------------------- main
 def main() -> None:
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
+        print(_cpu_worker((sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]))))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--perms-per-step", type=int, default=PERMS_PER_STEP)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--total-perms", type=int, default=100_000, help="--scaling strong: permutations per step over ALL ranks (config 5)")
     ap.add_argument("--rows", type=int, default=ROWS)
     ap.add_argument("--cols", type=int, default=COLS)
     ap.add_argument("--label-dist", choices=["uniform", "dirichlet"], default="uniform",
@@ -216,27 +400,14 @@ def main() -> None:
                     "that concentrates the LDS-atomic traffic of the count kernel on few counters)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the Moran's I genes/sec leg")
+    ap.add_argument("--no-legs", action="store_true", help="skip the co_occurrence / Ripley L legs (config 4)")
     ap.add_argument("--no-numpy-leg", action="store_true", help="skip the bit-compatible numpy-stream leg")
     ap.add_argument("--tune", type=str, default="", help="perms_per_pass,blocks_per_batch,batches_per_launch")
-    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
-        print(_cpu_worker((sys.argv[2], N_CLS, int(sys.argv[3]), int(sys.argv[4]))))
-        return
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = torch = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-
-        torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
-        backend = os.environ.get("SQGR_DIST_BACKEND", "nccl")  # "gloo" lets one GPU host several ranks (testing only)
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1)))
-        else:
-            dist.init_process_group(backend=backend)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
@@ -245,6 +416,10 @@ def main() -> None:
     from squidpy_amd.gr._nhood import expected_counts, zscore_from_moments
 
     ctx = _lib.default_context(local_rank % max(_lib.device_count(), 1))
+    comm = None
+    if world > 1:
+        _dist.init()                 # socket rendezvous from the launcher's environment; torch is not imported
+        comm = _dist.device_comm()   # RCCL communicator owned by libsqgr (None: host fall-back through the rendezvous)
     adj = hex_grid_graph(args.rows, args.cols)
     n, nnz = adj.shape[0], int(adj.nnz)
     lab_rng = np.random.default_rng(0)
@@ -256,22 +431,36 @@ def main() -> None:
     plan = _lib.NhoodPlan(ctx, graph, labels, N_CLS)
     if args.tune:
         plan.tune(*[int(v) for v in args.tune.split(",")])
+    if comm is not None:
+        plan.set_comm(comm)
     count = _lib.nhood_counts(ctx, graph, labels, N_CLS)
     shift = expected_counts(labels, N_CLS, nnz)
-    P = args.perms_per_step
+    strong = args.scaling == "strong"
+    P = args.total_perms if strong else args.perms_per_step   # strong: per step over all ranks; weak: per step per rank
 
     def step(i: int):
-        lo = (i * world + rank) * P                         # disjoint global permutation indices per rank & step
-        s1, s2, _ = plan.run(12345, lo, lo + P, shift)
-        if world > 1:
-            s1, s2 = _dist.allreduce_sum_([s1, s2])         # the path's only exchange (RCCL over xGMI)
+        if strong:
+            lo, hi = _dist.shard_range(P, rank, world, begin=i * P)
+        else:
+            lo = (i * world + rank) * P                     # disjoint global permutation indices per rank & step
+            hi = lo + P
+        s1, s2, _ = plan.run(12345, lo, hi, shift)          # with a communicator: moments all-reduced on the device (RCCL)
+        if world > 1 and comm is None:
+            s1, s2 = _dist.allreduce_sum_([s1, s2])         # host fall-back
         return s1, s2
 
     def fence():
         if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-        ctx.sync()
+            _dist.barrier()
+        ctx.sync()                                          # both library streams (== device synchronise for this process)
+
+    def reduce_max(seconds: float) -> float:
+        if world <= 1:
+            return seconds
+        ns = np.array([int(seconds * 1e9)], dtype=np.int64)
+        if comm is not None:
+            return float(comm.allreduce_i64(ns, op=_lib.Comm.MAX)[0]) / 1e9
+        return max(float(v) for v in _dist.allgather_object(seconds))
 
     for i in range(args.warmup):
         step(i)
@@ -286,42 +475,108 @@ def main() -> None:
         tot1 += s1
         tot2 += s2
     fence()
-    elapsed = time.perf_counter() - t0
+    elapsed = reduce_max(time.perf_counter() - t0)
     kernels = ctx.timer_report()
     ctx.timer_enable(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    collective = "none" if world == 1 else ("rccl-in-library (device all-reduce of the moments)" if comm is not None else _dist.collective_kind() + " (host fall-back)")
 
+    ceil = load_ceilings()
+    counters = load_counters()
     secondary = None
     if not args.no_secondary:
-        secondary = moran_secondary(ctx, world, rank, fence, max(1, min(args.steps, 3)), world == 1 and rank == 0 and not args.no_cpu_baseline)
+        secondary = moran_secondary(ctx, world, fence, reduce_max, max(1, min(args.steps, 3)), world == 1 and rank == 0 and not args.no_cpu_baseline,
+                                    counters)
+    legs = None
+    if world == 1 and not args.no_legs:
+        legs = config4_legs(ctx, ceil, not args.no_cpu_baseline)
 
     if rank == 0:
-        total_perms = args.steps * P * world
+        total_perms = args.steps * (P if strong else P * world)
         z = zscore_from_moments(count, shift, tot1, tot2, total_perms)
         assert np.isfinite(z).all(), "non-finite z-score in benchmark run"
-        # ---- roofline of the CSR-gather kernel (nhood_count*), HIP events on the library's stream
+        info = plan.info()
+        list_edges = info["list_edges"]                    # edges the count kernel walks (half list on a symmetric graph)
+        per_rank_step = (P // world) if strong else P
         cnt_name = [k for k in kernels if k.startswith("nhood_count") and kernels[k][0] > 0]
         launches = sum(kernels[k][0] for k in cnt_name)
-        ms = sum(kernels[k][1] for k in cnt_name)
-        perms_per_launch = args.steps * P / max(launches, 1)
-        # algorithmic bytes per permutation: indices + indptr streamed once, shuffled labels read once
-        # by this kernel (their write, N bytes, belongs to the shuffle kernel and is counted in the pipeline figure)
-        b_gather = 4 * nnz + 4 * (n + 1) + n
-        b_perm = 4 * nnz + 4 * (n + 1) + 2 * n
-        achieved = b_gather * perms_per_launch / (ms / max(launches, 1) * 1e-3) if ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
-        if os.path.exists(tpath):
-            try:
-                with open(tpath) as fh:
-                    traffic = json.load(fh).get("nhood_count_bytes_per_launch")
-            except Exception:
-                traffic = None
+        ms_count = sum(kernels[k][1] for k in cnt_name)
+        perms_per_launch = args.steps * per_rank_step / max(launches, 1)
+        workload = {"spots": n, "nnz": nnz, "clusters": N_CLS, "list_edges": list_edges, "perms_per_launch": round(perms_per_launch, 3)}
+        shuf_launch, ms_shuf = kernels.get("nhood_shuffle", (0, 0.0))
+        red_launch, ms_red = kernels.get("nhood_reduce", (0, 0.0))
+
+        def hbm_side(prefix: str, algorithmic_bytes_per_launch: float, launch_ms: float) -> dict:
+            rec = kernel_counters(counters.get("nhood", {}), prefix, workload)
+            side = {"algorithmic_bytes_per_launch": algorithmic_bytes_per_launch,
+                    "algorithmic_GBps": algorithmic_bytes_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else None,
+                    "traffic_bytes_per_launch": None, "traffic_source": None}
+            if rec and rec.get("FETCH_SIZE_bytes") is not None and rec.get("WRITE_SIZE_bytes") is not None:
+                # MI355X_MICROARCH.md §HBM: FETCH_SIZE counts half the bytes of wide coalesced reads on gfx950 -> doubled
+                traffic = 2.0 * rec["FETCH_SIZE_bytes"] + rec["WRITE_SIZE_bytes"]
+                side["traffic_bytes_per_launch"] = traffic
+                side["traffic_source"] = counters.get("_source")
+                side["traffic_GBps"] = traffic / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else None
+                side["traffic_frac_of_hbm_peak"] = traffic / (launch_ms * 1e-3) / HBM_PEAK if launch_ms > 0 else None
+                side["algorithmic_reuse"] = algorithmic_bytes_per_launch / traffic if traffic > 0 else None
+            return side, rec
+
+        # ---- CSR-gather kernel: one ds_add_u32 lane-operation per (list edge, permutation)
+        avg_count_ms = ms_count / max(launches, 1)
+        atomics_per_launch = list_edges * perms_per_launch / 64.0                  # wave-instructions (64 lanes each)
+        lds_rate = atomics_per_launch / (avg_count_ms * 1e-3) if avg_count_ms > 0 else 0.0
+        b_gather = 4 * nnz + 4 * (n + 1) + n                                        # SURVEY §8d, per permutation
+        side, rec = hbm_side("k_count", b_gather * perms_per_launch, avg_count_ms)
+        roof = {
+            "kernel": "+".join(cnt_name) or "nhood_count",
+            "bound": "lds_atomic",
+            "achieved": lds_rate,
+            "peak": ceil.get("lds_add"),
+            "unit": "ds_add_u32 wave-instr/s",
+            "frac": lds_rate / ceil["lds_add"] if ceil.get("lds_add") else None,
+            "traffic": side["traffic_bytes_per_launch"],
+            "launches": launches,
+            "avg_launch_ms": avg_count_ms,
+            "perms_per_launch": perms_per_launch,
+            "list_edges": list_edges,
+            "symmetric_half_list": info["symmetric"],
+            "workload_key": workload,
+            "frac_of_pattern_ceiling": lds_rate / ceil["lds_add_pattern"] if ceil.get("lds_add_pattern") else None,
+            "ceiling_source": ceil.get("source"),
+            "hbm": side,
+            "note": "the CSR gather of the permutation test: every edge of the (half) list adds 1 to one LDS counter per permutation, so "
+            "ds_add_u32 issue is the floor (conflict-free chip rate measured by tools/ubench_ops.hip; `frac_of_pattern_ceiling` uses the "
+            "rate of this kernel's own quad-staggered address pattern).  HBM is NOT the bound: one pass over the edge list serves 16 "
+            "permutations, so SURVEY §8d's algorithmic bytes (4*nnz + 4*(N+1) + N per permutation) exceed the measured traffic by "
+            "`hbm.algorithmic_reuse`",
+        }
+        if rec and rec.get("SQ_INSTS_VALU") is not None:
+            vi = rec["SQ_INSTS_VALU"]
+            roof["valu"] = {"wave_instr_per_launch": vi, "per_atomic": vi / max(atomics_per_launch, 1.0),
+                            "achieved": vi / (avg_count_ms * 1e-3), "peak": valu_mix_peak(ceil, 0.8), "unit": "wave-instr/s",
+                            "frac": vi / (avg_count_ms * 1e-3) / valu_mix_peak(ceil, 0.8) if valu_mix_peak(ceil, 0.8) else None,
+                            "note": "VALU side of the same kernel (SDWA/DPP/shift-add address arithmetic, ~80 % complex class): co-limiter"}
+        # ---- label shuffle: VALU issue
+        avg_shuf_ms = ms_shuf / max(shuf_launch, 1)
+        side_s, rec_s = hbm_side("k_shuffle", n * perms_per_launch, avg_shuf_ms)
+        shuf = {"kernel": "nhood_shuffle", "bound": "valu_issue", "achieved": None, "peak": valu_mix_peak(ceil, 0.65), "unit": "wave-instr/s", "frac": None,
+                "traffic": side_s["traffic_bytes_per_launch"], "avg_launch_ms": avg_shuf_ms, "launches": shuf_launch, "hbm": side_s,
+                "labels_per_s": n * perms_per_launch / (avg_shuf_ms * 1e-3) if avg_shuf_ms > 0 else None,
+                "note": "two-level generator: one 8-round bijection per spot and 16 permutations + a 2-round network and a table look-up per "
+                "label, two labels per packed-16 instruction; ~65 % of its VALU instructions are of the complex class (packed-16 / SDWA), "
+                "the ceiling is the measured mix rate (profiles/r02_ubench_ops.json); instruction count per launch from PMC SQ_INSTS_VALU"}
+        if rec_s and rec_s.get("SQ_INSTS_VALU") is not None and avg_shuf_ms > 0:
+            shuf["achieved"] = rec_s["SQ_INSTS_VALU"] / (avg_shuf_ms * 1e-3)
+            shuf["frac"] = shuf["achieved"] / shuf["peak"] if shuf["peak"] else None
+            shuf["valu_wave_instr_per_label"] = rec_s["SQ_INSTS_VALU"] * 64.0 / (n * perms_per_launch)
+        # ---- reduce: HBM (reads the partial histograms once)
+        avg_red_ms = ms_red / max(red_launch, 1)
+        red_bytes = info["partial_bytes_per_launch"] * (2 if info["symmetric"] else 1)
+        red = {"kernel": "nhood_reduce", "bound": "hbm", "achieved": red_bytes / (avg_red_ms * 1e-3) / 1e9 if avg_red_ms > 0 else None, "peak": HBM_PEAK / 1e9,
+               "unit": "GB/s", "frac": red_bytes / (avg_red_ms * 1e-3) / HBM_PEAK if avg_red_ms > 0 else None, "traffic": None, "avg_launch_ms": avg_red_ms,
+               "launches": red_launch, "note": "block-partial histograms (blocks x K*K*16 x 4 B per batch) read once (twice on the half list: h and h^T); L2-resident"}
         kern_ms = {k: round(v[1] / max(v[0], 1), 4) for k, v in kernels.items() if v[0] > 0}
         gpu_ms = sum(v[1] for v in kernels.values())
+        b_perm = 4 * nnz + 4 * (n + 1) + 2 * n
         out = {
             "metric": "nhood_enrichment permutations/sec (1e6 spots x 30 clusters)",
             "value": total_perms / elapsed,
@@ -331,62 +586,52 @@ def main() -> None:
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u8 labels / u32 counts / i64 moments",
             "data": "synthetic",
             "config": {
                 "workload": f"nhood_enrichment: {n} spots ({args.rows}x{args.cols} hex grid, nnz={nnz}), {N_CLS} clusters, "
-                f"{P} permutations per step per GPU, on-device Philox/Feistel shuffles"
-                + ("" if args.label_dist == "uniform" else ", Dirichlet(0.5) cluster proportions"),
+                + (f"{P} permutations per step split over {world} rank(s) (BASELINE config 5)" if strong else f"{P} permutations per step per GPU")
+                + ", on-device Philox-keyed label shuffles" + ("" if args.label_dist == "uniform" else ", Dirichlet(0.5) cluster proportions"),
                 "label_dist": args.label_dist,
-                "perms_per_step_per_gpu": P,
-                "parallelism": f"permutation ranges over {world} rank(s), all-reduce of int64 moments",
+                "perms_per_step": P,
+                "perms_per_step_per_gpu": per_rank_step,
+                "parallelism": f"permutation ranges over {world} rank(s), one all-reduce of int64[2*K*K] moments per step",
+                "collective": collective,
             },
-            "roofline": {
-                "kernel": "+".join(cnt_name) or "nhood_count",
-                "bound": "hbm",
-                "achieved": achieved / 1e9,
-                "peak": HBM_PEAK / 1e9,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK,
-                "traffic": traffic,
-                "launches": launches,
-                "avg_launch_ms": ms / max(launches, 1),
-                "perms_per_launch": perms_per_launch,
-                "algorithmic_bytes_per_perm": b_gather,
-                "note": "algorithmic bytes / HIP-event time; >1 is possible because one pass over the CSR serves 16-32 "
-                "permutations (see DESIGN.md); pipeline figure below prices the whole permutation (30.0 MB) against "
-                "the sum of all kernels",
-            },
+            "roofline": roof,
+            "kernels": {"nhood_shuffle": shuf, "nhood_count": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms")}, "nhood_reduce": red},
             "pipeline": {
                 "algorithmic_bytes_per_perm": b_perm,
                 "gpu_ms_all_kernels": gpu_ms,
-                "achieved_GBps": b_perm * args.steps * P / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else None,
-                "frac_of_hbm_peak": b_perm * args.steps * P / (gpu_ms * 1e-3) / HBM_PEAK if gpu_ms > 0 else None,
-                "wall_frac_of_hbm_peak": b_perm * (total_perms / world) / elapsed / HBM_PEAK,
+                "algorithmic_GBps": b_perm * args.steps * per_rank_step / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else None,
+                "algorithmic_reuse_vs_hbm_peak": b_perm * args.steps * per_rank_step / (gpu_ms * 1e-3) / HBM_PEAK if gpu_ms > 0 else None,
                 "avg_kernel_ms": kern_ms,
                 "time_share": {k: round(v[1] / gpu_ms, 3) for k, v in kernels.items() if v[0] > 0 and gpu_ms > 0},
-                "note": "nhood_shuffle (label generation, VALU-bound: ~45 packed-16 ops per spot and permutation, no HBM "
-                "roofline applies) and nhood_count (the CSR gather the roofline object prices) share the step",
+                "gpu_busy_frac_of_wall": gpu_ms * 1e-3 / (elapsed) if elapsed > 0 else None,
+                "note": "SURVEY §8d's B_perm (30.0 MB) against the sum of all kernel times; > HBM peak because one pass over the graph serves "
+                "16 permutations — an algorithmic-reuse figure, NOT a roofline fraction (those are in `roofline` / `kernels`)",
             },
         }
         if secondary is not None:
             out["secondary"] = secondary
+        if legs is not None:
+            out["legs"] = legs
         if world == 1 and not args.no_numpy_leg:  # bonus leg: the same test with numpy's own PCG64 streams reproduced bit for bit on the GPU
             from squidpy_amd._utils import pcg64_states
 
-            legs = {}
+            res = {}
             for n_exact in (1000, 8192):  # Squidpy's default n_perms, and a throughput-sized batch
                 states = pcg64_states(0, n_exact)
                 plan.run_pcg64(states, shift)  # warm-up at full size: the workspaces are allocated (and first touched) here
                 t1 = time.perf_counter()
                 plan.run_pcg64(states, shift)
-                legs[n_exact] = n_exact / (time.perf_counter() - t1)
+                res[n_exact] = n_exact / (time.perf_counter() - t1)
             out["numpy_stream_mode"] = {
-                "value": legs[8192],
+                "value": res[8192],
                 "unit": "permutations/s",
-                "at_n_perms_1000": legs[1000],
+                "at_n_perms_1000": res[1000],
                 "note": "rng='numpy': PCG64 + Generator.shuffle reproduced on the device, one wave per permutation (LCG "
                 "jump-ahead draws, parallel swaps, exact replay of conflicting steps); z-scores equal Squidpy's for the same "
                 "seed bit for bit",
@@ -394,10 +639,12 @@ def main() -> None:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(adj, labels)
             out["speedup_vs_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"]
+            if "value" in out["cpu_baseline"].get("all_cores", {}):
+                out["speedup_vs_cpu_all_cores"] = out["value"] / out["cpu_baseline"]["all_cores"]["value"]
         print(json.dumps(out))
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        _dist.barrier()
+        _dist.shutdown()
 
 
 if __name__ == "__main__":

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SQGR_ABI_VERSION 1
+#define SQGR_ABI_VERSION 2
 
 typedef enum sqgr_status {
     SQGR_OK = 0,
@@ -64,6 +64,30 @@ int sqgr_timer_reset(sqgr_ctx* ctx);
 int sqgr_timer_get(sqgr_ctx* ctx, const char* prefix, double* total_ms, int64_t* launches);
 /* writes a ';'-separated list "name:launches:ms" of everything timed so far */
 int sqgr_timer_report(sqgr_ctx* ctx, char* buf, int len);
+
+/* ------------------------------------------------------------------ multi-GPU: RCCL communicator
+ * One process per GPU.  The path shards by permutation range / row tiles / feature blocks and has ONE exchange: an
+ * all-reduce(sum) of exact 64-bit integer accumulators (`Σcount`, `Σcount²`: replaces the reduction the reference's
+ * joblib fan-out does by concatenating per-job chunks, gr/_nhood.py:215-231, _utils.py:223-231).  The library binds
+ * RCCL itself (librccl.so.1, at the first sqgr_comm_* call); the caller only moves rank 0's unique id to the other
+ * ranks (any side channel) — no torch.distributed in the data path.
+ *   sqgr_comm_unique_id : rank 0 fills out_id[SQGR_UNIQUE_ID_BYTES] (ncclGetUniqueId)
+ *   sqgr_comm_create    : collective over all `world` ranks (ncclCommInitRank) on ctx's device
+ *   sqgr_comm_allreduce_i64 : in-place all-reduce of a HOST buffer int64[count] (staged through the device; uint64
+ *                             data may be passed through its int64 view for SQGR_OP_SUM: addition modulo 2^64)
+ *   sqgr_nhood_set_comm : attaches the communicator to a plan — sqgr_nhood_run then all-reduces the moments ON THE
+ *                         DEVICE before its one 2*K*K*8-byte copy-out (every rank returns the global sums), and
+ *                         sqgr_nhood_run_pcg64_stats all-gathers the per-permutation counts of the ranks' ranges. */
+#define SQGR_UNIQUE_ID_BYTES 128
+#define SQGR_OP_SUM 0
+#define SQGR_OP_MAX 1
+typedef struct sqgr_comm sqgr_comm;
+int sqgr_comm_unique_id(uint8_t* out_id);
+int sqgr_comm_create(sqgr_ctx* ctx, const uint8_t* unique_id, int32_t rank, int32_t world, sqgr_comm** out_comm);
+int sqgr_comm_destroy(sqgr_comm* comm);
+int sqgr_comm_info(const sqgr_comm* comm, int32_t* rank, int32_t* world);
+int sqgr_comm_allreduce_i64(sqgr_comm* comm, int64_t* buf, int64_t count, int32_t op);
+int sqgr_comm_barrier(sqgr_comm* comm);
 
 /* ------------------------------------------------------------------ spatial graph (CSR)
  * Device-resident copy of `adata.obsp[<key>_connectivities]` (scipy CSR): what
@@ -118,6 +142,15 @@ int sqgr_nhood_run_pcg64(sqgr_nhood* plan, const uint64_t* pcg_states, int64_t n
  * float64 accumulation in permutation order, as numpy does over a leading axis), so that
  * `(count - mean) / std` is Squidpy's z-score for the seed — without moving the n_perms*K*K counts to the host. */
 int sqgr_nhood_run_pcg64_stats(sqgr_nhood* plan, const uint64_t* pcg_states, int64_t n_perms, double* out_mean, double* out_std);
+
+/* Launch geometry of a plan, int64[8]: {permutations per pass over the edge list (16|32), batches per launch group,
+ * count blocks per batch, edges of the list the count kernel walks (the half list r < c + self loops on a structurally
+ * symmetric graph, else nnz), 0 full list | 1 half list | 2 half list with self loops, LDS histogram words per block,
+ * self loops, permutations per group of the label generator}.  bench.py derives its per-kernel ceilings from these. */
+int sqgr_nhood_info(sqgr_nhood* plan, int64_t* out_info);
+
+/* Attaches (comm != NULL) or detaches an RCCL communicator: see "multi-GPU" above. */
+int sqgr_nhood_set_comm(sqgr_nhood* plan, sqgr_comm* comm);
 
 /* numpy's `Generator.permutation(n)` for n_perms generator states (layout as above), on the device:
  * out_idx int32[n_perms][n] — the row permutations of `_score_helper` (gr/_ppatterns.py:269-271). */

@@ -151,18 +151,19 @@ def _sigma(a: np.ndarray, b: np.ndarray, A: int, B: int, Bmask: int, sk: np.ndar
     return a, b
 
 
-def grouped_permutation_batch(n: int, gks: np.ndarray, sks: np.ndarray) -> np.ndarray:
+def grouped_permutation_batch(n: int, gks: np.ndarray, sks: np.ndarray, x: np.ndarray | None = None) -> np.ndarray:
     """Two-level label permutations: pi[p, i] = sigma(sks[p]) o pi(gks[p]) (i), both cycle-walked into [0, n)
-    (sqgr_rng.h: grouped_perm).  ``gks``: (P, 8) — row p holds the keys of permutation p's GROUP; ``sks``: (P, 2)."""
+    (sqgr_rng.h: grouped_perm).  ``gks``: (P, 8) — row p holds the keys of permutation p's GROUP; ``sks``: (P, 2).
+    ``x``: evaluate only these ranks (default: all of [0, n))."""
     P = gks.shape[0]
     if n <= 1:
-        return np.zeros((P, n), dtype=np.int64)
+        return np.zeros((P, n if x is None else len(x)), dtype=np.int64)
     A, B, Bmask = domain_dims(n)
     B64 = np.uint64(B)
     keys = gks.astype(np.uint64) & MASK16
     key = lambda r: keys[:, r : r + 1]  # noqa: E731
     sk = sks.astype(np.uint64) & MASK16
-    x = np.tile(np.arange(n, dtype=np.uint64), (P, 1))
+    x = np.tile(np.arange(n, dtype=np.uint64) if x is None else np.asarray(x, dtype=np.uint64), (P, 1))
     a, b = _rounds(x // B64, x % B64, A, B, Bmask, key)
     bad = a * B64 + b >= np.uint64(n)
     while bad.any():
@@ -178,10 +179,11 @@ def grouped_permutation_batch(n: int, gks: np.ndarray, sks: np.ndarray) -> np.nd
     return (a * B64 + b).astype(np.int64)
 
 
-def label_permutations(n: int, seed: int, perms: np.ndarray, lib: int = 0) -> np.ndarray:
-    """(len(perms), n) label-shuffle permutations of the global permutation indices ``perms``."""
+def label_permutations(n: int, seed: int, perms: np.ndarray, lib: int = 0, x: np.ndarray | None = None) -> np.ndarray:
+    """(len(perms), n) label-shuffle permutations of the global permutation indices ``perms`` (only the images of the
+    ranks ``x`` when given)."""
     perms = np.asarray(perms, dtype=np.int64)
-    return grouped_permutation_batch(n, group_keys(seed, perms // FEISTEL_GROUP, lib), sigma_keys(seed, perms, lib))
+    return grouped_permutation_batch(n, group_keys(seed, perms // FEISTEL_GROUP, lib), sigma_keys(seed, perms, lib), x)
 
 
 def permutation(n: int, rk: np.ndarray) -> np.ndarray:

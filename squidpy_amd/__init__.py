@@ -6,6 +6,8 @@ All compute runs in ``libsqgr.so`` (hand-written HIP for gfx950); there is no CP
 
 from . import gr
 from ._anndata_lite import AnnDataLite
+from ._dist import init as init_distributed
+from ._dist import shutdown as shutdown_distributed
 
-__all__ = ["gr", "AnnDataLite"]
+__all__ = ["gr", "AnnDataLite", "init_distributed", "shutdown_distributed"]
 __version__ = "0.1.0"

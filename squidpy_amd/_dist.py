@@ -1,35 +1,249 @@
-"""Multi-GPU plumbing: one process per GPU, ``torch.distributed`` (backend "nccl" == RCCL over xGMI).
+"""Multi-GPU plumbing: one process per GPU, the data-path collective is RCCL *inside libsqgr*.
 
-The hot path shards by *permutation range* (nhood, autocorr) or *row-tile range* (co-occurrence, Ripley);
-every rank holds the full (small) inputs, so the only exchange is one all-reduce of exact integer
-accumulators (< 1 MB, latency-bound).  torch is imported lazily and only when a process group exists, so
-the single-GPU product path has no torch dependency."""
+The hot path shards by *permutation range* (nhood, autocorr, ligrec), *row tiles* (co-occurrence), *feature blocks*
+(autocorr) or *clusters* (Ripley); every rank holds the full (small) inputs, so the only exchange is one all-reduce
+of exact 64-bit integer accumulators (< 1 MB, latency-bound): ``sqgr_comm_allreduce_i64`` / the on-device all-reduce
+of ``sqgr_nhood_run`` (``include/sqgr.h``, RCCL over xGMI).  What the ranks need from the host side is only a side
+channel that (i) carries the 128-byte ``ncclUniqueId`` from rank 0 to the others and (ii) moves a few host objects
+(a seed, gathered result blocks).  Two side channels, no torch in the data path:
+
+* ``SocketGroup`` — a star of TCP connections on one node built from the launcher's environment (``RANK``,
+  ``WORLD_SIZE``, ``MASTER_ADDR``, ``MASTER_PORT``: what ``python -m torch.distributed.run`` or any other launcher
+  exports).  Pure Python, torch is never imported.  ``init()`` creates it.
+* ``TorchGroup`` — adopts a ``torch.distributed`` process group the caller has already initialised (any backend).
+  With backend ``gloo`` (CPU tests, several ranks sharing one GPU) the integer all-reduce runs on the host through
+  that group, because RCCL refuses two ranks on one device.
+
+``is_distributed()`` is true once a group with more than one rank exists: after ``init()`` or automatically when a
+torch process group is already initialised (also one created programmatically without torchrun's environment)."""
 
 from __future__ import annotations
 
 import os
+import pickle
+import socket
+import struct
+import sys
+import tempfile
+import time
+from typing import Any
 
 import numpy as np
 
+_TIMEOUT_S = float(os.environ.get("SQGR_DIST_TIMEOUT", "120"))
 
-def is_distributed() -> bool:
-    force = os.environ.get("SQGR_DIST_FORCE") == "1"  # exercise the collective path with a single rank (tests)
-    if int(os.environ.get("WORLD_SIZE", "1")) <= 1 and not force:
-        return False
+
+# ----------------------------------------------------------------------------------------------- side channels
+def _send_msg(sock: socket.socket, payload: bytes) -> None:
+    sock.sendall(struct.pack("<Q", len(payload)) + payload)
+
+
+def _recv_exact(sock: socket.socket, n: int) -> bytes:
+    chunks, got = [], 0
+    while got < n:
+        b = sock.recv(min(n - got, 1 << 20))
+        if not b:
+            raise ConnectionError("peer closed the rendezvous connection")
+        chunks.append(b)
+        got += len(b)
+    return b"".join(chunks)
+
+
+def _recv_msg(sock: socket.socket) -> bytes:
+    (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
+    return _recv_exact(sock, n)
+
+
+class SocketGroup:
+    """All ranks of ONE node connected to rank 0 over TCP (loopback or ``MASTER_ADDR``).
+
+    Rank 0 listens on an ephemeral port and publishes it in ``$TMPDIR/sqgr_rdzv_<MASTER_PORT>_<launcher pid>``
+    (``MASTER_PORT`` itself belongs to the launcher's own store); the others poll that file and connect.  Every
+    collective is an all-gather through the hub — the payloads on this path are a unique id, a seed, a few result
+    blocks."""
+
+    kind = "socket"
+
+    def __init__(self, rank: int, world: int, addr: str = "127.0.0.1", key: str | None = None):
+        self.rank, self.world = int(rank), int(world)
+        key = key or f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+        self._path = os.path.join(tempfile.gettempdir(), f"sqgr_rdzv_{key}")
+        self._peers: list[socket.socket] = []
+        self._hub: socket.socket | None = None
+        deadline = time.monotonic() + _TIMEOUT_S
+        if self.rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            try:
+                srv.bind((addr, 0))
+            except OSError:
+                srv.bind(("127.0.0.1", 0))
+            srv.listen(self.world)
+            srv.settimeout(_TIMEOUT_S)
+            tmp = f"{self._path}.{os.getpid()}.tmp"
+            with open(tmp, "w") as fh:
+                fh.write(f"{srv.getsockname()[0]} {srv.getsockname()[1]}")
+            os.replace(tmp, self._path)
+            by_rank: dict[int, socket.socket] = {}
+            try:
+                while len(by_rank) < self.world - 1:
+                    conn, _ = srv.accept()
+                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    conn.settimeout(_TIMEOUT_S)
+                    r, w = struct.unpack("<ii", _recv_exact(conn, 8))
+                    if w != self.world or not 0 < r < self.world or r in by_rank:
+                        conn.close()
+                        raise RuntimeError(f"rendezvous: unexpected peer (rank {r} of {w}) for a {self.world}-rank group")
+                    by_rank[r] = conn
+            finally:
+                srv.close()
+                try:
+                    os.remove(self._path)
+                except OSError:
+                    pass
+            self._peers = [by_rank[r] for r in range(1, self.world)]
+        else:
+            last: Exception | None = None
+            while time.monotonic() < deadline:
+                try:
+                    with open(self._path) as fh:
+                        host, port = fh.read().split()
+                    s = socket.create_connection((host, int(port)), timeout=5.0)
+                    s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    s.settimeout(_TIMEOUT_S)
+                    s.sendall(struct.pack("<ii", self.rank, self.world))
+                    self._hub = s
+                    break
+                except (OSError, ValueError) as exc:  # file not there yet / stale port of an earlier run
+                    last = exc
+                    time.sleep(0.05)
+            if self._hub is None:
+                raise TimeoutError(f"rank {self.rank}: no rendezvous with rank 0 within {_TIMEOUT_S:.0f} s ({last!r})")
+        self.barrier()
+
+    def allgather_bytes(self, payload: bytes) -> list[bytes]:
+        if self.world == 1:
+            return [payload]
+        if self.rank == 0:
+            parts = [payload] + [_recv_msg(p) for p in self._peers]
+            blob = pickle.dumps(parts, protocol=pickle.HIGHEST_PROTOCOL)
+            for p in self._peers:
+                _send_msg(p, blob)
+            return parts
+        assert self._hub is not None
+        _send_msg(self._hub, payload)
+        return pickle.loads(_recv_msg(self._hub))
+
+    def barrier(self) -> None:
+        self.allgather_bytes(b"")
+
+    def close(self) -> None:
+        for s in self._peers + ([self._hub] if self._hub is not None else []):
+            try:
+                s.close()
+            except OSError:
+                pass
+        self._peers, self._hub = [], None
+
+
+class TorchGroup:
+    """An already initialised ``torch.distributed`` default group, used as the side channel."""
+
+    kind = "torch"
+
+    def __init__(self) -> None:
+        import torch.distributed as dist
+
+        self._dist = dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.backend = dist.get_backend()
+
+    def allgather_bytes(self, payload: bytes) -> list[bytes]:
+        objs: list[Any] = [None] * self.world
+        self._dist.all_gather_object(objs, payload)
+        return objs
+
+    def barrier(self) -> None:
+        self._dist.barrier()
+
+    def allreduce_i64_host(self, flat: np.ndarray) -> np.ndarray:
+        import torch
+
+        t = torch.from_numpy(flat.copy())
+        if self.backend == "nccl":
+            t = t.cuda(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
+        return t.cpu().numpy()
+
+    def close(self) -> None:
+        pass
+
+
+# ----------------------------------------------------------------------------------------------- module state
+_group: SocketGroup | TorchGroup | None = None
+_comm: Any = None          # squidpy_amd._lib.Comm once created
+_comm_tried = False
+_collective = "none"      # what allreduce_sum_ last used: "rccl-in-library" | "torch.distributed" | "socket-hub"
+
+
+def _torch_group_ready() -> bool:
+    if "torch" not in sys.modules and int(os.environ.get("WORLD_SIZE", "1")) <= 1 and os.environ.get("SQGR_DIST_FORCE") != "1":
+        return False  # do not import torch just to find out that nothing was initialised
     try:
         import torch.distributed as dist
     except ImportError:  # pragma: no cover
         return False
-    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force)
+    return dist.is_available() and dist.is_initialized()
+
+
+def init(method: str = "auto") -> None:
+    """Join the process group of this launch.  ``"auto"``: adopt an initialised ``torch.distributed`` group if there
+    is one, else build the socket rendezvous from ``RANK`` / ``WORLD_SIZE`` / ``MASTER_ADDR`` / ``MASTER_PORT``
+    (``"socket"`` forces the latter).  A no-op for a single process."""
+    global _group
+    if _group is not None:
+        return
+    if method == "auto" and _torch_group_ready():
+        _group = TorchGroup()
+        return
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_size <= 1:
+        return
+    _group = SocketGroup(int(os.environ["RANK"]), world_size, os.environ.get("MASTER_ADDR", "127.0.0.1"))
+
+
+def shutdown() -> None:
+    global _group, _comm, _comm_tried
+    if _comm is not None:
+        _comm.close()
+    if _group is not None:
+        _group.close()
+    _group, _comm, _comm_tried = None, None, False
+
+
+def group() -> SocketGroup | TorchGroup | None:
+    global _group
+    if _group is not None and isinstance(_group, TorchGroup) and not _torch_group_ready():
+        _group = None  # the caller destroyed its process group
+    if _group is None and _torch_group_ready():
+        _group = TorchGroup()
+    return _group
+
+
+def is_distributed() -> bool:
+    g = group()
+    if g is None:
+        return False
+    return g.world > 1 or os.environ.get("SQGR_DIST_FORCE") == "1"  # FORCE: exercise the collective path with one rank
 
 
 def world() -> tuple[int, int]:
-    """(rank, world_size); (0, 1) when no process group is initialised."""
+    """(rank, world_size); (0, 1) without a process group."""
     if not is_distributed():
         return 0, 1
-    import torch.distributed as dist
-
-    return dist.get_rank(), dist.get_world_size()
+    g = group()
+    assert g is not None
+    return g.rank, g.world
 
 
 def shard_range(n: int, rank: int, world_size: int, begin: int = 0) -> tuple[int, int]:
@@ -41,21 +255,71 @@ def shard_range(n: int, rank: int, world_size: int, begin: int = 0) -> tuple[int
     return lo, hi
 
 
+def device_comm() -> Any:
+    """The RCCL communicator libsqgr owns for this group (created on first use: rank 0 draws the unique id, the side
+    channel carries it), or ``None`` when the device collective is unavailable — a gloo group (several ranks may
+    share a GPU), ``SQGR_DIST_COLLECTIVE=host``, or a creation failure on any rank (all ranks then agree on the host
+    path)."""
+    global _comm, _comm_tried
+    if _comm is not None or _comm_tried:
+        return _comm
+    g = group()
+    if g is None:
+        return None
+    _comm_tried = True
+    if os.environ.get("SQGR_DIST_COLLECTIVE", "") == "host" or (isinstance(g, TorchGroup) and g.backend != "nccl"):
+        return None
+    from . import _lib
+
+    uid, err = b"", ""
+    if g.rank == 0:
+        try:
+            uid = _lib.comm_unique_id()
+        except Exception as exc:  # RCCL missing
+            err = repr(exc)
+    uid = g.allgather_bytes(uid)[0]
+    comm = None
+    if len(uid) == _lib.UNIQUE_ID_BYTES:
+        try:
+            comm = _lib.Comm(_lib.default_context(), uid, g.rank, g.world)
+        except Exception as exc:
+            err = repr(exc)
+    oks = g.allgather_bytes(b"1" if comm is not None else b"0")
+    if all(o == b"1" for o in oks):
+        _comm = comm
+    else:
+        if comm is not None:
+            comm.close()
+        if g.rank == 0:
+            print(f"squidpy_amd: RCCL communicator unavailable ({err or 'a peer failed'}); integer all-reduce falls back to the host side channel", file=sys.stderr)
+    return _comm
+
+
+def collective_kind() -> str:
+    """Which implementation the last ``allreduce_sum_`` used (reported by bench.py)."""
+    return _collective
+
+
 def allreduce_sum_(arrays: list[np.ndarray]) -> list[np.ndarray]:
     """Exact all-reduce(sum) of 64-bit integer arrays (uint64 is summed modulo 2**64 via its int64 view).
     No-op without a process group."""
+    global _collective
     if not is_distributed():
         return arrays
-    import torch
-    import torch.distributed as dist
-
-    backend = dist.get_backend()
+    g = group()
+    assert g is not None
     flat = np.concatenate([np.ascontiguousarray(a).view(np.int64).reshape(-1) for a in arrays])
-    t = torch.from_numpy(flat.copy())
-    if backend == "nccl":
-        t = t.cuda(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    flat = t.cpu().numpy()
+    comm = device_comm()
+    if comm is not None:
+        flat = comm.allreduce_i64(np.ascontiguousarray(flat))
+        _collective = "rccl-in-library"
+    elif isinstance(g, TorchGroup):
+        flat = g.allreduce_i64_host(flat)
+        _collective = "torch.distributed"
+    else:
+        parts = g.allgather_bytes(flat.tobytes())
+        flat = np.sum([np.frombuffer(p, dtype=np.int64) for p in parts], axis=0, dtype=np.int64)
+        _collective = "socket-hub"
     out, off = [], 0
     for a in arrays:
         out.append(flat[off : off + a.size].view(a.dtype).reshape(a.shape).copy())
@@ -63,12 +327,21 @@ def allreduce_sum_(arrays: list[np.ndarray]) -> list[np.ndarray]:
     return out
 
 
-def allgather_object(a: np.ndarray) -> list[np.ndarray]:
+def allgather_object(a: Any) -> list[Any]:
     """One copy of ``a`` from every rank, in rank order (autocorr: feature blocks are gathered, not reduced)."""
     if not is_distributed():
         return [a]
-    import torch.distributed as dist
+    g = group()
+    assert g is not None
+    return [pickle.loads(b) for b in g.allgather_bytes(pickle.dumps(a, protocol=pickle.HIGHEST_PROTOCOL))]
 
-    objs: list = [None] * dist.get_world_size()
-    dist.all_gather_object(objs, a)
-    return objs
+
+def broadcast_object(a: Any, src: int = 0) -> Any:
+    """``a`` of rank ``src`` on every rank."""
+    return allgather_object(a)[src] if is_distributed() else a
+
+
+def barrier() -> None:
+    g = group()
+    if g is not None:
+        g.barrier()

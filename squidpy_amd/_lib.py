@@ -37,6 +37,14 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "sqgr_timer_reset": (C.c_int, [C.c_void_p]),
     "sqgr_timer_get": (C.c_int, [C.c_void_p, C.c_char_p, c_f64p, c_i64p]),
     "sqgr_timer_report": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "sqgr_comm_unique_id": (C.c_int, [c_u8p]),
+    "sqgr_comm_create": (C.c_int, [C.c_void_p, c_u8p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "sqgr_comm_destroy": (C.c_int, [C.c_void_p]),
+    "sqgr_comm_info": (C.c_int, [C.c_void_p, c_i32p, c_i32p]),
+    "sqgr_comm_allreduce_i64": (C.c_int, [C.c_void_p, c_i64p, C.c_int64, C.c_int32]),
+    "sqgr_comm_barrier": (C.c_int, [C.c_void_p]),
+    "sqgr_nhood_set_comm": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sqgr_nhood_info": (C.c_int, [C.c_void_p, c_i64p]),
     "sqgr_graph_create": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, c_i64p, c_i32p, c_f32p, C.POINTER(C.c_void_p)]),
     "sqgr_graph_destroy": (C.c_int, [C.c_void_p]),
     "sqgr_nhood_counts": (C.c_int, [C.c_void_p, C.c_void_p, c_i32p, C.c_int32, c_u32p]),
@@ -79,6 +87,9 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
 }
 
 
+ABI_VERSION = 2  # SQGR_ABI_VERSION of include/sqgr.h
+
+
 class SqgrError(RuntimeError):
     """A libsqgr call returned a negative status."""
 
@@ -108,8 +119,8 @@ def load_library(path: str | None = None) -> C.CDLL:
             fn = getattr(lib, name)
             fn.restype = restype
             fn.argtypes = argtypes
-        if lib.sqgr_abi_version() != 1:
-            raise OSError(f"{p}: ABI version {lib.sqgr_abi_version()} != 1")
+        if lib.sqgr_abi_version() != ABI_VERSION:
+            raise OSError(f"{p}: ABI version {lib.sqgr_abi_version()} != {ABI_VERSION} (rebuild: python -m squidpy_amd._build)")
         if path is None:
             _lib = lib
         return lib
@@ -207,6 +218,53 @@ def default_context(device: int | None = None) -> Context:
     return _default_ctx[device]
 
 
+UNIQUE_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """``ncclGetUniqueId`` through the library (rank 0 calls this and hands the bytes to the other ranks)."""
+    lib = load_library()
+    buf = np.zeros(UNIQUE_ID_BYTES, dtype=np.uint8)
+    _check(lib, lib.sqgr_comm_unique_id(_ptr(buf, c_u8p)))
+    return buf.tobytes()
+
+
+class Comm:
+    """RCCL communicator owned by libsqgr (``sqgr_comm``): one rank per process and GPU."""
+
+    SUM, MAX = 0, 1
+
+    def __init__(self, ctx: Context, unique_id: bytes, rank: int, world: int):
+        if len(unique_id) != UNIQUE_ID_BYTES:
+            raise ValueError(f"Expected a {UNIQUE_ID_BYTES}-byte unique id, found {len(unique_id)} bytes.")
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        uid = np.frombuffer(unique_id, dtype=np.uint8).copy()
+        h = C.c_void_p()
+        _check(ctx.lib, ctx.lib.sqgr_comm_create(ctx.h, _ptr(uid, c_u8p), self.rank, self.world, C.byref(h)))
+        self.h = h
+
+    def allreduce_i64(self, buf: np.ndarray, op: int = 0) -> np.ndarray:
+        """In-place all-reduce of a C-contiguous int64 array (uint64 through its int64 view for sums)."""
+        if buf.dtype != np.int64 or not buf.flags.c_contiguous:
+            raise ValueError("allreduce_i64 needs a C-contiguous int64 array")
+        _check(self.ctx.lib, self.ctx.lib.sqgr_comm_allreduce_i64(self.h, _ptr(buf, c_i64p), buf.size, int(op)))
+        return buf
+
+    def barrier(self) -> None:
+        _check(self.ctx.lib, self.ctx.lib.sqgr_comm_barrier(self.h))
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.ctx.lib.sqgr_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self) -> None:  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Graph:
     """Device-resident CSR (``sqgr_graph``) built from a scipy sparse matrix."""
 
@@ -292,6 +350,22 @@ class NhoodPlan:
             ),
         )
         self.h = h
+
+    def info(self) -> dict[str, Any]:
+        """Launch geometry (``sqgr_nhood_info``)."""
+        v = np.zeros(8, dtype=np.int64)
+        _check(self.ctx.lib, self.ctx.lib.sqgr_nhood_info(self.h, _ptr(v, c_i64p)))
+        return {
+            "perms_per_pass": int(v[0]), "batches_per_launch": int(v[1]), "blocks_per_batch": int(v[2]), "list_edges": int(v[3]),
+            "symmetric": int(v[4]) != 0, "self_loops": int(v[6]), "hist_words": int(v[5]), "generator_group": int(v[7]),
+            "partial_bytes_per_launch": int(v[1]) * int(v[2]) * int(v[5]) * 4,
+        }
+
+    def set_comm(self, comm: "Comm | None") -> None:
+        """Attach an RCCL communicator: :meth:`run` / :meth:`run_pcg64` then return the moments summed over all ranks
+        (all-reduced on the device), :meth:`run_pcg64_stats` gathers the ranks' per-permutation counts."""
+        self._comm = comm  # keep it alive
+        _check(self.ctx.lib, self.ctx.lib.sqgr_nhood_set_comm(self.h, comm.h if comm is not None else None))
 
     def tune(self, perms_per_pass: int = 0, blocks_per_batch: int = 0, batches_per_launch: int = 0) -> None:
         _check(self.ctx.lib, self.ctx.lib.sqgr_nhood_tune(self.h, perms_per_pass, blocks_per_batch, batches_per_launch))

@@ -119,6 +119,15 @@ struct DevBuf {
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// zero entries behind the nhood edge lists (sqgr_graph::coo / half): the count kernel's look-ahead loads stay in bounds
+constexpr int LIST_PAD = 2064;
+
+// device-side collectives of an sqgr_comm (sqgr_comm.hip); no-ops for a NULL communicator or a single rank
+int comm_allreduce_i64_dev(sqgr_comm* c, int64_t* dev_buf, size_t count, bool op_max, hipStream_t st);
+int comm_allgather_dev(sqgr_comm* c, const void* dev_send, void* dev_recv, size_t bytes_per_rank, hipStream_t st);
+int comm_rank(const sqgr_comm* c);
+int comm_world(const sqgr_comm* c);
+
 }  // namespace sqgr
 
 struct sqgr_graph {
@@ -127,7 +136,8 @@ struct sqgr_graph {
     sqgr::DevBuf<int64_t> indptr;   // [n+1]
     sqgr::DevBuf<int32_t> indices;  // [nnz]
     sqgr::DevBuf<int32_t> erow;     // [nnz] row of every stored edge (COO expansion, built on device)
-    sqgr::DevBuf<int2> coo;         // [nnz] (row, col) pairs: one 8-byte load per edge in the nhood count kernel
+    sqgr::DevBuf<int2> coo;         // [nnz + LIST_PAD] (16*row, 16*col): byte offsets of the endpoints' 16-byte label rows,
+                                    // what the nhood count kernel gathers with; zero padding behind the list
     sqgr::DevBuf<float> data;       // [nnz] or empty
     bool has_data = false;
     // Structurally symmetric graphs (every stored (r, c) has a stored (c, r); canonical CSR: rows sorted, no duplicates):

@@ -25,7 +25,7 @@ __global__ void k_expand_rows(const int64_t* __restrict__ indptr, const int32_t*
         if (indptr[mid] <= e) lo = mid; else hi = mid;
     }
     erow[e] = (int32_t)lo;
-    coo[e] = make_int2((int)lo, indices[e]);
+    coo[e] = make_int2((int)((uint32_t)lo * 16u), (int)((uint32_t)indices[e] * 16u));  // byte offsets of 16-byte label rows
 }
 
 // ---------------------------------------------------------------------------------------------- symmetric half list
@@ -184,7 +184,8 @@ int sqgr_graph::ensure_half() const {
                       (long long)nnz);
             return SQGR_ERR_HIP;
         }
-        SQGR_TRY(half.alloc((size_t)(h_tot[0] + h_tot[1])));
+        SQGR_TRY(half.alloc((size_t)(h_tot[0] + h_tot[1]) + LIST_PAD));
+        SQGR_HIP(hipMemsetAsync(half.p + (h_tot[0] + h_tot[1]), 0, (size_t)LIST_PAD * sizeof(int2), st));
         k_half_scatter<<<(unsigned)ntiles, HALF_TILE, 0, st>>>(coo.p, nnz, t_lt.p, t_self.p, (uint32_t)h_tot[0], half.p);
         SQGR_HIP(hipGetLastError());
     }
@@ -420,7 +421,8 @@ int sqgr_graph_create(sqgr_ctx* ctx, int64_t n, int64_t nnz, const int64_t* indp
         if ((rc = g->indptr.alloc((size_t)n + 1)) != SQGR_OK) break;
         if ((rc = g->indices.alloc((size_t)nnz)) != SQGR_OK) break;
         if ((rc = g->erow.alloc((size_t)nnz)) != SQGR_OK) break;
-        if ((rc = g->coo.alloc((size_t)nnz)) != SQGR_OK) break;
+        if ((rc = g->coo.alloc((size_t)nnz + LIST_PAD)) != SQGR_OK) break;
+        if (hipMemsetAsync(g->coo.p + nnz, 0, (size_t)LIST_PAD * sizeof(int2), ctx->stream) != hipSuccess) { rc = SQGR_ERR_HIP; break; }
         if (data && (rc = g->data.alloc((size_t)nnz)) != SQGR_OK) break;
         hipError_t e = hipMemcpyAsync(g->indptr.p, indptr, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess && nnz)

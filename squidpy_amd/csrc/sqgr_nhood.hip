@@ -66,32 +66,57 @@ __global__ void k_keygen(uint64_t seed, int64_t perm0, int nrows, int B, int n_l
 // the base is taken *sorted by label* (inside each library): the label at sorted rank x is
 //   #{k >= 1 : cum[k] <= x},   cum[k] = number of spots with label < k   (cum[K] = UINT_MAX sentinel).
 // No memory gather: rank x = a*B + b arrives as its two digits; one LDS word per high digit a (block table, see
-// nhood_build) holds the label of the block's first rank and the low digit where the next label starts, so the label is
-// `lab0 + (b >= next)`.  Blocks flagged BLK_EXACT (several label starts, skipped empty categories, or ranks >= n — the
-// cycle-walking case) take the exact route: x = a*B + b against the boundary table, and a re-walk where x >= n.
+// nhood_build) holds the label of the block's first rank (byte 0) and the low digit where the next label starts
+// (bits 16-31, 0xFFFF: none), so the label is `lab0 + (b >= next)`.  The value K — one past the last label — is the
+// SENTINEL: blocks the two-field form cannot describe (several label starts, skipped empty categories) carry lab0 = K,
+// and in the block that reaches past the library's last rank "next" is the first low digit outside [0, n) when that
+// block ends in label K-1 (so the cycle-walking case yields K as well).  Sentinel bytes are rare (ranks >= n: fewer than
+// 1 in B') and take the exact route afterwards: re-walk where x >= n, then x against the boundary table.
 //   slab[(batch*n + i)*B + b] = label_at_rank( sigma_p( pi_g( rank_i ) ) ),  p = perm_row + b, g = p / 16
 // One evaluation of the 8-round group bijection per spot and 16 permutations; per permutation the 2-round sigma network
-// (two permutations per packed-16 instruction) and the table look-up.
-constexpr uint32_t BLK_EXACT = 0x100u;
-
+// (two permutations per packed-16 instruction) and the table look-up: the compare reads its operands as 16-bit halves
+// in place and the add-with-carry writes the label straight into its byte of the output word (SDWA) — two VALU
+// instructions per label after the LDS read.
 struct LibDom {
     FeistelDomain dom;
     uint32_t aoff;  // offset of this library's block table
 };
 
-template <int B, bool HAS_LIBS>
-__global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __restrict__ cum, int kpad, int blk_words,
+// label byte J of `word` <- e.byte0 + (b.half H >= e.half1)
+template <int J, int H>
+__device__ __forceinline__ void put_label(uint32_t& word, uint32_t e, uint32_t bpk, uint32_t zero) {
+#define SQGR_PUT(JS, HS)                                                                                                      \
+    asm("v_cmp_le_u32_sdwa vcc, %1, %2 src0_sel:WORD_1 src1_sel:WORD_" HS "\n\t"                                              \
+        "v_addc_co_u32_sdwa %0, vcc, %1, %3, vcc dst_sel:BYTE_" JS " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:DWORD\n\t" \
+        "s_nop 0"                                                                                                            \
+        : "+v"(word)                                                                                                         \
+        : "v"(e), "v"(bpk), "v"(zero)                                                                                        \
+        : "vcc")
+    if constexpr (J == 0 && H == 0) SQGR_PUT("0", "0");
+    else if constexpr (J == 1 && H == 1) SQGR_PUT("1", "1");
+    else if constexpr (J == 2 && H == 0) SQGR_PUT("2", "0");
+    else if constexpr (J == 3 && H == 1) SQGR_PUT("3", "1");
+    else static_assert(J < 0, "byte J of the word holds the permutation of packed half J & 1");
+#undef SQGR_PUT
+}
+
+template <int B, bool HAS_LIBS, bool SMALLK>
+__global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __restrict__ cum, int kpad, int blk_words, int K,
                                                  const uint32_t* __restrict__ keys, LibDom dom0, int n_libs,
                                                  const int32_t* __restrict__ lib_of, const int32_t* __restrict__ rank_of,
                                                  const LibDom* __restrict__ libdoms, uint8_t* __restrict__ slab_all) {
-    extern __shared__ uint32_t s_cum[];               // [n_libs][kpad] boundaries, then [blk_words] block table
-    uint32_t* s_blk = s_cum + n_libs * kpad;
-    for (int t = threadIdx.x; t < n_libs * kpad + blk_words; t += 256) s_cum[t] = cum[t];
+    extern __shared__ uint32_t s_lds[];               // [blk_words] block table (byte offset 0), then [n_libs][kpad] boundaries
+    uint32_t* s_cum = s_lds + blk_words;
+    for (int t = threadIdx.x; t < n_libs * kpad; t += 256) s_cum[t] = cum[t];
+    for (int t = threadIdx.x; t < blk_words; t += 256) s_lds[t] = cum[n_libs * kpad + t];
     __syncthreads();
     const int batch = blockIdx.y;
     constexpr int NG = B / FEISTEL_GROUP;
     const uint32_t* kg = keys + (size_t)batch * key_words_per_row(B, n_libs);  // group keys of this row
     const uint32_t* ks = kg + (size_t)NG * n_libs * 8;                           // sigma keys
+    const uint32_t zero = 0;
+    // any label byte >= K ?  K <= 126: bytes are < 128, adding 128 - K sets bit 7 exactly for the sentinels
+    const uint32_t sent_add = (uint32_t)(128 - K) * 0x01010101u;
     // grid-stride over spots (launch_shuffle_raw caps the grid)
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     uint32_t out[B / 4];
@@ -104,7 +129,7 @@ __global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __re
     }
     const FeistelDomain dom = ld.dom;
     const uint32_t* tab = s_cum + lib * kpad + 1;  // tab[k] = cum[k + 1]
-    const uint32_t* blk = s_blk + ld.aoff;
+    const char* blk = reinterpret_cast<const char*>(s_lds) + (HAS_LIBS ? ld.aoff * 4 : 0u);  // !HAS_LIBS: LDS byte offset 0
     const uint32_t a0 = x0 / dom.B, b0 = x0 - a0 * dom.B;  // one division per spot, shared by all B permutations
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
@@ -117,40 +142,52 @@ __global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __re
 #pragma unroll
         for (int w = 0; w < FEISTEL_GROUP / 4; ++w) {
             uint32_t word = 0;
+            uint32_t apk[2], bpk[2];  // sigma images of the word's two pairs (kept for the exact route)
 #pragma unroll
-            for (int j = 0; j < 4; j += 2) {  // two permutations per evaluation (packed 16-bit lanes)
-                const uint32_t* const pk[1] = {ks + ((size_t)(g * (FEISTEL_GROUP / 2) + w * 2 + j / 2) * n_libs + lib) * 2};
+            for (int jj = 0; jj < 2; ++jj) {  // two permutations per evaluation (packed 16-bit lanes)
+                const uint32_t* const pk[1] = {ks + ((size_t)(g * (FEISTEL_GROUP / 2) + w * 2 + jj) * n_libs + lib) * 2};
                 u16x2 a[1] = {ga[0]}, b[1] = {gb[0]};
                 sigma_rounds<1>(a, b, dom, pk);
-                uint32_t l0, l1;
-                bool again;
-                do {
-                    const uint32_t ax = a[0].x, ay = a[0].y, bx = b[0].x, by = b[0].y;
-                    const uint32_t e0 = blk[ax], e1 = blk[ay];
-                    l0 = (e0 & 0xFFu) + (bx >= (e0 >> 16) ? 1u : 0u);
-                    l1 = (e1 & 0xFFu) + (by >= (e1 >> 16) ? 1u : 0u);
-                    again = false;
-                    if ((e0 | e1) & BLK_EXACT) {
-                        const uint32_t xx0 = __umul24(ax, dom.B) + bx, xx1 = __umul24(ay, dom.B) + by;  // digits < 2^14
-                        const bool w0 = xx0 >= dom.n, w1 = xx1 >= dom.n;
-                        if (!w0) {
-                            l0 = e0 & 0xFFu;
-                            while (xx0 >= tab[l0]) ++l0;  // sentinel UINT_MAX stops it
-                        }
-                        if (!w1) {
-                            l1 = e1 & 0xFFu;
-                            while (xx1 >= tab[l1]) ++l1;
-                        }
-                        again = w0 | w1;
-                        if (again) {  // cycle walk: re-apply sigma where the image left [0, n)
-                            u16x2 a2[1] = {a[0]}, b2[1] = {b[0]};
-                            sigma_rounds<1>(a2, b2, dom, pk);
-                            if (w0) { a[0].x = a2[0].x; b[0].x = b2[0].x; }
-                            if (w1) { a[0].y = a2[0].y; b[0].y = b2[0].y; }
-                        }
+                apk[jj] = __builtin_bit_cast(uint32_t, a[0]);
+                bpk[jj] = __builtin_bit_cast(uint32_t, b[0]);
+                const uint32_t a4 = apk[jj] << 2;  // both halves at once (a < 2^14): byte offsets into the block table
+                const uint32_t e0 = *reinterpret_cast<const uint32_t*>(blk + (a4 & 0xFFFFu));
+                const uint32_t e1 = *reinterpret_cast<const uint32_t*>(blk + (a4 >> 16));
+                if (jj == 0) {
+                    put_label<0, 0>(word, e0, bpk[jj], zero);
+                    put_label<1, 1>(word, e1, bpk[jj], zero);
+                } else {
+                    put_label<2, 0>(word, e0, bpk[jj], zero);
+                    put_label<3, 1>(word, e1, bpk[jj], zero);
+                }
+            }
+            bool sentinel;
+            if constexpr (SMALLK) {
+                sentinel = ((word + sent_add) & 0x80808080u) != 0;
+            } else {  // K = 256 has no sentinel value left in a byte: every label takes the exact route
+                const uint32_t k = (uint32_t)K;
+                sentinel = k > 255u || (word & 0xFFu) >= k || ((word >> 8) & 0xFFu) >= k || ((word >> 16) & 0xFFu) >= k || (word >> 24) >= k;
+            }
+            if (sentinel) {  // exact route (rare): re-walk sigma where the image left [0, n), then rank against the boundaries
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (K <= 255 && ((word >> (8 * j)) & 0xFFu) < (uint32_t)K) continue;
+                    const int jj = j >> 1, sh = (j & 1) * 16;
+                    const uint32_t* sk = ks + ((size_t)(g * (FEISTEL_GROUP / 2) + w * 2 + jj) * n_libs + lib) * 2;
+                    const uint32_t k0 = (sk[0] >> sh) & 0xFFFFu, k1 = (sk[1] >> sh) & 0xFFFFu;
+                    uint32_t a = (apk[jj] >> sh) & 0xFFFFu, b = (bpk[jj] >> sh) & 0xFFFFu;
+                    uint32_t x = a * dom.B + b;
+                    while (x >= dom.n) {
+                        uint32_t t = b + feistel_F1(a, k0, dom.bsh);
+                        t = t >= dom.B ? t - dom.B : t;
+                        b = t >= dom.B ? t - dom.B : t;
+                        a = (a + feistel_F1(b, k1, dom.ash)) & (dom.A - 1u);
+                        x = a * dom.B + b;
                     }
-                } while (again);
-                word |= (l0 << (8 * j)) | (l1 << (8 * (j + 1)));
+                    uint32_t l = 0;
+                    while (x >= tab[l]) ++l;  // sentinel UINT_MAX stops it
+                    word = (word & ~(0xFFu << (8 * j))) | (l << (8 * j));
+                }
             }
             out[g * (FEISTEL_GROUP / 4) + w] = word;
         }
@@ -212,14 +249,16 @@ __device__ __forceinline__ uint32_t pair_index(uint32_t la, uint32_t lb, uint32_
 // The edge list is either the full COO view or, on structurally symmetric graphs, the half list of sqgr_graph (edges
 // r < c, then the self loops from `self_begin` on): k_reduce then forms count = h + h^T.  SELF (the half list has self
 // loops): half edges add 2, self loops 1 and k_reduce halves the sum — exact, every sum is even by construction.
+// List entries hold BYTE OFFSETS of the endpoints' 16-byte slab rows (16*r, 16*c) and the list is followed by
+// LIST_PAD zero entries (sqgr_ctx.hip), so the look-ahead loads below never need a clamp.
 template <int B, int MIN_WAVES, bool SELF>
 __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz, const int2* __restrict__ coo,
                                                                     const uint8_t* __restrict__ slab_all, int64_t n, int K,
                                                                     int hist_words, uint32_t edges_per_block,
                                                                     uint32_t self_begin, uint32_t* __restrict__ partial_all) {
     extern __shared__ uint32_t hist[];
-    // this kernel is bound by LDS-atomic throughput and needs few VALU slots; when the VALU-bound shuffle kernel of the
-    // next launch group shares the CU (SQGR_NHOOD_STREAMS=2), issue priority keeps the LDS pipe fed
+    // this kernel is bound by LDS-atomic and VALU issue; when the VALU-bound shuffle kernel of the next launch group
+    // shares the CU (SQGR_NHOOD_STREAMS=2), issue priority keeps the LDS pipe fed
     __builtin_amdgcn_s_setprio(3);
     constexpr int BPL = B / 4;  // label bytes per lane
     constexpr int LOGW = (B == 32) ? 7 : 6;  // log2(bytes of one pair's B counters)
@@ -231,6 +270,8 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
     const uint32_t chunk = (uint32_t)xcd_chunk(blockIdx.x, gridDim.x);
     const uint32_t e0 = chunk * edges_per_block;
     const uint32_t e1 = min(nnz, e0 + edges_per_block);
+    // block-uniform: every edge slot of every iteration is a real edge of one weight -> no per-edge bookkeeping at all
+    const bool uniform_block = (e0 + edges_per_block <= nnz) && (!SELF || e0 + edges_per_block <= self_begin);
     const uint32_t q = tid & 3;
     const uint32_t el = tid >> 2;
     const uint32_t rot = (el & (BPL - 1)) * 8;  // bits to rotate right
@@ -240,38 +281,50 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
     const uint32_t qoff = q * BPL;
     char* hist_bytes = reinterpret_cast<char*>(hist);
 
-    // The 4 lanes of a quad share U = 4 consecutive edges per iteration: lane q loads the (row, col) pair of edge
-    // eb + q with ONE 8-byte load (a wave reads 64 consecutive pairs: one coalesced 512-byte request) and the quad
-    // exchanges them with DPP quad_perm broadcasts (VALU, no LDS, no extra memory instructions).  All slab-row
-    // gathers of the 4 edges are then in flight together, so the two dependent memory latencies are paid once per
-    // 4 edges (LDS caps residency at 16-32 waves per CU).
+    // A quad of lanes shares U = 4 consecutive edges per iteration; lane q owns the B/4 permutations [q*B/4, (q+1)*B/4) of
+    // each.  Lane q loads the offset pair of edge eb + q with ONE 8-byte load (a wave reads 64 consecutive pairs: one
+    // coalesced 512-byte request) and the quad exchanges them with DPP quad_perm broadcasts (VALU, no LDS, no extra memory
+    // instructions: letting every lane load all four pairs itself quadruples the bytes through the vector memory pipe
+    // and was measured 10 % slower).  All slab-row gathers of the 4 edges are then in flight together, so the two
+    // dependent memory latencies are paid once per 4 edges.
     // Software pipeline, two stages deep: while iteration k is histogrammed, the slab rows of iteration k+1 and the
-    // (row, col) pairs of iteration k+2 are in flight (every load gets a full processing phase of slack).
+    // offset pairs of iteration k+2 are in flight (every load gets a full processing phase of slack).
     constexpr int U = 4;
     constexpr uint32_t STEP = (COUNT_THREADS / 4) * U;
+    static_assert(2 * STEP + U <= LIST_PAD, "look-ahead exceeds the padding of the edge lists");
     using Row = typename std::conditional<B == 16, uint32_t, uint2>::type;
-    const uint32_t last = nnz - 1;
-    auto gather_rows = [&](const int2 mine, Row (&ra)[U], Row (&rb)[U]) {
-        uint32_t r[U], c[U];
-        r[0] = (uint32_t)__builtin_amdgcn_update_dpp(mine.x, mine.x, 0x00, 0xF, 0xF, false);  // quad_perm:[0,0,0,0]
-        c[0] = (uint32_t)__builtin_amdgcn_update_dpp(mine.y, mine.y, 0x00, 0xF, 0xF, false);
-        r[1] = (uint32_t)__builtin_amdgcn_update_dpp(mine.x, mine.x, 0x55, 0xF, 0xF, false);  // quad_perm:[1,1,1,1]
-        c[1] = (uint32_t)__builtin_amdgcn_update_dpp(mine.y, mine.y, 0x55, 0xF, 0xF, false);
-        r[2] = (uint32_t)__builtin_amdgcn_update_dpp(mine.x, mine.x, 0xAA, 0xF, 0xF, false);  // quad_perm:[2,2,2,2]
-        c[2] = (uint32_t)__builtin_amdgcn_update_dpp(mine.y, mine.y, 0xAA, 0xF, 0xF, false);
-        r[3] = (uint32_t)__builtin_amdgcn_update_dpp(mine.x, mine.x, 0xFF, 0xF, 0xF, false);  // quad_perm:[3,3,3,3]
-        c[3] = (uint32_t)__builtin_amdgcn_update_dpp(mine.y, mine.y, 0xFF, 0xF, 0xF, false);
+    struct Pairs { int4 a, b; };  // edges (0, 1) and (2, 3) of the lane's group
+    auto load_pair = [&](uint32_t e) { return coo[e + q]; };
+    auto spread = [&](const int2 mine) {
+        Pairs pr;
+        pr.a.x = __builtin_amdgcn_update_dpp(mine.x, mine.x, 0x00, 0xF, 0xF, false);  // quad_perm:[0,0,0,0]
+        pr.a.y = __builtin_amdgcn_update_dpp(mine.y, mine.y, 0x00, 0xF, 0xF, false);
+        pr.a.z = __builtin_amdgcn_update_dpp(mine.x, mine.x, 0x55, 0xF, 0xF, false);  // quad_perm:[1,1,1,1]
+        pr.a.w = __builtin_amdgcn_update_dpp(mine.y, mine.y, 0x55, 0xF, 0xF, false);
+        pr.b.x = __builtin_amdgcn_update_dpp(mine.x, mine.x, 0xAA, 0xF, 0xF, false);  // quad_perm:[2,2,2,2]
+        pr.b.y = __builtin_amdgcn_update_dpp(mine.y, mine.y, 0xAA, 0xF, 0xF, false);
+        pr.b.z = __builtin_amdgcn_update_dpp(mine.x, mine.x, 0xFF, 0xF, 0xF, false);  // quad_perm:[3,3,3,3]
+        pr.b.w = __builtin_amdgcn_update_dpp(mine.y, mine.y, 0xFF, 0xF, 0xF, false);
+        return pr;
+    };
+    auto gather_rows = [&](const Pairs& pr, Row (&ra)[U], Row (&rb)[U]) {
+        const uint32_t r[U] = {(uint32_t)pr.a.x, (uint32_t)pr.a.z, (uint32_t)pr.b.x, (uint32_t)pr.b.z};
+        const uint32_t c[U] = {(uint32_t)pr.a.y, (uint32_t)pr.a.w, (uint32_t)pr.b.y, (uint32_t)pr.b.w};
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            ra[u] = *reinterpret_cast<const Row*>(slab + (r[u] * B + qoff));
-            rb[u] = *reinterpret_cast<const Row*>(slab + (c[u] * B + qoff));
+            ra[u] = *reinterpret_cast<const Row*>(slab + ((B == 16 ? r[u] : 2u * r[u]) + qoff));
+            rb[u] = *reinterpret_cast<const Row*>(slab + ((B == 16 ? c[u] : 2u * c[u]) + qoff));
         }
     };
-    auto histogram = [&](const Row (&row_a)[U], const Row (&row_b)[U], uint32_t eb) {
+    auto histogram = [&](const Row (&row_a)[U], const Row (&row_b)[U], uint32_t eb, auto general_tag) {
+        constexpr bool GENERAL = decltype(general_tag)::value;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            uint32_t inc = (eb + u < e1) ? 1u : 0u;  // branch-free tail: out-of-range edges add 0
-            if constexpr (SELF) inc += (eb + u < min(e1, self_begin)) ? 1u : 0u;
+            uint32_t inc = SELF ? 2u : 1u;
+            if constexpr (GENERAL) {  // branch-free tail: out-of-range edges add 0, self loops 1
+                inc = (eb + u < e1) ? 1u : 0u;
+                if constexpr (SELF) inc += (eb + u < min(e1, self_begin)) ? 1u : 0u;
+            }
             uint32_t la[2], lb[2];
             if constexpr (B == 16) {
                 la[0] = __builtin_amdgcn_alignbit(row_a[u], row_a[u], rot);
@@ -302,20 +355,28 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
             }
         }
     };
-    uint32_t e = e0 + el * U;
-    Row p_a[U], p_b[U], q_a[U], q_b[U];  // ping-pong row buffers: no register rotation at the end of an iteration
-    gather_rows(coo[min(e + q, last)], p_a, p_b);                         // rows of iteration 0
-    int2 nxt_rc = coo[min(e + STEP + q, last)];                           // pairs of iteration 1 (clamped: in bounds)
-    while (e < e1) {
-        gather_rows(nxt_rc, q_a, q_b);                                    // rows of iteration k+1
-        nxt_rc = coo[min(e + 2 * STEP + q, last)];                        // pairs of iteration k+2
-        histogram(p_a, p_b, e);
-        e += STEP;
-        if (e >= e1) break;
-        gather_rows(nxt_rc, p_a, p_b);
-        nxt_rc = coo[min(e + 2 * STEP + q, last)];
-        histogram(q_a, q_b, e);
-        e += STEP;
+    auto sweep = [&](auto general_tag) {
+        uint32_t e = e0 + el * U;
+        Row p_a[U], p_b[U], q_a[U], q_b[U];  // ping-pong row buffers: no register rotation at the end of an iteration
+        gather_rows(spread(load_pair(e)), p_a, p_b);                      // rows of iteration 0
+        int2 nxt = load_pair(e + STEP);                                    // pairs of iteration 1 (list padding: in bounds)
+        while (e < e1) {
+            gather_rows(spread(nxt), q_a, q_b);                            // rows of iteration k+1
+            nxt = load_pair(e + 2 * STEP);                                 // pairs of iteration k+2
+            histogram(p_a, p_b, e, general_tag);
+            e += STEP;
+            if (e >= e1) break;
+            gather_rows(spread(nxt), p_a, p_b);
+            nxt = load_pair(e + 2 * STEP);
+            histogram(q_a, q_b, e, general_tag);
+            e += STEP;
+        }
+    };
+    if (e0 < nnz) {  // (chunks past the end of a short list stay empty; their look-ahead would leave the padding)
+        if (uniform_block)
+            sweep(std::false_type{});
+        else
+            sweep(std::true_type{});
     }
     __syncthreads();
     uint32_t* dst = partial_all + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * hist_words;
@@ -407,20 +468,35 @@ __global__ __launch_bounds__(256) void k_reduce(const uint32_t* __restrict__ par
     if (perms_out) perms_out[(size_t)(p - perm_begin) * K2 + pair] = (uint32_t)c;
 }
 
-__global__ void k_finalize(const int64_t* __restrict__ acc_sum, const uint64_t* __restrict__ acc_sq, int nbatch,
-                           int hist_words, int B, int K2, int64_t* __restrict__ out_sum, uint64_t* __restrict__ out_sq) {
-    int pair = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pair >= K2) return;
+// one block per pair: sums the nbatch*B private slots (fixed order inside a thread, fixed tree across threads:
+// bit-reproducible, and integer addition is exact anyway)
+__global__ __launch_bounds__(256) void k_finalize(const int64_t* __restrict__ acc_sum, const uint64_t* __restrict__ acc_sq, int nbatch,
+                                                  int hist_words, int B, int K2, int64_t* __restrict__ out_sum,
+                                                  uint64_t* __restrict__ out_sq) {
+    __shared__ int64_t s_s[256];
+    __shared__ uint64_t s_q[256];
+    const int pair = blockIdx.x;
     int64_t s = 0;
     uint64_t q = 0;
-    for (int batch = 0; batch < nbatch; ++batch)
-        for (int b = 0; b < B; ++b) {
-            size_t slot = (size_t)batch * hist_words + (size_t)pair * B + b;
-            s += acc_sum[slot];
-            q += acc_sq[slot];
+    for (int t = threadIdx.x; t < nbatch * B; t += 256) {
+        const size_t slot = (size_t)(t / B) * hist_words + (size_t)pair * B + (t % B);
+        s += acc_sum[slot];
+        q += acc_sq[slot];
+    }
+    s_s[threadIdx.x] = s;
+    s_q[threadIdx.x] = q;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            s_s[threadIdx.x] += s_s[threadIdx.x + off];
+            s_q[threadIdx.x] += s_q[threadIdx.x + off];
         }
-    out_sum[pair] = s;
-    out_sq[pair] = q;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out_sum[pair] = s_s[0];
+        out_sq[pair] = s_q[0];
+    }
 }
 
 // observed counts / interaction matrix: one pass, thread per edge
@@ -458,17 +534,33 @@ __global__ __launch_bounds__(256) void k_columns_to_slab(int64_t n, int64_t stri
 // the first axis of a C-contiguous array is a plain sequential accumulation per cell (one rounded add per permutation,
 // in permutation order) — `mean = sum / P`, then `sum((x - mean)**2) / P` accumulated the same way, then sqrt.  One
 // thread per cell walks the permutations in order; every operation is individually rounded (-ffp-contract=off).
-__global__ __launch_bounds__(64) void k_numpy_mean_std(const uint32_t* __restrict__ perms, int64_t P, int K2,
-                                                       double* __restrict__ mean, double* __restrict__ stdev) {
+__global__ __launch_bounds__(64) void k_numpy_mean_std(const uint32_t* __restrict__ perms, int64_t P, int K2, int64_t base,
+                                                       int64_t rem, int64_t rank_stride, double* __restrict__ mean,
+                                                       double* __restrict__ stdev) {
+    // Layout: permutation q lives at perms[r * rank_stride + j * K2] with (r, j) = its owner under the contiguous split
+    // of [0, P) into chunks of base + 1 (the first `rem` ranks) and base permutations — the all-gathered per-rank slices
+    // of sqgr_nhood_run_pcg64_stats; a single rank passes base = P, rem = 0.
     const int c = blockIdx.x * 64 + threadIdx.x;
     if (c >= K2) return;
     const uint32_t* col = perms + c;
+    auto at = [&](int64_t q) -> double {
+        const int64_t cut = rem * (base + 1);
+        int64_t r, j;
+        if (q < cut) {
+            r = q / (base + 1);
+            j = q - r * (base + 1);
+        } else {
+            r = rem + (base > 0 ? (q - cut) / base : 0);
+            j = q - cut - (r - rem) * base;
+        }
+        return (double)col[(size_t)r * rank_stride + (size_t)j * K2];
+    };
     double acc = 0.0;
-    for (int64_t q = 0; q < P; ++q) acc += (double)col[(size_t)q * K2];
+    for (int64_t q = 0; q < P; ++q) acc += at(q);
     const double m = acc / (double)P;
     double acc2 = 0.0;
     for (int64_t q = 0; q < P; ++q) {
-        const double d = (double)col[(size_t)q * K2] - m;
+        const double d = at(q) - m;
         acc2 += d * d;
     }
     mean[c] = m;
@@ -532,8 +624,9 @@ struct sqgr_nhood {
     DevBuf<uint32_t> partial;
     DevBuf<int64_t> acc_sum;
     DevBuf<uint64_t> acc_sq;
-    DevBuf<int64_t> shift, fin_sum;
-    DevBuf<uint64_t> fin_sq;
+    DevBuf<int64_t> shift, fin;  // fin: [K2] sum of d, then [K2] sum of d*d (uint64 bit patterns) — one all-reduce
+    sqgr_comm* comm = nullptr;   // optional: moments are all-reduced on the device (sqgr_nhood_set_comm)
+    DevBuf<uint32_t> perms_all;  // all-gathered per-permutation counts (numpy-stream statistics over several ranks)
     DevBuf<uint32_t> perms_dev;
     DevBuf<uint8_t> stage;
 
@@ -598,8 +691,7 @@ int sqgr_nhood::ensure_workspace(bool need_perms) {
     SQGR_TRY(acc_sum.ensure((size_t)nbatch * hw));
     SQGR_TRY(acc_sq.ensure((size_t)nbatch * hw));
     SQGR_TRY(shift.ensure((size_t)K2));
-    SQGR_TRY(fin_sum.ensure((size_t)K2));
-    SQGR_TRY(fin_sq.ensure((size_t)K2));
+    SQGR_TRY(fin.ensure((size_t)2 * K2));
     (void)need_perms;
     return SQGR_OK;
 }
@@ -625,7 +717,7 @@ int sqgr_nhood::count_batches(int nb, int buf) {
         const uint32_t self_begin = (uint32_t)(half ? g->n_half : nnz);
         const bool self = half && g->n_self > 0;
         sym_launch = half ? (self ? 2 : 1) : 0;
-        const uint32_t epb = (uint32_t)(ceil_div(ceil_div((int64_t)m, nblk), 256) * 256);
+        const uint32_t epb = (uint32_t)(ceil_div(ceil_div((int64_t)m, nblk), 1024) * 1024);  // whole iterations of a block
         const size_t lds = (size_t)hw * 4;
         const dim3 grid(nblk, nb);
 #define SQGR_COUNT(BB, MW, SELF) \
@@ -828,33 +920,42 @@ static int nhood_build(sqgr_ctx* ctx, const sqgr_graph* g, int64_t n, const int3
             break;
         }
         // block table (appended to the boundary table): one word per high digit a describing the ranks [a*B, (a+1)*B) of
-        // the label-sorted base — bits 0-7 the label of rank a*B, bits 16-31 the low digit at which the NEXT label starts
-        // (0xFFFF: none), bit 8 set when that is not the whole story (several label starts inside the block, empty
-        // categories skipped, or the block reaches past the library's last rank) and the exact search must run.
+        // the label-sorted base — byte 0 the label of rank a*B, bits 16-31 the low digit at which the NEXT label starts
+        // (0xFFFF: none).  "Events" inside a block are label starts and the library's end (ranks >= n_l read as label K,
+        // the sentinel that sends the kernel to its exact route); a block with one event whose label is lab + 1 fits the
+        // two-field form, a block with no event too, everything else is marked with lab0 = K.
         std::vector<uint32_t> blk(blk_total, 0);
         for (int l = 0; l < p->n_libs; ++l) {
             const uint32_t* c = &cum[(size_t)l * p->kpad];
             const uint64_t n_l = (uint64_t)cnt[l];
+            const uint32_t SENT = (uint32_t)K | (0xFFFFu << 16);
             uint32_t lab = 0;
             for (uint32_t a = 0; a < doms[l].dom.A; ++a) {
                 const uint64_t lo = (uint64_t)a * doms[l].dom.B, hi = lo + doms[l].dom.B;
                 uint32_t word;
                 if (lo >= n_l) {
-                    word = BLK_EXACT | (0xFFFFu << 16);
+                    word = SENT;
                 } else {
-                    while (lab + 1 < (uint32_t)K && c[lab + 1] <= lo) ++lab;
-                    uint32_t starts = 0, first_k = 0;
-                    for (uint32_t k2 = lab + 1; k2 < (uint32_t)K && c[k2] < hi; ++k2) {  // labels starting inside (lo, hi)
-                        if (starts == 0) first_k = k2;
-                        ++starts;
+                    while (lab + 1 < (uint32_t)K && c[lab + 1] <= lo) ++lab;  // label of rank lo: the largest k with c[k] <= lo
+                    const uint64_t end = hi < n_l ? hi : n_l;
+                    uint32_t events = 0, ev_label = 0;
+                    uint64_t ev_pos = 0;
+                    for (uint32_t k2 = lab + 1; k2 < (uint32_t)K && c[k2] < end; ++k2) {  // label changes inside (lo, end)
+                        const uint64_t nxt = k2 + 1 < (uint32_t)K ? c[k2 + 1] : n_l;
+                        if (c[k2] >= nxt) continue;  // empty category: no rank carries it
+                        if (events == 0) { ev_label = k2; ev_pos = c[k2] - lo; }
+                        ++events;
                     }
-                    if (starts == 0)
+                    if (hi > n_l) {  // the library ends inside this block: ranks >= n_l read as the sentinel label K
+                        if (events == 0) { ev_label = (uint32_t)K; ev_pos = n_l - lo; }
+                        ++events;
+                    }
+                    if (events == 0)
                         word = lab | (0xFFFFu << 16);
-                    else if (starts == 1 && first_k == lab + 1)
-                        word = lab | ((uint32_t)(c[first_k] - lo) << 16);
+                    else if (events == 1 && ev_label == lab + 1 && ev_pos > 0)
+                        word = lab | ((uint32_t)ev_pos << 16);
                     else
-                        word = lab | BLK_EXACT | (0xFFFFu << 16);
-                    if (hi > n_l) word |= BLK_EXACT;
+                        word = SENT;
                 }
                 blk[doms[l].aoff + a] = word;
             }
@@ -939,14 +1040,17 @@ static int launch_shuffle_raw(sqgr_nhood* p, int B, int nb, const uint32_t* keys
     gx = std::min<unsigned>(gx, (unsigned)(per_cu * std::max(p->ctx->cu_count, 1)) / (unsigned)std::max(nb, 1) + 1);
     LaunchTimer t(p->ctx, "nhood_shuffle", st);
     const size_t lds = (size_t)p->n_libs * p->kpad * 4 + (size_t)p->blk_bytes * 4;
-#define SQGR_SHUFFLE(BB, LIBS)                                                                                  \
-    k_shuffle<BB, LIBS><<<dim3(gx, nb), 256, lds, st>>>(p->n, p->cum.p, p->kpad, p->blk_bytes, keys, p->dom0, p->n_libs, p->lib_of.p, \
-                                                        p->rank_of.p, p->libs.p, slab)
+#define SQGR_SHUFFLE(BB, LIBS, SK)                                                                                            \
+    k_shuffle<BB, LIBS, SK><<<dim3(gx, nb), 256, lds, st>>>(p->n, p->cum.p, p->kpad, p->blk_bytes, p->K, keys, p->dom0, p->n_libs, \
+                                                            p->lib_of.p, p->rank_of.p, p->libs.p, slab)
+#define SQGR_SHUFFLE_K(BB, LIBS) \
+    if (p->K <= 126) SQGR_SHUFFLE(BB, LIBS, true); else SQGR_SHUFFLE(BB, LIBS, false)
     if (B == 32) {
-        if (p->has_libs) SQGR_SHUFFLE(32, true); else SQGR_SHUFFLE(32, false);
+        if (p->has_libs) { SQGR_SHUFFLE_K(32, true); } else { SQGR_SHUFFLE_K(32, false); }
     } else {
-        if (p->has_libs) SQGR_SHUFFLE(16, true); else SQGR_SHUFFLE(16, false);
+        if (p->has_libs) { SQGR_SHUFFLE_K(16, true); } else { SQGR_SHUFFLE_K(16, false); }
     }
+#undef SQGR_SHUFFLE_K
 #undef SQGR_SHUFFLE
     SQGR_HIP(hipGetLastError());
     return SQGR_OK;
@@ -1005,12 +1109,15 @@ int sqgr_nhood_run(sqgr_nhood* plan, uint64_t seed, int64_t perm_begin, int64_t 
     }
     {
         LaunchTimer t(ctx, "nhood_finalize");
-        k_finalize<<<(unsigned)ceil_div(K2, 256), 256, 0, st>>>(p->acc_sum.p, p->acc_sq.p, p->nbatch, hw, B, K2, p->fin_sum.p,
-                                                               p->fin_sq.p);
+        k_finalize<<<(unsigned)K2, 256, 0, st>>>(p->acc_sum.p, p->acc_sq.p, p->nbatch, hw, B, K2, p->fin.p,
+                                                reinterpret_cast<uint64_t*>(p->fin.p + K2));
         SQGR_HIP(hipGetLastError());
     }
-    SQGR_HIP(hipMemcpyAsync(out_sum, p->fin_sum.p, (size_t)K2 * 8, hipMemcpyDeviceToHost, st));
-    SQGR_HIP(hipMemcpyAsync(out_sumsq, p->fin_sq.p, (size_t)K2 * 8, hipMemcpyDeviceToHost, st));
+    // multi-GPU: the ranks ran disjoint permutation ranges; one RCCL all-reduce of the 2*K*K exact integer moments on the
+    // device, then every rank copies out the global sums
+    SQGR_TRY(comm_allreduce_i64_dev(p->comm, p->fin.p, (size_t)2 * K2, false, st));
+    SQGR_HIP(hipMemcpyAsync(out_sum, p->fin.p, (size_t)K2 * 8, hipMemcpyDeviceToHost, st));
+    SQGR_HIP(hipMemcpyAsync(out_sumsq, p->fin.p + K2, (size_t)K2 * 8, hipMemcpyDeviceToHost, st));
     if (out_perms && nperm > 0)
         SQGR_HIP(hipMemcpyAsync(out_perms, p->perms_dev.p, (size_t)nperm * K2 * 4, hipMemcpyDeviceToHost, st));
     SQGR_HIP(hipStreamSynchronize(st));
@@ -1105,7 +1212,7 @@ static int run_pcg64_impl(sqgr_nhood* plan, const uint64_t* pcg_states, int64_t 
         SQGR_HIP(hipMemsetAsync(p->shift.p, 0, (size_t)K2 * 8, st));
     SQGR_HIP(hipMemsetAsync(p->acc_sum.p, 0, (size_t)p->nbatch * hw * 8, st));
     SQGR_HIP(hipMemsetAsync(p->acc_sq.p, 0, (size_t)p->nbatch * hw * 8, st));
-    if (keep_perms && n_perms > 0) SQGR_TRY(p->perms_dev.ensure((size_t)n_perms * K2));
+    if (keep_perms) SQGR_TRY(p->perms_dev.ensure((size_t)(n_perms + 1) * K2));  // + 1: the all-gather of ragged rank chunks sends one padded row
     // permutations per chunk: one thread each; the column matrix takes n bytes per permutation (<= 25 % of free HBM)
     size_t free_b = 0, total_b = 0;
     SQGR_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -1140,12 +1247,15 @@ static int run_pcg64_impl(sqgr_nhood* plan, const uint64_t* pcg_states, int64_t 
     }
     {
         LaunchTimer t(ctx, "nhood_finalize");
-        k_finalize<<<(unsigned)ceil_div(K2, 256), 256, 0, st>>>(p->acc_sum.p, p->acc_sq.p, p->nbatch, hw, B, K2, p->fin_sum.p,
-                                                               p->fin_sq.p);
+        k_finalize<<<(unsigned)K2, 256, 0, st>>>(p->acc_sum.p, p->acc_sq.p, p->nbatch, hw, B, K2, p->fin.p,
+                                                reinterpret_cast<uint64_t*>(p->fin.p + K2));
         SQGR_HIP(hipGetLastError());
     }
-    SQGR_HIP(hipMemcpyAsync(out_sum, p->fin_sum.p, (size_t)K2 * 8, hipMemcpyDeviceToHost, st));
-    SQGR_HIP(hipMemcpyAsync(out_sumsq, p->fin_sq.p, (size_t)K2 * 8, hipMemcpyDeviceToHost, st));
+    // multi-GPU: the ranks ran disjoint permutation ranges; one RCCL all-reduce of the 2*K*K exact integer moments on the
+    // device, then every rank copies out the global sums
+    SQGR_TRY(comm_allreduce_i64_dev(p->comm, p->fin.p, (size_t)2 * K2, false, st));
+    SQGR_HIP(hipMemcpyAsync(out_sum, p->fin.p, (size_t)K2 * 8, hipMemcpyDeviceToHost, st));
+    SQGR_HIP(hipMemcpyAsync(out_sumsq, p->fin.p + K2, (size_t)K2 * 8, hipMemcpyDeviceToHost, st));
     if (out_perms && n_perms > 0)
         SQGR_HIP(hipMemcpyAsync(out_perms, p->perms_dev.p, (size_t)n_perms * K2 * 4, hipMemcpyDeviceToHost, st));
     SQGR_HIP(hipStreamSynchronize(st));
@@ -1158,24 +1268,71 @@ int sqgr_nhood_run_pcg64(sqgr_nhood* plan, const uint64_t* pcg_states, int64_t n
 }
 
 int sqgr_nhood_run_pcg64_stats(sqgr_nhood* plan, const uint64_t* pcg_states, int64_t n_perms, double* out_mean, double* out_std) {
-    SQGR_REQUIRE(plan && out_mean && out_std && n_perms >= 1, "null argument or n_perms < 1");
+    SQGR_REQUIRE(plan && pcg_states && out_mean && out_std && n_perms >= 1, "null argument or n_perms < 1");
     const int K2 = plan->K2;
     std::vector<int64_t> s1((size_t)K2);
     std::vector<uint64_t> s2((size_t)K2);
-    SQGR_TRY(run_pcg64_impl(plan, pcg_states, n_perms, nullptr, s1.data(), s2.data(), nullptr, true));
+    // several ranks: `pcg_states` holds ALL n_perms generator states on every rank; this rank runs the contiguous chunk
+    // it owns (chunks of base + 1 permutations on the first `rem` ranks, base on the others), the per-permutation counts
+    // are all-gathered on the device (RCCL) and every rank reduces the full set in numpy's order: the result does not
+    // depend on the number of ranks, bit for bit.
+    const int world = comm_world(plan->comm), rank = comm_rank(plan->comm);
+    const int64_t base = n_perms / world, rem = n_perms % world;
+    const int64_t lo = rank * base + std::min<int64_t>(rank, rem), mine = base + (rank < rem ? 1 : 0);
+    sqgr_comm* comm = plan->comm;
+    plan->comm = nullptr;  // the moments of the slice are not what is wanted here: no all-reduce inside the run
+    const int rc = run_pcg64_impl(plan, pcg_states + (size_t)lo * 4, mine, nullptr, s1.data(), s2.data(), nullptr, true);
+    plan->comm = comm;
+    SQGR_TRY(rc);
     sqgr_ctx* ctx = plan->ctx;
     hipStream_t st = ctx->stream;
+    const uint32_t* perms = plan->perms_dev.p;
+    int64_t rank_stride = 0, kbase = n_perms, krem = 0;
+    if (world > 1) {
+        const int64_t maxc = base + (rem ? 1 : 0);
+        rank_stride = maxc * K2;
+        SQGR_TRY(plan->perms_all.ensure((size_t)world * rank_stride));
+        SQGR_TRY(comm_allgather_dev(comm, plan->perms_dev.p, plan->perms_all.p, (size_t)rank_stride * 4, st));
+        perms = plan->perms_all.p;
+        kbase = base;
+        krem = rem;
+    }
     DevBuf<double> d_mean, d_std;
     SQGR_TRY(d_mean.alloc((size_t)K2));
     SQGR_TRY(d_std.alloc((size_t)K2));
     {
         LaunchTimer t(ctx, "nhood_numpy_mean_std");
-        k_numpy_mean_std<<<(unsigned)ceil_div(K2, 64), 64, 0, st>>>(plan->perms_dev.p, n_perms, K2, d_mean.p, d_std.p);
+        k_numpy_mean_std<<<(unsigned)ceil_div(K2, 64), 64, 0, st>>>(perms, n_perms, K2, kbase, krem, rank_stride, d_mean.p, d_std.p);
         SQGR_HIP(hipGetLastError());
     }
     SQGR_HIP(hipMemcpyAsync(out_mean, d_mean.p, (size_t)K2 * 8, hipMemcpyDeviceToHost, st));
     SQGR_HIP(hipMemcpyAsync(out_std, d_std.p, (size_t)K2 * 8, hipMemcpyDeviceToHost, st));
     SQGR_HIP(hipStreamSynchronize(st));
+    return SQGR_OK;
+}
+
+int sqgr_nhood_info(sqgr_nhood* plan, int64_t* out_info) {
+    SQGR_REQUIRE(plan && out_info, "plan/out_info is NULL");
+    sqgr_nhood* p = plan;
+    SQGR_HIP(hipSetDevice(p->ctx->device));
+    SQGR_TRY(p->resolve_tuning());
+    const bool lds_path = p->g && (p->B == 32 || p->be() == 16);
+    if (lds_path) SQGR_TRY(p->g->ensure_half());
+    const bool half = lds_path && p->g->sym_state == 1;
+    out_info[0] = p->B;
+    out_info[1] = p->nbatch;
+    out_info[2] = p->partial_blocks(p->nbatch);
+    out_info[3] = p->g ? (half ? p->g->n_half + p->g->n_self : p->g->nnz) : 0;
+    out_info[4] = half ? (p->g->n_self > 0 ? 2 : 1) : 0;
+    out_info[5] = p->hist_words();
+    out_info[6] = half ? p->g->n_self : 0;
+    out_info[7] = FEISTEL_GROUP;
+    return SQGR_OK;
+}
+
+int sqgr_nhood_set_comm(sqgr_nhood* plan, sqgr_comm* comm) {
+    SQGR_REQUIRE(plan, "plan is NULL");
+    plan->comm = comm;  // NULL detaches
     return SQGR_OK;
 }
 

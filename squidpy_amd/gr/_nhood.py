@@ -102,8 +102,9 @@ def nhood_enrichment(
     device
         HIP device index (default: ``LOCAL_RANK`` or 0).
 
-    When a ``torch.distributed`` process group is initialised, the permutation range is split across ranks
-    and the integer moments are all-reduced (RCCL); every rank returns the full result.
+    With a process group (``squidpy_amd.init_distributed()`` under any one-process-per-GPU launcher, or an already
+    initialised ``torch.distributed`` group) the permutation range is split across ranks and the exact integer moments
+    are all-reduced on the device by RCCL inside libsqgr; every rank returns the full result.
     """
     adata = extract_adata_if_sdata(adata, table_key=table_key)
     connectivity_key = Key.obsp.spatial_conn(connectivity_key)
@@ -137,16 +138,20 @@ def nhood_enrichment(
             lo, hi = _dist.shard_range(n_perms, rank, world)
             if seed is None:
                 seed = _broadcast_seed(resolve_seed(None))
+            comm = _device_comm(ctx)
             plan = NhoodPlan(ctx, graph, int_clust, n_cls, lib_codes, n_libs)
             try:
-                if world == 1:  # the float64 mean/std of gr/_nhood.py:231 formed on the device, bit for bit
+                if world == 1 or comm is not None:
+                    # the float64 mean/std of gr/_nhood.py:231 formed on the device, bit for bit; with several ranks each
+                    # runs its contiguous chunk of the streams and the per-permutation counts are all-gathered by RCCL
+                    plan.set_comm(comm)
                     mean, std = plan.run_pcg64_stats(pcg64_states(seed, n_perms))
                     perms = None
                 else:
                     _, _, perms = plan.run_pcg64(pcg64_states(seed, n_perms, lo, hi), return_perms=True)
             finally:
                 plan.close()
-            if perms is not None:  # several ranks: the sequential float64 reduction needs all counts in permutation order
+            if perms is not None:  # host side channel only (ranks sharing a GPU): numpy reduces the gathered counts
                 perms = np.concatenate(_dist.allgather_object(perms), axis=0).astype(np.float64)
                 mean, std = perms.mean(axis=0), perms.std(axis=0)
             with np.errstate(divide="ignore", invalid="ignore"):
@@ -155,13 +160,16 @@ def nhood_enrichment(
             rank, world = _dist.world()
             lo, hi = _dist.shard_range(n_perms, rank, world)
             shift = expected_counts(int_clust, n_cls, graph.nnz)
+            comm = _device_comm(ctx)
             plan = NhoodPlan(ctx, graph, int_clust, n_cls, lib_codes, n_libs)
             try:
                 key = _broadcast_seed(resolve_seed(seed))
+                plan.set_comm(comm)  # the exact integer moments are all-reduced on the device (RCCL inside libsqgr)
                 s1, s2, _ = plan.run(key, lo, hi, shift)
             finally:
                 plan.close()
-            s1, s2 = _dist.allreduce_sum_([s1, s2])
+            if comm is None:
+                s1, s2 = _dist.allreduce_sum_([s1, s2])
             zscore = zscore_from_moments(count, shift, s1, s2, n_perms)
     finally:
         graph.close()
@@ -172,12 +180,19 @@ def nhood_enrichment(
     return None
 
 
+def _device_comm(ctx: Context):
+    """libsqgr's RCCL communicator of the process group, if it lives on ``ctx`` (else the host side channel is used)."""
+    if not _dist.is_distributed():
+        return None
+    comm = _dist.device_comm()
+    return comm if comm is not None and comm.ctx is ctx else None
+
+
 def _broadcast_seed(key: int) -> int:
     """All ranks must use rank 0's key when ``seed=None`` drew fresh entropy."""
     if not _dist.is_distributed():
         return key
-    arr = np.array([key if _dist.world()[0] == 0 else 0], dtype=np.uint64)
-    return int(_dist.allreduce_sum_([arr])[0][0])
+    return int(_dist.broadcast_object(int(key), src=0))
 
 
 MAX_DEVICE_SHUFFLE_CLUSTERS = 256  # the batched permutation kernels keep labels as uint8

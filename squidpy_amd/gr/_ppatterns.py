@@ -228,6 +228,11 @@ def spatial_autocorr(
     perm_idx = None
     states = None
     key = resolve_seed(seed)
+    if seed is None:  # fresh entropy: every rank must score its feature blocks against rank 0's permutation set
+        from ._nhood import _broadcast_seed
+
+        key = _broadcast_seed(key)
+        seed = key
     ctx = default_context(device)
     if n_perms is not None and rng == "numpy-host":
         gens = spawn_generators(seed, n_perms)

@@ -1,4 +1,6 @@
-"""Worker of tests/test_dist_gloo.py: runs under ``python -m torch.distributed.run`` with the gloo backend (CPU).
+"""Worker of tests/test_dist_gloo.py: runs under ``python -m torch.distributed.run`` with the gloo backend (CPU), or —
+``SQGR_TEST_GROUP=socket`` — as plain subprocesses with RANK / WORLD_SIZE / MASTER_PORT in the environment and NO torch:
+the product's own socket rendezvous (squidpy_amd._dist.SocketGroup).
 
 Exercises the multi-GPU plumbing of the product (squidpy_amd._dist: permutation-range sharding, exact integer
 all-reduce, feature-block merge) with per-rank partial results computed by the CPU oracle standing in for the HIP
@@ -17,11 +19,17 @@ sys.path.insert(0, ROOT)
 
 
 def main() -> None:
-    import torch.distributed as dist
-
-    dist.init_process_group(backend="gloo")
-    from oracle import restate as O
+    socket_mode = os.environ.get("SQGR_TEST_GROUP") == "socket"
     from squidpy_amd import _dist
+
+    if socket_mode:
+        os.environ["SQGR_DIST_COLLECTIVE"] = "host"  # no GPU here: the integer all-reduce goes through the hub
+        _dist.init("socket")
+    else:
+        import torch.distributed as dist
+
+        dist.init_process_group(backend="gloo")
+    from oracle import restate as O
     from squidpy_amd.gr._nhood import _broadcast_seed, expected_counts, zscore_from_moments
     from squidpy_amd.gr._ppatterns import _merge_blocks
 
@@ -87,10 +95,18 @@ def main() -> None:
     sims = _merge_blocks(sims, blocks, world, axis=1)
     assert np.array_equal(score, np.arange(G)) and np.array_equal(sims[2], np.arange(G) + 200)
 
-    dist.barrier()
+    out["collective"] = _dist.collective_kind()
+    assert out["collective"] == ("socket-hub" if socket_mode else "torch.distributed")
+    assert _dist.broadcast_object({"r": rank}, src=world - 1) == {"r": world - 1}
+    _dist.barrier()
+    if socket_mode:
+        assert "torch" not in sys.modules, "the socket side channel must not import torch"
     if rank == 0:
         print("DIST_OK " + json.dumps(out))
-    dist.destroy_process_group()
+    if socket_mode:
+        _dist.shutdown()
+    else:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

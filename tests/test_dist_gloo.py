@@ -27,3 +27,19 @@ def test_two_rank_gloo():
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     assert "DIST_OK" in res.stdout
+
+
+def test_two_and_three_rank_socket_rendezvous_without_torch():
+    """The product's own side channel: plain processes, launcher-style environment, no torch anywhere."""
+    for world in (2, 3):
+        port = _free_port()
+        procs = []
+        for rank in range(world):
+            env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1", SQGR_TEST_GROUP="socket", RANK=str(rank), LOCAL_RANK=str(rank),
+                       WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py")], env=env,
+                                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        outs = [p.communicate(timeout=600) for p in procs]
+        for p, (o, e) in zip(procs, outs):
+            assert p.returncode == 0, o[-2000:] + e[-3000:]
+        assert "DIST_OK" in outs[0][0]
