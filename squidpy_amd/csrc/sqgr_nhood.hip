@@ -184,8 +184,12 @@ __global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __re
                         a = (a + feistel_F1(b, k1, dom.ash)) & (dom.A - 1u);
                         x = a * dom.B + b;
                     }
-                    uint32_t l = 0;
-                    while (x >= tab[l]) ++l;  // sentinel UINT_MAX stops it
+                    const uint32_t e = *reinterpret_cast<const uint32_t*>(blk + a * 4u);  // the table again: nearly always enough
+                    uint32_t l = (e & 0xFFu) + (b >= (e >> 16) ? 1u : 0u);
+                    if (l >= (uint32_t)K || (e & 0x100u)) {  // a block the two-field form cannot describe: rank against the boundaries
+                        l = 0;
+                        while (x >= tab[l]) ++l;  // sentinel UINT_MAX stops it
+                    }
                     word = (word & ~(0xFFu << (8 * j))) | (l << (8 * j));
                 }
             }
@@ -928,7 +932,7 @@ static int nhood_build(sqgr_ctx* ctx, const sqgr_graph* g, int64_t n, const int3
         for (int l = 0; l < p->n_libs; ++l) {
             const uint32_t* c = &cum[(size_t)l * p->kpad];
             const uint64_t n_l = (uint64_t)cnt[l];
-            const uint32_t SENT = (uint32_t)K | (0xFFFFu << 16);
+            const uint32_t SENT = ((uint32_t)K & 0xFFu) | 0x100u | (0xFFFFu << 16);  // byte 0 = K (mod 256), bit 8 marks it for the exact route
             uint32_t lab = 0;
             for (uint32_t a = 0; a < doms[l].dom.A; ++a) {
                 const uint64_t lo = (uint64_t)a * doms[l].dom.B, hi = lo + doms[l].dom.B;
