@@ -92,9 +92,13 @@ int sqgr_comm_barrier(sqgr_comm* comm);
 /* ------------------------------------------------------------------ spatial graph (CSR)
  * Device-resident copy of `adata.obsp[<key>_connectivities]` (scipy CSR): what
  * gr/_nhood.py:194,205 and gr/_ppatterns.py:212 read.  `data` may be NULL (binarised use).
- * indptr: int64[n+1]; indices: int32[nnz]; data: float32[nnz]. */
+ * indptr: int64[n+1]; indices: int32[nnz]; data: float32[nnz] (sqgr_graph_create) or float64[nnz] (…_f64). */
 int sqgr_graph_create(sqgr_ctx* ctx, int64_t n, int64_t nnz, const int64_t* indptr, const int32_t* indices,
                       const float* data, sqgr_graph** out_graph);
+/* The same with float64 weights (a float64 `obsp` matrix, or one row-normalised in float64 as gr/_ppatterns.py:212-214
+ * does): the device keeps and uses float64 weights in either case — float32 input is widened exactly. */
+int sqgr_graph_create_f64(sqgr_ctx* ctx, int64_t n, int64_t nnz, const int64_t* indptr, const int32_t* indices,
+                          const double* data, sqgr_graph** out_graph);
 int sqgr_graph_destroy(sqgr_graph* g);
 
 /* ------------------------------------------------------------------ nhood_enrichment

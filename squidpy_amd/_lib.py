@@ -46,6 +46,7 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "sqgr_nhood_set_comm": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sqgr_nhood_info": (C.c_int, [C.c_void_p, c_i64p]),
     "sqgr_graph_create": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, c_i64p, c_i32p, c_f32p, C.POINTER(C.c_void_p)]),
+    "sqgr_graph_create_f64": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, c_i64p, c_i32p, c_f64p, C.POINTER(C.c_void_p)]),
     "sqgr_graph_destroy": (C.c_int, [C.c_void_p]),
     "sqgr_nhood_counts": (C.c_int, [C.c_void_p, C.c_void_p, c_i32p, C.c_int32, c_u32p]),
     "sqgr_nhood_counts_batch": (C.c_int, [C.c_void_p, C.c_void_p, c_u8p, C.c_int64, C.c_int32, c_u32p]),
@@ -279,14 +280,14 @@ class Graph:
         self.nnz = int(adj.nnz)
         indptr = _as(adj.indptr, np.int64)
         indices = _as(adj.indices, np.int32)
-        data = _as(adj.data, np.float32) if with_data else None
         h = C.c_void_p()
-        _check(
-            ctx.lib,
-            ctx.lib.sqgr_graph_create(
-                ctx.h, self.n, self.nnz, _ptr(indptr, c_i64p), _ptr(indices, c_i32p), _ptr(data, c_f32p), C.byref(h)
-            ),
-        )
+        if with_data and adj.dtype != np.float32:  # float64 (and integer / bool) weights go over as float64: exact
+            data = _as(adj.data, np.float64)
+            rc = ctx.lib.sqgr_graph_create_f64(ctx.h, self.n, self.nnz, _ptr(indptr, c_i64p), _ptr(indices, c_i32p), _ptr(data, c_f64p), C.byref(h))
+        else:
+            data = _as(adj.data, np.float32) if with_data else None
+            rc = ctx.lib.sqgr_graph_create(ctx.h, self.n, self.nnz, _ptr(indptr, c_i64p), _ptr(indices, c_i32p), _ptr(data, c_f32p), C.byref(h))
+        _check(ctx.lib, rc)
         self.h = h
 
     def close(self) -> None:

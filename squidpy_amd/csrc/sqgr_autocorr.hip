@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void k_center_transpose(const double* __restri
 
 // ---- Yt = G Zt, Qt = G Zt^2 (row i, 64 genes per wave; CSR metadata is wave-uniform => scalar loads)
 __global__ __launch_bounds__(256) void k_spmv_tiles(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
-                                                    const float* __restrict__ data, int64_t n, const double* __restrict__ Zt,
+                                                    const double* __restrict__ data, int64_t n, const double* __restrict__ Zt,
                                                     double* __restrict__ Yt, double* __restrict__ Qt) {
     const int gl = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void k_spmv_tiles(const int64_t* __restrict__ 
     const double* Z = Zt + (size_t)blockIdx.y * n * GT;
     double y = 0.0, q = 0.0;
     for (int64_t e = indptr[i]; e < indptr[i + 1]; ++e) {
-        const double w = (double)data[e];
+        const double w = data[e];
         const double zc = Z[(size_t)indices[e] * GT + gl];
         y += w * zc;
         q += w * (zc * zc);
@@ -115,11 +115,11 @@ __global__ __launch_bounds__(256) void k_spmv_tiles(const int64_t* __restrict__ 
     Qt[o] = q;
 }
 
-__global__ void k_rowsum(const int64_t* __restrict__ indptr, const float* __restrict__ data, int64_t n, double* __restrict__ rs) {
+__global__ void k_rowsum(const int64_t* __restrict__ indptr, const double* __restrict__ data, int64_t n, double* __restrict__ rs) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     double s = 0.0;
-    for (int64_t e = indptr[i]; e < indptr[i + 1]; ++e) s += (double)data[e];
+    for (int64_t e = indptr[i]; e < indptr[i + 1]; ++e) s += data[e];
     rs[i] = s;
 }
 
@@ -128,7 +128,7 @@ __global__ void k_rowsum(const int64_t* __restrict__ indptr, const float* __rest
 template <int MODE>
 __global__ __launch_bounds__(256) void k_colsum(const double* __restrict__ A, const double* __restrict__ Bm, int64_t n, int R,
                                                 const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
-                                                const float* __restrict__ data, double* __restrict__ partial) {
+                                                const double* __restrict__ data, double* __restrict__ partial) {
     __shared__ double red[4][GT];
     const int gl = threadIdx.x & 63, sub = threadIdx.x >> 6;
     const int chunk = blockIdx.x, tile = blockIdx.y;
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_colsum(const double* __restrict__ A, co
             double t = 0.0;
             for (int64_t e = indptr[i]; e < indptr[i + 1]; ++e) {
                 const double d = av - a[(size_t)indices[e] * GT + gl];
-                t += (double)data[e] * (d * d);
+                t += data[e] * (d * d);
             }
             s += t;
         }
@@ -381,7 +381,7 @@ static int autocorr_create(sqgr_ctx* ctx, const sqgr_graph* g, const double* val
         return fail(SQGR_ERR_HIP);
     }
     if ((rc = column_sum(h, 1, h->Zt.p, nullptr, h->z2ss.p)) || (rc = column_sum(h, 2, h->Qt.p, nullptr, h->qsum.p))) return fail(rc);
-    // W = sum of all weights (float64 accumulation of the float32 data, CSR order)
+    // W = sum of all weights (float64 accumulation, CSR order)
     std::vector<double> rs((size_t)n);
     e = hipMemcpyAsync(rs.data(), h->rowsum.p, (size_t)n * 8, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);

@@ -138,7 +138,7 @@ struct sqgr_graph {
     sqgr::DevBuf<int32_t> erow;     // [nnz] row of every stored edge (COO expansion, built on device)
     sqgr::DevBuf<int2> coo;         // [nnz + LIST_PAD] (16*row, 16*col): byte offsets of the endpoints' 16-byte label rows,
                                     // what the nhood count kernel gathers with; zero padding behind the list
-    sqgr::DevBuf<float> data;       // [nnz] or empty
+    sqgr::DevBuf<double> data;      // [nnz] edge weights in float64 (float32 input is widened exactly) or empty
     bool has_data = false;
     // Structurally symmetric graphs (every stored (r, c) has a stored (c, r); canonical CSR: rows sorted, no duplicates):
     // the neighbourhood counts of a labelling satisfy count = h + h^T with h taken over the edges r < c only, so the

@@ -397,9 +397,14 @@ int sqgr_timer_report(sqgr_ctx* ctx, char* buf, int len) {
     return SQGR_OK;
 }
 
-int sqgr_graph_create(sqgr_ctx* ctx, int64_t n, int64_t nnz, const int64_t* indptr, const int32_t* indices,
-                      const float* data, sqgr_graph** out_graph) {
+static int graph_create_impl(sqgr_ctx* ctx, int64_t n, int64_t nnz, const int64_t* indptr, const int32_t* indices,
+                             const float* data32, const double* data, sqgr_graph** out_graph) {
     SQGR_REQUIRE(ctx && out_graph, "ctx/out_graph is NULL");
+    std::vector<double> widened;
+    if (data32) {  // float32 weights are widened exactly; every kernel computes with float64 weights like the reference
+        widened.assign(data32, data32 + nnz);
+        data = widened.data();
+    }
     *out_graph = nullptr;
     SQGR_REQUIRE(n > 0 && n < (int64_t)0x7fffffff, "n=%lld out of range", (long long)n);
     SQGR_REQUIRE(nnz >= 0, "nnz=%lld negative", (long long)nnz);
@@ -428,7 +433,7 @@ int sqgr_graph_create(sqgr_ctx* ctx, int64_t n, int64_t nnz, const int64_t* indp
         if (e == hipSuccess && nnz)
             e = hipMemcpyAsync(g->indices.p, indices, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess && data && nnz)
-            e = hipMemcpyAsync(g->data.p, data, (size_t)nnz * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+            e = hipMemcpyAsync(g->data.p, data, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess && nnz) {
             LaunchTimer t(ctx, "graph_expand_rows");
             k_expand_rows<<<(unsigned)ceil_div(nnz, 256), 256, 0, ctx->stream>>>(g->indptr.p, g->indices.p, n, nnz, g->erow.p, g->coo.p);
@@ -447,6 +452,16 @@ int sqgr_graph_create(sqgr_ctx* ctx, int64_t n, int64_t nnz, const int64_t* indp
     g->has_data = data != nullptr;
     *out_graph = g;
     return SQGR_OK;
+}
+
+int sqgr_graph_create(sqgr_ctx* ctx, int64_t n, int64_t nnz, const int64_t* indptr, const int32_t* indices,
+                      const float* data, sqgr_graph** out_graph) {
+    return graph_create_impl(ctx, n, nnz, indptr, indices, data, nullptr, out_graph);
+}
+
+int sqgr_graph_create_f64(sqgr_ctx* ctx, int64_t n, int64_t nnz, const int64_t* indptr, const int32_t* indices,
+                          const double* data, sqgr_graph** out_graph) {
+    return graph_create_impl(ctx, n, nnz, indptr, indices, nullptr, data, out_graph);
 }
 
 int sqgr_graph_destroy(sqgr_graph* g) {

@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void k_finalize(const int64_t* __restrict__ ac
 // observed counts / interaction matrix: one pass, thread per edge
 template <bool WEIGHTED>
 __global__ __launch_bounds__(256) void k_edge_pairs(int64_t nnz, const int32_t* __restrict__ erow,
-                                                    const int32_t* __restrict__ indices, const float* __restrict__ data,
+                                                    const int32_t* __restrict__ indices, const double* __restrict__ data,
                                                     const int32_t* __restrict__ labels, int K,
                                                     unsigned long long* __restrict__ out_u64, double* __restrict__ out_f64) {
     int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -514,9 +514,47 @@ __global__ __launch_bounds__(256) void k_edge_pairs(int64_t nnz, const int32_t* 
     int la = labels[erow[e]], lb = labels[indices[e]];
     if (la < 0 || lb < 0) return;  // masked (NaN category) spots: interaction_matrix semantics
     if (WEIGHTED)
-        atomicAdd(&out_f64[la * K + lb], (double)data[e]);
+        atomicAdd(&out_f64[la * K + lb], data[e]);  // only where K*K doubles do not fit LDS (K > 143): order-dependent rounding
     else
         atomicAdd(&out_u64[la * K + lb], 1ull);
+}
+
+// Weighted edge sums (gr/_nhood.py:412-429 sums float64 weights serially), run-to-run reproducible: every WAVE owns a
+// contiguous run of edges and a private K*K float64 accumulator in LDS.  A wave's LDS operations complete in program order
+// and the lanes of one ds_add_f64 that meet in a cell are applied in a fixed hardware order, so a wave's partial sums are a
+// pure function of its inputs (no cross-wave atomics anywhere); k_sum_partials adds the partials in wave order.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_edge_weight_partials(int64_t nnz, const int32_t* __restrict__ erow,
+                                                                      const int32_t* __restrict__ indices, const double* __restrict__ data,
+                                                                      const int32_t* __restrict__ labels, int K, int64_t edges_per_wave,
+                                                                      double* __restrict__ partials) {
+    extern __shared__ double s_acc[];  // [WAVES][K*K]
+    const int K2 = K * K, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* acc = s_acc + (size_t)wave * K2;
+    for (int c = lane; c < K2; c += 64) acc[c] = 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const int64_t w = (int64_t)blockIdx.x * WAVES + wave;
+    const int64_t e0 = w * edges_per_wave, e1 = e0 + edges_per_wave < nnz ? e0 + edges_per_wave : nnz;
+    for (int64_t base = e0; base < e1; base += 64) {
+        const int64_t e = base + lane;
+        if (e < e1) {
+            const int la = labels[erow[e]], lb = labels[indices[e]];
+            if (la >= 0 && lb >= 0)
+                __hip_atomic_fetch_add(&acc[la * K + lb], data[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    double* dst = partials + (size_t)w * K2;
+    for (int c = lane; c < K2; c += 64) dst[c] = acc[c];
+}
+
+__global__ __launch_bounds__(64) void k_sum_partials(const double* __restrict__ partials, int64_t nparts, int K2, double* __restrict__ out) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= K2) return;
+    double s = 0.0;
+    for (int64_t p = 0; p < nparts; ++p) s += partials[(size_t)p * K2 + c];  // fixed order
+    out[c] = s;
 }
 
 // columns of W -> slab rows of the batched count kernel: slab[(batch*n + i)*B + b] = W[pos(i)][p0 + batch*B + b]
@@ -816,8 +854,29 @@ static int edge_pairs(sqgr_ctx* ctx, const sqgr_graph* g, const int32_t* labels,
     if (g->nnz > 0) {
         LaunchTimer t(ctx, "nhood_edge_pairs");
         unsigned grid = (unsigned)ceil_div(g->nnz, 256);
-        if (weighted)
-            k_edge_pairs<true><<<grid, 256, 0, ctx->stream>>>(g->nnz, g->erow.p, g->indices.p, g->data.p, dl.p, K, nullptr, dd.p);
+        if (weighted) {
+            const size_t cell_bytes = K2 * 8;
+            const int waves = cell_bytes * 4 <= 64 * 1024 ? 4 : (cell_bytes <= LDS_BUDGET ? 1 : 0);
+            if (waves == 0) {  // K > 143: the accumulator of one wave does not fit LDS
+                k_edge_pairs<true><<<grid, 256, 0, ctx->stream>>>(g->nnz, g->erow.p, g->indices.p, g->data.p, dl.p, K, nullptr, dd.p);
+            } else {
+                const int64_t epw = std::max<int64_t>(64, ceil_div(ceil_div(g->nnz, 4096), 64) * 64);
+                const int64_t nwaves = ceil_div(ceil_div(g->nnz, epw), waves) * waves;
+                DevBuf<double> parts;
+                SQGR_TRY(parts.alloc((size_t)nwaves * K2));
+                if (waves == 4) {
+                    k_edge_weight_partials<4><<<(unsigned)(nwaves / 4), 256, cell_bytes * 4, ctx->stream>>>(g->nnz, g->erow.p, g->indices.p, g->data.p,
+                                                                                                           dl.p, K, epw, parts.p);
+                } else {
+                    SQGR_TRY(allow_lds(k_edge_weight_partials<1>, cell_bytes));
+                    k_edge_weight_partials<1><<<(unsigned)nwaves, 64, cell_bytes, ctx->stream>>>(g->nnz, g->erow.p, g->indices.p, g->data.p, dl.p, K,
+                                                                                                epw, parts.p);
+                }
+                k_sum_partials<<<(unsigned)ceil_div((int64_t)K2, 64), 64, 0, ctx->stream>>>(parts.p, nwaves, (int)K2, dd.p);
+                SQGR_HIP(hipGetLastError());
+                SQGR_HIP(hipStreamSynchronize(ctx->stream));  // `parts` is released on return
+            }
+        }
         else
             k_edge_pairs<false><<<grid, 256, 0, ctx->stream>>>(g->nnz, g->erow.p, g->indices.p, nullptr, dl.p, K, du.p, nullptr);
         SQGR_HIP(hipGetLastError());

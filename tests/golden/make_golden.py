@@ -42,8 +42,35 @@ def export_h5ad() -> None:
         leiden_categories=np.array([c.decode() if isinstance(c, bytes) else c for c in f["obs/leiden/categories"][:]]),
         X40=X[:, :40],
         highly_variable40=hv[:40],
+        var_names40=np.array([v.decode() if isinstance(v, bytes) else v for v in f["var/_index"][:40]]),
     )
     print("wrote visium49.npz")
+    export_ligrec_reference()
+
+
+def export_ligrec_reference() -> None:
+    """tests/_data/ligrec_pvalues_reference.h5ad — the ONE pinned numeric result the reference's tests hold next to the hot
+    path (fixture tests/conftest.py:316-327, used by tests/graph/test_ligrec.py:346-360: ``ligrec(adata, "leiden",
+    interactions=product(raw.var_names[:5], raw.var_names[:5]), n_perms=25, seed=42)`` on tests/_data/test_data.h5ad):
+    X = p-values, layers/means = means, rows = (source, target) gene pairs, columns = (cluster_1, cluster_2)."""
+    import h5py
+
+    f = h5py.File("/root/reference/tests/_data/ligrec_pvalues_reference.h5ad", "r")
+
+    def cat(group: str) -> np.ndarray:
+        cats = np.array([c.decode() if isinstance(c, bytes) else c for c in f[f"{group}/categories"][:]])
+        return cats[f[f"{group}/codes"][:]]
+
+    np.savez_compressed(
+        os.path.join(HERE, "ligrec_pvalues_reference.npz"),
+        pvalues=f["X"][:],
+        means=f["layers/means"][:],
+        source=cat("obs/source"),
+        target=cat("obs/target"),
+        cluster_1=cat("var/cluster_1"),
+        cluster_2=cat("var/cluster_2"),
+    )
+    print("wrote ligrec_pvalues_reference.npz")
 
 
 def main() -> None:

@@ -206,3 +206,22 @@ def test_use_raw_and_missing_raw(L):
     df = sq.gr.spatial_autocorr(adata, genes=["gene1", "gene2"], copy=True)
     assert sorted(df_raw.index) == ["gene1", "gene2"]  # intersected with raw.var_names
     np.testing.assert_allclose(df_raw.loc[df.index, "I"], df["I"], rtol=1e-9)
+
+
+def test_moran_geary_exact_rational_known_answers_on_the_device(L, ctx):
+    """The HIP kernels against the exact-rational known answers of tests/golden/autocorr_kat.json (the reference's 5-node
+    fixture graph, raw and row-normalised, and its 49-spot Visium fixture; constant features -> NaN).  Weights travel as
+    float64, so agreement is to rounding (1e-12), far inside the 1e-6 bar."""
+    from tests.test_oracle_pinned import _autocorr_kat
+
+    for name, g, X, want in _autocorr_kat():
+        graph = L.Graph(ctx, g)
+        plan = L.AutocorrPlan(ctx, graph, X)
+        np.testing.assert_allclose(plan.scores("moran"), want["I"], rtol=1e-12, atol=1e-15, equal_nan=True, err_msg=name)
+        np.testing.assert_allclose(plan.scores("geary"), want["C"], rtol=1e-12, atol=1e-15, equal_nan=True, err_msg=name)
+        # the permutation scores under the identity permutation are the observed scores
+        idx = np.arange(g.shape[0], dtype=np.int32)[None, :]
+        np.testing.assert_allclose(plan.perms("moran", perm_idx=idx)[0], want["I"], rtol=1e-12, atol=1e-15, equal_nan=True)
+        np.testing.assert_allclose(plan.perms("geary", perm_idx=idx)[0], want["C"], rtol=1e-12, atol=1e-15, equal_nan=True)
+        plan.close()
+        graph.close()

@@ -201,3 +201,37 @@ def test_front_end_slots_fdr_and_clusters_subset():
         q = r["pvalues"].to_numpy(dtype=np.float64)
         assert np.nanmin(q) >= 0 and np.nanmax(q) <= 1
     assert "foo" not in adata.uns
+
+
+def test_pvalues_reference_held_by_the_reference_repo():
+    """The reference's own pinned result (tests/graph/test_ligrec.py:346-360 `test_pvalues_reference` against
+    tests/_data/ligrec_pvalues_reference.h5ad): ligrec(adata, "leiden", interactions=product(raw.var_names[:5] x 2), n_perms=25,
+    seed=42) on the tests/_data/test_data.h5ad fixture (raw = the AnnData itself, tests/conftest.py:40-41).  Both files are
+    exported to tests/golden/*.npz by `make_golden.py --export-h5ad`; with rng="numpy" the device must reproduce Squidpy's
+    p-values for that seed: assert_allclose like the reference test, and the same NaN pattern."""
+    import os
+    from itertools import product
+
+    import pandas as pd
+
+    import squidpy_amd as sq
+
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    v = np.load(os.path.join(gold, "visium49.npz"))
+    ref = np.load(os.path.join(gold, "ligrec_pvalues_reference.npz"))
+    names = [str(s) for s in v["var_names40"]]
+    obs = pd.DataFrame({"leiden": pd.Categorical.from_codes(v["leiden_codes"].astype(int), [str(c) for c in v["leiden_categories"]])},
+                       index=[f"s{i}" for i in range(len(v["leiden_codes"]))])
+    X = v["X40"].astype(np.float32)
+    raw = sq.AnnDataLite(X=X, obs=obs.copy(), var=pd.DataFrame(index=names))
+    adata = sq.AnnDataLite(X=X, obs=obs, var=pd.DataFrame(index=names), raw=raw)
+    interactions = tuple(product(names[:5], names[:5]))
+    r = sq.gr.ligrec(adata, "leiden", interactions=interactions, n_perms=25, copy=True, show_progress_bar=False, seed=42, n_jobs=1, rng="numpy")
+    index = pd.MultiIndex.from_arrays([ref["source"], ref["target"]], names=["source", "target"])
+    columns = pd.MultiIndex.from_arrays([ref["cluster_1"], ref["cluster_2"]], names=["cluster_1", "cluster_2"])
+    for key in ("means", "pvalues"):
+        np.testing.assert_array_equal(np.array(r[key].index.tolist()), np.array(index.tolist()))
+        np.testing.assert_array_equal(np.array(r[key].columns.tolist()), np.array(columns.tolist()))
+    np.testing.assert_allclose(r["means"].to_numpy(dtype=np.float64), ref["means"])
+    np.testing.assert_allclose(r["pvalues"].to_numpy(dtype=np.float64), ref["pvalues"])
+    np.testing.assert_array_equal(np.where(np.isnan(r["pvalues"].to_numpy(dtype=np.float64))), np.where(np.isnan(ref["pvalues"])))

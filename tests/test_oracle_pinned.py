@@ -4,6 +4,8 @@ reference's tests hold for this path.  CPU only."""
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -200,3 +202,26 @@ def test_c_port_matches_golden(golden):
     g = _csr(golden, "autocorr_g")
     np.testing.assert_allclose(cport.morans_i(g, golden["autocorr_vals"]), golden["unpinned_moran_score"], rtol=1e-12)
     np.testing.assert_allclose(cport.gearys_c(g, golden["autocorr_vals"]), golden["unpinned_geary_score"], rtol=1e-12)
+
+
+def _autocorr_kat():
+    import json
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "autocorr_kat.json")) as fh:
+        cases = json.load(fh)
+    for rec in cases:
+        n = rec["n"]
+        g = sp.csr_matrix((np.array([float.fromhex(h) for h in rec["data_hex"]]), np.array(rec["indices"], dtype=np.int32),
+                           np.array(rec["indptr"], dtype=np.int32)), shape=(n, n))
+        X = np.array([[float.fromhex(h) for h in row] for row in rec["X_hex"]])
+        want = {k: np.array([np.nan if h is None else float.fromhex(h) for h in rec[k]]) for k in ("I", "C")}
+        yield rec["name"], g, X, want
+
+
+def test_moran_geary_exact_rational_known_answers():
+    """The statistic's arithmetic is third-party (scanpy.metrics, absent): pinned instead to the documented definitions
+    evaluated in exact rational arithmetic (tests/golden/make_autocorr_kat.py) on the reference's own 5-node fixture graph
+    (tests/conftest.py:177-194) and on its 49-spot Visium fixture.  The restatement must agree to a few ulps."""
+    for name, g, X, want in _autocorr_kat():
+        np.testing.assert_allclose(O.morans_i(g, X), want["I"], rtol=1e-13, equal_nan=True, err_msg=name)
+        np.testing.assert_allclose(O.gearys_c(g, X), want["C"], rtol=1e-13, equal_nan=True, err_msg=name)
