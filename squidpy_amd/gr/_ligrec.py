@@ -359,8 +359,6 @@ class PermutationTest:
         """gr/_ligrec.py:677-775 with the permutation loop on the device."""
         from ._nhood import _broadcast_seed
 
-        if n_cls < 2:
-            raise ValueError(f"Expected at least `2` clusters, found `{n_cls}`.")
         mean_obs, mask, inv_counts = self._observed(x, codes, n_cls, threshold)
         rec, lig = inter[:, 0], inter[:, 1]
         c1, c2 = cpairs[:, 0], cpairs[:, 1]
@@ -371,6 +369,22 @@ class PermutationTest:
         means = np.where(nonzero, (m_rec + m_lig) / 2.0, 0.0)
         obs = m_rec + m_lig
 
+        if n_cls == 1:
+            # A cluster subset that resolves to ONE cluster (e.g. clusters=[("A", "A")]): the reference has no check here and
+            # computes it (gr/_ligrec.py:677-775).  Shuffling a constant label vector changes nothing, so every permutation
+            # yields the same group mean — the kernel's sequential sum over the cells times 1/size (gr/_ligrec.py:647-655),
+            # which need not equal pandas' `groupby().mean()` of the observed side bit for bit: `shuffled > observed` is
+            # then true in all permutations or in none.  Formed here exactly like that, on the host (no shuffles needed).
+            sums = np.zeros(x.shape[1], dtype=np.float64)
+            for g in range(x.shape[1]):
+                col = x.data[x.indptr[g] : x.indptr[g + 1]]
+                if len(col):
+                    sums[g] = np.cumsum(col.astype(np.float64))[-1]  # strictly sequential float64 accumulation, cell order
+            grp = sums * inv_counts[0]
+            exceeds = (grp[rec] + grp[lig])[:, None] > obs
+            pvalues = np.where(exceeds, 1.0, 0.0)
+            pvalues[~valid] = np.nan
+            return means, pvalues
         ctx = default_context(device)
         rank, world = _dist.world()
         lo, hi = _dist.shard_range(n_perms, rank, world)

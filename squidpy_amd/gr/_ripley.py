@@ -12,6 +12,7 @@ import numpy as np
 import pandas as pd
 
 from .._constants import Key, RipleyStat
+from .. import _dist
 from .._lib import METRICS, Context, DevicePoints, default_context, knn_dist, pair_counts
 from .._utils import _assert_categorical_obs, _assert_spatial_basis, _save_data, extract_adata_if_sdata, spawn_generators
 
@@ -112,6 +113,19 @@ class _Engine:
         return np.concatenate((np.zeros((1,), dtype=float), fracs))
 
 
+def _assign_by_cost(cost: np.ndarray, world: int) -> np.ndarray:
+    """Longest-processing-time greedy: item -> rank, deterministic (ties by index), balanced on ``cost``."""
+    owner = np.zeros(len(cost), dtype=np.int64)
+    if world <= 1:
+        return owner
+    load = np.zeros(world)
+    for i in sorted(range(len(cost)), key=lambda j: (-cost[j], j)):
+        r = int(np.argmin(load))
+        owner[i] = r
+        load[r] += cost[i]
+    return owner
+
+
 def _tail_pvalues(obs: np.ndarray, sims: np.ndarray) -> np.ndarray:
     """gr/_ripley.py:175-180: ``(1 + #{sim >= obs}) / (n_sim + 1)`` folded to the smaller tail."""
     exceed = (sims[:, None, :] >= obs[None, :, :]).sum(axis=0)
@@ -167,23 +181,35 @@ def ripley(
     engine = _Engine(default_context(device), stat, metric, support, xy.shape[0], area)
     first_rng, *other_rngs = spawn_generators(seed, n_simulations + 1)
 
+    # Multi-GPU: clusters are independent point sets -> spread over the ranks by cost (longest-processing-time
+    # greedy on m_c^2 pair tests for L, m_c reference points for F/G); simulations round-robin.  Every rank draws the host-side
+    # random streams it needs in the reference's order, so the result does not depend on the number of ranks.
+    rank, world = _dist.world()
+    sizes = np.bincount(codes, minlength=n_groups).astype(np.float64)
+    owner = _assign_by_cost(sizes * sizes if stat == RipleyStat.L else sizes, world)
+
     # observed statistic per cluster (F: each cluster is probed with its own Poisson pattern drawn from `first_rng`)
-    observed = np.empty((n_groups, n_steps))
+    observed = np.full((n_groups, n_steps), np.nan)
     probe = None
     everyone = DevicePoints(engine.ctx, xy64, codes) if stat == RipleyStat.G else None  # G queries (nearly) all points
     for gidx in range(int(codes.max()) + 1):
+        if stat == RipleyStat.F:  # the stream of `first_rng` runs through all clusters: drawn on every rank
+            probe = _ppp(hull, n_simulations=1, n_observations=n_observations, rng=first_rng)
+        if owner[gidx] != rank:
+            continue
         members = xy64[codes == gidx]
         if stat == RipleyStat.L:
             observed[gidx] = engine.l_stat(members)
         elif stat == RipleyStat.G:
             observed[gidx] = engine.nn_stat_resident(everyone, members, n_neigh, exclude_label=gidx)
         else:
-            probe = _ppp(hull, n_simulations=1, n_observations=n_observations, rng=first_rng)
             observed[gidx] = engine.nn_stat(probe, members, n_neigh)
 
     # null distribution: complete spatial randomness inside the hull, one pattern per generator
-    simulated = np.empty((n_simulations, n_steps))
+    simulated = np.full((n_simulations, n_steps), np.nan)
     for s_idx, rng in enumerate(other_rngs):
+        if s_idx % world != rank:
+            continue
         pattern = _ppp(hull, n_simulations=1, n_observations=n_observations, rng=rng)
         if stat == RipleyStat.L:
             simulated[s_idx] = engine.l_stat(pattern)
@@ -191,6 +217,12 @@ def ripley(
             simulated[s_idx] = engine.nn_stat_resident(everyone, pattern, 1)
         else:  # the reference reuses the probe pattern of the LAST cluster here (gr/_ripley.py:163-165)
             simulated[s_idx] = engine.nn_stat(probe, pattern, 1)
+    if world > 1:  # rows are owned by exactly one rank: gather and take each from its owner (int64[n_steps]-sized rows)
+        parts = _dist.allgather_object((observed, simulated))
+        for gidx in range(n_groups):
+            observed[gidx] = parts[owner[gidx]][0][gidx]
+        for s_idx in range(n_simulations):
+            simulated[s_idx] = parts[s_idx % world][1][s_idx]
 
     if everyone is not None:
         everyone.close()

@@ -47,10 +47,13 @@ def main():
     _, pv = O.ligrec_analysis(np.asarray(adata.X)[:, :6], lab, np.array([(gi[a], gi[b]) for a, b in inter]),
                               np.array([(a, b) for a in range(5) for b in range(5)]), threshold=0.1, n_perms=33, seed=6)
     assert np.array_equal(lr["pvalues"].to_numpy(dtype=np.float64), pv, equal_nan=True)
-    # ripley: replicas
-    rp = sq.gr.ripley(adata, "cluster", mode="L", n_simulations=3, n_observations=60, n_steps=10, seed=2, copy=True)
-    rref = O.ripley(adata.obsm["spatial"], adata.obs["cluster"].values, mode="L", n_simulations=3, n_observations=60, n_steps=10, seed=2)
-    assert np.array_equal(rp["pvalues"], rref["pvalues"])
+    # ripley: clusters spread over the ranks by cost, simulations round-robin, rows gathered from their owners
+    for mode in ("L", "F", "G"):
+        rp = sq.gr.ripley(adata, "cluster", mode=mode, n_simulations=5, n_observations=60, n_steps=10, seed=2, copy=True)
+        rref = O.ripley(adata.obsm["spatial"], adata.obs["cluster"].values, mode=mode, n_simulations=5, n_observations=60, n_steps=10, seed=2)
+        np.testing.assert_allclose(rp[f"{mode}_stat"]["stats"].to_numpy().reshape(5, 10), rref["obs"], rtol=1e-12)
+        np.testing.assert_allclose(rp["sims_stat"]["stats"].to_numpy().reshape(5, 10), rref["sims"], rtol=1e-12)
+        assert np.array_equal(rp["pvalues"], rref["pvalues"]), mode
     dist.barrier()
     print(f"DIST2_OK rank {rank}", flush=True)
     dist.destroy_process_group()

@@ -115,3 +115,15 @@ def test_anndata_lite_subsetting():
     assert adata[:, ["g1"]].X.shape == (20, 1)
     with pytest.raises(KeyError):
         adata[:, ["zzz"]]
+
+
+def test_ripley_cluster_assignment_is_balanced_and_deterministic():
+    from squidpy_amd.gr._ripley import _assign_by_cost
+
+    cost = np.array([9.0, 1.0, 4.0, 4.0, 16.0, 1.0, 25.0, 0.0]) ** 2
+    assert (_assign_by_cost(cost, 1) == 0).all()
+    for world in (2, 3, 8):
+        own = _assign_by_cost(cost, world)
+        assert np.array_equal(own, _assign_by_cost(cost, world)) and own.min() >= 0 and own.max() < world
+        load = np.bincount(own, weights=cost, minlength=world)
+        assert load.max() <= cost.sum() / world + cost.max()  # LPT bound

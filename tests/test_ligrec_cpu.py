@@ -213,3 +213,26 @@ def test_gene_symbols_are_swapped_in_and_restored(adata):
         ligrec(adata, "leiden", interactions=sym, gene_symbols="nope")
     with pytest.raises(ValueError, match=r"After filtering by genes"):  # without the swap the symbols are unknown genes
         ligrec(adata, "leiden", interactions=sym)
+
+
+def test_single_cluster_subset_is_computed_like_the_reference(adata, pairs):
+    """`clusters=[("0", "0")]` resolves to ONE cluster: the reference's `_analysis` has no check and computes it
+    (gr/_ligrec.py:677-775; only `<= 1` categories in `obs` are rejected, :300).  No device is needed: a constant label vector
+    does not change under shuffling: every permuted mean is the kernel's sequential sum / size, which either exceeds pandas'
+    observed mean by a rounding error in ALL permutations or in none (p = 1 or 0).  Checked against the literal reference source."""
+    res = PermutationTest(adata).prepare(pairs).test("leiden", clusters=[("0", "0")], n_perms=7, seed=1, copy=True, threshold=0.2)
+    assert res["pvalues"].shape == (len(res["means"]), 1)
+    pv = res["pvalues"].to_numpy(dtype=np.float64)
+    assert set(np.unique(pv[~np.isnan(pv)])) <= {0.0, 1.0}
+    if ref_shim.available():
+        genes = [g.upper() for g in dict.fromkeys(g for p in pairs for g in p)]
+        x = adata.raw.X.toarray()[:, :5]
+        keep = (adata.obs["leiden"].astype(str) == "0").to_numpy()
+        df = pd.DataFrame(x[keep], columns=list(range(5)))
+        df["clusters"] = pd.Categorical(np.zeros(int(keep.sum()), dtype=np.int32))
+        gi = {g: i for i, g in enumerate(genes)}
+        inter = np.array([(gi[a], gi[b]) for a, b in res["means"].index], dtype=np.int32)
+        ref = ref_shim.ligrec()["_analysis"](df, inter, np.array([(0, 0)], dtype=np.int32), threshold=0.2, n_perms=7, seed=1, n_jobs=1,
+                                           show_progress_bar=False)
+        np.testing.assert_array_equal(res["means"].to_numpy(dtype=np.float64), np.asarray(ref.means))
+        np.testing.assert_array_equal(pv, np.asarray(ref.pvalues))
