@@ -185,8 +185,8 @@ __global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __re
                         x = a * dom.B + b;
                     }
                     const uint32_t e = *reinterpret_cast<const uint32_t*>(blk + a * 4u);  // the table again: nearly always enough
-                    uint32_t l = (e & 0xFFu) + (b >= (e >> 16) ? 1u : 0u);
-                    if (l >= (uint32_t)K || (e & 0x100u)) {  // a block the two-field form cannot describe: rank against the boundaries
+                    uint32_t l = (e & 0xFFFFu) + (b >= (e >> 16) ? 1u : 0u);
+                    if (l >= (uint32_t)K) {  // a block the two-field form cannot describe: rank against the boundaries
                         l = 0;
                         while (x >= tab[l]) ++l;  // sentinel UINT_MAX stops it
                     }
@@ -199,6 +199,115 @@ __global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __re
     uint4* dst = reinterpret_cast<uint4*>(slab_all + ((size_t)batch * n + i) * B);
 #pragma unroll
     for (int v = 0; v < B / 16; ++v) dst[v] = make_uint4(out[4 * v], out[4 * v + 1], out[4 * v + 2], out[4 * v + 3]);
+    }
+}
+
+// More than 256 clusters: the same two-level generator writing 16-bit labels, slab16[(batch*n + i)*16 + b] (32-byte rows).
+// Plain arithmetic on the unpacked digits; blocks the two-field table form cannot describe are frequent here (many label
+// starts per block), so the exact route ranks x against the boundary table by binary search.
+template <bool HAS_LIBS>
+__global__ __launch_bounds__(256) void k_shuffle16(int64_t n, const uint32_t* __restrict__ cum, int kpad, int blk_words, int K,
+                                                   const uint32_t* __restrict__ keys, LibDom dom0, int n_libs,
+                                                   const int32_t* __restrict__ lib_of, const int32_t* __restrict__ rank_of,
+                                                   const LibDom* __restrict__ libdoms, uint16_t* __restrict__ slab_all) {
+    extern __shared__ uint32_t s_lds[];
+    uint32_t* s_cum = s_lds + blk_words;
+    for (int t = threadIdx.x; t < n_libs * kpad; t += 256) s_cum[t] = cum[t];
+    for (int t = threadIdx.x; t < blk_words; t += 256) s_lds[t] = cum[n_libs * kpad + t];
+    __syncthreads();
+    constexpr int B = 16;
+    const int batch = blockIdx.y;
+    const uint32_t* kg = keys + (size_t)batch * key_words_per_row(B, n_libs);
+    const uint32_t* ks = kg + (size_t)n_libs * 8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        LibDom ld = dom0;
+        uint32_t x0 = (uint32_t)i, lib = 0;
+        if (HAS_LIBS) {
+            lib = (uint32_t)lib_of[i];
+            ld = libdoms[lib];
+            x0 = (uint32_t)rank_of[i];
+        }
+        const FeistelDomain dom = ld.dom;
+        const uint32_t* tab = s_cum + lib * kpad + 1;  // tab[k] = cum[k + 1]
+        const uint32_t* blk = s_lds + ld.aoff;
+        uint32_t ga = x0 / dom.B, gb = x0 - ga * dom.B;
+        const uint32_t* gk = kg + (size_t)lib * 8;
+        do {  // pi_g (low halves of the packed key words)
+            for (int r = 0; r < FEISTEL_ROUNDS; r += 2) {
+                ga = (ga + feistel_F1(gb, gk[r], dom.ash)) & (dom.A - 1u);
+                uint32_t t = gb + feistel_F1(ga, gk[r + 1], dom.bsh);
+                t = t >= dom.B ? t - dom.B : t;
+                gb = t >= dom.B ? t - dom.B : t;
+            }
+        } while (ga * dom.B + gb >= dom.n);
+        uint32_t out[B / 2];
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+            const uint32_t* sk = ks + ((size_t)(j >> 1) * n_libs + lib) * 2;
+            const int sh = (j & 1) * 16;
+            const uint32_t k0 = (sk[0] >> sh) & 0xFFFFu, k1 = (sk[1] >> sh) & 0xFFFFu;
+            uint32_t a = ga, b = gb, x;
+            do {  // sigma_p, cycle-walked
+                uint32_t t = b + feistel_F1(a, k0, dom.bsh);
+                t = t >= dom.B ? t - dom.B : t;
+                b = t >= dom.B ? t - dom.B : t;
+                a = (a + feistel_F1(b, k1, dom.ash)) & (dom.A - 1u);
+                x = a * dom.B + b;
+            } while (x >= dom.n);
+            const uint32_t e = blk[a];
+            uint32_t l = (e & 0xFFFFu) + (b >= (e >> 16) ? 1u : 0u);
+            if (l >= (uint32_t)K) {  // largest l with cum[l] <= x  <=>  first l with x < tab[l]
+                uint32_t lo = 0, hi = (uint32_t)K - 1u;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (x < tab[mid]) hi = mid; else lo = mid + 1;
+                }
+                l = lo;
+            }
+            if (j & 1) out[j >> 1] |= l << 16; else out[j >> 1] = l;
+        }
+        uint4* dst = reinterpret_cast<uint4*>(slab_all + ((size_t)batch * n + i) * B);
+        dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
+        dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
+    }
+}
+
+// numpy streams with 16-bit labels: Generator.shuffle(x) leaves x[perm] behind, perm = the same generator's permutation(n)
+// (both run the same Fisher-Yates on the same draws): slab16[(batch*n + i)*16 + b] = base16[idx[p][i]], p = p0 + batch*16 + b
+__global__ __launch_bounds__(256) void k_gather_labels16(int64_t n, const uint16_t* __restrict__ base16, const int32_t* __restrict__ idx,
+                                                         int64_t p0, int64_t p_valid, uint16_t* __restrict__ slab_all) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int batch = blockIdx.y;
+    uint32_t out[8];
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+        const int64_t p = p0 + (int64_t)batch * 16 + b;
+        const uint32_t l = p < p_valid ? base16[idx[(size_t)p * n + i]] : 0u;
+        if (b & 1) out[b >> 1] |= l << 16; else out[b >> 1] = l;
+    }
+    uint4* dst = reinterpret_cast<uint4*>(slab_all + ((size_t)batch * n + i) * 16);
+    dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
+    dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
+}
+
+// counts for 16-bit labels: K*K counters per permutation do not fit LDS -> device-scope atomics into partial[batch][pair*16 + b]
+__global__ __launch_bounds__(256) void k_count_wide16(int64_t nnz, const int32_t* __restrict__ erow, const int32_t* __restrict__ indices,
+                                                      const uint16_t* __restrict__ slab_all, int64_t n, int K,
+                                                      uint32_t* __restrict__ partial_all) {
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= nnz) return;
+    const uint16_t* slab = slab_all + (size_t)blockIdx.y * n * 16;
+    uint32_t* dst = partial_all + (size_t)blockIdx.y * ((size_t)K * K * 16);
+    const uint4* ra = reinterpret_cast<const uint4*>(slab + (size_t)erow[e] * 16);
+    const uint4* rb = reinterpret_cast<const uint4*>(slab + (size_t)indices[e] * 16);
+    const uint4 a0 = ra[0], a1 = ra[1], b0 = rb[0], b1 = rb[1];
+    const uint32_t wa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    const uint32_t wb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+        const uint32_t la = (wa[b >> 1] >> ((b & 1) * 16)) & 0xFFFFu, lb = (wb[b >> 1] >> ((b & 1) * 16)) & 0xFFFFu;
+        atomicAdd(&dst[((size_t)la * K + lb) * 16 + b], 1u);
     }
 }
 
@@ -642,6 +751,8 @@ struct sqgr_nhood {
     DevBuf<int32_t> lib_of, rank_of;
     DevBuf<LibDom> libs;
     DevBuf<uint8_t> base_pos;   // base labels in library-grouped position order (numpy-compatible mode)
+    DevBuf<uint16_t> base16;    // the same as 16-bit labels (more than 256 clusters)
+    DevBuf<int32_t> perm_idx;   // numpy permutations of a chunk (more than 256 clusters: labels are gathered through them)
     DevBuf<uint32_t> lib_off;   // [n_libs + 1] first position of every library
     DevBuf<uint8_t> wcol;       // [position][stride] column workspace of the numpy-compatible shuffle
     DevBuf<uint64_t> pcg_states;
@@ -662,7 +773,8 @@ struct sqgr_nhood {
         }
     }
     size_t keys_stride() const { return (size_t)nbatch * key_words_per_row(B, n_libs); }
-    size_t slab_stride() const { return (size_t)nbatch * n * B; }
+    bool wide() const { return K > 256; }  // 16-bit labels, device-scope counters
+    size_t slab_stride() const { return (size_t)nbatch * n * B * (wide() ? 2 : 1); }  // bytes
     DevBuf<uint32_t> partial;
     DevBuf<int64_t> acc_sum;
     DevBuf<uint64_t> acc_sq;
@@ -689,7 +801,7 @@ struct sqgr_nhood {
     }
     int nblk_launch = 0;  // blocks per batch of the launch in flight (count -> reduce)
     int sym_launch = 0;   // k_reduce mode of the launch in flight (0 full edge list, 1 half list, 2 half list with self loops)
-    int partial_blocks(int nb) const { return (B == 16 && be() == 0) ? 1 : blocks_for(nb); }
+    int partial_blocks(int nb) const { return (wide() || (B == 16 && be() == 0)) ? 1 : blocks_for(nb); }
     size_t partial_words() const {  // largest nb * blocks_for(nb) * hist_words over the launches this plan can issue
         size_t m = 0;
         for (int nb = 1; nb <= nbatch; ++nb) m = std::max(m, (size_t)nb * partial_blocks(nb));
@@ -702,6 +814,11 @@ struct sqgr_nhood {
 };
 
 int sqgr_nhood::resolve_tuning() {
+    if (wide()) {  // K*K*16 device-scope counters per batch: at most ~1 GiB of them in flight
+        B = 16;
+        const int64_t cap = std::max<int64_t>(1, ((int64_t)1 << 30) / ((int64_t)K2 * 16 * 4));
+        if (nbatch <= 0 || nbatch > cap) nbatch = (int)std::min<int64_t>(cap, 64);
+    }
     if (B == 32 && (size_t)K2 * 32 * 4 > LDS_BUDGET) B = 16;
     if (B != 16 && B != 32) B = 16;
     const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
@@ -750,7 +867,12 @@ int sqgr_nhood::count_batches(int nb, int buf) {
         SQGR_HIP(hipMemsetAsync(partial.p, 0, (size_t)nb * nblk_launch * hw * 4, st));
         return SQGR_OK;
     }
-    if (B == 32 || be() == 16) {
+    if (wide()) {
+        LaunchTimer t(ctx, "nhood_count_wide16");
+        SQGR_HIP(hipMemsetAsync(partial.p, 0, (size_t)nb * hw * 4, st));
+        k_count_wide16<<<dim3((unsigned)ceil_div(nnz, 256), nb), 256, 0, st>>>(nnz, g->erow.p, g->indices.p,
+                                                                              reinterpret_cast<const uint16_t*>(slab_p), n, K, partial.p);
+    } else if (B == 32 || be() == 16) {
         // LDS-histogram kernels: on a structurally symmetric graph they walk the half list (see sqgr_graph::ensure_half)
         SQGR_TRY(g->ensure_half());
         const bool half = g->sym_state == 1;
@@ -918,8 +1040,8 @@ static int nhood_build(sqgr_ctx* ctx, const sqgr_graph* g, int64_t n, const int3
     *out_plan = nullptr;
     SQGR_REQUIRE(!g || g->ctx == ctx, "graph belongs to a different context");
     SQGR_REQUIRE(K >= 2, "Expected at least `2` clusters, found `%d`.", K);
-    if (K > 256) {
-        set_error("K=%d > 256 clusters is not supported by the uint8 label slab", K);
+    if (K > 2048) {
+        set_error("K=%d > 2048 clusters is not supported by the batched permutation kernels", K);
         return SQGR_ERR_UNSUPPORTED;
     }
     if (n > (int64_t)1 << 27 || (g && g->nnz > (int64_t)0xFFF00000u)) {
@@ -991,7 +1113,7 @@ static int nhood_build(sqgr_ctx* ctx, const sqgr_graph* g, int64_t n, const int3
         for (int l = 0; l < p->n_libs; ++l) {
             const uint32_t* c = &cum[(size_t)l * p->kpad];
             const uint64_t n_l = (uint64_t)cnt[l];
-            const uint32_t SENT = ((uint32_t)K & 0xFFu) | 0x100u | (0xFFFFu << 16);  // byte 0 = K (mod 256), bit 8 marks it for the exact route
+            const uint32_t SENT = (uint32_t)K | (0xFFFFu << 16);  // bits 0-15: label K (byte 0 = K for K <= 255; K = 256 reads 0 + bit 8)
             uint32_t lab = 0;
             for (uint32_t a = 0; a < doms[l].dom.A; ++a) {
                 const uint64_t lo = (uint64_t)a * doms[l].dom.B, hi = lo + doms[l].dom.B;
@@ -1034,6 +1156,12 @@ static int nhood_build(sqgr_ctx* ctx, const sqgr_graph* g, int64_t n, const int3
             if (labels)
                 for (int64_t i = 0; i < n; ++i) base[libs_on ? off[lib_ids[i]] + (uint32_t)rank[i] : (uint32_t)i] = (uint8_t)labels[i];
             p->has_labels = labels != nullptr;
+            if (K > 256 && labels) {  // 16-bit copy of the same vector
+                std::vector<uint16_t> b16((size_t)n, 0);
+                for (int64_t i = 0; i < n; ++i) b16[libs_on ? off[lib_ids[i]] + (uint32_t)rank[i] : (uint32_t)i] = (uint16_t)labels[i];
+                if ((rc = p->base16.alloc((size_t)n)) != SQGR_OK) break;
+                if (hipMemcpy(p->base16.p, b16.data(), (size_t)n * 2, hipMemcpyHostToDevice) != hipSuccess) { rc = SQGR_ERR_HIP; break; }
+            }
             if ((rc = p->base_pos.alloc((size_t)n)) != SQGR_OK) break;
             if ((rc = p->lib_off.alloc(off.size())) != SQGR_OK) break;
             hipError_t e2 = hipMemcpy(p->base_pos.p, base.data(), (size_t)n, hipMemcpyHostToDevice);
@@ -1101,8 +1229,26 @@ static int launch_shuffle_raw(sqgr_nhood* p, int B, int nb, const uint32_t* keys
     const char* env_blocks = getenv("SQGR_SHUFFLE_BLOCKS_PER_CU");
     if (env_blocks && atoi(env_blocks) > 0) per_cu = atoi(env_blocks);
     gx = std::min<unsigned>(gx, (unsigned)(per_cu * std::max(p->ctx->cu_count, 1)) / (unsigned)std::max(nb, 1) + 1);
-    LaunchTimer t(p->ctx, "nhood_shuffle", st);
+    LaunchTimer t(p->ctx, p->wide() ? "nhood_shuffle16" : "nhood_shuffle", st);
     const size_t lds = (size_t)p->n_libs * p->kpad * 4 + (size_t)p->blk_bytes * 4;
+    if (p->wide()) {
+        if (B != 16) {
+            set_error("more than 256 clusters: 16 permutations per pass only");
+            return SQGR_ERR_UNSUPPORTED;
+        }
+        uint16_t* slab16 = reinterpret_cast<uint16_t*>(slab);
+        if (p->has_libs) {
+            SQGR_TRY(allow_lds(k_shuffle16<true>, lds));
+            k_shuffle16<true><<<dim3(gx, nb), 256, lds, st>>>(p->n, p->cum.p, p->kpad, p->blk_bytes, p->K, keys, p->dom0, p->n_libs, p->lib_of.p,
+                                                              p->rank_of.p, p->libs.p, slab16);
+        } else {
+            SQGR_TRY(allow_lds(k_shuffle16<false>, lds));
+            k_shuffle16<false><<<dim3(gx, nb), 256, lds, st>>>(p->n, p->cum.p, p->kpad, p->blk_bytes, p->K, keys, p->dom0, p->n_libs, p->lib_of.p,
+                                                               p->rank_of.p, p->libs.p, slab16);
+        }
+        SQGR_HIP(hipGetLastError());
+        return SQGR_OK;
+    }
 #define SQGR_SHUFFLE(BB, LIBS, SK)                                                                                            \
     k_shuffle<BB, LIBS, SK><<<dim3(gx, nb), 256, lds, st>>>(p->n, p->cum.p, p->kpad, p->blk_bytes, p->K, keys, p->dom0, p->n_libs, \
                                                             p->lib_of.p, p->rank_of.p, p->libs.p, slab)
@@ -1189,6 +1335,7 @@ int sqgr_nhood_run(sqgr_nhood* plan, uint64_t seed, int64_t perm_begin, int64_t 
 
 int sqgr_nhood_shuffled_labels(sqgr_nhood* plan, uint64_t seed, int64_t perm, uint8_t* out_labels) {
     SQGR_REQUIRE(plan && out_labels && perm >= 0, "plan/out_labels is NULL or perm < 0");
+    SQGR_REQUIRE(plan->K <= 256, "sqgr_nhood_shuffled_labels returns uint8 labels: K=%d > 256", plan->K);
     sqgr_nhood* p = plan;
     sqgr_ctx* ctx = p->ctx;
     SQGR_HIP(hipSetDevice(ctx->device));
@@ -1211,6 +1358,7 @@ int sqgr_nhood_counts_batch(sqgr_ctx* ctx, const sqgr_graph* g, const uint8_t* l
                             uint32_t* out_counts) {
     SQGR_REQUIRE(ctx && g && labels && out_counts, "ctx/graph/labels/out is NULL");
     SQGR_REQUIRE(n_perms >= 0, "n_perms < 0");
+    SQGR_REQUIRE(K <= 256, "sqgr_nhood_counts_batch takes uint8 labels: K=%d > 256", K);
     const int64_t n = g->n;
     for (int64_t t = 0; t < n_perms * n; ++t)
         SQGR_REQUIRE(labels[t] < K, "labels[%lld]=%d outside [0,%d)", (long long)t, (int)labels[t], K);
@@ -1276,36 +1424,71 @@ static int run_pcg64_impl(sqgr_nhood* plan, const uint64_t* pcg_states, int64_t 
     SQGR_HIP(hipMemsetAsync(p->acc_sum.p, 0, (size_t)p->nbatch * hw * 8, st));
     SQGR_HIP(hipMemsetAsync(p->acc_sq.p, 0, (size_t)p->nbatch * hw * 8, st));
     if (keep_perms) SQGR_TRY(p->perms_dev.ensure((size_t)(n_perms + 1) * K2));  // + 1: the all-gather of ragged rank chunks sends one padded row
-    // permutations per chunk: one thread each; the column matrix takes n bytes per permutation (<= 25 % of free HBM)
-    size_t free_b = 0, total_b = 0;
-    SQGR_HIP(hipMemGetInfo(&free_b, &total_b));
-    int64_t budget = (int64_t)std::min<size_t>(free_b / 4, (size_t)64 << 30);
-    int64_t chunk = std::max<int64_t>(64, std::min<int64_t>(budget / std::max<int64_t>(n, 1), 1 << 17));
-    chunk = std::min<int64_t>(chunk, ceil_div(std::max<int64_t>(n_perms, 1), 64) * 64) / 64 * 64;
-    const int64_t stride = chunk;  // multiple of 64 => 16-byte aligned slab gathers
-    SQGR_TRY(p->wcol.ensure((size_t)n * stride));
-    SQGR_TRY(p->pcg_states.ensure((size_t)chunk * 4));
-    const int64_t per_launch = (int64_t)p->nbatch * B;
-    for (int64_t c0 = 0; c0 < n_perms; c0 += chunk) {
-        const int64_t pc = std::min(chunk, n_perms - c0);
-        SQGR_HIP(hipMemcpyAsync(p->pcg_states.p, pcg_states + (size_t)c0 * 4, (size_t)pc * 32, hipMemcpyHostToDevice, st));
-        SQGR_TRY(pcg_shuffle_labels(ctx, p->pcg_ws, n, p->n_libs, p->lib_off.p, p->base_pos.p, p->pcg_states.p, pc, stride, p->wcol.p, st,
-                                    "nhood_pcg64_shuffle"));
-        for (int64_t q0 = 0; q0 < pc; q0 += per_launch) {
-            const int64_t todo = std::min(per_launch, pc - q0);
-            const int nb = (int)ceil_div(todo, B);
-            {
-                LaunchTimer t(ctx, "nhood_columns_to_slab");
-                dim3 grid((unsigned)ceil_div(n, 256), nb);
-#define SQGR_C2S(BB, LIBS) k_columns_to_slab<BB, LIBS><<<grid, 256, 0, st>>>(n, stride, p->wcol.p, q0, p->lib_of.p, p->rank_of.p, p->lib_off.p, p->slab.p)
-                if (B == 32) { if (p->has_libs) SQGR_C2S(32, true); else SQGR_C2S(32, false); }
-                else { if (p->has_libs) SQGR_C2S(16, true); else SQGR_C2S(16, false); }
-#undef SQGR_C2S
-                SQGR_HIP(hipGetLastError());
+    if (p->wide()) {
+        // more than 256 clusters: `Generator.shuffle(x)` leaves x[perm] behind with perm = the same generator's
+        // `permutation(n)` (one Fisher-Yates, the same draws), so the permutations are drawn on the device (4*n bytes each) and
+        // the 16-bit labels gathered through them.  Per-library sub-shuffles (`_shuffle_group`) are not offered on this path.
+        if (p->has_libs) {
+            set_error("K=%d > 256 clusters with library_key: numpy-stream shuffles are not available on the device", p->K);
+            return SQGR_ERR_UNSUPPORTED;
+        }
+        size_t free_b = 0, total_b = 0;
+        SQGR_HIP(hipMemGetInfo(&free_b, &total_b));
+        const int64_t per_launch = (int64_t)p->nbatch * B;
+        int64_t chunk = (int64_t)std::min<size_t>(free_b / 4, (size_t)16 << 30) / std::max<int64_t>(4 * n, 1);
+        chunk = std::max<int64_t>(per_launch, chunk / per_launch * per_launch);
+        chunk = std::min<int64_t>(chunk, ceil_div(std::max<int64_t>(n_perms, 1), per_launch) * per_launch);
+        SQGR_TRY(p->perm_idx.ensure((size_t)chunk * n));
+        SQGR_TRY(p->pcg_states.ensure((size_t)chunk * 4));
+        for (int64_t c0 = 0; c0 < n_perms; c0 += chunk) {
+            const int64_t pc = std::min(chunk, n_perms - c0);
+            SQGR_HIP(hipMemcpyAsync(p->pcg_states.p, pcg_states + (size_t)c0 * 4, (size_t)pc * 32, hipMemcpyHostToDevice, st));
+            SQGR_TRY(pcg_permutations_dev(ctx, p->pcg_ws, n, p->pcg_states.p, pc, p->perm_idx.p, st));
+            for (int64_t q0 = 0; q0 < pc; q0 += per_launch) {
+                const int64_t todo = std::min(per_launch, pc - q0);
+                const int nb = (int)ceil_div(todo, B);
+                {
+                    LaunchTimer t(ctx, "nhood_gather_labels16");
+                    k_gather_labels16<<<dim3((unsigned)ceil_div(n, 256), nb), 256, 0, st>>>(n, p->base16.p, p->perm_idx.p, q0, pc,
+                                                                                           reinterpret_cast<uint16_t*>(p->slab.p));
+                    SQGR_HIP(hipGetLastError());
+                }
+                SQGR_TRY(p->count_batches(nb, 0));
+                SQGR_TRY(p->reduce_batches(nb, c0 + q0, 0, c0 + pc, keep_perms ? p->perms_dev.p : nullptr));
             }
-            SQGR_TRY(p->count_batches(nb, 0));
-            // columns past `pc` of the last batch hold stale data: reduce masks permutations >= n_perms
-            SQGR_TRY(p->reduce_batches(nb, c0 + q0, 0, c0 + pc, keep_perms ? p->perms_dev.p : nullptr));
+        }
+    } else {
+        // permutations per chunk: one thread each; the column matrix takes n bytes per permutation (<= 25 % of free HBM)
+        size_t free_b = 0, total_b = 0;
+        SQGR_HIP(hipMemGetInfo(&free_b, &total_b));
+        int64_t budget = (int64_t)std::min<size_t>(free_b / 4, (size_t)64 << 30);
+        int64_t chunk = std::max<int64_t>(64, std::min<int64_t>(budget / std::max<int64_t>(n, 1), 1 << 17));
+        chunk = std::min<int64_t>(chunk, ceil_div(std::max<int64_t>(n_perms, 1), 64) * 64) / 64 * 64;
+        const int64_t stride = chunk;  // multiple of 64 => 16-byte aligned slab gathers
+        SQGR_TRY(p->wcol.ensure((size_t)n * stride));
+        SQGR_TRY(p->pcg_states.ensure((size_t)chunk * 4));
+        const int64_t per_launch = (int64_t)p->nbatch * B;
+        for (int64_t c0 = 0; c0 < n_perms; c0 += chunk) {
+            const int64_t pc = std::min(chunk, n_perms - c0);
+            SQGR_HIP(hipMemcpyAsync(p->pcg_states.p, pcg_states + (size_t)c0 * 4, (size_t)pc * 32, hipMemcpyHostToDevice, st));
+            SQGR_TRY(pcg_shuffle_labels(ctx, p->pcg_ws, n, p->n_libs, p->lib_off.p, p->base_pos.p, p->pcg_states.p, pc, stride, p->wcol.p, st,
+                                        "nhood_pcg64_shuffle"));
+            for (int64_t q0 = 0; q0 < pc; q0 += per_launch) {
+                const int64_t todo = std::min(per_launch, pc - q0);
+                const int nb = (int)ceil_div(todo, B);
+                {
+                    LaunchTimer t(ctx, "nhood_columns_to_slab");
+                    dim3 grid((unsigned)ceil_div(n, 256), nb);
+    #define SQGR_C2S(BB, LIBS) k_columns_to_slab<BB, LIBS><<<grid, 256, 0, st>>>(n, stride, p->wcol.p, q0, p->lib_of.p, p->rank_of.p, p->lib_off.p, p->slab.p)
+                    if (B == 32) { if (p->has_libs) SQGR_C2S(32, true); else SQGR_C2S(32, false); }
+                    else { if (p->has_libs) SQGR_C2S(16, true); else SQGR_C2S(16, false); }
+    #undef SQGR_C2S
+                    SQGR_HIP(hipGetLastError());
+                }
+                SQGR_TRY(p->count_batches(nb, 0));
+                // columns past `pc` of the last batch hold stale data: reduce masks permutations >= n_perms
+                SQGR_TRY(p->reduce_batches(nb, c0 + q0, 0, c0 + pc, keep_perms ? p->perms_dev.p : nullptr));
+            }
         }
     }
     {
@@ -1409,6 +1592,10 @@ namespace sqgr {
 
 int label_shuffler_create(sqgr_ctx* ctx, int64_t n, const int32_t* labels, int K, LabelShuffler** out) {
     SQGR_REQUIRE(ctx && labels && out && n > 0, "ctx/labels/out is NULL or n <= 0");
+    if (K > 256) {
+        set_error("K=%d > 256 clusters: the ligand-receptor kernels keep K x 64 float64 accumulators per gene in LDS and uint8 labels", K);
+        return SQGR_ERR_UNSUPPORTED;
+    }
     SQGR_HIP(hipSetDevice(ctx->device));
     sqgr_nhood* plan = nullptr;
     SQGR_TRY(nhood_build(ctx, nullptr, n, labels, K, nullptr, 0, &plan));

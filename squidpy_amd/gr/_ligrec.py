@@ -257,7 +257,10 @@ class PermutationTest:
 
         ``n_jobs`` and ``show_progress_bar`` are accepted (``n_jobs`` validated) and do not influence the GPU path.
         ``rng='philox'`` shuffles with the device generator keyed by ``(seed, permutation)``; ``rng='numpy'``
-        reproduces the reference's PCG64 streams bit for bit, i.e. Squidpy's p-values for that ``seed``."""
+        reproduces the reference's PCG64 streams bit for bit, i.e. Squidpy's p-values for that ``seed``.
+
+        Limits of the GPU path: at most ``256`` clusters among the requested cluster pairs (``NotImplementedError`` beyond;
+        the reference has no limit); a subset that resolves to a single cluster is computed on the host like the reference does."""
         assert_positive(n_perms, name="n_perms")
         _assert_categorical_obs(self._adata, key=cluster_key)
         if rng not in ("philox", "numpy"):
@@ -369,6 +372,11 @@ class PermutationTest:
         means = np.where(nonzero, (m_rec + m_lig) / 2.0, 0.0)
         obs = m_rec + m_lig
 
+        if n_cls > 256:
+            raise NotImplementedError(
+                f"`{n_cls}` clusters: the ligand-receptor kernels keep `n_clusters x 64` float64 accumulators per gene in LDS and "
+                "uint8 labels, i.e. at most `256` clusters per call (there is no CPU fallback); restrict `clusters` to at most 256."
+            )
         if n_cls == 1:
             # A cluster subset that resolves to ONE cluster (e.g. clusters=[("A", "A")]): the reference has no check here and
             # computes it (gr/_ligrec.py:677-775).  Shuffling a constant label vector changes nothing, so every permutation

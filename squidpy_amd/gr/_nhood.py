@@ -129,7 +129,8 @@ def nhood_enrichment(
     graph = Graph(ctx, adj, with_data=False)
     try:
         count = nhood_counts(ctx, graph, int_clust, n_cls)
-        if n_cls > MAX_DEVICE_SHUFFLE_CLUSTERS:
+        if n_cls > MAX_DEVICE_SHUFFLE_CLUSTERS or (n_cls > 256 and rng == "numpy" and lib_codes is not None):
+            # (numpy streams + libraries + more than 256 clusters: per-library sub-shuffles of 16-bit labels are not on the device)
             zscore = _zscore_many_clusters(ctx, graph, int_clust, n_cls, lib_codes, n_libs, seed, n_perms, count)
         elif rng == "numpy-host":
             zscore = _zscore_numpy_streams(ctx, graph, int_clust, n_cls, lib_codes, n_libs, seed, n_perms, count)
@@ -195,7 +196,8 @@ def _broadcast_seed(key: int) -> int:
     return int(_dist.broadcast_object(int(key), src=0))
 
 
-MAX_DEVICE_SHUFFLE_CLUSTERS = 256  # the batched permutation kernels keep labels as uint8
+MAX_DEVICE_SHUFFLE_CLUSTERS = 2048  # batched permutation kernels: uint8 labels + LDS counters up to 256 clusters, uint16 labels + device-scope
+# counters up to 2048 (K*K*16 counters per batch); beyond that the any-K edge-pair kernel counts host-drawn numpy shuffles
 
 
 def _zscore_many_clusters(
@@ -209,7 +211,7 @@ def _zscore_many_clusters(
     n_perms: int,
     count: np.ndarray,
 ) -> np.ndarray:
-    """More than 256 clusters: the batched device shuffle does not apply (uint8 labels, K*K*16 counters per pass), so each
+    """More than 2048 clusters: the batched device shuffle does not apply (K*K*16 counters per pass), so each
     permutation is drawn with the reference's own numpy stream on the host (gr/_nhood.py:213, 530-539) and counted by the
     general edge-pair kernel (`sqgr_nhood_counts`, any K) — Squidpy's z-scores for the seed, at ~1 ms per permutation
     plus the shuffle.  Permutation ranges are split over ranks like the other paths."""

@@ -365,27 +365,98 @@ def test_skewed_cluster_sizes(L, ctx):
     assert np.isnan(res.zscore[k - 1]).all() and np.isnan(ref[k - 1]).all()  # empty category: 0/0 as in the reference
 
 
-def test_more_than_256_clusters_use_the_general_path(L, ctx):
-    """K > 256 (uint8 labels do not apply): numpy streams on the host + the any-K edge-pair kernel; equals the oracle's
-    numpy-stream result (i.e. Squidpy's z-scores for the seed) for either `rng` spelling."""
+def test_more_than_256_clusters_run_batched_on_the_device(L, ctx):
+    """256 < K <= 2048: 16-bit label slab + device-scope counters, device shuffles in both rng modes — the
+    device generator against its oracle restatement, numpy streams against Squidpy's z-scores for the seed, bit for bit."""
     import squidpy_amd as sq
 
     k = 300
-    adata = hex_adata(30, 40, 6, seed=8)
+    adata = hex_adata(30, 40, 6, seed=8, n_libs=3)
     n = adata.n_obs
     lab = np.random.default_rng(8).integers(0, k, n).astype(np.int32)
     lab[:k] = np.arange(k)
     adata.obs["cluster"] = pd.Categorical.from_codes(lab, [f"c{i:03d}" for i in range(k)])
     adj = adata.obsp["spatial_connectivities"]
-    res = sq.gr.nhood_enrichment(adata, "cluster", n_perms=12, seed=3, copy=True)
-    ref_perms = O.nhood_perm_counts_numpy(adj.indices, adj.indptr, lab, k, 3, 12)
-    np.testing.assert_array_equal(res.counts, O.nhood_counts(adj.indices, adj.indptr, lab, k))
-    want = O.nhood_zscore(res.counts, ref_perms)
+    count = O.nhood_counts(adj.indices, adj.indptr, lab, k)
+    res = sq.gr.nhood_enrichment(adata, "cluster", n_perms=40, seed=3, copy=True)
+    np.testing.assert_array_equal(res.counts, count)
+    want = O.nhood_zscore(count, O.nhood_perm_counts_philox(adj.indices, adj.indptr, lab, k, 3, 0, 40))
     np.testing.assert_array_equal(np.isnan(res.zscore), np.isnan(want))
     ok = np.isfinite(want)
-    np.testing.assert_array_equal(res.zscore[ok], want[ok])
+    np.testing.assert_allclose(res.zscore[ok], want[ok], rtol=1e-9)
+    # per-permutation counts through the C ABI, an unaligned range
+    g = L.Graph(ctx, adj, with_data=False)
+    plan = L.NhoodPlan(ctx, g, lab, k)
+    _, _, perms = plan.run(3, 5, 39, return_perms=True)
+    np.testing.assert_array_equal(perms, O.nhood_perm_counts_philox(adj.indices, adj.indptr, lab, k, 3, 5, 39).astype(np.uint32))
+    plan.close()
+    # libraries: per-library bijections with 16-bit labels
+    libs = codes(adata, "library")
+    plan = L.NhoodPlan(ctx, g, lab, k, libs, 3)
+    _, _, perms = plan.run(11, 0, 20, return_perms=True)
+    np.testing.assert_array_equal(perms, O.nhood_perm_counts_philox(adj.indices, adj.indptr, lab, k, 11, 0, 20, libs, 3).astype(np.uint32))
+    plan.close()
+    g.close()
+    # numpy streams: Squidpy's z-scores for the seed
+    ref_perms = O.nhood_perm_counts_numpy(adj.indices, adj.indptr, lab, k, 3, 12)
+    want = O.nhood_zscore(count, ref_perms)
+    ok = np.isfinite(want)
     res2 = sq.gr.nhood_enrichment(adata, "cluster", n_perms=12, seed=3, copy=True, rng="numpy")
     np.testing.assert_array_equal(res2.zscore[ok], want[ok])
+    # numpy streams + libraries + K > 256 take the host-drawn route (per-library sub-shuffles): still Squidpy's z-scores
+    ref_perms = O.nhood_perm_counts_numpy(adj.indices, adj.indptr, lab, k, 3, 6, libs, 3)
+    want = O.nhood_zscore(count, ref_perms)
+    ok = np.isfinite(want)
+    res3 = sq.gr.nhood_enrichment(adata, "cluster", library_key="library", n_perms=6, seed=3, copy=True, rng="numpy")
+    np.testing.assert_array_equal(res3.zscore[ok], want[ok])
+
+
+def test_300_clusters_at_1e5_spots_is_a_device_path(L, ctx):
+    """K = 300 on 1e5 spots, 1000 permutations: the batched device path (the host-shuffle route of round 1 needed ~1 ms per
+    permutation plus a numpy shuffle: > 2 s; 100x faster was the bar)."""
+    import time
+
+    import squidpy_amd as sq
+
+    k, P = 300, 1000
+    adata = hex_adata(250, 400, 6, seed=8)
+    n = adata.n_obs
+    lab = np.random.default_rng(8).integers(0, k, n).astype(np.int32)
+    adata.obs["cluster"] = pd.Categorical.from_codes(lab, [f"c{i:03d}" for i in range(k)])
+    adj = adata.obsp["spatial_connectivities"]
+    sq.gr.nhood_enrichment(adata, "cluster", n_perms=32, seed=1, copy=True)  # warm-up (allocations)
+    t0 = time.perf_counter()
+    res = sq.gr.nhood_enrichment(adata, "cluster", n_perms=P, seed=1, copy=True)
+    dt = time.perf_counter() - t0
+    assert np.isfinite(res.zscore).all()
+    g = L.Graph(ctx, adj, with_data=False)
+    plan = L.NhoodPlan(ctx, g, lab, k)
+    _, _, perms = plan.run(1, 0, P, return_perms=True)
+    np.testing.assert_allclose(res.zscore, O.nhood_zscore(res.counts, perms), rtol=1e-9)
+    for p in (0, 999):
+        np.testing.assert_array_equal(perms[p], O.nhood_counts(adj.indices, adj.indptr, devrng.shuffled_labels(lab, 1, p), k))
+    plan.close()
+    g.close()
+    assert dt < 1.0, f"{P} permutations took {dt:.2f} s"
+
+
+def test_more_than_2048_clusters_use_the_general_path(L, ctx):
+    """K > 2048: numpy streams on the host + the any-K edge-pair kernel; Squidpy's z-scores for the seed for either `rng`."""
+    import squidpy_amd as sq
+
+    k = 2100
+    adata = hex_adata(50, 60, 6, seed=8)
+    n = adata.n_obs
+    lab = np.random.default_rng(8).integers(0, k, n).astype(np.int32)
+    lab[:k] = np.arange(k)
+    adata.obs["cluster"] = pd.Categorical.from_codes(lab, [f"c{i:04d}" for i in range(k)])
+    adj = adata.obsp["spatial_connectivities"]
+    res = sq.gr.nhood_enrichment(adata, "cluster", n_perms=4, seed=3, copy=True)
+    ref_perms = O.nhood_perm_counts_numpy(adj.indices, adj.indptr, lab, k, 3, 4)
+    np.testing.assert_array_equal(res.counts, O.nhood_counts(adj.indices, adj.indptr, lab, k))
+    want = O.nhood_zscore(res.counts, ref_perms)
+    ok = np.isfinite(want)
+    np.testing.assert_array_equal(res.zscore[ok], want[ok])
 
 
 def test_null_distribution_matches_numpy_streams_at_high_power(L, ctx):
