@@ -576,10 +576,10 @@ def main() -> None:
             shuf["valu_wave_instr_per_label"] = rec_s["SQ_INSTS_VALU"] * 64.0 / (n * perms_per_launch)
         # ---- reduce: HBM (reads the partial histograms once)
         avg_red_ms = ms_red / max(red_launch, 1)
-        red_bytes = info["partial_bytes_per_launch"] * (2 if info["symmetric"] else 1)
+        red_bytes = info["partial_bytes_per_launch"]
         red = {"kernel": "nhood_reduce", "bound": "hbm", "achieved": red_bytes / (avg_red_ms * 1e-3) / 1e9 if avg_red_ms > 0 else None, "peak": HBM_PEAK / 1e9,
                "unit": "GB/s", "frac": red_bytes / (avg_red_ms * 1e-3) / HBM_PEAK if avg_red_ms > 0 else None, "traffic": None, "avg_launch_ms": avg_red_ms,
-               "launches": red_launch, "note": "block-partial histograms (blocks x K*K*16 x 4 B per batch) read once (twice on the half list: h and h^T); L2-resident"}
+               "launches": red_launch, "note": "block-partial histograms (blocks x K*K*16 x 4 B per batch, h + h^T already formed by the count kernel) read once; L2-resident"}
         kern_ms = {k: round(v[1] / max(v[0], 1), 4) for k, v in kernels.items() if v[0] > 0}
         gpu_ms = sum(v[1] for v in kernels.values())
         b_perm = 4 * nnz + 4 * (n + 1) + 2 * n

@@ -129,7 +129,11 @@ __global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __re
     }
     const FeistelDomain dom = ld.dom;
     const uint32_t* tab = s_cum + lib * kpad + 1;  // tab[k] = cum[k + 1]
-    const char* blk = reinterpret_cast<const char*>(s_lds) + (HAS_LIBS ? ld.aoff * 4 : 0u);  // !HAS_LIBS: LDS byte offset 0
+    // The block table sits at LDS byte offset 0 (this kernel has no static LDS, the dynamic segment starts at 0): reading it
+    // through an explicit address-space-3 address spares the add of the segment base the compiler otherwise emits per look-up.
+    typedef __attribute__((address_space(3))) const uint32_t lds_word;
+    const uint32_t blk_base = HAS_LIBS ? ld.aoff * 4u : 0u;
+    auto blk_at = [&](uint32_t byte_off) { return *reinterpret_cast<lds_word*>((uintptr_t)(blk_base + byte_off)); };
     const uint32_t a0 = x0 / dom.B, b0 = x0 - a0 * dom.B;  // one division per spot, shared by all B permutations
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
@@ -151,8 +155,8 @@ __global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __re
                 apk[jj] = __builtin_bit_cast(uint32_t, a[0]);
                 bpk[jj] = __builtin_bit_cast(uint32_t, b[0]);
                 const uint32_t a4 = apk[jj] << 2;  // both halves at once (a < 2^14): byte offsets into the block table
-                const uint32_t e0 = *reinterpret_cast<const uint32_t*>(blk + (a4 & 0xFFFFu));
-                const uint32_t e1 = *reinterpret_cast<const uint32_t*>(blk + (a4 >> 16));
+                const uint32_t e0 = blk_at(a4 & 0xFFFFu);
+                const uint32_t e1 = blk_at(a4 >> 16);
                 if (jj == 0) {
                     put_label<0, 0>(word, e0, bpk[jj], zero);
                     put_label<1, 1>(word, e1, bpk[jj], zero);
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __re
                         a = (a + feistel_F1(b, k1, dom.ash)) & (dom.A - 1u);
                         x = a * dom.B + b;
                     }
-                    const uint32_t e = *reinterpret_cast<const uint32_t*>(blk + a * 4u);  // the table again: nearly always enough
+                    const uint32_t e = blk_at(a * 4u);  // the table again: nearly always enough
                     uint32_t l = (e & 0xFFFFu) + (b >= (e >> 16) ? 1u : 0u);
                     if (l >= (uint32_t)K) {  // a block the two-field form cannot describe: rank against the boundaries
                         l = 0;
@@ -368,7 +372,8 @@ template <int B, int MIN_WAVES, bool SELF>
 __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz, const int2* __restrict__ coo,
                                                                     const uint8_t* __restrict__ slab_all, int64_t n, int K,
                                                                     int hist_words, uint32_t edges_per_block,
-                                                                    uint32_t self_begin, uint32_t* __restrict__ partial_all) {
+                                                                    uint32_t self_begin, int add_transposed,
+                                                                    uint32_t* __restrict__ partial_all) {
     extern __shared__ uint32_t hist[];
     // this kernel is bound by LDS-atomic and VALU issue; when the VALU-bound shuffle kernel of the next launch group
     // shares the CU (SQGR_NHOOD_STREAMS=2), issue priority keeps the LDS pipe fed
@@ -493,7 +498,15 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
     }
     __syncthreads();
     uint32_t* dst = partial_all + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * hist_words;
-    for (int i = tid; i < hist_words; i += COUNT_THREADS) dst[i] = hist[i];
+    if (add_transposed) {  // half list: the block's contribution to count = h + h^T is formed here, out of LDS
+        constexpr int LOGB = (B == 32) ? 5 : 4;
+        for (int i = tid; i < hist_words; i += COUNT_THREADS) {
+            const int pair = i >> LOGB, la = pair / K, lb = pair - la * K;
+            dst[i] = hist[i] + hist[((lb * K + la) << LOGB) + (i & (B - 1))];
+        }
+    } else {
+        for (int i = tid; i < hist_words; i += COUNT_THREADS) dst[i] = hist[i];
+    }
 }
 
 // Large-K variants: BE (< 16) permutations [b0, b0+BE) of a 16-wide slab per pass; BE == 0: K*K does not
@@ -545,8 +558,8 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_wide(int64_t nnz, const
 // ---------------------------------------------------------------------------------------------- reduction
 // word w = pair*B + b.  acc slots are private to (batch, w): no atomics, bit-reproducible.
 // 256 threads = 64 words x 4 slices of the block loop (combined through LDS).
-// sym: 0 the partials hold the counts; 1 they hold h over the half list: count[a,b] = h[a,b] + h[b,a];
-//      2 the same in doubled units (half lists with self loops): count = (h + h^T) / 2.
+// sym: 0 the partials hold the counts (for half lists k_count has already formed h + h^T per block);
+//      2 they hold them in doubled units (half lists with self loops): count = sum / 2.
 __global__ __launch_bounds__(256) void k_reduce(const uint32_t* __restrict__ partial_all, int nblk, int hist_words, int B,
                                                 int K, int sym, const int64_t* __restrict__ shift, int64_t perm_batch0,
                                                 int64_t perm_begin, int64_t perm_end, int64_t* __restrict__ acc_sum,
@@ -560,11 +573,6 @@ __global__ __launch_bounds__(256) void k_reduce(const uint32_t* __restrict__ par
     if (w < hist_words) {
         const uint32_t* src = partial_all + (size_t)batch * nblk * hist_words + w;
         for (int k = slice; k < nblk; k += 4) c += src[(size_t)k * hist_words];
-        if (sym) {
-            const int pair = w / B, la = pair / K, lb = pair - la * K;
-            const uint32_t* srcT = partial_all + (size_t)batch * nblk * hist_words + (size_t)(lb * K + la) * B + (w - pair * B);
-            for (int k = slice; k < nblk; k += 4) c += srcT[(size_t)k * hist_words];
-        }
     }
     part[slice][wl] = c;
     __syncthreads();
@@ -880,12 +888,12 @@ int sqgr_nhood::count_batches(int nb, int buf) {
         const uint32_t m = (uint32_t)(half ? g->n_half + g->n_self : nnz);
         const uint32_t self_begin = (uint32_t)(half ? g->n_half : nnz);
         const bool self = half && g->n_self > 0;
-        sym_launch = half ? (self ? 2 : 1) : 0;
+        sym_launch = self ? 2 : 0;  // the blocks' partials already hold h + h^T; half lists with self loops are in doubled units
         const uint32_t epb = (uint32_t)(ceil_div(ceil_div((int64_t)m, nblk), 1024) * 1024);  // whole iterations of a block
         const size_t lds = (size_t)hw * 4;
         const dim3 grid(nblk, nb);
 #define SQGR_COUNT(BB, MW, SELF) \
-    k_count<BB, MW, SELF><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, hw, epb, self_begin, partial.p)
+    k_count<BB, MW, SELF><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, hw, epb, self_begin, half ? 1 : 0, partial.p)
         if (B == 32) {
             LaunchTimer t(ctx, half ? "nhood_count_b32_half" : "nhood_count_b32");
             if (self) {
