@@ -411,27 +411,35 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
     constexpr uint32_t STEP = (COUNT_THREADS / 4) * U;
     static_assert(2 * STEP + U <= LIST_PAD, "look-ahead exceeds the padding of the edge lists");
     using Row = typename std::conditional<B == 16, uint32_t, uint2>::type;
-    struct Pairs { int4 a, b; };  // edges (0, 1) and (2, 3) of the lane's group
+    // offsets of the 4 edges' label rows for THIS lane: the quad broadcast rides on the add of the lane's byte offset inside
+    // the row (v_add_u32 with a DPP quad_perm source: one instruction instead of a broadcast and an add)
+#define SQGR_ADD_DPP(dst, src, sel)                                                                      \
+    asm("v_add_u32_dpp %0, %1, %2 quad_perm:[" sel "] row_mask:0xf bank_mask:0xf" : "=v"(dst) : "v"(src), "v"(qoff))
+    struct Pairs { uint32_t r[U], c[U]; };
     auto load_pair = [&](uint32_t e) { return coo[e + q]; };
     auto spread = [&](const int2 mine) {
         Pairs pr;
-        pr.a.x = __builtin_amdgcn_update_dpp(mine.x, mine.x, 0x00, 0xF, 0xF, false);  // quad_perm:[0,0,0,0]
-        pr.a.y = __builtin_amdgcn_update_dpp(mine.y, mine.y, 0x00, 0xF, 0xF, false);
-        pr.a.z = __builtin_amdgcn_update_dpp(mine.x, mine.x, 0x55, 0xF, 0xF, false);  // quad_perm:[1,1,1,1]
-        pr.a.w = __builtin_amdgcn_update_dpp(mine.y, mine.y, 0x55, 0xF, 0xF, false);
-        pr.b.x = __builtin_amdgcn_update_dpp(mine.x, mine.x, 0xAA, 0xF, 0xF, false);  // quad_perm:[2,2,2,2]
-        pr.b.y = __builtin_amdgcn_update_dpp(mine.y, mine.y, 0xAA, 0xF, 0xF, false);
-        pr.b.z = __builtin_amdgcn_update_dpp(mine.x, mine.x, 0xFF, 0xF, 0xF, false);  // quad_perm:[3,3,3,3]
-        pr.b.w = __builtin_amdgcn_update_dpp(mine.y, mine.y, 0xFF, 0xF, 0xF, false);
+        if constexpr (B == 16) {
+            SQGR_ADD_DPP(pr.r[0], mine.x, "0,0,0,0"); SQGR_ADD_DPP(pr.c[0], mine.y, "0,0,0,0");
+            SQGR_ADD_DPP(pr.r[1], mine.x, "1,1,1,1"); SQGR_ADD_DPP(pr.c[1], mine.y, "1,1,1,1");
+            SQGR_ADD_DPP(pr.r[2], mine.x, "2,2,2,2"); SQGR_ADD_DPP(pr.c[2], mine.y, "2,2,2,2");
+            SQGR_ADD_DPP(pr.r[3], mine.x, "3,3,3,3"); SQGR_ADD_DPP(pr.c[3], mine.y, "3,3,3,3");
+        } else {  // 32-byte rows: list offsets are for 16-byte rows
+            int2 m2 = make_int2(mine.x * 2, mine.y * 2);
+            asm volatile("s_nop 1" : "+v"(m2.x), "+v"(m2.y));  // a VALU result read through DPP needs two wait states
+            SQGR_ADD_DPP(pr.r[0], m2.x, "0,0,0,0"); SQGR_ADD_DPP(pr.c[0], m2.y, "0,0,0,0");
+            SQGR_ADD_DPP(pr.r[1], m2.x, "1,1,1,1"); SQGR_ADD_DPP(pr.c[1], m2.y, "1,1,1,1");
+            SQGR_ADD_DPP(pr.r[2], m2.x, "2,2,2,2"); SQGR_ADD_DPP(pr.c[2], m2.y, "2,2,2,2");
+            SQGR_ADD_DPP(pr.r[3], m2.x, "3,3,3,3"); SQGR_ADD_DPP(pr.c[3], m2.y, "3,3,3,3");
+        }
         return pr;
     };
+#undef SQGR_ADD_DPP
     auto gather_rows = [&](const Pairs& pr, Row (&ra)[U], Row (&rb)[U]) {
-        const uint32_t r[U] = {(uint32_t)pr.a.x, (uint32_t)pr.a.z, (uint32_t)pr.b.x, (uint32_t)pr.b.z};
-        const uint32_t c[U] = {(uint32_t)pr.a.y, (uint32_t)pr.a.w, (uint32_t)pr.b.y, (uint32_t)pr.b.w};
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            ra[u] = *reinterpret_cast<const Row*>(slab + ((B == 16 ? r[u] : 2u * r[u]) + qoff));
-            rb[u] = *reinterpret_cast<const Row*>(slab + ((B == 16 ? c[u] : 2u * c[u]) + qoff));
+            ra[u] = *reinterpret_cast<const Row*>(slab + pr.r[u]);
+            rb[u] = *reinterpret_cast<const Row*>(slab + pr.c[u]);
         }
     };
     auto histogram = [&](const Row (&row_a)[U], const Row (&row_b)[U], uint32_t eb, auto general_tag) {
