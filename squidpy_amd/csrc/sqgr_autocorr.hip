@@ -317,7 +317,7 @@ static int autocorr_create(sqgr_ctx* ctx, const sqgr_graph* g, const double* val
     SQGR_REQUIRE(ctx && g && (vals || dev_x) && out, "null argument");
     *out = nullptr;
     SQGR_REQUIRE(g->ctx == ctx, "graph belongs to a different context");
-    SQGR_REQUIRE(g->has_data, "graph was uploaded without edge weights");
+    SQGR_REQUIRE(g->has_data || g->nnz == 0, "graph was uploaded without edge weights");
     SQGR_REQUIRE(G >= 1, "G=%lld", (long long)G);
     SQGR_HIP(hipSetDevice(ctx->device));
     const int64_t n = g->n;

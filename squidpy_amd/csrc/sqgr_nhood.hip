@@ -982,7 +982,7 @@ static int edge_pairs(sqgr_ctx* ctx, const sqgr_graph* g, const int32_t* labels,
     SQGR_TRY(dl.alloc((size_t)g->n));
     SQGR_HIP(hipMemcpyAsync(dl.p, labels, (size_t)g->n * 4, hipMemcpyHostToDevice, ctx->stream));
     if (weighted) {
-        SQGR_REQUIRE(g->has_data, "graph was uploaded without edge data; weights unavailable");
+        SQGR_REQUIRE(g->has_data || g->nnz == 0, "graph was uploaded without edge data; weights unavailable");
         SQGR_TRY(dd.alloc(K2));
         SQGR_HIP(hipMemsetAsync(dd.p, 0, K2 * 8, ctx->stream));
     } else {

@@ -1,4 +1,8 @@
-"""Randomised differential test of libsqgr against the CPU oracle (run on the GPU box: python tools/fuzz_gpu.py [seconds])."""
+"""Randomised differential test of libsqgr against the CPU oracle (run on the GPU box):
+
+    python tools/fuzz_gpu.py [seconds] [seed]            # time budget
+    FUZZ_ITERS=12 python tools/fuzz_gpu.py 0 7           # fixed number of iterations (tests/test_fuzz_gpu.py)
+"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -15,15 +19,20 @@ print('fuzz seed', seed0, flush=True)
 VERBOSE = os.environ.get('FUZZ_VERBOSE') == '1'
 def note(*a):
     if VERBOSE: print(*a, flush=True)
+ITERS = int(os.environ.get('FUZZ_ITERS', '0'))
 t0 = time.time(); it = 0
-while time.time() - t0 < budget:
+while (it < ITERS) if ITERS else (time.time() - t0 < budget):
     it += 1
     n = int(rng.choice([3, 17, 64, 255, 257, 1000, 4097, 20000]))
-    k = int(rng.choice([2, 3, 7, 30, 50, 51, 64, 100, 203, 256]))
+    k = int(rng.choice([2, 3, 7, 30, 50, 51, 64, 100, 127, 203, 256, 300, 1000]))
     dens = rng.choice([0.0, 2.0, 6.0, 20.0]) / max(n, 1)
     A = sp.random(n, n, density=min(1.0, dens), format="csr", random_state=int(rng.integers(1 << 31)))
-    if rng.random() < 0.3: A = A + sp.identity(n, format="csr")
-    A = sp.csr_matrix(A); A.data[:] = rng.random(A.nnz).astype(np.float32) + 0.5
+    shape = rng.random()
+    if shape < 0.45: A = A + A.T                                   # structurally symmetric: the half-list path of the count kernel
+    if rng.random() < 0.3: A = A + sp.identity(n, format="csr")     # ... with self loops (weights 2 / 1, halved sum)
+    A = sp.csr_matrix(A); A.sort_indices()
+    if shape > 0.9 and A.nnz > 4: A.indices[A.indptr[1]:A.indptr[2]] = A.indices[A.indptr[1]:A.indptr[2]][::-1]  # unsorted row: not canonical
+    A.data = (rng.random(A.nnz) + 0.5).astype(np.float32 if rng.random() < 0.5 else np.float64)
     labels = rng.integers(0, k, n).astype(np.int32)
     if rng.random() < 0.3: labels[:] = rng.integers(0, max(1, k // 3), n)  # empty categories
     note('iter', it, 'nhood n', n, 'k', k, 'nnz', A.nnz)
@@ -32,8 +41,13 @@ while time.time() - t0 < budget:
     use_libs = rng.random() < 0.4
     nl = int(rng.integers(1, 5)); libs = rng.integers(0, nl, n).astype(np.int32) if use_libs else None
     note('  plan libs', use_libs, nl)
+    cats = labels.copy(); cats[rng.random(n) < 0.1] = -1
+    if (cats >= 0).any():  # weighted / unweighted interaction matrix with masked spots (float64 accumulation on the device)
+        keep = cats >= 0; sub = A[keep][:, keep].tocsr()
+        np.testing.assert_allclose(L.interaction_matrix(ctx, g, cats, k, True), O.interaction_matrix(sub.data.astype(np.float64), sub.indices, sub.indptr, cats[keep], k, True), rtol=1e-12, atol=1e-300)
+        assert np.array_equal(L.interaction_matrix(ctx, g, cats, k, False), O.interaction_matrix(sub.data, sub.indices, sub.indptr, cats[keep], k, False))
     plan = L.NhoodPlan(ctx, g, labels, k, libs, nl if use_libs else 0)
-    plan.tune(int(rng.choice([16, 32])), int(rng.choice([0, 8, 256])), int(rng.choice([1, 3, 32])))
+    plan.tune(int(rng.choice([16, 32])) if k <= 256 else 16, int(rng.choice([0, 8, 256])), int(rng.choice([1, 3, 32])))
     P = int(rng.integers(1, 70)); seed = int(rng.integers(1 << 62)); lo = int(rng.integers(0, 1 << 40))
     note('  run P', P, 'seed', seed, 'lo', lo)
     s1, s2, perms = plan.run(seed, lo, lo + P, None, return_perms=True)
@@ -41,7 +55,7 @@ while time.time() - t0 < budget:
     assert np.array_equal(perms, ref.astype(np.uint32)), ("philox", n, k, use_libs)
     assert np.array_equal(s1, ref.astype(np.int64).sum(0))
     note('  pcg')
-    if n <= 4097:
+    if n <= 4097 and not (k > 256 and use_libs):  # (numpy streams + libraries + 16-bit labels: host route in the front end)
         _, _, pp = plan.run_pcg64(pcg64_states(seed % 1000, P), return_perms=True)
         refn = O.nhood_perm_counts_numpy(A.indices, A.indptr, labels, k, seed % 1000, P, libs, nl if use_libs else 0)
         assert np.array_equal(pp, refn.astype(np.uint32)), ("pcg64", n, k, use_libs)
