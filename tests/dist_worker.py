@@ -97,6 +97,13 @@ def main() -> None:
 
     out["collective"] = _dist.collective_kind()
     assert out["collective"] == ("socket-hub" if socket_mode else "torch.distributed")
+    if socket_mode:
+        # without a GPU the RCCL communicator cannot be created: every rank must learn that and agree on the host side channel
+        os.environ.pop("SQGR_DIST_COLLECTIVE", None)
+        _dist._comm_tried = False
+        assert _dist.device_comm() is None
+        (again,) = _dist.allreduce_sum_([np.array([rank + 1], dtype=np.int64)])
+        assert int(again[0]) == world * (world + 1) // 2 and _dist.collective_kind() == "socket-hub"
     assert _dist.broadcast_object({"r": rank}, src=world - 1) == {"r": world - 1}
     _dist.barrier()
     if socket_mode:
