@@ -1,9 +1,11 @@
 """``squidpy_amd.gr`` — the MI355X-native ``sq.gr`` spatial-statistics hot path."""
 
+from . import neighbors
 from ._build import (
     SpatialNeighborsResult,
     spatial_neighbors,
     spatial_neighbors_delaunay,
+    spatial_neighbors_from_builder,
     spatial_neighbors_grid,
     spatial_neighbors_knn,
     spatial_neighbors_radius,
@@ -14,4 +16,5 @@ from ._ppatterns import co_occurrence, spatial_autocorr
 from ._ripley import ripley
 
 __all__ = ["nhood_enrichment", "interaction_matrix", "NhoodEnrichmentResult", "co_occurrence", "spatial_autocorr", "ripley", "ligrec", "PermutationTest", "spatial_neighbors",
-           "spatial_neighbors_knn", "spatial_neighbors_delaunay", "spatial_neighbors_radius", "spatial_neighbors_grid", "SpatialNeighborsResult"]
+           "spatial_neighbors_knn", "spatial_neighbors_delaunay", "spatial_neighbors_radius", "spatial_neighbors_grid", "spatial_neighbors_from_builder",
+           "neighbors", "SpatialNeighborsResult"]

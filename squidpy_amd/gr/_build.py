@@ -30,6 +30,7 @@ __all__ = [
     "spatial_neighbors_radius",
     "spatial_neighbors_grid",
     "spatial_neighbors_delaunay",
+    "spatial_neighbors_from_builder",
     "SpatialNeighborsResult",
 ]
 
@@ -238,6 +239,47 @@ def _run(adata: Any, spec: _Spec, *, spatial_key: str, library_key: str | None, 
     _save_data(adata, attr="obsp", key=dist_key, data=dst)
     _save_data(adata, attr="uns", key=f"{key_added}_neighbors",
                data={"connectivities_key": conn_key, "distances_key": dist_key, "params": spec.uns_params()})
+    return None
+
+
+def spatial_neighbors_from_builder(
+    data: Any,
+    builder: Any,
+    *,
+    spatial_key: str = "spatial",
+    elements_to_coordinate_systems: dict[str, str] | None = None,
+    table_key: str | None = None,
+    library_key: str | None = None,
+    key_added: str = "spatial",
+    copy: bool = False,
+    n_jobs: int = 1,
+) -> SpatialNeighborsResult | None:
+    """Create a graph from spatial coordinates using an explicit builder instance (drop-in for
+    ``squidpy.gr.spatial_neighbors_from_builder``, gr/_build.py:388-452 + `_run_spatial_neighbors` :789-849).
+
+    ``builder`` is any object with the :class:`squidpy_amd.gr.neighbors.GraphBuilder` interface — ``build(coords)``
+    returning ``(adj, dst)``, ``uns_params()`` and, for ``library_key``, ``combine(mats, ixs)``; the built-in builders of
+    :mod:`squidpy_amd.gr.neighbors` run their neighbour searches on the GPU.  ``n_jobs`` is accepted and ignored."""
+    adata = _resolve_input(data, spatial_key, elements_to_coordinate_systems, table_key)
+    coords = np.asarray(adata.obsm[spatial_key])
+    if library_key is not None:
+        _assert_categorical_obs(adata, key=library_key)
+        codes = adata.obs[library_key].cat.codes.to_numpy()
+        mats, ixs = [], []
+        for code in range(len(adata.obs[library_key].cat.categories)):
+            members = np.where(codes == code)[0]
+            mats.append(builder.build(np.ascontiguousarray(coords[members])))
+            ixs.extend(members.tolist())
+        adj, dst = builder.combine(mats, ixs)
+    else:
+        adj, dst = builder.build(coords)
+    if copy:
+        return SpatialNeighborsResult(connectivities=adj, distances=dst)
+    conn_key, dist_key = f"{key_added}_connectivities", f"{key_added}_distances"
+    _save_data(adata, attr="obsp", key=conn_key, data=adj)
+    _save_data(adata, attr="obsp", key=dist_key, data=dst)
+    _save_data(adata, attr="uns", key=f"{key_added}_neighbors",
+               data={"connectivities_key": conn_key, "distances_key": dist_key, "params": builder.uns_params()})
     return None
 
 

@@ -80,3 +80,57 @@ def test_legacy_dispatcher_delaunay_rules():
     adj, dst = O.spatial_graph(adata.obsm["spatial"], "delaunay", radius=(0.0, 8.0))
     _same(b.connectivities, adj)
     _same(b.distances, dst)
+
+
+def test_spatial_neighbors_from_builder_with_a_custom_builder():
+    """The reference's extension API (gr/neighbors.py:54-106, gr/_build.py:388-452, docs/extensibility.md): any object with
+    `build` / `uns_params` / `combine`.  A custom host-side builder (everything within distance 1.5) and the built-in
+    Delaunay builder (host-only: Qhull) through `spatial_neighbors_from_builder`, with and without `library_key`."""
+    import pandas as pd
+    import scipy.sparse as sp
+
+    import squidpy_amd as sq
+    from squidpy_amd.gr.neighbors import DelaunayBuilder, GraphBuilder, GraphBuilderCSR
+
+    class Within(GraphBuilderCSR):
+        def __init__(self, r):
+            super().__init__()
+            self.r = r
+
+        def build_graph(self, coords):
+            d = np.sqrt(((coords[:, None, :] - coords[None, :, :]) ** 2).sum(-1))
+            adj = sp.csr_matrix(((d <= self.r) & (d > 0)).astype(np.float32))
+            return adj, sp.csr_matrix(adj.multiply(d))
+
+        def uns_params(self):
+            return {"coord_type": "generic", "radius": self.r, "transform": None}
+
+    rng = np.random.default_rng(0)
+    xy = np.stack(np.meshgrid(np.arange(6.0), np.arange(5.0)), -1).reshape(-1, 2)
+    obs = pd.DataFrame({"lib": pd.Categorical(rng.integers(0, 2, len(xy)).astype(str))})
+    adata = sq.AnnDataLite(obs=obs, obsm={"spatial": xy})
+    res = sq.gr.spatial_neighbors_from_builder(adata, Within(1.5), copy=True)
+    assert res.connectivities.shape == (30, 30) and res.connectivities[0].nnz == 3  # corner: right, up, diagonal
+    sq.gr.spatial_neighbors_from_builder(adata, Within(1.5), key_added="near")
+    assert adata.uns["near_neighbors"]["params"]["radius"] == 1.5 and "near_connectivities" in adata.obsp
+    # libraries: block-diagonal, no edge between libraries, observation order restored
+    lib = sq.gr.spatial_neighbors_from_builder(adata, Within(1.5), library_key="lib", copy=True).connectivities.tocoo()
+    codes = obs["lib"].cat.codes.to_numpy()
+    assert (codes[lib.row] == codes[lib.col]).all() and lib.nnz > 0
+    same = res.connectivities.tocoo()
+    keep = codes[same.row] == codes[same.col]
+    assert lib.nnz == int(keep.sum())
+    # a builder without `combine` cannot do libraries
+    class NoCombine(GraphBuilder):
+        def build_graph(self, coords):
+            return sp.identity(len(coords), format="csr"), sp.identity(len(coords), format="csr")
+
+        def uns_params(self):
+            return {}
+
+    with pytest.raises(NotImplementedError, match="library_key"):
+        sq.gr.spatial_neighbors_from_builder(adata, NoCombine(), library_key="lib", copy=True)
+    # the built-in Delaunay builder == the function that wraps it
+    a = sq.gr.spatial_neighbors_from_builder(adata, DelaunayBuilder(radius=3.0), copy=True)
+    b = sq.gr.spatial_neighbors_delaunay(adata, radius=3.0, copy=True)
+    assert (a.connectivities != b.connectivities).nnz == 0 and (a.distances != b.distances).nnz == 0
