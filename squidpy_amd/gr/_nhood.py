@@ -14,7 +14,7 @@ import pandas as pd
 
 from .. import _dist
 from .._constants import Key
-from .._lib import Context, Graph, NhoodPlan, default_context, interaction_matrix as _intmat, nhood_counts, nhood_counts_batch
+from .._lib import Context, Graph, NhoodPlan, cached_graph, default_context, interaction_matrix as _intmat, nhood_counts, nhood_counts_batch
 from .._utils import (
     _assert_categorical_obs,
     _assert_connectivity_key,
@@ -126,54 +126,51 @@ def nhood_enrichment(
     get_n_processes(n_jobs)
 
     ctx = default_context(device)
-    graph = Graph(ctx, adj, with_data=False)
-    try:
-        count = nhood_counts(ctx, graph, int_clust, n_cls)
-        if n_cls > MAX_DEVICE_SHUFFLE_CLUSTERS or (n_cls > 256 and rng == "numpy" and lib_codes is not None):
-            # (numpy streams + libraries + more than 256 clusters: per-library sub-shuffles of 16-bit labels are not on the device)
-            zscore = _zscore_many_clusters(ctx, graph, int_clust, n_cls, lib_codes, n_libs, seed, n_perms, count)
-        elif rng == "numpy-host":
-            zscore = _zscore_numpy_streams(ctx, graph, int_clust, n_cls, lib_codes, n_libs, seed, n_perms, count)
-        elif rng == "numpy":
-            rank, world = _dist.world()
-            lo, hi = _dist.shard_range(n_perms, rank, world)
-            if seed is None:
-                seed = _broadcast_seed(resolve_seed(None))
-            comm = _device_comm(ctx)
-            plan = NhoodPlan(ctx, graph, int_clust, n_cls, lib_codes, n_libs)
-            try:
-                if world == 1 or comm is not None:
-                    # the float64 mean/std of gr/_nhood.py:231 formed on the device, bit for bit; with several ranks each
-                    # runs its contiguous chunk of the streams and the per-permutation counts are all-gathered by RCCL
-                    plan.set_comm(comm)
-                    mean, std = plan.run_pcg64_stats(pcg64_states(seed, n_perms))
-                    perms = None
-                else:
-                    _, _, perms = plan.run_pcg64(pcg64_states(seed, n_perms, lo, hi), return_perms=True)
-            finally:
-                plan.close()
-            if perms is not None:  # host side channel only (ranks sharing a GPU): numpy reduces the gathered counts
-                perms = np.concatenate(_dist.allgather_object(perms), axis=0).astype(np.float64)
-                mean, std = perms.mean(axis=0), perms.std(axis=0)
-            with np.errstate(divide="ignore", invalid="ignore"):
-                zscore = (count - mean) / std  # gr/_nhood.py:231
-        else:
-            rank, world = _dist.world()
-            lo, hi = _dist.shard_range(n_perms, rank, world)
-            shift = expected_counts(int_clust, n_cls, graph.nnz)
-            comm = _device_comm(ctx)
-            plan = NhoodPlan(ctx, graph, int_clust, n_cls, lib_codes, n_libs)
-            try:
-                key = _broadcast_seed(resolve_seed(seed))
-                plan.set_comm(comm)  # the exact integer moments are all-reduced on the device (RCCL inside libsqgr)
-                s1, s2, _ = plan.run(key, lo, hi, shift)
-            finally:
-                plan.close()
-            if comm is None:
-                s1, s2 = _dist.allreduce_sum_([s1, s2])
-            zscore = zscore_from_moments(count, shift, s1, s2, n_perms)
-    finally:
-        graph.close()
+    graph = cached_graph(ctx, adj, with_data=False)  # stays resident for the next statistic on the same matrix
+    count = nhood_counts(ctx, graph, int_clust, n_cls)
+    if n_cls > MAX_DEVICE_SHUFFLE_CLUSTERS or (n_cls > 256 and rng == "numpy" and lib_codes is not None):
+        # (numpy streams + libraries + more than 256 clusters: per-library sub-shuffles of 16-bit labels are not on the device)
+        zscore = _zscore_many_clusters(ctx, graph, int_clust, n_cls, lib_codes, n_libs, seed, n_perms, count)
+    elif rng == "numpy-host":
+        zscore = _zscore_numpy_streams(ctx, graph, int_clust, n_cls, lib_codes, n_libs, seed, n_perms, count)
+    elif rng == "numpy":
+        rank, world = _dist.world()
+        lo, hi = _dist.shard_range(n_perms, rank, world)
+        if seed is None:
+            seed = _broadcast_seed(resolve_seed(None))
+        comm = _device_comm(ctx)
+        plan = NhoodPlan(ctx, graph, int_clust, n_cls, lib_codes, n_libs)
+        try:
+            if world == 1 or comm is not None:
+                # the float64 mean/std of gr/_nhood.py:231 formed on the device, bit for bit; with several ranks each
+                # runs its contiguous chunk of the streams and the per-permutation counts are all-gathered by RCCL
+                plan.set_comm(comm)
+                mean, std = plan.run_pcg64_stats(pcg64_states(seed, n_perms))
+                perms = None
+            else:
+                _, _, perms = plan.run_pcg64(pcg64_states(seed, n_perms, lo, hi), return_perms=True)
+        finally:
+            plan.close()
+        if perms is not None:  # host side channel only (ranks sharing a GPU): numpy reduces the gathered counts
+            perms = np.concatenate(_dist.allgather_object(perms), axis=0).astype(np.float64)
+            mean, std = perms.mean(axis=0), perms.std(axis=0)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            zscore = (count - mean) / std  # gr/_nhood.py:231
+    else:
+        rank, world = _dist.world()
+        lo, hi = _dist.shard_range(n_perms, rank, world)
+        shift = expected_counts(int_clust, n_cls, graph.nnz)
+        comm = _device_comm(ctx)
+        plan = NhoodPlan(ctx, graph, int_clust, n_cls, lib_codes, n_libs)
+        try:
+            key = _broadcast_seed(resolve_seed(seed))
+            plan.set_comm(comm)  # the exact integer moments are all-reduced on the device (RCCL inside libsqgr)
+            s1, s2, _ = plan.run(key, lo, hi, shift)
+        finally:
+            plan.close()
+        if comm is None:
+            s1, s2 = _dist.allreduce_sum_([s1, s2])
+        zscore = zscore_from_moments(count, shift, s1, s2, n_perms)
 
     if copy:
         return NhoodEnrichmentResult(zscore=zscore, counts=count)
@@ -303,11 +300,7 @@ def interaction_matrix(
     is_int = pd.api.types.is_bool_dtype(g.dtype) or pd.api.types.is_integer_dtype(g.dtype)
 
     ctx = default_context(device)
-    graph = Graph(ctx, g, with_data=weights)
-    try:
-        out = _intmat(ctx, graph, codes, n_cats, weights)
-    finally:
-        graph.close()
+    out = _intmat(ctx, cached_graph(ctx, g, with_data=weights), codes, n_cats, weights)
     output = out.astype(int) if is_int else out
     if normalized:
         with np.errstate(divide="ignore", invalid="ignore"):

@@ -17,7 +17,7 @@ import pandas as pd
 from scipy import sparse
 
 from .._constants import SpatialAutocorr
-from .._lib import AutocorrPlan, DeviceMatrix, Graph, cooccur_counts, default_context
+from .._lib import AutocorrPlan, DeviceMatrix, cached_graph, cooccur_counts, default_context
 from .._stats import multipletests_pvals, p_value_calc
 from .._utils import (
     _assert_categorical_obs,
@@ -240,7 +240,7 @@ def spatial_autocorr(
     elif n_perms is not None and rng == "numpy":  # numpy's `rng.permutation(N)` streams, reproduced on the device per block
         states = pcg64_states(seed if seed is not None else key, n_perms)
 
-    graph = Graph(ctx, g, with_data=True)
+    graph = cached_graph(ctx, g, with_data=True)  # stays resident for the next call on the same (normalised) matrix
     rank, world = _dist.world()
     blocks = [(b0, min(n_feat, b0 + gene_block)) for b0 in range(0, n_feat, max(int(gene_block), 1))]
     score = np.full(n_feat, np.nan)
@@ -273,7 +273,6 @@ def spatial_autocorr(
     finally:
         if resident is not None:
             resident.close()
-        graph.close()
     if world > 1:
         score = _merge_blocks(score, blocks, world, axis=0)
         if sims is not None:

@@ -507,3 +507,33 @@ def test_numpy_streams_partial_last_batch_with_device_scope_counters(L, ctx):
         ref = O.nhood_perm_counts_numpy(A.indices, A.indptr, labels, k, 1, P)
         np.testing.assert_array_equal(perms, ref.astype(np.uint32))
         plan.close()
+
+
+def test_graph_stays_resident_between_calls_and_is_keyed_by_content(L, ctx):
+    """The statistics of one analysis read the same `adata.obsp` matrix: it is uploaded once (`_lib.cached_graph`), the cache
+    is keyed by the matrix CONTENT, so an in-place edit is never served stale."""
+    import squidpy_amd as sq
+
+    sq.clear_graph_cache()
+    adata = hex_adata(20, 30, 4, seed=3)
+    adj = adata.obsp["spatial_connectivities"]
+    lab = codes(adata, "cluster")
+    a = sq.gr.nhood_enrichment(adata, "cluster", n_perms=32, seed=1, copy=True)
+    g1 = L.cached_graph(ctx, adj, with_data=False)
+    b = sq.gr.nhood_enrichment(adata, "cluster", n_perms=32, seed=1, copy=True)
+    assert L.cached_graph(ctx, adj, with_data=False) is g1 and len(L._graph_cache) == 1
+    np.testing.assert_array_equal(a.zscore, b.zscore)
+    sq.gr.interaction_matrix(adata, "cluster", weights=True, copy=True)
+    assert len(L._graph_cache) == 2  # the weighted copy is another entry
+    # in-place edit of the matrix: drop all edges of spot 0 by pointing them at itself -> different content, fresh upload
+    edited = adj.copy()
+    edited.indices[edited.indptr[0] : edited.indptr[1]] = 0
+    adata.obsp["spatial_connectivities"] = edited
+    c = sq.gr.nhood_enrichment(adata, "cluster", n_perms=32, seed=1, copy=True)
+    np.testing.assert_array_equal(c.counts, O.nhood_counts(edited.indices, edited.indptr, lab, 4))
+    assert not np.array_equal(c.counts, a.counts) and L.cached_graph(ctx, edited, with_data=False) is not g1
+    for k in range(6):  # least recently used entries are evicted and freed
+        L.cached_graph(ctx, O.hex_grid_graph(5 + k, 7), with_data=False)
+    assert len(L._graph_cache) == L._GRAPH_CACHE_SLOTS and g1.h is None
+    sq.clear_graph_cache()
+    assert not L._graph_cache
