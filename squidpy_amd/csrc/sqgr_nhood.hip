@@ -102,7 +102,7 @@ __device__ __forceinline__ void put_label(uint32_t& word, uint32_t e, uint32_t b
 
 template <int B, bool HAS_LIBS, bool SMALLK>
 __global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __restrict__ cum, int kpad, int blk_words, int K,
-                                                 const uint32_t* __restrict__ keys, LibDom dom0, int n_libs,
+                                                 const uint32_t* __restrict__ keys, LibDom dom0, int n_libs, int nrows,
                                                  const int32_t* __restrict__ lib_of, const int32_t* __restrict__ rank_of,
                                                  const LibDom* __restrict__ libdoms, uint8_t* __restrict__ slab_all) {
     extern __shared__ uint32_t s_lds[];               // [blk_words] block table (byte offset 0), then [n_libs][kpad] boundaries
@@ -110,16 +110,24 @@ __global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __re
     for (int t = threadIdx.x; t < n_libs * kpad; t += 256) s_cum[t] = cum[t];
     for (int t = threadIdx.x; t < blk_words; t += 256) s_lds[t] = cum[n_libs * kpad + t];
     __syncthreads();
-    const int batch = blockIdx.y;
+    // A thread evaluates TWO groups of 16 permutations per spot, one in each 16-bit half of the packed registers, so the
+    // 8-round group bijection costs one packed evaluation per 32 labels: the two groups of a 32-permutation row, or the
+    // groups of two consecutive 16-permutation rows (blockIdx.y counts row pairs then).
     constexpr int NG = B / FEISTEL_GROUP;
-    const uint32_t* kg = keys + (size_t)batch * key_words_per_row(B, n_libs);  // group keys of this row
-    const uint32_t* ks = kg + (size_t)NG * n_libs * 8;                           // sigma keys
+    const int row0 = (NG == 2) ? blockIdx.y : 2 * blockIdx.y;
+    const int row1 = (NG == 2) ? row0 : min(row0 + 1, nrows - 1);  // an odd last row is paired with itself (stored once)
+    const bool store1 = (NG == 2) || row0 + 1 < nrows;
+    const size_t row_words = key_words_per_row(B, n_libs);
+    const uint32_t* kgA = keys + (size_t)row0 * row_words;                                   // group keys of group A ...
+    const uint32_t* kgB = (NG == 2) ? kgA + (size_t)n_libs * 8 : keys + (size_t)row1 * row_words;  // ... and of group B
+    const uint32_t* ksA = keys + (size_t)row0 * row_words + (size_t)NG * n_libs * 8;         // sigma keys of group A's 8 pairs
+    const uint32_t* ksB = (NG == 2) ? ksA + (size_t)(FEISTEL_GROUP / 2) * n_libs * 2
+                                    : keys + (size_t)row1 * row_words + (size_t)NG * n_libs * 8;
     const uint32_t zero = 0;
     // any label byte >= K ?  K <= 126: bytes are < 128, adding 128 - K sets bit 7 exactly for the sentinels
     const uint32_t sent_add = (uint32_t)(128 - K) * 0x01010101u;
     // grid-stride over spots (launch_shuffle_raw caps the grid)
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    uint32_t out[B / 4];
     LibDom ld = dom0;
     uint32_t x0 = (uint32_t)i, lib = 0;
     if (HAS_LIBS) {
@@ -134,23 +142,35 @@ __global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __re
     typedef __attribute__((address_space(3))) const uint32_t lds_word;
     const uint32_t blk_base = HAS_LIBS ? ld.aoff * 4u : 0u;
     auto blk_at = [&](uint32_t byte_off) { return *reinterpret_cast<lds_word*>((uintptr_t)(blk_base + byte_off)); };
-    const uint32_t a0 = x0 / dom.B, b0 = x0 - a0 * dom.B;  // one division per spot, shared by all B permutations
+    const uint32_t a0 = x0 / dom.B, b0 = x0 - a0 * dom.B;  // one division per spot, shared by all permutations
+
+    // pi_gA (low halves) and pi_gB (high halves) in one packed evaluation; cycle walk per half (rare: < 1/B of the ranks)
+    u16x2 ga = (u16x2)((unsigned short)a0), gb = (u16x2)((unsigned short)b0);
+    {
+        uint32_t kp[8];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        // pi_g: the strong bijection of the group, both packed lanes carry the same value
-        u16x2 ga[1] = {(u16x2)((unsigned short)a0)}, gb[1] = {(u16x2)((unsigned short)b0)};
-        const uint32_t* const pg[1] = {kg + ((size_t)g * n_libs + lib) * 8};  // uniform when !HAS_LIBS
+        for (int r = 0; r < 8; ++r) kp[r] = (kgA[(size_t)lib * 8 + r] & 0xFFFFu) | (kgB[(size_t)lib * 8 + r] & 0xFFFF0000u);
+        const uint32_t* const pg[1] = {kp};
+        bool need0 = true, need1 = true;
         do {
-            feistel_rounds<1>(ga, gb, dom, pg);
-        } while (__umul24((uint32_t)ga[0].x, dom.B) + (uint32_t)gb[0].x >= dom.n);  // cycle walk (rare: < 1/B of the ranks)
+            u16x2 na[1] = {ga}, nb[1] = {gb};
+            feistel_rounds<1>(na, nb, dom, pg);
+            if (need0) { ga.x = na[0].x; gb.x = nb[0].x; }
+            if (need1) { ga.y = na[0].y; gb.y = nb[0].y; }
+            need0 = __umul24((uint32_t)ga.x, dom.B) + (uint32_t)gb.x >= dom.n;
+            need1 = __umul24((uint32_t)ga.y, dom.B) + (uint32_t)gb.y >= dom.n;
+        } while (need0 | need1);
+    }
+    // the 16 labels of one group: sigma_p on the group's image (in both halves), two permutations per packed evaluation
+    auto emit_group = [&](const u16x2 gsa, const u16x2 gsb, const uint32_t* ks, uint32_t (&out)[4]) {
 #pragma unroll
         for (int w = 0; w < FEISTEL_GROUP / 4; ++w) {
             uint32_t word = 0;
             uint32_t apk[2], bpk[2];  // sigma images of the word's two pairs (kept for the exact route)
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {  // two permutations per evaluation (packed 16-bit lanes)
-                const uint32_t* const pk[1] = {ks + ((size_t)(g * (FEISTEL_GROUP / 2) + w * 2 + jj) * n_libs + lib) * 2};
-                u16x2 a[1] = {ga[0]}, b[1] = {gb[0]};
+            for (int jj = 0; jj < 2; ++jj) {
+                const uint32_t* const pk[1] = {ks + ((size_t)(w * 2 + jj) * n_libs + lib) * 2};
+                u16x2 a[1] = {gsa}, b[1] = {gsb};
                 sigma_rounds<1>(a, b, dom, pk);
                 apk[jj] = __builtin_bit_cast(uint32_t, a[0]);
                 bpk[jj] = __builtin_bit_cast(uint32_t, b[0]);
@@ -177,7 +197,7 @@ __global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __re
                 for (int j = 0; j < 4; ++j) {
                     if (K <= 255 && ((word >> (8 * j)) & 0xFFu) < (uint32_t)K) continue;
                     const int jj = j >> 1, sh = (j & 1) * 16;
-                    const uint32_t* sk = ks + ((size_t)(g * (FEISTEL_GROUP / 2) + w * 2 + jj) * n_libs + lib) * 2;
+                    const uint32_t* sk = ks + ((size_t)(w * 2 + jj) * n_libs + lib) * 2;
                     const uint32_t k0 = (sk[0] >> sh) & 0xFFFFu, k1 = (sk[1] >> sh) & 0xFFFFu;
                     uint32_t a = (apk[jj] >> sh) & 0xFFFFu, b = (bpk[jj] >> sh) & 0xFFFFu;
                     uint32_t x = a * dom.B + b;
@@ -197,12 +217,20 @@ __global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __re
                     word = (word & ~(0xFFu << (8 * j))) | (l << (8 * j));
                 }
             }
-            out[g * (FEISTEL_GROUP / 4) + w] = word;
+            out[w] = word;
         }
+    };
+    uint32_t outA[4], outB[4];
+    emit_group((u16x2)(ga.x), (u16x2)(gb.x), ksA, outA);
+    if (store1) emit_group((u16x2)(ga.y), (u16x2)(gb.y), ksB, outB);
+    if constexpr (NG == 2) {
+        uint4* dst = reinterpret_cast<uint4*>(slab_all + ((size_t)row0 * n + i) * B);
+        dst[0] = make_uint4(outA[0], outA[1], outA[2], outA[3]);
+        dst[1] = make_uint4(outB[0], outB[1], outB[2], outB[3]);
+    } else {
+        *reinterpret_cast<uint4*>(slab_all + ((size_t)row0 * n + i) * B) = make_uint4(outA[0], outA[1], outA[2], outA[3]);
+        if (store1) *reinterpret_cast<uint4*>(slab_all + ((size_t)row1 * n + i) * B) = make_uint4(outB[0], outB[1], outB[2], outB[3]);
     }
-    uint4* dst = reinterpret_cast<uint4*>(slab_all + ((size_t)batch * n + i) * B);
-#pragma unroll
-    for (int v = 0; v < B / 16; ++v) dst[v] = make_uint4(out[4 * v], out[4 * v + 1], out[4 * v + 2], out[4 * v + 3]);
     }
 }
 
@@ -1265,8 +1293,9 @@ static int launch_shuffle_raw(sqgr_nhood* p, int B, int nb, const uint32_t* keys
         SQGR_HIP(hipGetLastError());
         return SQGR_OK;
     }
-#define SQGR_SHUFFLE(BB, LIBS, SK)                                                                                            \
-    k_shuffle<BB, LIBS, SK><<<dim3(gx, nb), 256, lds, st>>>(p->n, p->cum.p, p->kpad, p->blk_bytes, p->K, keys, p->dom0, p->n_libs, \
+    const unsigned gy = (unsigned)(B == 32 ? nb : (nb + 1) / 2);  // 16-permutation rows are shuffled in pairs
+#define SQGR_SHUFFLE(BB, LIBS, SK)                                                                                               \
+    k_shuffle<BB, LIBS, SK><<<dim3(gx, gy), 256, lds, st>>>(p->n, p->cum.p, p->kpad, p->blk_bytes, p->K, keys, p->dom0, p->n_libs, nb, \
                                                             p->lib_of.p, p->rank_of.p, p->libs.p, slab)
 #define SQGR_SHUFFLE_K(BB, LIBS) \
     if (p->K <= 126) SQGR_SHUFFLE(BB, LIBS, true); else SQGR_SHUFFLE(BB, LIBS, false)
