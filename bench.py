@@ -49,6 +49,7 @@ N_CLS = 30
 PERMS_PER_STEP = 10_000
 HBM_PEAK = 8.0e12   # B/s, MI355X_MICROARCH.md
 L2_PEAK = 34.5e12   # B/s aggregate L2 bandwidth, MI355X_MICROARCH.md §L2
+LDS_READ_PEAK = 256 * 256 * 2.4e9  # B/s: 256 B/clk/CU (ds_read_b64/b128, MI355X_MICROARCH.md §LDS) x 256 CUs x 2.4 GHz
 PROFILE_TAG = "r02"
 
 
@@ -82,6 +83,23 @@ def load_counters() -> dict:
         return d
     except Exception:
         return {}
+
+
+def load_lds_read_ceilings() -> dict:
+    """LDS read rates measured by tools/ubench_lds_read.hip on an MI355X (committed: profiles/r02_ubench_lds_read.json)."""
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_ubench_lds_read.json")
+    out = {"source": os.path.relpath(path, ROOT), "random_b128_bytes_per_s": None, "linear_b128_bytes_per_s": None}
+    try:
+        with open(path) as fh:
+            rows = json.load(fh)["lds_read"]
+        for r in rows:
+            if r["pattern"].startswith("ds_read_b128 random"):
+                out["random_b128_bytes_per_s"] = r["bytes_per_s"]
+            if r["pattern"].startswith("ds_read_b128 conflict-free"):
+                out["linear_b128_bytes_per_s"] = r["bytes_per_s"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return out
 
 
 def kernel_counters(counters: dict, kernel_prefix: str, workload: dict) -> dict | None:
@@ -204,39 +222,12 @@ def cpu_baseline(adj, labels: np.ndarray, budget_s: float = 12.0) -> dict:
 
 
 # --------------------------------------------------------------------------------------------- Moran's I leg
-def moran_secondary(ctx, world: int, fence, reduce_max, steps: int, with_cpu: bool, counters: dict) -> dict:
-    """Second half of BASELINE.json's metric: Moran's I genes/sec on the C3 shape (1e5 spots, k=6 CSR graph,
-    n_perms=1000); one step = observed score + 1000 permuted scores for a resident block of 2048 genes per GPU."""
-    from sklearn.preprocessing import normalize
-
-    from squidpy_amd import _lib
-    from squidpy_amd._synthetic import hex_grid_graph
-
-    rows, cols, G, P = 250, 400, 2048, 1000
-    n = rows * cols
-    rank = int(os.environ.get("RANK", "0"))
-    g = normalize(hex_grid_graph(rows, cols), norm="l1", axis=1)
-    vals = np.random.default_rng(1 + rank).gamma(2.0, 1.0, size=(G, n))
-    graph = _lib.Graph(ctx, g, with_data=True)
-    plan = _lib.AutocorrPlan(ctx, graph, vals)  # resident from here on
-    plan.perms("moran", seed=1, perm_begin=0, perm_end=32)
-    fence()
-    ctx.timer_enable(True)
-    ctx.timer_reset()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        score = plan.scores("moran")
-        sims = plan.perms("moran", seed=7, perm_begin=i * P, perm_end=(i + 1) * P)
-    fence()
-    elapsed = reduce_max(time.perf_counter() - t0)
-    kernels = ctx.timer_report()
-    ctx.timer_enable(False)
-    assert np.isfinite(score).all() and np.isfinite(sims).all()
+def gather_roofline(kernels: dict, counters: dict, n: int, G: int, P: int, steps: int, b_gene: int) -> dict:
+    """Roofline entry of the gather kernel (k_perm_dot): fabric-bound 512-byte row gathers."""
     cnt, ms = kernels.get("autocorr_perm_dot_moran", (0, 0.0))
-    b_gene = (P + 1) * 8 * n
     gather_bps = (b_gene * G * steps / (ms * 1e-3)) if ms > 0 else None
     avg_ms = ms / max(cnt, 1)
-    pmc = kernel_counters(counters.get("moran", {}), "k_perm_dot", {"spots": n, "genes": G, "perms": P})
+    pmc = kernel_counters(counters.get("moran", {}), "k_perm_dot<", {"spots": n, "genes": G, "perms": P})
     roof = {
         "kernel": "autocorr_perm_dot_moran",
         "bound": "hbm",
@@ -267,6 +258,82 @@ def moran_secondary(ctx, world: int, fence, reduce_max, steps: int, with_cpu: bo
             roof["l2_hit_rate"] = pmc["TCC_HIT_sum"] / max(pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"], 1.0)
     if roof["achieved"] is None and gather_bps:  # no matching PMC file: price the algorithmic gather bytes against the aggregate L2 bandwidth
         roof.update({"bound": "l2_gather", "achieved": gather_bps / 1e9, "peak": L2_PEAK / 1e9, "frac": gather_bps / L2_PEAK})
+    return roof
+
+
+def moran_secondary(ctx, world: int, fence, reduce_max, steps: int, with_cpu: bool, counters: dict) -> dict:
+    """Second half of BASELINE.json's metric: Moran's I genes/sec on the C3 shape (1e5 spots, k=6 CSR graph,
+    n_perms=1000); one step = observed score + 1000 permuted scores for a resident block of 2048 genes per GPU."""
+    from sklearn.preprocessing import normalize
+
+    from squidpy_amd import _lib
+    from squidpy_amd._synthetic import hex_grid_graph
+
+    rows, cols, G, P = 250, 400, 2048, 1000
+    n = rows * cols
+    rank = int(os.environ.get("RANK", "0"))
+    g = normalize(hex_grid_graph(rows, cols), norm="l1", axis=1)
+    vals = np.random.default_rng(1 + rank).gamma(2.0, 1.0, size=(G, n))
+    graph = _lib.Graph(ctx, g, with_data=True)
+    plan = _lib.AutocorrPlan(ctx, graph, vals)  # resident from here on
+    plan.perms("moran", seed=1, perm_begin=0, perm_end=32)
+    fence()
+    ctx.timer_enable(True)
+    ctx.timer_reset()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        score = plan.scores("moran")
+        sims = plan.perms("moran", seed=7, perm_begin=i * P, perm_end=(i + 1) * P)
+    fence()
+    elapsed = reduce_max(time.perf_counter() - t0)
+    kernels = ctx.timer_report()
+    ctx.timer_enable(False)
+    assert np.isfinite(score).all() and np.isfinite(sims).all()
+    lds_cnt, lds_ms = kernels.get("autocorr_perm_dot_lds_moran", (0, 0.0))
+    cnt, ms = kernels.get("autocorr_perm_dot_moran", (0, 0.0))
+    b_gene = (P + 1) * 8 * n
+    if lds_cnt:  # the LDS-bucketed kernel (n_perms >= 512): both operands of every z*y product are read from LDS
+        avg_ms = lds_ms / lds_cnt
+        lds_bytes = 16.0 * n * P * G  # two float64 operands per (spot, permutation, gene): what the statistic needs
+        achieved = lds_bytes * lds_cnt / (lds_ms * 1e-3)
+        ceil = load_lds_read_ceilings()
+        roof = {
+            "kernel": "autocorr_perm_dot_lds_moran",
+            "bound": "lds_read",
+            "achieved": achieved / 1e9,
+            "peak": LDS_READ_PEAK / 1e9,
+            "unit": "GB/s",
+            "frac": achieved / LDS_READ_PEAK,
+            "traffic": None,
+            "launches": lds_cnt,
+            "avg_launch_ms": avg_ms,
+            "workload_key": {"spots": n, "genes": G, "perms": P},
+            "algorithmic_bytes_per_gene": b_gene,
+            "algorithmic_GBps": b_gene * G * lds_cnt / (lds_ms * 1e-3) / 1e9,
+            "list_build_ms_per_launch": kernels.get("autocorr_bucket_lists", (0, 0.0))[1] / max(lds_cnt, 1),
+            "note": "spots are cut into chunks, the pairs (i, idx_p(i)) of every permutation are bucketed by (chunk of i, chunk of idx_p(i)) once "
+            "per gene block; a workgroup keeps Z[chunk a] and Y[chunk b] of two genes in LDS and every lane walks the list of its own "
+            "permutation: two random ds_read_b128 per pair, no global gather.  `achieved` = 16 B x spots x permutations x genes / time "
+            "(padding pairs not counted) against the LDS read peak of the guide (256 B/clk/CU); random 16-byte rows conflict ~3-way inside a "
+            "16-lane group, `frac_of_pattern_ceiling` prices it against the measured rate of exactly that pattern "
+            "(tools/ubench_lds_read.hip).  HBM side: lists + chunks, `traffic` from PMC when the committed profile matches",
+        }
+        if ceil.get("random_b128_bytes_per_s"):
+            roof["pattern_ceiling_GBps"] = ceil["random_b128_bytes_per_s"] / 1e9
+            roof["frac_of_pattern_ceiling"] = achieved / ceil["random_b128_bytes_per_s"]
+            roof["ceiling_source"] = ceil["source"]
+        pmc = kernel_counters(counters.get("moran", {}), "k_perm_dot_lds<", {"spots": n, "genes": G, "perms": P})
+        if pmc and pmc.get("FETCH_SIZE_bytes") is not None and pmc.get("WRITE_SIZE_bytes") is not None:
+            roof["traffic"] = 2.0 * pmc["FETCH_SIZE_bytes"] + pmc["WRITE_SIZE_bytes"]
+            roof["traffic_source"] = counters.get("_source")
+            roof["hbm_GBps"] = roof["traffic"] / (avg_ms * 1e-3) / 1e9
+            roof["hbm_frac_of_peak"] = roof["hbm_GBps"] * 1e9 / HBM_PEAK
+            if pmc.get("TCC_HIT_sum") is not None and pmc.get("TCC_MISS_sum") is not None:
+                roof["l2_hit_rate"] = pmc["TCC_HIT_sum"] / max(pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"], 1.0)
+            if pmc.get("SQ_LDS_BANK_CONFLICT") is not None and pmc.get("SQ_LDS_IDX_ACTIVE"):
+                roof["lds_conflict_cycle_share"] = pmc["SQ_LDS_BANK_CONFLICT"] / pmc["SQ_LDS_IDX_ACTIVE"]
+    else:
+        roof = gather_roofline(kernels, counters, n, G, P, steps, b_gene)
     out = {
         "metric": "Moran's I genes/sec (1e5 spots, CSR k=6, n_perms=1000)",
         "value": steps * G * world / elapsed,

@@ -256,6 +256,304 @@ __global__ __launch_bounds__(256) void k_perm_final(const double* __restrict__ p
     sims[(size_t)p * G + g] = isconst[g] ? __builtin_nan("") : v;
 }
 
+// ================================================================================================================
+// The LDS-bucketed permutation dot (the hot kernel for n_perms >= 512): BOTH operands of z_i * y[idx_p(i)] on chip.
+//
+// The spots are cut into `nch` chunks of `m` consecutive spots; a pair (i, j = idx_p(i)) of permutation p belongs to
+// bucket (a, b) = (i / m, j / m).  A workgroup owns (gene pair, chunk a): Z[chunk a] of its two genes stays in LDS, the
+// Y chunks b = 0 .. nch-1 pass through LDS one after the other, and lane = permutation: every lane walks the list of ITS
+// permutation's pairs of bucket (a, b) and accumulates z*y in registers — two random 16-byte LDS reads per pair and two
+// genes, no global gather at all.  The lists are shared by all genes (the permutations are), so their construction
+// (k_bucket_*, ~1e8 pairs at config 3) is amortised over the gene block; they are stored [group of 64 permutations]
+// [a][b][k][lane], padded with a pair that points at a zero row of Z to the longest list of the group (a multiple of
+// LIST_UNROLL), so a wave reads 256 contiguous bytes per step and needs no tail.  Sum order: list order (ascending i)
+// inside (a, b), b ascending, then a ascending in k_perm_final_lds: fixed => bit-reproducible.
+constexpr int GP = 2;             // genes per LDS tile (one ds_read_b128 per operand)
+constexpr int LIST_UNROLL = 8;    // pairs per lane between two waits; list lengths are multiples of it
+constexpr int LDS_MAX_CHUNKS = 240;  // bucket kernels: (64 + 1) * nch counters in <= 64 KiB of LDS
+constexpr int LDS_BYTES = 160 * 1024;
+constexpr int LDS_PERM_BLOCK = 1024;  // lanes (= permutations) per workgroup
+
+// chunk length for n spots: (m+1) Z rows + m Y rows (+ m row sums for Geary) in 160 KiB
+static inline int lds_chunk(int64_t n, bool geary, int* nch_out) {
+    const int per_spot = 2 * GP * 8 + (geary ? 8 : 0);
+    int m_max = ((LDS_BYTES - GP * 8) / per_spot) & ~3;
+    if (const char* env = getenv("SQGR_AUTOCORR_LDS_CHUNK"))  // tests: several chunks on small inputs
+        m_max = std::max(8, std::min(m_max, atoi(env) & ~3));
+    const int64_t nch = ceil_div(n, m_max);
+    *nch_out = (int)nch;
+    return (int)((ceil_div(n, nch) + 3) & ~(int64_t)3);
+}
+
+// chunk of spot j (j < 2^24: exact in float; the estimate is off by at most one)
+__device__ __forceinline__ uint32_t chunk_of(uint32_t j, uint32_t m, float inv_m) {
+    uint32_t b = (uint32_t)((float)j * inv_m);
+    if (b * m > j) --b;
+    else if ((b + 1) * m <= j) ++b;
+    return b;
+}
+
+// Zp[tile2][i][c] = Zt[gene 2*tile2 + c][i]   (pair layout of the 64-gene tiles; genes past G read the tiles' zero padding)
+__global__ __launch_bounds__(256) void k_repack_pairs(const double* __restrict__ Zt, int64_t n, int64_t ntiles, int64_t G2,
+                                                      double* __restrict__ Zp) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;  // (i, gene) with gene fastest inside a 64-tile
+    const int gl = (int)(t & 63);
+    const int64_t i = (t >> 6) % n, tile = (t >> 6) / n;
+    if (tile >= ntiles) return;
+    const int64_t g = tile * GT + gl;
+    if ((g >> 1) >= G2) return;
+    Zp[((g >> 1) * n + i) * GP + (g & 1)] = Zt[t];
+}
+
+// len[pg][a][b] = longest list (over the 64 permutations of group pg) of bucket (a, b), rounded up to LIST_UNROLL.
+// grid (a, pg), one wave; lane = permutation.  Permutations >= pc have empty lists.
+__global__ __launch_bounds__(64) void k_bucket_count(const int32_t* __restrict__ idx, int64_t n, int64_t pc, int m, int nch,
+                                                     uint32_t* __restrict__ len) {
+    extern __shared__ uint32_t cnt[];  // [b][lane]
+    const int lane = threadIdx.x, a = blockIdx.x;
+    const int64_t pg = blockIdx.y, p = pg * 64 + lane;
+    for (int b = 0; b < nch; ++b) cnt[b * 64 + lane] = 0;
+    const float inv_m = 1.0f / (float)m;
+    const int64_t i0 = (int64_t)a * m, i1 = min(n, i0 + m);
+    if (p < pc) {
+        const int32_t* row = idx + (size_t)p * n;
+#pragma unroll 8
+        for (int64_t i = i0; i < i1; ++i) cnt[chunk_of((uint32_t)row[i], (uint32_t)m, inv_m) * 64 + lane] += 1;
+    }
+    for (int b = 0; b < nch; ++b) {
+        uint32_t v = cnt[b * 64 + lane];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
+        if (lane == 0) len[((size_t)pg * nch + a) * nch + b] = (v + LIST_UNROLL - 1) / LIST_UNROLL * LIST_UNROLL;
+    }
+}
+
+// off[pg][a][b] = rows (of 64 entries) in front of bucket (a, b) inside group pg's lists; total[pg] = rows of the group
+__global__ __launch_bounds__(256) void k_bucket_offsets(const uint32_t* __restrict__ len, int nb, uint32_t* __restrict__ off,
+                                                        uint32_t* __restrict__ total) {
+    __shared__ uint32_t part[256];
+    const int tid = threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * nb;
+    const int per = (nb + 255) / 256;
+    const int j0 = min(nb, tid * per), j1 = min(nb, j0 + per);
+    uint32_t s = 0;
+    for (int j = j0; j < j1; ++j) s += len[base + j];
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int t = 0; t < 256; ++t) {
+            const uint32_t v = part[t];
+            part[t] = run;
+            run += v;
+        }
+        total[blockIdx.x] = run;
+    }
+    __syncthreads();
+    uint32_t run = part[tid];
+    for (int j = j0; j < j1; ++j) {
+        off[base + j] = run;
+        run += len[base + j];
+    }
+}
+
+// base[pg] = rows in front of group pg (exclusive prefix of total), base[npg] = all rows
+__global__ void k_bucket_bases(const uint32_t* __restrict__ total, int npg, uint64_t* __restrict__ base) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint64_t run = 0;
+    for (int g = 0; g < npg; ++g) {
+        base[g] = run;
+        run += total[g];
+    }
+    base[npg] = run;
+}
+
+// lists[(base[pg] + off[pg][a][b] + k) * 64 + lane] = (i - a*m) | (idx_p(i) - b*m) << 16, pairs in ascending i; the rest of
+// the bucket's len[pg][a][b] rows = the padding pair (m, 0): row m of the Z chunk is zero.
+__global__ __launch_bounds__(64) void k_bucket_fill(const int32_t* __restrict__ idx, int64_t n, int64_t pc, int m, int nch,
+                                                    const uint32_t* __restrict__ len, const uint32_t* __restrict__ off,
+                                                    const uint64_t* __restrict__ base, uint32_t* __restrict__ lists) {
+    extern __shared__ uint32_t cur[];  // [b][lane], then the nch row offsets of this (pg, a)
+    const int lane = threadIdx.x, a = blockIdx.x;
+    const int64_t pg = blockIdx.y, p = pg * 64 + lane;
+    for (int b = 0; b < nch; ++b) cur[b * 64 + lane] = 0;
+    const float inv_m = 1.0f / (float)m;
+    const size_t bk = ((size_t)pg * nch + a) * nch;
+    uint32_t* offl = cur + nch * 64;
+    for (int b = lane; b < nch; b += 64) offl[b] = off[bk + b];
+    __syncthreads();
+    uint32_t* out = lists + (size_t)base[pg] * 64 + lane;
+    const int64_t i0 = (int64_t)a * m, i1 = min(n, i0 + m);
+    if (p < pc) {
+        const int32_t* row = idx + (size_t)p * n;
+#pragma unroll 4
+        for (int64_t i = i0; i < i1; ++i) {
+            const uint32_t j = (uint32_t)row[i], b = chunk_of(j, (uint32_t)m, inv_m);
+            const uint32_t k = cur[b * 64 + lane];
+            cur[b * 64 + lane] = k + 1;
+            out[((size_t)offl[b] + k) * 64] = (uint32_t)(i - i0) | ((j - b * (uint32_t)m) << 16);
+        }
+    }
+    const uint32_t pad = (uint32_t)m;
+    for (int b = 0; b < nch; ++b) {
+        const uint32_t l = len[bk + b];
+        for (uint32_t k = cur[b * 64 + lane]; k < l; ++k) out[((size_t)offl[b] + k) * 64] = pad;
+    }
+}
+
+// grid (ceil(G2 / 256) * 256 * nch, perm blocks); block = 64 * (groups in a perm block) lanes, lane = permutation.
+// Block -> (gene pair, chunk a) with XCD affinity: hardware places block b on XCD (b % 8); the 32 workgroups an XCD runs
+// side by side own 32 different gene pairs and the SAME chunk a, so they walk the same lists in step and the lists
+// (shared by all genes) are served by that XCD's L2 — only the Y chunks are private traffic.
+// part1[((tile2 * pc + p) * nch + a) * 2 + c]
+constexpr int LDS_STAGE = 5;  // rows per thread of one chunk at LDS_PERM_BLOCK threads (m <= 5 * 1024)
+template <bool GEARY>
+__global__ __launch_bounds__(LDS_PERM_BLOCK) void k_perm_dot_lds(const double* __restrict__ Zp, const double* __restrict__ Yp,
+                                                                 const double* __restrict__ rowsum, int64_t n, int64_t pc, int npg,
+                                                                 int64_t G2, int m, int nch, const uint32_t* __restrict__ len,
+                                                                 const uint32_t* __restrict__ off, const uint64_t* __restrict__ base,
+                                                                 const uint32_t* __restrict__ lists, double* __restrict__ part1,
+                                                                 double* __restrict__ part2) {
+    constexpr int UNR = GEARY ? LIST_UNROLL / 2 : LIST_UNROLL;  // pairs per lane between two waits (register budget: 128)
+    extern __shared__ double2 smem2[];
+    double2* Zc = smem2;            // [m + 1] rows (z of gene 0, z of gene 1); row m = 0
+    double2* Yc = smem2 + (m + 1);  // [m]
+    double* Rc = reinterpret_cast<double*>(Yc + m);  // [m] row sums (Geary)
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    int a;
+    int64_t tile2;
+    {
+        const uint32_t bid = blockIdx.x, x = bid & 7, k = bid >> 3, slot = k & 31, group = k >> 5;
+        a = (int)(group % (uint32_t)nch);
+        tile2 = (int64_t)(group / (uint32_t)nch) * 256 + x * 32 + slot;
+    }
+    if (tile2 >= G2) return;  // whole workgroup
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pg_raw = (int)blockIdx.y * (LDS_PERM_BLOCK / 64) + wave;
+    const bool live = pg_raw < npg;  // waves past the last group only help with the chunk loads
+    const int pg = live ? pg_raw : 0;
+    const int64_t p = live ? (int64_t)pg * 64 + (tid & 63) : pc;
+    const double2* Zg = reinterpret_cast<const double2*>(Zp) + (size_t)tile2 * n;
+    const double2* Yg = reinterpret_cast<const double2*>(Yp) + (size_t)tile2 * n;
+    const bool staged = nthr * LDS_STAGE >= m;  // block-uniform: a whole chunk fits the threads' staging registers
+    double2 sy[LDS_STAGE];
+    double sr[LDS_STAGE];
+#pragma unroll
+    for (int u = 0; u < LDS_STAGE; ++u) {
+        sy[u] = make_double2(0.0, 0.0);
+        sr[u] = 0.0;
+    }
+    auto fetch = [&](int b) {  // chunk b of Y (and of the row sums) -> registers
+        const int64_t j0 = (int64_t)b * m;
+        const int mb = (int)min((int64_t)m, n - j0);
+#pragma unroll
+        for (int u = 0; u < LDS_STAGE; ++u) {
+            const int t = tid + u * nthr;
+            if (t < mb) {
+                sy[u] = Yg[j0 + t];
+                if (GEARY) sr[u] = rowsum[j0 + t];
+            }
+        }
+    };
+    auto commit = [&](int b) {  // registers -> LDS
+        const int mb = (int)min((int64_t)m, n - (int64_t)b * m);
+#pragma unroll
+        for (int u = 0; u < LDS_STAGE; ++u) {
+            const int t = tid + u * nthr;
+            if (t < mb) {
+                Yc[t] = sy[u];
+                if (GEARY) Rc[t] = sr[u];
+            }
+        }
+    };
+    {
+        const int64_t i0 = (int64_t)a * m;
+        const int ma = (int)min((int64_t)m, n - i0);
+        for (int t = tid; t < ma; t += nthr) Zc[t] = Zg[i0 + t];
+        if (tid == 0) Zc[m] = make_double2(0.0, 0.0);
+    }
+    if (staged) fetch(0);
+    const size_t bk = ((size_t)pg * nch + a) * nch;
+    const uint32_t* lst = lists + (size_t)base[pg] * 64 + (tid & 63);
+    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+    for (int b = 0; b < nch; ++b) {
+        __syncthreads();  // the previous Y chunk is no longer read (first pass: nothing to wait for but the Z stores)
+        if (staged) {
+            commit(b);
+        } else {
+            const int64_t j0 = (int64_t)b * m;
+            const int mb = (int)min((int64_t)m, n - j0);
+            for (int t = tid; t < mb; t += nthr) {
+                Yc[t] = Yg[j0 + t];
+                if (GEARY) Rc[t] = rowsum[j0 + t];
+            }
+        }
+        __syncthreads();
+        if (staged && b + 1 < nch) fetch(b + 1);  // in flight while this chunk is consumed
+        const uint32_t L = live ? (uint32_t)__builtin_amdgcn_readfirstlane((int)len[bk + b]) : 0u;
+        const uint32_t* q = lst + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)off[bk + b]) * 64;
+        uint32_t code[UNR];
+        if (L > 0) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) code[u] = q[u * 64];
+        }
+        for (uint32_t k = 0; k < L; k += UNR) {
+            uint32_t cur[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) cur[u] = code[u];
+            q += UNR * 64;
+            if (k + UNR < L) {  // the next rows are in flight while these are consumed
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) code[u] = q[u * 64];
+            }
+            double2 z[UNR], y[UNR];
+            double r[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                z[u] = Zc[cur[u] & 0xffffu];
+                y[u] = Yc[cur[u] >> 16];
+                if (GEARY) r[u] = Rc[cur[u] >> 16];
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                a0 = fma(z[u].x, y[u].x, a0);
+                a1 = fma(z[u].y, y[u].y, a1);
+                if (GEARY) {
+                    b0 = fma(z[u].x * z[u].x, r[u], b0);
+                    b1 = fma(z[u].y * z[u].y, r[u], b1);
+                }
+            }
+        }
+    }
+    if (p < pc) {
+        const size_t o = (((size_t)tile2 * pc + p) * nch + a) * GP;
+        *reinterpret_cast<double2*>(part1 + o) = make_double2(a0, a1);
+        if (GEARY) *reinterpret_cast<double2*>(part2 + o) = make_double2(b0, b1);
+    }
+}
+
+template <bool GEARY>
+__global__ __launch_bounds__(256) void k_perm_final_lds(const double* __restrict__ part1, const double* __restrict__ part2, int nch,
+                                                        int64_t pc, int64_t G, int64_t n, double W, const double* __restrict__ z2ss,
+                                                        const double* __restrict__ qsum, const uint8_t* __restrict__ isconst,
+                                                        double* __restrict__ sims) {
+    const int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t p = blockIdx.y;
+    if (g >= G) return;
+    const size_t o = (((size_t)(g >> 1) * pc + p) * nch) * GP + (g & 1);
+    double s1 = 0.0, s2 = 0.0;
+    for (int a = 0; a < nch; ++a) {
+        s1 += part1[o + (size_t)a * GP];
+        if (GEARY) s2 += part2[o + (size_t)a * GP];
+    }
+    double v;
+    if (GEARY)
+        v = ((double)(n - 1) * ((s2 - 2.0 * s1) + qsum[g])) / (2.0 * W * z2ss[g]);
+    else
+        v = (double)n / W * s1 / z2ss[g];
+    sims[(size_t)p * G + g] = isconst[g] ? __builtin_nan("") : v;
+}
+
 __global__ void k_scores(int mode, int64_t G, int64_t n, double W, const double* __restrict__ num, const double* __restrict__ z2ss,
                          const uint8_t* __restrict__ isconst, double* __restrict__ out) {
     int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -287,7 +585,96 @@ struct sqgr_autocorr {
     DevBuf<double> part1, part2, sims;
     PcgWorkspace pcg_ws;          // numpy-stream permutations generated in place (sqgr_autocorr_perms_pcg64)
     DevBuf<uint64_t> pcg_states;
+    // LDS-bucketed permutation dot: gene-pair layout of Z and Y, and the bucket lists of the permutations in flight
+    DevBuf<double> Zp, Yp;
+    bool pairs_ready = false;
+    DevBuf<uint32_t> b_len, b_off, b_total, lists;
+    DevBuf<uint64_t> b_base;
 };
+
+// 0: the gather kernel (k_perm_dot), 1: the LDS-bucketed kernel.  SQGR_AUTOCORR_KERNEL=gather|lds overrides the choice
+// (tests run both); the LDS kernel needs <= LDS_MAX_CHUNKS chunks and pays off with many permutations per gene block.
+static int perm_kernel_choice(int64_t n, int64_t G, int64_t P, bool geary) {
+    int nch = 0;
+    (void)lds_chunk(n, geary, &nch);
+    if (nch > LDS_MAX_CHUNKS) return 0;
+    if (const char* env = getenv("SQGR_AUTOCORR_KERNEL")) {
+        if (!strcmp(env, "lds")) return 1;
+        if (!strcmp(env, "gather")) return 0;
+    }
+    return (P >= 512 && G >= 256 && n >= 4096) ? 1 : 0;
+}
+
+// permutation scores of the pc permutations whose indices are in h->idx, through the LDS-bucketed kernel -> h->sims
+static int perms_pass_lds(sqgr_autocorr* h, int32_t mode, int64_t pc) {
+    sqgr_ctx* ctx = h->ctx;
+    hipStream_t st = ctx->stream;
+    const int64_t n = h->n, G = h->G, G2 = (G + 1) / 2;
+    const bool geary = mode == 1;
+    int nch = 0;
+    const int m = lds_chunk(n, geary, &nch);
+    const int npg = (int)ceil_div(pc, 64);
+    const int nb = nch * nch;
+    if (!h->pairs_ready) {
+        SQGR_TRY(h->Zp.ensure((size_t)G2 * n * GP));
+        SQGR_TRY(h->Yp.ensure((size_t)G2 * n * GP));
+        LaunchTimer t(ctx, "autocorr_repack");
+        const int64_t total = h->ntiles * n * GT;
+        k_repack_pairs<<<(unsigned)ceil_div(total, 256), 256, 0, st>>>(h->Zt.p, n, h->ntiles, G2, h->Zp.p);
+        k_repack_pairs<<<(unsigned)ceil_div(total, 256), 256, 0, st>>>(h->Yt.p, n, h->ntiles, G2, h->Yp.p);
+        SQGR_HIP(hipGetLastError());
+        h->pairs_ready = true;
+    }
+    SQGR_TRY(h->b_len.ensure((size_t)npg * nb));
+    SQGR_TRY(h->b_off.ensure((size_t)npg * nb));
+    SQGR_TRY(h->b_total.ensure((size_t)npg));
+    SQGR_TRY(h->b_base.ensure((size_t)npg + 1));
+    const size_t cnt_lds = (size_t)nch * 64 * sizeof(uint32_t);
+    uint64_t rows = 0;
+    {
+        LaunchTimer t(ctx, "autocorr_bucket_lists");
+        k_bucket_count<<<dim3((unsigned)nch, (unsigned)npg), 64, cnt_lds, st>>>(h->idx.p, n, pc, m, nch, h->b_len.p);
+        k_bucket_offsets<<<(unsigned)npg, 256, 0, st>>>(h->b_len.p, nb, h->b_off.p, h->b_total.p);
+        k_bucket_bases<<<1, 64, 0, st>>>(h->b_total.p, npg, h->b_base.p);
+        SQGR_HIP(hipGetLastError());
+        SQGR_HIP(hipMemcpyAsync(&rows, h->b_base.p + npg, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        SQGR_HIP(hipStreamSynchronize(st));
+        SQGR_TRY(h->lists.ensure((size_t)rows * 64));
+        k_bucket_fill<<<dim3((unsigned)nch, (unsigned)npg), 64, cnt_lds + (size_t)nch * sizeof(uint32_t), st>>>(h->idx.p, n, pc, m, nch, h->b_len.p, h->b_off.p,
+                                                                               h->b_base.p, h->lists.p);
+        SQGR_HIP(hipGetLastError());
+    }
+    SQGR_TRY(h->part1.ensure((size_t)G2 * pc * nch * GP));
+    if (geary) SQGR_TRY(h->part2.ensure((size_t)G2 * pc * nch * GP));
+    const size_t lds = ((size_t)(2 * m + 1) * GP + (geary ? (size_t)m : 0)) * sizeof(double);
+    const int threads = 64 * std::min(npg, LDS_PERM_BLOCK / 64);
+    dim3 grid((unsigned)(ceil_div(G2, 256) * 256 * nch), (unsigned)ceil_div(npg, LDS_PERM_BLOCK / 64));
+    {
+        LaunchTimer t(ctx, geary ? "autocorr_perm_dot_lds_geary" : "autocorr_perm_dot_lds_moran");
+        if (geary) {
+            if (lds > 64 * 1024)
+                SQGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_perm_dot_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            k_perm_dot_lds<true><<<grid, threads, lds, st>>>(h->Zp.p, h->Yp.p, h->rowsum.p, n, pc, npg, G2, m, nch, h->b_len.p, h->b_off.p,
+                                                              h->b_base.p, h->lists.p, h->part1.p, h->part2.p);
+        } else {
+            if (lds > 64 * 1024)
+                SQGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_perm_dot_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            k_perm_dot_lds<false><<<grid, threads, lds, st>>>(h->Zp.p, h->Yp.p, h->rowsum.p, n, pc, npg, G2, m, nch, h->b_len.p, h->b_off.p,
+                                                               h->b_base.p, h->lists.p, h->part1.p, nullptr);
+        }
+        SQGR_HIP(hipGetLastError());
+    }
+    {
+        LaunchTimer t(ctx, "autocorr_perm_final");
+        dim3 g2((unsigned)ceil_div(G, 256), (unsigned)pc);
+        if (geary)
+            k_perm_final_lds<true><<<g2, 256, 0, st>>>(h->part1.p, h->part2.p, nch, pc, G, n, h->W, h->z2ss.p, h->qsum.p, h->isconst.p, h->sims.p);
+        else
+            k_perm_final_lds<false><<<g2, 256, 0, st>>>(h->part1.p, nullptr, nch, pc, G, n, h->W, h->z2ss.p, h->qsum.p, h->isconst.p, h->sims.p);
+        SQGR_HIP(hipGetLastError());
+    }
+    return SQGR_OK;
+}
 
 static int column_sum(sqgr_autocorr* h, int mode, const double* A, const double* B, double* out_dev) {
     sqgr_ctx* ctx = h->ctx;
@@ -488,11 +875,20 @@ static int autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_id
     if (const char* env_r = getenv("SQGR_AUTOCORR_ROW_CHUNKS")) R = std::max(1, atoi(env_r));  // tuning knob
     R = (int)std::min<int64_t>(R, std::max<int64_t>(1, n / 256));
     const int64_t by_idx = std::max<int64_t>(PERM_TILE, ((int64_t)1 << 30) / (n * 4));
-    const int64_t by_part = std::max<int64_t>(PERM_TILE, ((int64_t)1 << 30) / ((int64_t)h->ntiles * R * GT * 8));
-    const int64_t chunk = std::min<int64_t>(std::min<int64_t>(P, 32768), std::min(by_idx, by_part));  // grid.y limit
+    const bool use_lds = perm_kernel_choice(n, G, P, mode == 1) == 1;
+    int64_t by_part = std::max<int64_t>(PERM_TILE, ((int64_t)1 << 30) / ((int64_t)h->ntiles * R * GT * 8));
+    if (use_lds) {
+        int nch = 0;
+        (void)lds_chunk(n, mode == 1, &nch);
+        by_part = std::max<int64_t>(64, ((int64_t)1 << 30) / (((G + 1) / 2) * nch * GP * 8));
+    }
+    int64_t chunk = std::min<int64_t>(std::min<int64_t>(P, 32768), std::min(by_idx, by_part));  // grid.y limit
+    if (use_lds && chunk > LDS_PERM_BLOCK) chunk = chunk / LDS_PERM_BLOCK * LDS_PERM_BLOCK;  // whole workgroups of permutations
     SQGR_TRY(h->idx.ensure((size_t)chunk * n));
-    SQGR_TRY(h->part1.ensure((size_t)h->ntiles * chunk * R * GT));
-    if (mode == 1) SQGR_TRY(h->part2.ensure((size_t)h->ntiles * chunk * R * GT));
+    if (!use_lds) {
+        SQGR_TRY(h->part1.ensure((size_t)h->ntiles * chunk * R * GT));
+        if (mode == 1) SQGR_TRY(h->part2.ensure((size_t)h->ntiles * chunk * R * GT));
+    }
     SQGR_TRY(h->sims.ensure((size_t)chunk * G));
     if (pcg_states) SQGR_TRY(h->pcg_states.ensure((size_t)chunk * 4));
     if (perm_idx)
@@ -510,6 +906,12 @@ static int autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_id
             LaunchTimer t(ctx, "autocorr_perm_indices");
             k_perm_indices<<<dim3((unsigned)ceil_div(n, 256), (unsigned)pc), 256, 0, st>>>(seed, perm_begin + c0, n, dom, h->idx.p);
             SQGR_HIP(hipGetLastError());
+        }
+        if (use_lds) {
+            SQGR_TRY(perms_pass_lds(h, mode, pc));
+            SQGR_HIP(hipMemcpyAsync(out_sims + (size_t)c0 * G, h->sims.p, (size_t)pc * G * 8, hipMemcpyDeviceToHost, st));
+            SQGR_HIP(hipStreamSynchronize(st));
+            continue;
         }
         dim3 grid((unsigned)ceil_div(pc, PERM_TILE), (unsigned)R, (unsigned)h->ntiles);
         {

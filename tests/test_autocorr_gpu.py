@@ -17,6 +17,17 @@ pytestmark = pytest.mark.gpu
 RTOL, ATOL = 1e-6, 1e-12
 
 
+@pytest.fixture(autouse=True, params=["gather", "lds", "lds-small-chunks"])
+def perm_kernel(request, monkeypatch):
+    """Every test of this module runs through both permutation kernels of csrc/sqgr_autocorr.hip: the gather-dot
+    (k_perm_dot) and the LDS-bucketed dot (k_perm_dot_lds), the latter also with 64-spot chunks so that small inputs are
+    cut into many (a, b) buckets.  The library reads the variables at every call."""
+    monkeypatch.setenv("SQGR_AUTOCORR_KERNEL", "gather" if request.param == "gather" else "lds")
+    if request.param == "lds-small-chunks":
+        monkeypatch.setenv("SQGR_AUTOCORR_LDS_CHUNK", "64")
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def L():
     from squidpy_amd import _lib
@@ -80,6 +91,38 @@ def test_vs_oracle_various_shapes(L, ctx, mode, n, G):
     np.testing.assert_allclose(dev, O.score_perms(mode, g, vals, idx), rtol=RTOL, atol=ATOL)
     two = np.concatenate([plan.perms(mode, seed=9, perm_begin=0, perm_end=8), plan.perms(mode, seed=9, perm_begin=8, perm_end=21)])
     np.testing.assert_array_equal(two, dev)
+
+
+@pytest.mark.parametrize("mode", ["moran", "geary"])
+def test_lds_kernel_full_workgroups(L, ctx, mode, perm_kernel):
+    """More than 1024 permutations (two permutation blocks, the second with one live wave), three full-size chunks, an odd
+    number of features: the LDS-bucketed kernel's staged chunk loads and its list padding against the oracle."""
+    if perm_kernel != "lds":
+        pytest.skip("default chunking of the LDS kernel only")
+    rng = np.random.default_rng(5)
+    n, G, P = 12001, 67, 1030
+    xy = rng.random((n, 2))
+    g = knn_graph(xy, 6)
+    g.data = rng.random(g.nnz).astype(np.float32) + 0.1
+    vals = rng.gamma(2.0, 1.0, size=(G, n))
+    vals[1] += 2 * np.sin(xy[:, 1] * 5)
+    vals[4] = -2.0
+    graph = L.Graph(ctx, g)
+    plan = L.AutocorrPlan(ctx, graph, vals)
+    dev = plan.perms(mode, seed=3, perm_begin=2, perm_end=2 + P)
+    assert dev.shape == (P, G) and np.isnan(dev[:, 4]).all()
+    sel_p = [0, 1, 63, 64, 511, 1023, 1024, 1029]
+    idx = np.stack([devrng.autocorr_permutation(n, 3, 2 + p) for p in sel_p])
+    np.testing.assert_allclose(dev[sel_p], O.score_perms(mode, g, vals, idx), rtol=RTOL, atol=ATOL)
+    # the gather kernel on the same permutations: two independent summation orders of the same sums
+    import os
+
+    os.environ["SQGR_AUTOCORR_KERNEL"] = "gather"
+    try:
+        ref = plan.perms(mode, seed=3, perm_begin=2, perm_end=2 + P)
+    finally:
+        os.environ["SQGR_AUTOCORR_KERNEL"] = "lds"
+    np.testing.assert_allclose(dev, ref, rtol=1e-9, atol=1e-13)
 
 
 def _adata(n=600, G=40, seed=0):

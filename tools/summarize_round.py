@@ -64,7 +64,7 @@ rep = {
     "from KiB to bytes, FETCH_SIZE NOT yet doubled (bench.py applies the gfx950 correction of MI355X_MICROARCH.md §HBM)",
     "command": pmc_cmd,
     "nhood": {"workload": (pmc_bench or {}).get("roofline", {}).get("workload_key"), "kernels": section(lambda k: "k_count" in k or "k_shuffle" in k or "k_reduce" in k or "k_keygen" in k or "k_finalize" in k)},
-    "moran": {"workload": ((pmc_bench or {}).get("secondary") or {}).get("roofline", {}).get("workload_key"), "kernels": section(lambda k: "k_perm_dot" in k or "k_spmv" in k or "k_perm_ind" in k)},
+    "moran": {"workload": ((pmc_bench or {}).get("secondary") or {}).get("roofline", {}).get("workload_key"), "kernels": section(lambda k: "k_perm_dot" in k or "k_spmv" in k or "k_perm_ind" in k or "k_bucket" in k)},
 }
 json.dump(rep, open(os.path.join(out, f"{tag}_counters.json"), "w"), indent=1)
 print(json.dumps(rep["nhood"], indent=1)[:3000])
