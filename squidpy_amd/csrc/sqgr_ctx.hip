@@ -3,6 +3,8 @@
 
 #include <cstdlib>
 
+#include <hipcub/hipcub.hpp>
+
 namespace sqgr {
 
 static thread_local char g_err[1024] = "";
@@ -143,9 +145,47 @@ __global__ __launch_bounds__(HALF_TILE) void k_half_scatter(const int2* __restri
     if (self) out[(size_t)n_lt + o_self + (uint32_t)__popcll(m_self & below)] = rc;
 }
 
+// key of a list entry (16 * row, 16 * col): (row block, column block) of 2^sh spots
+__global__ __launch_bounds__(256) void k_tile_keys(const int2* __restrict__ list, int64_t m, int sh, uint64_t* __restrict__ keys) {
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= m) return;
+    const int2 rc = list[e];
+    const uint64_t rb = ((uint32_t)rc.x >> 4) >> sh, cb = ((uint32_t)rc.y >> 4) >> sh;
+    keys[e] = (rb << 31) | cb;
+}
+
 }  // namespace sqgr
 
 using namespace sqgr;
+
+// Cache blocking of an edge list of the count kernel (any order gives the same integer counts): the entries are stably sorted
+// by (row block, column block) of 2^sh spots, so that consecutive entries gather label rows out of two windows of 2^sh * 16
+// bytes — a scan-line order touches every row again one grid line later, long after it left the 32 KB L1.
+// SQGR_TILE_EDGES=<sh> (0: off).
+static int tile_edge_list(sqgr_ctx* ctx, int2* list, int64_t m, int64_t n) {
+    int sh = 0;
+    if (const char* env = getenv("SQGR_TILE_EDGES")) sh = atoi(env);
+    if (sh <= 0 || m < 2) return SQGR_OK;
+    hipStream_t st = ctx->stream;
+    DevBuf<uint64_t> keys, keys_out, vals_out;
+    SQGR_TRY(keys.alloc((size_t)m));
+    SQGR_TRY(keys_out.alloc((size_t)m));
+    SQGR_TRY(vals_out.alloc((size_t)m));
+    LaunchTimer t(ctx, "graph_tile_edges");
+    k_tile_keys<<<(unsigned)ceil_div(m, 256), 256, 0, st>>>(list, m, sh, keys.p);
+    SQGR_HIP(hipGetLastError());
+    (void)n;
+    const int bits = 31;  // key = row block << 31 | column block
+    size_t tmp_bytes = 0;
+    uint64_t* vals_in = reinterpret_cast<uint64_t*>(list);
+    SQGR_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys.p, keys_out.p, vals_in, vals_out.p, (int)m, 0, 2 * bits, st));
+    DevBuf<uint8_t> tmp;
+    SQGR_TRY(tmp.alloc(tmp_bytes));
+    SQGR_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, keys.p, keys_out.p, vals_in, vals_out.p, (int)m, 0, 2 * bits, st));
+    SQGR_HIP(hipMemcpyAsync(list, vals_out.p, (size_t)m * sizeof(int2), hipMemcpyDeviceToDevice, st));
+    SQGR_HIP(hipStreamSynchronize(st));
+    return SQGR_OK;
+}
 
 int sqgr_graph::ensure_half() const {
     if (sym_state != 0) return SQGR_OK;
@@ -193,6 +233,7 @@ int sqgr_graph::ensure_half() const {
     n_half = (int64_t)h_tot[0];
     n_self = (int64_t)h_tot[1];
     sym_state = 1;
+    SQGR_TRY(tile_edge_list(ctx, half.p, n_half, n));
     return SQGR_OK;
 }
 

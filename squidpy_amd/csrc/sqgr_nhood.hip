@@ -396,7 +396,10 @@ __device__ __forceinline__ uint32_t pair_index(uint32_t la, uint32_t lb, uint32_
 // loops): half edges add 2, self loops 1 and k_reduce halves the sum — exact, every sum is even by construction.
 // List entries hold BYTE OFFSETS of the endpoints' 16-byte slab rows (16*r, 16*c) and the list is followed by
 // LIST_PAD zero entries (sqgr_ctx.hip), so the look-ahead loads below never need a clamp.
-template <int B, int MIN_WAVES, bool SELF>
+// DOT2 (B = 16): the counter address in TWO instructions per (edge, permutation): v_perm_b32 with a PER-LANE selector picks the
+// staggered label byte of both rows into the 16-bit halves (la << 16 | lb) — the selector carries the lane's rotation, so no
+// v_alignbit — and v_dot2_u32_u16 forms la * (K << 6) + lb * 64 + bank offset in one VOP3P.
+template <int B, int MIN_WAVES, bool SELF, bool DOT2 = false, int DBG = 0>  // DBG (developer probes, bit mask): 1 no atomics, 2 no row gathers, 4 no list loads
 __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz, const int2* __restrict__ coo,
                                                                     const uint8_t* __restrict__ slab_all, int64_t n, int K,
                                                                     int hist_words, uint32_t edges_per_block,
@@ -426,6 +429,18 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
     for (int s = 0; s < BPL; ++s) bank_ofs[s] = (q * BPL + ((s + el) & (BPL - 1))) * 4;
     const uint32_t qoff = q * BPL;
     char* hist_bytes = reinterpret_cast<char*>(hist);
+    static_assert(!DOT2 || B == 16, "the dot2 address path is written for 16 permutations per pass");
+    uint32_t sel[BPL];  // DOT2: byte (s + el) & 3 of the b row -> bits 0..7, of the a row -> bits 16..23, zeros elsewhere
+#pragma unroll
+    for (int s = 0; s < BPL; ++s) sel[s] = 0x0c000c00u | ((4u + ((s + el) & 3u)) << 16) | ((s + el) & 3u);
+    const uint32_t dot_k = ((uint32_t)K << (LOGW + 16)) | (1u << LOGW);  // {hi: K << 6, lo: 64}
+    uint32_t dbg_acc = 0;
+    const uint32_t dbg_lin = (uint32_t)((((size_t)blockIdx.x * 40503u) % (size_t)(n - 4096)) * 16) + tid * 4;
+    if constexpr (DOT2) {
+        const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)hist;
+#pragma unroll
+        for (int s = 0; s < BPL; ++s) bank_ofs[s] += lds_base;
+    }
 
     // A quad of lanes shares U = 4 consecutive edges per iteration; lane q owns the B/4 permutations [q*B/4, (q+1)*B/4) of
     // each.  Lane q loads the offset pair of edge eb + q with ONE 8-byte load (a wave reads 64 consecutive pairs: one
@@ -437,14 +452,22 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
     // offset pairs of iteration k+2 are in flight (every load gets a full processing phase of slack).
     constexpr int U = 4;
     constexpr uint32_t STEP = (COUNT_THREADS / 4) * U;
-    static_assert(2 * STEP + U <= LIST_PAD, "look-ahead exceeds the padding of the edge lists");
+    static_assert(6 * STEP + U <= LIST_PAD, "look-ahead exceeds the padding of the edge lists");
     using Row = typename std::conditional<B == 16, uint32_t, uint2>::type;
     // offsets of the 4 edges' label rows for THIS lane: the quad broadcast rides on the add of the lane's byte offset inside
     // the row (v_add_u32 with a DPP quad_perm source: one instruction instead of a broadcast and an add)
 #define SQGR_ADD_DPP(dst, src, sel)                                                                      \
     asm("v_add_u32_dpp %0, %1, %2 quad_perm:[" sel "] row_mask:0xf bank_mask:0xf" : "=v"(dst) : "v"(src), "v"(qoff))
     struct Pairs { uint32_t r[U], c[U]; };
-    auto load_pair = [&](uint32_t e) { return coo[e + q]; };
+    auto load_pair = [&](uint32_t e) {
+        if constexpr ((DBG & 4) != 0) {  // constant offsets: no list traffic, no extra VALU
+            int2 v = make_int2((int)(q * 64u), (int)(q * 64u + 16u));
+            asm volatile("" : "+v"(v.x), "+v"(v.y));
+            return v;
+        } else {
+            return coo[e + q];
+        }
+    };
     auto spread = [&](const int2 mine) {
         Pairs pr;
         if constexpr (B == 16) {
@@ -466,8 +489,13 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
     auto gather_rows = [&](const Pairs& pr, Row (&ra)[U], Row (&rb)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            ra[u] = *reinterpret_cast<const Row*>(slab + pr.r[u]);
-            rb[u] = *reinterpret_cast<const Row*>(slab + pr.c[u]);
+            if constexpr ((DBG & 2) != 0 && B == 16) {  // real (random) labels through COALESCED loads: the LDS pattern without the gathers
+                ra[u] = *reinterpret_cast<const Row*>(slab + dbg_lin + u * 8192);
+                rb[u] = *reinterpret_cast<const Row*>(slab + dbg_lin + u * 8192 + 4096);
+            } else {
+                ra[u] = *reinterpret_cast<const Row*>(slab + pr.r[u]);
+                rb[u] = *reinterpret_cast<const Row*>(slab + pr.c[u]);
+            }
         }
     };
     auto histogram = [&](const Row (&row_a)[U], const Row (&row_b)[U], uint32_t eb, auto general_tag) {
@@ -480,7 +508,10 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
                 if constexpr (SELF) inc += (eb + u < min(e1, self_begin)) ? 1u : 0u;
             }
             uint32_t la[2], lb[2];
-            if constexpr (B == 16) {
+            if constexpr (DOT2) {
+                la[0] = row_a[u];
+                lb[0] = row_b[u];
+            } else if constexpr (B == 16) {
                 la[0] = __builtin_amdgcn_alignbit(row_a[u], row_a[u], rot);
                 lb[0] = __builtin_amdgcn_alignbit(row_b[u], row_b[u], rot);
             } else {
@@ -491,6 +522,24 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
                 la[1] = __builtin_amdgcn_alignbit(alo, ahi, rot);
                 lb[0] = __builtin_amdgcn_alignbit(bhi, blo, rot);
                 lb[1] = __builtin_amdgcn_alignbit(blo, bhi, rot);
+            }
+            if constexpr (DOT2) {  // 4 addresses in 4 registers, then the 4 atomics back to back
+                typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+                uint32_t addr[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    addr[s] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(la[0], lb[0], sel[s])),
+                                                     __builtin_bit_cast(u16x2, dot_k), bank_ofs[s], false);
+                // (the LDS offset of the histogram is folded into bank_ofs: no per-atomic base add)
+                if constexpr ((DBG & 1) != 0) {  // keep the address arithmetic alive, drop the atomics
+                    asm volatile("" : : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]) : "memory");
+                    continue;
+                }
+                asm volatile("ds_add_u32 %0, %4\n\tds_add_u32 %1, %4\n\tds_add_u32 %2, %4\n\tds_add_u32 %3, %4"
+                             :
+                             : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(inc)
+                             : "memory");
+                continue;
             }
             auto bump = [&](auto s_tag) {
                 constexpr int s = decltype(s_tag)::value;
@@ -510,7 +559,40 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
         }
     };
     auto sweep = [&](auto general_tag) {
+        // (quad el owns the 4 consecutive list entries 4 * el .. 4 * el + 3: the four gather instructions of a stage then walk the
+        // SAME ~21 spots' rows.  Giving one instruction 16 consecutive entries instead — a quarter of the lines per instruction —
+        // measured 24 % SLOWER: the repeated touches of a line are what the L1 serves best.)
         uint32_t e = e0 + el * U;
+        if constexpr (DOT2) {
+            // Three stages deep: while iteration t-2 is histogrammed, the slab rows of iterations t-1 and t and the offset
+            // pairs of iterations t+1 and t+2 are in flight (PMC of the two-stage loop: waves parked on vmcnt for 47 % of
+            // their cycles while the LDS pipe idled a third of the time).  vmcnt retires in order and the compiler derives
+            // ONE wait per loop position from all paths into it, so (i) the offset pair a stage spreads was issued BEFORE the
+            // rows still in flight (pairs run two stages ahead of their gather), (ii) there is no prologue/epilogue code with
+            // a different issue pattern: the loop runs T + 2 stages, the first two histogram nothing, and two dummy row
+            // gathers in front of it put the same 18 loads in flight that a steady-state stage sees.
+            Row ra[3][U], rb[3][U];
+            int2 pr[3];
+            const uint32_t T = (e1 - e0 + STEP - 1) / STEP;  // block-uniform: chunks are whole iterations
+            Pairs dummy;
+#pragma unroll
+            for (int u = 0; u < U; ++u) dummy.r[u] = dummy.c[u] = qoff;
+            pr[0] = load_pair(e);
+            gather_rows(dummy, ra[1], rb[1]);
+            pr[1] = load_pair(e + STEP);
+            gather_rows(dummy, ra[2], rb[2]);
+            for (uint32_t j = 0; j < T + 2; j += 3) {
+#pragma unroll
+                for (int st = 0; st < 3; ++st) {  // stage t = j + st: buffers t % 3 = st
+                    pr[(st + 2) % 3] = load_pair(e + (st + 2) * STEP);       // pairs of iteration t + 2
+                    gather_rows(spread(pr[st]), ra[st], rb[st]);               // rows of iteration t
+                    if (j + st >= 2 && j + st - 2 < T)
+                        histogram(ra[(st + 1) % 3], rb[(st + 1) % 3], e + st * STEP - 2 * STEP, general_tag);  // iteration t - 2
+                }
+                e += 3 * STEP;
+            }
+            return;
+        }
         Row p_a[U], p_b[U], q_a[U], q_b[U];  // ping-pong row buffers: no register rotation at the end of an iteration
         gather_rows(spread(load_pair(e)), p_a, p_b);                      // rows of iteration 0
         int2 nxt = load_pair(e + STEP);                                    // pairs of iteration 1 (list padding: in bounds)
@@ -532,6 +614,7 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
         else
             sweep(std::true_type{});
     }
+    if constexpr ((DBG & 1) != 0) hist[tid] = dbg_acc;
     __syncthreads();
     uint32_t* dst = partial_all + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * hist_words;
     if (add_transposed) {  // half list: the block's contribution to count = h + h^T is formed here, out of LDS
@@ -841,7 +924,9 @@ struct sqgr_nhood {
     int blocks_for(int nb) const {
         if (nblk > 0) return nblk;
         const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
-        return (int)std::max<int64_t>(32, std::min<int64_t>(cus, ceil_div((int64_t)8 * cus, std::max(nb, 1))));
+        // rounded DOWN to a multiple of 8 (whole XCD shares): nb * blocks must not spill a few blocks into one more round of
+        // 2 blocks per CU — 49 batches x 42 blocks = 2058 blocks ran 5 rounds for 4.02 rounds of work
+        return (int)std::max<int64_t>(32, std::min<int64_t>(cus, (((int64_t)8 * cus) / std::max(nb, 1)) & ~(int64_t)7));
     }
     int nblk_launch = 0;  // blocks per batch of the launch in flight (count -> reduce)
     int sym_launch = 0;   // k_reduce mode of the launch in flight (0 full edge list, 1 half list, 2 half list with self loops)
@@ -930,6 +1015,9 @@ int sqgr_nhood::count_batches(int nb, int buf) {
         const dim3 grid(nblk, nb);
 #define SQGR_COUNT(BB, MW, SELF) \
     k_count<BB, MW, SELF><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, hw, epb, self_begin, half ? 1 : 0, partial.p)
+#define SQGR_COUNT_D(BB, MW, SELF) \
+    k_count<BB, MW, SELF, true><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, hw, epb, self_begin, half ? 1 : 0, partial.p)
+        static const bool dot2 = [] { const char* e = getenv("SQGR_COUNT_DOT2"); return !(e && atoi(e) == 0); }();
         if (B == 32) {
             LaunchTimer t(ctx, half ? "nhood_count_b32_half" : "nhood_count_b32");
             if (self) {
@@ -941,7 +1029,26 @@ int sqgr_nhood::count_batches(int nb, int buf) {
             }
         } else {
             LaunchTimer t(ctx, half ? "nhood_count_b16_half" : "nhood_count_b16");
-            if (lds * 2 <= LDS_BUDGET) {
+            static const int dbg = [] { const char* e = getenv("SQGR_COUNT_DEBUG"); return e ? atoi(e) : 0; }();
+            if (dot2 && dbg && lds * 2 <= LDS_BUDGET && !self) {
+#define SQGR_COUNT_DBG(D) \
+    case D: k_count<16, 8, false, true, D><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, hw, epb, self_begin, half ? 1 : 0, partial.p); break
+                switch (dbg) {
+                    SQGR_COUNT_DBG(1); SQGR_COUNT_DBG(2); SQGR_COUNT_DBG(3); SQGR_COUNT_DBG(4); SQGR_COUNT_DBG(5); SQGR_COUNT_DBG(6);
+                    default: k_count<16, 8, false, true, 7><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, hw, epb, self_begin, half ? 1 : 0, partial.p);
+                }
+#undef SQGR_COUNT_DBG
+            } else if (dot2) {
+                if (lds * 2 <= LDS_BUDGET) {
+                    if (self) SQGR_COUNT_D(16, 8, true); else SQGR_COUNT_D(16, 8, false);
+                } else if (self) {
+                    SQGR_TRY(allow_lds(k_count<16, 4, true, true>, lds));
+                    SQGR_COUNT_D(16, 4, true);
+                } else {
+                    SQGR_TRY(allow_lds(k_count<16, 4, false, true>, lds));
+                    SQGR_COUNT_D(16, 4, false);
+                }
+            } else if (lds * 2 <= LDS_BUDGET) {
                 if (self) SQGR_COUNT(16, 8, true); else SQGR_COUNT(16, 8, false);
             } else if (self) {
                 SQGR_TRY(allow_lds(k_count<16, 4, true>, lds));
@@ -952,6 +1059,7 @@ int sqgr_nhood::count_batches(int nb, int buf) {
             }
         }
 #undef SQGR_COUNT
+#undef SQGR_COUNT_D
     } else {
         const int e = be();
         const int64_t epb = ceil_div(nnz, nblk);

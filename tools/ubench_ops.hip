@@ -76,6 +76,14 @@
     "v_add_u32_sdwa %" #d ", %" #d ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n"
 #define OP_DPP_QUAD(d) "v_mov_b32_dpp %" #d ", %" #d " quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n"
 #define OP_DPP_ADD(d) "v_add_u32_dpp %" #d ", %" #d ", %8 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n"
+#define OP_DOT2(d) "v_dot2_u32_u16 %" #d ", %" #d ", %8, %9\n"
+#define OP_DOT4(d) "v_dot4_u32_u8 %" #d ", %" #d ", %8, %9\n"
+#define OP_CVTUB(d) "v_cvt_f32_ubyte1 %" #d ", %" #d "\n"
+#define OP_CVTU32(d) "v_cvt_u32_f32 %" #d ", %" #d "\n"
+#define OP_MADU16(d) "v_mad_u32_u16 %" #d ", %" #d ", %8, %9\n"
+#define OP_LSHL(d) "v_lshlrev_b32 %" #d ", 3, %" #d "\n"
+#define OP_OR(d) "v_or_b32 %" #d ", %" #d ", %8\n"
+#define OP_ADDLSHL(d) "v_add_lshl_u32 %" #d ", %" #d ", %8, 3\n"
 #define OP_MAD64(d) "v_mad_u64_u32 v[20:21], vcc, %" #d ", %8, v[20:21]\n"
 
 VALU_KERNEL(k_fma, OP_FMA)
@@ -112,6 +120,14 @@ VALU_KERNEL(k_sdwa_add, OP_SDWA_ADD)
 VALU_KERNEL(k_sdwa_w1, OP_SDWA_W1)
 VALU_KERNEL(k_dpp_quad, OP_DPP_QUAD)
 VALU_KERNEL(k_dpp_add, OP_DPP_ADD)
+VALU_KERNEL(k_dot2, OP_DOT2)
+VALU_KERNEL(k_dot4, OP_DOT4)
+VALU_KERNEL(k_cvtub, OP_CVTUB)
+VALU_KERNEL(k_cvtu32, OP_CVTU32)
+VALU_KERNEL(k_madu16, OP_MADU16)
+VALU_KERNEL(k_lshl, OP_LSHL)
+VALU_KERNEL(k_or, OP_OR)
+VALU_KERNEL(k_addlshl, OP_ADDLSHL)
 
 // ---- LDS rows: 16 ds_add_u32 (no return) per trip on 8 address registers; MODE selects the address pattern
 //   0: lane*4 (+ per-register offset)        conflict-free, the guide's ds_write_b32-class figure
@@ -233,6 +249,14 @@ int main(int argc, char** argv) {
     TV("v_add_u32_sdwa(WORD_1)", k_sdwa_w1);
     TV("v_mov_b32_dpp(quad_perm)", k_dpp_quad);
     TV("v_add_u32_dpp(quad_perm)", k_dpp_add);
+    TV("v_dot2_u32_u16", k_dot2);
+    TV("v_dot4_u32_u8", k_dot4);
+    TV("v_cvt_f32_ubyte1", k_cvtub);
+    TV("v_cvt_u32_f32", k_cvtu32);
+    TV("v_mad_u32_u16", k_madu16);
+    TV("v_lshlrev_b32", k_lshl);
+    TV("v_or_b32", k_or);
+    TV("v_add_lshl_u32", k_addlshl);
     const double fma_rate = rows[0].winstr_per_s;
 
     std::vector<Row> lrows;
