@@ -568,6 +568,7 @@ def main() -> None:
         z = zscore_from_moments(count, shift, tot1, tot2, total_perms)
         assert np.isfinite(z).all(), "non-finite z-score in benchmark run"
         info = plan.info()
+        cu_count = ctx.device_info().get("cu_count") or 256
         list_edges = info["list_edges"]                    # edges the count kernel walks (half list on a symmetric graph)
         per_rank_step = (P // world) if strong else P
         cnt_name = [k for k in kernels if k.startswith("nhood_count") and kernels[k][0] > 0]
@@ -622,12 +623,38 @@ def main() -> None:
             "permutations, so SURVEY §8d's algorithmic bytes (4*nnz + 4*(N+1) + N per permutation) exceed the measured traffic by "
             "`hbm.algorithmic_reuse`",
         }
+        if rec and rec.get("TCP_TOTAL_CACHE_ACCESSES_sum") is not None and avg_count_ms > 0:
+            # the measured limiter (profiles/r02_count_probes.json): the label-row gathers.  The L1 serves one cache access
+            # (64-byte granule of a gather instruction) per clock and CU (tools/ubench_gather.hip: 16 lines -> 16.05 clk)
+            acc = rec["TCP_TOTAL_CACHE_ACCESSES_sum"]
+            l1_peak = cu_count * 2.4e9
+            roof["lds_atomic"] = {k: roof[k] for k in ("achieved", "peak", "unit", "frac", "frac_of_pattern_ceiling")}
+            roof.update({
+                "bound": "l1_gather",
+                "achieved": acc / (avg_count_ms * 1e-3),
+                "peak": l1_peak,
+                "unit": "L1 cache accesses/s",
+                "frac": acc / (avg_count_ms * 1e-3) / l1_peak,
+                "l1": {"cache_accesses_per_launch": acc, "tcc_read_requests_per_launch": rec.get("TCP_TCC_READ_REQ_sum"),
+                       "l1_hit_rate": 1.0 - rec["TCP_TCC_READ_REQ_sum"] / acc if rec.get("TCP_TCC_READ_REQ_sum") is not None else None,
+                       "gather_wave_instr_per_launch": rec.get("TA_FLAT_READ_WAVEFRONTS_sum"),
+                       "td_busy_frac": rec["TD_TD_BUSY_sum"] / (cu_count * avg_count_ms * 1e-3 * 2.4e9) if rec.get("TD_TD_BUSY_sum") is not None else None,
+                       "probes": "profiles/r02_count_probes.json"},
+                "note": "the CSR gather of the permutation test.  Developer probes of this kernel (profiles/r02_count_probes.json) show what bounds "
+                "it: without the ds_add_u32 atomics it is NOT faster (0.48 vs 0.51 ms per 1024 permutations), without the label-row gathers it "
+                "runs at the LDS-atomic rate of its address pattern (0.355 ms) — the gathers of 16-byte label rows (4 lanes x 4 bytes, two rows per "
+                "edge and 16 permutations) through the vector-memory/L1 path are the limiter.  `achieved` = L1 cache accesses per launch (PMC "
+                "TCP_TOTAL_CACHE_ACCESSES) / HIP-event time against one access per clock and CU; `lds_atomic` keeps the previous figure (one "
+                "ds_add_u32 lane-operation per list edge and permutation against the measured ds_add_u32 rates); HBM is not the bound: one pass "
+                "over the edge list serves 16 permutations (`hbm.algorithmic_reuse`)",
+            })
         if rec and rec.get("SQ_INSTS_VALU") is not None:
             vi = rec["SQ_INSTS_VALU"]
             roof["valu"] = {"wave_instr_per_launch": vi, "per_atomic": vi / max(atomics_per_launch, 1.0),
                             "achieved": vi / (avg_count_ms * 1e-3), "peak": valu_mix_peak(ceil, 0.8), "unit": "wave-instr/s",
                             "frac": vi / (avg_count_ms * 1e-3) / valu_mix_peak(ceil, 0.8) if valu_mix_peak(ceil, 0.8) else None,
-                            "note": "VALU side of the same kernel (SDWA/DPP/shift-add address arithmetic, ~80 % complex class): co-limiter"}
+                            "note": "VALU side of the same kernel (v_perm_b32 + v_dot2_u32_u16 address, DPP offset spread; ~90 % complex class): "
+                            "the VALU-only skeleton of the kernel takes 0.24 ms per 1024 permutations (profiles/r02_count_probes.json)"}
         # ---- label shuffle: VALU issue
         avg_shuf_ms = ms_shuf / max(shuf_launch, 1)
         side_s, rec_s = hbm_side("k_shuffle", n * perms_per_launch, avg_shuf_ms)
@@ -674,7 +701,7 @@ def main() -> None:
                 "collective": collective,
             },
             "roofline": roof,
-            "kernels": {"nhood_shuffle": shuf, "nhood_count": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms")}, "nhood_reduce": red},
+            "kernels": {"nhood_shuffle": shuf, "nhood_count": {k: roof.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "lds_atomic")}, "nhood_reduce": red},
             "pipeline": {
                 "algorithmic_bytes_per_perm": b_perm,
                 "gpu_ms_all_kernels": gpu_ms,

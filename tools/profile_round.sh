@@ -20,5 +20,6 @@ timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $PMC
 timeout 900 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAVES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES --output-format csv -d $OUT/sqa -- $PMC > $OUT/sqa.log 2>&1
 timeout 900 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/sqb -- $PMC > $OUT/sqb.log 2>&1
 timeout 900 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/tcc -- $PMC > $OUT/tcc.log 2>&1
+timeout 900 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TD_TD_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum --output-format csv -d $OUT/tcp -- $PMC > $OUT/tcp.log 2>&1
 python $REPO/tools/summarize_round.py $OUT $TAG "$CMD" "$PMC" && cp $OUT/${TAG}_rocprofv3_summary.txt $OUT/${TAG}_counters.json $REPO/profiles/
 tail -2 $OUT/stats.log | cut -c1-600

@@ -30,7 +30,7 @@ open(os.path.join(out, f"{tag}_rocprofv3_summary.txt"), "w").write("\n".join(lin
 print("\n".join(lines))
 
 agg = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))  # kernel -> counter -> [dispatches, total]
-for sub in ("fetch", "write", "sqa", "sqb", "tcc"):
+for sub in ("fetch", "write", "sqa", "sqb", "tcc", "tcp"):
     for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             a = agg[short(r["Kernel_Name"])][r["Counter_Name"]]
