@@ -269,7 +269,8 @@ __global__ __launch_bounds__(256) void k_perm_final(const double* __restrict__ p
 // LIST_UNROLL), so a wave reads 256 contiguous bytes per step and needs no tail.  Sum order: list order (ascending i)
 // inside (a, b), b ascending, then a ascending in k_perm_final_lds: fixed => bit-reproducible.
 constexpr int GP = 2;             // genes per LDS tile (one ds_read_b128 per operand)
-constexpr int LIST_UNROLL = 8;    // pairs per lane between two waits; list lengths are multiples of it
+constexpr int LIST_UNROLL = 8;    // pairs per lane between two waits
+constexpr int LIST_ROUND = 16;    // list lengths are multiples of it (k_bucket_order schedules whole rounds of 16 classes)
 constexpr int LDS_MAX_CHUNKS = 240;  // bucket kernels: (64 + 1) * nch counters in <= 64 KiB of LDS
 constexpr int LDS_BYTES = 160 * 1024;
 constexpr int LDS_PERM_BLOCK = 1024;  // lanes (= permutations) per workgroup
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(256) void k_repack_pairs(const double* __restrict__
     Zp[((g >> 1) * n + i) * GP + (g & 1)] = Zt[t];
 }
 
-// len[pg][a][b] = longest list (over the 64 permutations of group pg) of bucket (a, b), rounded up to LIST_UNROLL.
+// len[pg][a][b] = longest list (over the 64 permutations of group pg) of bucket (a, b), rounded up to LIST_ROUND.
 // grid (a, pg), one wave; lane = permutation.  Permutations >= pc have empty lists.
 __global__ __launch_bounds__(64) void k_bucket_count(const int32_t* __restrict__ idx, int64_t n, int64_t pc, int m, int nch,
                                                      uint32_t* __restrict__ len) {
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(64) void k_bucket_count(const int32_t* __restrict__
         uint32_t v = cnt[b * 64 + lane];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
-        if (lane == 0) len[((size_t)pg * nch + a) * nch + b] = (v + LIST_UNROLL - 1) / LIST_UNROLL * LIST_UNROLL;
+        if (lane == 0) len[((size_t)pg * nch + a) * nch + b] = (v + LIST_ROUND - 1) / LIST_ROUND * LIST_ROUND;
     }
 }
 
@@ -398,6 +399,74 @@ __global__ __launch_bounds__(64) void k_bucket_fill(const int32_t* __restrict__ 
     for (int b = 0; b < nch; ++b) {
         const uint32_t l = len[bk + b];
         for (uint32_t k = cur[b * 64 + lane]; k < l; ++k) out[((size_t)offl[b] + k) * 64] = pad;
+    }
+}
+
+// Bank-aware order of every lane's list (any order of a list is valid; the sum order stays fixed by construction).
+// A `ds_read_b128` serves a wave in 4 groups of 16 lanes, one LDS cycle per group when the 16 rows fall into 16 different
+// 4-bank slots (row index mod 16); random rows collide ~3-way (tools/ubench_lds_read.hip: 11.1 instead of 4.2 clk).  Here
+// lane l' of a group reads a Z row of class (k + l') mod 16 at step k: entry j of class c goes to step ((c - l') mod 16) + 16 j;
+// classes with fewer entries than steps leave holes, which take the surplus entries of the fuller classes (in class order)
+// and then the padding pair.  Simulated: 2.85 -> 1.46 cycles per group on the Z side (the Y side stays random).
+// grid (nch * nch buckets, groups); one wave; lists longer than ORDER_MAX rows are left as they are.
+constexpr int ORDER_MAX = 320;
+// The rotation l' = (global permutation index) mod 16 — every ds_read_b128 lane group ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...,
+// MI355X_MICROARCH.md §LDS) holds each residue once — and the schedule runs over the lane's OWN length rounded up to 16, so the
+// order of a permutation's list depends on that permutation alone: results stay bit-identical however a range is split.
+__global__ __launch_bounds__(64) void k_bucket_order(int m, int nb, int64_t perm0, const uint32_t* __restrict__ len,
+                                                     const uint32_t* __restrict__ off, const uint64_t* __restrict__ base,
+                                                     uint32_t* __restrict__ lists) {
+    __shared__ uint32_t ent[ORDER_MAX * 64];   // [k][lane] the list as built (ascending i)
+    __shared__ uint16_t hole[ORDER_MAX * 64];  // [s][lane] step of the lane's s-th hole
+    __shared__ uint16_t ncls[16 * 64], rank[16 * 64], sbase[16 * 64];  // per lane and class: entries, running rank, surplus offset
+    const int lane = threadIdx.x;
+    const int64_t pg = blockIdx.y;
+    const size_t bk = (size_t)pg * nb + blockIdx.x;
+    const int L = (int)len[bk];
+    if (L == 0 || L > ORDER_MAX) return;
+    uint32_t* lst = lists + ((size_t)base[pg] + off[bk]) * 64 + lane;
+    const uint32_t pad = (uint32_t)m;
+    const int lp = (int)((perm0 + pg * 64 + lane) & 15);
+    for (int c = 0; c < 16; ++c) ncls[c * 64 + lane] = rank[c * 64 + lane] = 0;
+    int cnt = 0;
+    for (int k0 = 0; k0 < L; k0 += 16) {  // L is a multiple of LIST_ROUND = 16: sixteen loads in flight per lane
+        uint32_t e[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) e[u] = lst[(size_t)(k0 + u) * 64];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            ent[(k0 + u) * 64 + lane] = e[u];
+            if (e[u] != pad) {
+                ncls[(e[u] & 15u) * 64 + lane] += 1;
+                ++cnt;
+            }
+        }
+    }
+    const int Lo = (cnt + 15) & ~15, D = Lo >> 4;  // own length: D demands of every class
+    int surplus = 0;
+    for (int c = 0; c < 16; ++c) {
+        sbase[c * 64 + lane] = (uint16_t)surplus;
+        surplus += max(0, (int)ncls[c * 64 + lane] - D);
+    }
+    int nholes = 0;
+    for (int k = 0; k < L; ++k) {  // holes in step order; they hold the padding pair unless a surplus entry lands there
+        const int c = (k + lp) & 15;
+        if (k >= Lo || (k >> 4) >= (int)ncls[c * 64 + lane]) {
+            if (k < Lo) {
+                hole[nholes * 64 + lane] = (uint16_t)k;
+                ++nholes;
+            }
+            lst[(size_t)k * 64] = pad;
+        }
+    }
+    for (int k = 0; k < L; ++k) {
+        const uint32_t e = ent[k * 64 + lane];
+        if (e == pad) continue;
+        const int c = (int)(e & 15u);
+        const int j = rank[c * 64 + lane];
+        rank[c * 64 + lane] = (uint16_t)(j + 1);
+        const int pos = j < D ? ((c - lp) & 15) + 16 * j : (int)hole[((int)sbase[c * 64 + lane] + j - D) * 64 + lane];
+        lst[(size_t)pos * 64] = e;
     }
 }
 
@@ -588,9 +657,30 @@ struct sqgr_autocorr {
     // LDS-bucketed permutation dot: gene-pair layout of Z and Y, and the bucket lists of the permutations in flight
     DevBuf<double> Zp, Yp;
     bool pairs_ready = false;
+};
+
+// The bucket lists depend on the permutations alone: every feature block of a call (and the next call with the same seed)
+// walks the same ones, so they live in the context, keyed by what determines them.
+struct PermLists : sqgr::CtxCache {
+    // key
+    int64_t n = -1, pc = 0, perm0 = 0;
+    int m = 0, nch = 0, kind = -1;  // kind 0: device generator (seed), 1: numpy streams (states)
+    uint64_t seed = 0;
+    std::vector<uint64_t> states;
+    // lists
     DevBuf<uint32_t> b_len, b_off, b_total, lists;
     DevBuf<uint64_t> b_base;
+    bool matches(int64_t n_, int64_t pc_, int64_t perm0_, int m_, int nch_, int kind_, uint64_t seed_, const uint64_t* st_) const {
+        if (n != n_ || pc != pc_ || perm0 != perm0_ || m != m_ || nch != nch_ || kind != kind_) return false;
+        if (kind == 0) return seed == seed_;
+        return kind == 1 && st_ && states.size() == (size_t)pc_ * 4 && !memcmp(states.data(), st_, (size_t)pc_ * 32);
+    }
 };
+
+static PermLists* perm_lists(sqgr_ctx* ctx) {
+    if (!ctx->autocorr_lists) ctx->autocorr_lists = new PermLists();
+    return static_cast<PermLists*>(ctx->autocorr_lists);
+}
 
 // 0: the gather kernel (k_perm_dot), 1: the LDS-bucketed kernel.  SQGR_AUTOCORR_KERNEL=gather|lds overrides the choice
 // (tests run both); the LDS kernel needs <= LDS_MAX_CHUNKS chunks and pays off with many permutations per gene block.
@@ -605,8 +695,39 @@ static int perm_kernel_choice(int64_t n, int64_t G, int64_t P, bool geary) {
     return (P >= 512 && G >= 256 && n >= 4096) ? 1 : 0;
 }
 
-// permutation scores of the pc permutations whose indices are in h->idx, through the LDS-bucketed kernel -> h->sims
-static int perms_pass_lds(sqgr_autocorr* h, int32_t mode, int64_t pc) {
+// bucket lists of the pc permutations whose indices are in idx (the first one is permutation `perm0` of its stream) -> pl
+static int build_perm_lists(sqgr_ctx* ctx, PermLists* pl, const int32_t* idx, int64_t n, int64_t pc, int64_t perm0, int m, int nch) {
+    hipStream_t st = ctx->stream;
+    const int npg = (int)ceil_div(pc, 64);
+    const int nb = nch * nch;
+    pl->n = -1;  // invalid until complete
+    SQGR_TRY(pl->b_len.ensure((size_t)npg * nb));
+    SQGR_TRY(pl->b_off.ensure((size_t)npg * nb));
+    SQGR_TRY(pl->b_total.ensure((size_t)npg));
+    SQGR_TRY(pl->b_base.ensure((size_t)npg + 1));
+    const size_t cnt_lds = (size_t)nch * 64 * sizeof(uint32_t);
+    uint64_t rows = 0;
+    LaunchTimer t(ctx, "autocorr_bucket_lists");
+    k_bucket_count<<<dim3((unsigned)nch, (unsigned)npg), 64, cnt_lds, st>>>(idx, n, pc, m, nch, pl->b_len.p);
+    k_bucket_offsets<<<(unsigned)npg, 256, 0, st>>>(pl->b_len.p, nb, pl->b_off.p, pl->b_total.p);
+    k_bucket_bases<<<1, 64, 0, st>>>(pl->b_total.p, npg, pl->b_base.p);
+    SQGR_HIP(hipGetLastError());
+    SQGR_HIP(hipMemcpyAsync(&rows, pl->b_base.p + npg, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    SQGR_HIP(hipStreamSynchronize(st));
+    SQGR_TRY(pl->lists.ensure((size_t)rows * 64));
+    k_bucket_fill<<<dim3((unsigned)nch, (unsigned)npg), 64, cnt_lds + (size_t)nch * sizeof(uint32_t), st>>>(idx, n, pc, m, nch, pl->b_len.p, pl->b_off.p,
+                                                                                                          pl->b_base.p, pl->lists.p);
+    SQGR_HIP(hipGetLastError());
+    static const bool order_lists = [] { const char* e = getenv("SQGR_AUTOCORR_ORDER_LISTS"); return !(e && atoi(e) == 0); }();
+    if (order_lists) {
+        k_bucket_order<<<dim3((unsigned)nb, (unsigned)npg), 64, 0, st>>>(m, nb, perm0, pl->b_len.p, pl->b_off.p, pl->b_base.p, pl->lists.p);
+        SQGR_HIP(hipGetLastError());
+    }
+    return SQGR_OK;
+}
+
+// permutation scores of the pc permutations behind the bucket lists `pl`, through the LDS-bucketed kernel -> h->sims
+static int perms_pass_lds(sqgr_autocorr* h, int32_t mode, int64_t pc, const PermLists* pl) {
     sqgr_ctx* ctx = h->ctx;
     hipStream_t st = ctx->stream;
     const int64_t n = h->n, G = h->G, G2 = (G + 1) / 2;
@@ -614,7 +735,6 @@ static int perms_pass_lds(sqgr_autocorr* h, int32_t mode, int64_t pc) {
     int nch = 0;
     const int m = lds_chunk(n, geary, &nch);
     const int npg = (int)ceil_div(pc, 64);
-    const int nb = nch * nch;
     if (!h->pairs_ready) {
         SQGR_TRY(h->Zp.ensure((size_t)G2 * n * GP));
         SQGR_TRY(h->Yp.ensure((size_t)G2 * n * GP));
@@ -624,25 +744,6 @@ static int perms_pass_lds(sqgr_autocorr* h, int32_t mode, int64_t pc) {
         k_repack_pairs<<<(unsigned)ceil_div(total, 256), 256, 0, st>>>(h->Yt.p, n, h->ntiles, G2, h->Yp.p);
         SQGR_HIP(hipGetLastError());
         h->pairs_ready = true;
-    }
-    SQGR_TRY(h->b_len.ensure((size_t)npg * nb));
-    SQGR_TRY(h->b_off.ensure((size_t)npg * nb));
-    SQGR_TRY(h->b_total.ensure((size_t)npg));
-    SQGR_TRY(h->b_base.ensure((size_t)npg + 1));
-    const size_t cnt_lds = (size_t)nch * 64 * sizeof(uint32_t);
-    uint64_t rows = 0;
-    {
-        LaunchTimer t(ctx, "autocorr_bucket_lists");
-        k_bucket_count<<<dim3((unsigned)nch, (unsigned)npg), 64, cnt_lds, st>>>(h->idx.p, n, pc, m, nch, h->b_len.p);
-        k_bucket_offsets<<<(unsigned)npg, 256, 0, st>>>(h->b_len.p, nb, h->b_off.p, h->b_total.p);
-        k_bucket_bases<<<1, 64, 0, st>>>(h->b_total.p, npg, h->b_base.p);
-        SQGR_HIP(hipGetLastError());
-        SQGR_HIP(hipMemcpyAsync(&rows, h->b_base.p + npg, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-        SQGR_HIP(hipStreamSynchronize(st));
-        SQGR_TRY(h->lists.ensure((size_t)rows * 64));
-        k_bucket_fill<<<dim3((unsigned)nch, (unsigned)npg), 64, cnt_lds + (size_t)nch * sizeof(uint32_t), st>>>(h->idx.p, n, pc, m, nch, h->b_len.p, h->b_off.p,
-                                                                               h->b_base.p, h->lists.p);
-        SQGR_HIP(hipGetLastError());
     }
     SQGR_TRY(h->part1.ensure((size_t)G2 * pc * nch * GP));
     if (geary) SQGR_TRY(h->part2.ensure((size_t)G2 * pc * nch * GP));
@@ -654,13 +755,13 @@ static int perms_pass_lds(sqgr_autocorr* h, int32_t mode, int64_t pc) {
         if (geary) {
             if (lds > 64 * 1024)
                 SQGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_perm_dot_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            k_perm_dot_lds<true><<<grid, threads, lds, st>>>(h->Zp.p, h->Yp.p, h->rowsum.p, n, pc, npg, G2, m, nch, h->b_len.p, h->b_off.p,
-                                                              h->b_base.p, h->lists.p, h->part1.p, h->part2.p);
+            k_perm_dot_lds<true><<<grid, threads, lds, st>>>(h->Zp.p, h->Yp.p, h->rowsum.p, n, pc, npg, G2, m, nch, pl->b_len.p, pl->b_off.p,
+                                                              pl->b_base.p, pl->lists.p, h->part1.p, h->part2.p);
         } else {
             if (lds > 64 * 1024)
                 SQGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_perm_dot_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            k_perm_dot_lds<false><<<grid, threads, lds, st>>>(h->Zp.p, h->Yp.p, h->rowsum.p, n, pc, npg, G2, m, nch, h->b_len.p, h->b_off.p,
-                                                               h->b_base.p, h->lists.p, h->part1.p, nullptr);
+            k_perm_dot_lds<false><<<grid, threads, lds, st>>>(h->Zp.p, h->Yp.p, h->rowsum.p, n, pc, npg, G2, m, nch, pl->b_len.p, pl->b_off.p,
+                                                               pl->b_base.p, pl->lists.p, h->part1.p, nullptr);
         }
         SQGR_HIP(hipGetLastError());
     }
@@ -897,18 +998,33 @@ static int autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_id
     const FeistelDomain dom = make_domain((uint32_t)n);
     for (int64_t c0 = 0; c0 < P; c0 += chunk) {
         const int64_t pc = std::min(chunk, P - c0);
-        if (perm_idx) {
-            SQGR_HIP(hipMemcpyAsync(h->idx.p, perm_idx + (size_t)c0 * n, (size_t)pc * n * 4, hipMemcpyHostToDevice, st));
-        } else if (pcg_states) {
-            SQGR_HIP(hipMemcpyAsync(h->pcg_states.p, pcg_states + (size_t)c0 * 4, (size_t)pc * 32, hipMemcpyHostToDevice, st));
-            SQGR_TRY(pcg_permutations_dev(ctx, h->pcg_ws, n, h->pcg_states.p, pc, h->idx.p, st));
-        } else {
-            LaunchTimer t(ctx, "autocorr_perm_indices");
-            k_perm_indices<<<dim3((unsigned)ceil_div(n, 256), (unsigned)pc), 256, 0, st>>>(seed, perm_begin + c0, n, dom, h->idx.p);
-            SQGR_HIP(hipGetLastError());
+        // the LDS kernel walks bucket lists that depend on the permutations alone: reuse the context's if they are these
+        PermLists* pl = use_lds ? perm_lists(ctx) : nullptr;
+        int lm = 0, lnch = 0;
+        if (use_lds) lm = lds_chunk(n, mode == 1, &lnch);
+        const int64_t perm0 = (perm_idx || pcg_states) ? c0 : perm_begin + c0;
+        const int kind = perm_idx ? 2 : (pcg_states ? 1 : 0);
+        const bool hit = use_lds && pl->matches(n, pc, perm0, lm, lnch, kind, seed, pcg_states ? pcg_states + (size_t)c0 * 4 : nullptr);
+        if (!hit) {
+            if (perm_idx) {
+                SQGR_HIP(hipMemcpyAsync(h->idx.p, perm_idx + (size_t)c0 * n, (size_t)pc * n * 4, hipMemcpyHostToDevice, st));
+            } else if (pcg_states) {
+                SQGR_HIP(hipMemcpyAsync(h->pcg_states.p, pcg_states + (size_t)c0 * 4, (size_t)pc * 32, hipMemcpyHostToDevice, st));
+                SQGR_TRY(pcg_permutations_dev(ctx, h->pcg_ws, n, h->pcg_states.p, pc, h->idx.p, st));
+            } else {
+                LaunchTimer t(ctx, "autocorr_perm_indices");
+                k_perm_indices<<<dim3((unsigned)ceil_div(n, 256), (unsigned)pc), 256, 0, st>>>(seed, perm_begin + c0, n, dom, h->idx.p);
+                SQGR_HIP(hipGetLastError());
+            }
         }
         if (use_lds) {
-            SQGR_TRY(perms_pass_lds(h, mode, pc));
+            if (!hit) {
+                SQGR_TRY(build_perm_lists(ctx, pl, h->idx.p, n, pc, perm0, lm, lnch));
+                pl->n = n; pl->pc = pc; pl->perm0 = perm0; pl->m = lm; pl->nch = lnch; pl->kind = kind; pl->seed = seed;
+                pl->states.clear();
+                if (pcg_states) pl->states.assign(pcg_states + (size_t)c0 * 4, pcg_states + (size_t)(c0 + pc) * 4);
+            }
+            SQGR_TRY(perms_pass_lds(h, mode, pc, pl));
             SQGR_HIP(hipMemcpyAsync(out_sims + (size_t)c0 * G, h->sims.p, (size_t)pc * G * 8, hipMemcpyDeviceToHost, st));
             SQGR_HIP(hipStreamSynchronize(st));
             continue;

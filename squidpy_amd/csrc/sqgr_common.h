@@ -48,6 +48,12 @@ struct TimedLaunch {
 
 }  // namespace sqgr
 
+namespace sqgr {
+struct CtxCache {  // device-resident state a translation unit keeps in the context between calls (freed with the context)
+    virtual ~CtxCache() {}
+};
+}  // namespace sqgr
+
 struct sqgr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -66,6 +72,7 @@ struct sqgr_ctx {
     // asked for; valid until the next request for the same slot.  Single stream, calls are synchronous: no aliasing.
     std::vector<std::pair<void*, size_t>> scratch;
     int scratch_get(int slot, size_t bytes, void** out);
+    sqgr::CtxCache* autocorr_lists = nullptr;  // bucket lists of the last permutation set (sqgr_autocorr.hip)
 
     int timer_id(const char* name);
     int begin_launch(const char* name, sqgr::TimedLaunch* tl, hipStream_t st);

@@ -364,6 +364,8 @@ int sqgr_ctx_destroy(sqgr_ctx* ctx) {
         (void)hipEventDestroy(tl.stop);
     }
     for (auto ev : ctx->event_pool) (void)hipEventDestroy(ev);
+    delete ctx->autocorr_lists;
+    ctx->autocorr_lists = nullptr;
     for (auto& sc : ctx->scratch)
         if (sc.first) (void)hipFree(sc.first);
     (void)hipStreamDestroy(ctx->stream);
