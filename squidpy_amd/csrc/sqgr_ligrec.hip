@@ -41,7 +41,7 @@ template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k_ligrec_sums(int G, int K, const int64_t* __restrict__ colptr,
                                                             const int32_t* __restrict__ rowidx, const double* __restrict__ vals,
                                                             LabelView lv, const double* __restrict__ inv_counts, int64_t npl,
-                                                            double* __restrict__ means) {
+                                                            int k_first, int k_out, int k_off, double* __restrict__ means) {
     extern __shared__ double s_acc[];  // [WAVES][K][64]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -80,8 +80,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_ligrec_sums(int G, int K, const 
     // the wave's own LDS atomics complete in order; wait for them before reading back
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    double* out = means + ((size_t)g * K) * npl + q;
-    for (int k = 0; k < K; ++k) out[(size_t)k * npl] = acc[k * 64 + lane] * inv_counts[k];
+    // (cluster tiles: local label k >= k_first is cluster k_off + k - k_first of k_out; local label 0 collects the other tiles' cells)
+    double* out = means + ((size_t)g * k_out + k_off) * npl + q;
+    for (int k = k_first; k < K; ++k) out[(size_t)(k - k_first) * npl] = acc[k * 64 + lane] * inv_counts[k];
 }
 
 __global__ __launch_bounds__(256) void k_ligrec_score(int K, int n_cp, const int32_t* __restrict__ inter,
@@ -117,6 +118,45 @@ __global__ __launch_bounds__(256) void k_ligrec_score(int K, int n_cp, const int
         for (int pl = (first_valid > p0 ? first_valid - p0 : 0); pl < np; ++pl) cnt += (ra[pl] + lb[pl] > o) ? 1 : 0;
     }
     if (live && valid[(size_t)i * n_cp + j]) counts[(size_t)i * n_cp + j] += cnt;
+}
+
+// More than 256 clusters: the clusters are processed in tiles of at most 255.  labels8[cell * npl + q] = 1 + (l - k0) for a
+// 16-bit label l of the tile [k0, k1), 0 for every other cluster; slab16[(q / 16 * n + cell) * 16 + q % 16] from the generators.
+__global__ __launch_bounds__(256) void k_ligrec_tile_labels(int64_t n, int64_t npl, const uint16_t* __restrict__ slab16, int k0, int k1,
+                                                            uint8_t* __restrict__ labels8) {
+    const int64_t cell = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (cell >= n) return;
+    const int batch = blockIdx.y;
+    const uint4* src = reinterpret_cast<const uint4*>(slab16 + ((size_t)batch * n + cell) * 16);
+    const uint4 lo = src[0], hi = src[1];
+    const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    uint32_t out[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+        const int l = (int)((w[b >> 1] >> ((b & 1) * 16)) & 0xFFFFu);
+        const uint32_t v = (l >= k0 && l < k1) ? (uint32_t)(l - k0 + 1) : 0u;
+        out[b >> 2] |= v << ((b & 3) * 8);
+    }
+    *reinterpret_cast<uint4*>(labels8 + (size_t)cell * npl + (size_t)batch * 16) = make_uint4(out[0], out[1], out[2], out[3]);
+}
+
+// the score kernel without the LDS tiles (2 * K * 33 float64 do not fit beyond K = 310): every thread streams the rows of its
+// own cluster pair
+__global__ __launch_bounds__(256) void k_ligrec_score_direct(int K, int n_cp, const int32_t* __restrict__ inter,
+                                                             const int32_t* __restrict__ cpairs, const double* __restrict__ obs,
+                                                             const uint8_t* __restrict__ valid, const double* __restrict__ means,
+                                                             int64_t npl, int first_valid, int n_valid_perms,
+                                                             int64_t* __restrict__ counts) {
+    const int i = blockIdx.x;
+    const int j = blockIdx.y * 256 + threadIdx.x;
+    if (j >= n_cp || !valid[(size_t)i * n_cp + j]) return;
+    const int rec = inter[2 * i], lig = inter[2 * i + 1];
+    const double o = obs[(size_t)i * n_cp + j];
+    const double* ra = means + ((size_t)rec * K + cpairs[2 * j]) * npl;
+    const double* lb = means + ((size_t)lig * K + cpairs[2 * j + 1]) * npl;
+    int cnt = 0;
+    for (int pl = first_valid; pl < n_valid_perms; ++pl) cnt += (ra[pl] + lb[pl] > o) ? 1 : 0;
+    counts[(size_t)i * n_cp + j] += cnt;
 }
 
 template <typename KernelT>
@@ -163,13 +203,20 @@ int sqgr_ligrec_counts(sqgr_ctx* ctx, int64_t n_cells, int32_t n_genes, int32_t 
     SQGR_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     ShufflerGuard sh;
-    SQGR_TRY(label_shuffler_create(ctx, n_cells, clustering, K, &sh.s));  // validates the labels, K in [2, 256]
+    SQGR_TRY(label_shuffler_create(ctx, n_cells, clustering, K, &sh.s));  // validates the labels, K in [2, 2048]
+    // more than 256 clusters: 16-bit labels from the generators, the group sums in cluster tiles of at most 255 (+ one bucket
+    // for the cells of the other tiles), the same permutation behind every tile
+    const bool wide = label_shuffler_wide(sh.s);
+    const int n_tiles = wide ? (int)ceil_div(K, 255) : 1;
+    const int tile = wide ? (int)ceil_div(K, n_tiles) : K;
+    const int Kt = wide ? tile + 1 : K;  // labels the sum kernel sees
 
     const size_t n_out = (size_t)n_inter * n_cp;
     DevBuf<int64_t> d_colptr, d_counts;
     DevBuf<int32_t> d_rowidx, d_inter, d_cpairs;
     DevBuf<double> d_vals, d_inv, d_obs, d_means;
     DevBuf<uint8_t> d_valid, d_labels;
+    DevBuf<uint16_t> d_slab16;
     DevBuf<uint32_t> d_keys;
     DevBuf<uint64_t> d_states;
     SQGR_TRY(d_colptr.alloc((size_t)n_genes + 1));
@@ -200,57 +247,85 @@ int sqgr_ligrec_counts(sqgr_ctx* ctx, int64_t n_cells, int32_t n_genes, int32_t 
     const int64_t n_perms = perm_end - perm_begin + skip;
     size_t free_b = 0, total_b = 0;
     SQGR_HIP(hipMemGetInfo(&free_b, &total_b));
-    const int64_t per_perm = n_cells + (int64_t)n_genes * K * 8;
+    const int64_t per_perm = n_cells * (wide ? (pcg_states ? 7 : 3) : 1) + (int64_t)n_genes * K * 8;
     int64_t npl = (int64_t)std::min<size_t>(free_b / 4, (size_t)32 << 30) / per_perm / 64 * 64;
     npl = std::max<int64_t>(64, std::min<int64_t>(npl, 16384));
     npl = std::min<int64_t>(npl, ceil_div(std::max<int64_t>(n_perms, 1), 64) * 64);
     SQGR_TRY(d_means.alloc((size_t)n_genes * K * npl));
     SQGR_TRY(d_labels.alloc((size_t)n_cells * npl));
+    if (wide) SQGR_TRY(d_slab16.alloc((size_t)n_cells * npl));
     if (pcg_states)
         SQGR_TRY(d_states.alloc((size_t)npl * 4));
     else
         SQGR_TRY(d_keys.alloc((size_t)npl * 8));
 
     // waves (= genes) per block of the sum kernel: K*64 doubles of LDS each
-    const size_t lds_wave = (size_t)K * 64 * 8;
+    const size_t lds_wave = (size_t)Kt * 64 * 8;
     int waves = (int)std::min<size_t>(4, (160 * 1024) / lds_wave);
     if (waves == 3) waves = 2;
-    SQGR_REQUIRE(waves >= 1, "K=%d: the per-wave accumulator does not fit LDS", K);
+    SQGR_REQUIRE(waves >= 1, "K=%d: the per-wave accumulator does not fit LDS", Kt);
     const size_t lds_sums = lds_wave * waves;
-    const size_t lds_score = (size_t)2 * K * SCORE_LD * 8;
+    const size_t lds_score = wide ? 0 : (size_t)2 * K * SCORE_LD * 8;
     if (waves == 4) SQGR_TRY(allow_lds(k_ligrec_sums<4>, lds_sums));
     else if (waves == 2) SQGR_TRY(allow_lds(k_ligrec_sums<2>, lds_sums));
     else SQGR_TRY(allow_lds(k_ligrec_sums<1>, lds_sums));
-    SQGR_TRY(allow_lds(k_ligrec_score, lds_score));
+    if (!wide) SQGR_TRY(allow_lds(k_ligrec_score, lds_score));
 
     for (int64_t c0 = 0; c0 < n_perms; c0 += npl) {
         const int64_t pc = std::min(npl, n_perms - c0);
         const int64_t pc64 = ceil_div(pc, 64) * 64;
         LabelView lv;
         lv.base = d_labels.p;
-        if (pcg_states) {
-            SQGR_HIP(hipMemcpyAsync(d_states.p, pcg_states + (size_t)c0 * 4, (size_t)pc * 32, hipMemcpyHostToDevice, st));
-            if (pc < pc64) SQGR_HIP(hipMemsetAsync(d_labels.p, 0, (size_t)n_cells * npl, st));  // columns past pc: label 0
-            SQGR_TRY(label_shuffler_pcg64(sh.s, d_states.p, pc, npl, d_labels.p, st));
-            lv.row_stride = npl;
-            lv.seg = (int)npl;
-            lv.seg_stride = 0;
-        } else {
-            SQGR_TRY(label_shuffler_philox(sh.s, seed, perm_begin - skip + c0, (int)(pc64 / 32), d_keys.p, d_labels.p, st));
-            lv.row_stride = 32;
-            lv.seg = 32;
-            lv.seg_stride = n_cells * 32;
-        }
-        {
+        auto launch_sums = [&](int k_local, const double* inv, int k_first, int k_off) -> int {
             LaunchTimer t(ctx, "ligrec_sums");
             dim3 grid((unsigned)ceil_div(n_genes, waves), (unsigned)(pc64 / 64));
             if (waves == 4)
-                k_ligrec_sums<4><<<grid, 256, lds_sums, st>>>(n_genes, K, d_colptr.p, d_rowidx.p, d_vals.p, lv, d_inv.p, npl, d_means.p);
+                k_ligrec_sums<4><<<grid, 256, lds_sums, st>>>(n_genes, k_local, d_colptr.p, d_rowidx.p, d_vals.p, lv, inv, npl, k_first, K, k_off, d_means.p);
             else if (waves == 2)
-                k_ligrec_sums<2><<<grid, 128, lds_sums, st>>>(n_genes, K, d_colptr.p, d_rowidx.p, d_vals.p, lv, d_inv.p, npl, d_means.p);
+                k_ligrec_sums<2><<<grid, 128, lds_sums, st>>>(n_genes, k_local, d_colptr.p, d_rowidx.p, d_vals.p, lv, inv, npl, k_first, K, k_off, d_means.p);
             else
-                k_ligrec_sums<1><<<grid, 64, lds_sums, st>>>(n_genes, K, d_colptr.p, d_rowidx.p, d_vals.p, lv, d_inv.p, npl, d_means.p);
+                k_ligrec_sums<1><<<grid, 64, lds_sums, st>>>(n_genes, k_local, d_colptr.p, d_rowidx.p, d_vals.p, lv, inv, npl, k_first, K, k_off, d_means.p);
             SQGR_HIP(hipGetLastError());
+            return SQGR_OK;
+        };
+        if (wide) {
+            if (pcg_states) {
+                SQGR_HIP(hipMemcpyAsync(d_states.p, pcg_states + (size_t)c0 * 4, (size_t)pc * 32, hipMemcpyHostToDevice, st));
+                SQGR_TRY(label_shuffler_pcg64_16(sh.s, d_states.p, pc, d_slab16.p, st));
+            } else {
+                SQGR_TRY(label_shuffler_philox16(sh.s, seed, perm_begin - skip + c0, (int)ceil_div(pc, 16), d_keys.p, d_slab16.p, st));
+            }
+            lv.row_stride = npl;
+            lv.seg = (int)npl;
+            lv.seg_stride = 0;
+            const int nb16 = (int)ceil_div(pc, 16);
+            if ((int64_t)nb16 * 16 < pc64) SQGR_HIP(hipMemsetAsync(d_labels.p, 0, (size_t)n_cells * npl, st));  // columns past the last batch
+            for (int k0 = 0; k0 < K; k0 += tile) {
+                const int k1 = std::min(K, k0 + tile);
+                {
+                    LaunchTimer t(ctx, "ligrec_tile_labels");
+                    k_ligrec_tile_labels<<<dim3((unsigned)ceil_div(n_cells, 256), (unsigned)nb16), 256, 0, st>>>(n_cells, npl, d_slab16.p, k0, k1,
+                                                                                                            d_labels.p);
+                    SQGR_HIP(hipGetLastError());
+                }
+                // (local label l >= 1 is cluster k0 + l - 1: its inverse count sits at d_inv[k0 - 1 + l])
+                SQGR_TRY(launch_sums(k1 - k0 + 1, d_inv.p + k0 - 1, 1, k0));
+            }
+        } else {
+            if (pcg_states) {
+                SQGR_HIP(hipMemcpyAsync(d_states.p, pcg_states + (size_t)c0 * 4, (size_t)pc * 32, hipMemcpyHostToDevice, st));
+                if (pc < pc64) SQGR_HIP(hipMemsetAsync(d_labels.p, 0, (size_t)n_cells * npl, st));  // columns past pc: label 0
+                SQGR_TRY(label_shuffler_pcg64(sh.s, d_states.p, pc, npl, d_labels.p, st));
+                lv.row_stride = npl;
+                lv.seg = (int)npl;
+                lv.seg_stride = 0;
+            } else {
+                SQGR_TRY(label_shuffler_philox(sh.s, seed, perm_begin - skip + c0, (int)(pc64 / 32), d_keys.p, d_labels.p, st));
+                lv.row_stride = 32;
+                lv.seg = 32;
+                lv.seg_stride = n_cells * 32;
+            }
+            SQGR_TRY(launch_sums(K, d_inv.p, 0, 0));
         }
         if (out_means_perm0 && c0 == 0) {
             // group means of the first permutation of the range, [K][G] like the reference's `groups` (testing hook)
@@ -263,8 +338,12 @@ int sqgr_ligrec_counts(sqgr_ctx* ctx, int64_t n_cells, int32_t n_genes, int32_t 
         {
             LaunchTimer t(ctx, "ligrec_score");
             dim3 grid((unsigned)n_inter, (unsigned)ceil_div(n_cp, 256));
-            k_ligrec_score<<<grid, 256, lds_score, st>>>(K, n_cp, d_inter.p, d_cpairs.p, d_obs.p, d_valid.p, d_means.p, npl,
-                                                         c0 == 0 ? (int)skip : 0, (int)pc, d_counts.p);
+            if (wide)
+                k_ligrec_score_direct<<<grid, 256, 0, st>>>(K, n_cp, d_inter.p, d_cpairs.p, d_obs.p, d_valid.p, d_means.p, npl,
+                                                            c0 == 0 ? (int)skip : 0, (int)pc, d_counts.p);
+            else
+                k_ligrec_score<<<grid, 256, lds_score, st>>>(K, n_cp, d_inter.p, d_cpairs.p, d_obs.p, d_valid.p, d_means.p, npl,
+                                                             c0 == 0 ? (int)skip : 0, (int)pc, d_counts.p);
             SQGR_HIP(hipGetLastError());
         }
     }

@@ -1745,14 +1745,49 @@ namespace sqgr {
 
 int label_shuffler_create(sqgr_ctx* ctx, int64_t n, const int32_t* labels, int K, LabelShuffler** out) {
     SQGR_REQUIRE(ctx && labels && out && n > 0, "ctx/labels/out is NULL or n <= 0");
-    if (K > 256) {
-        set_error("K=%d > 256 clusters: the ligand-receptor kernels keep K x 64 float64 accumulators per gene in LDS and uint8 labels", K);
+    if (K > 2048) {
+        set_error("K=%d > 2048 clusters: the label generators address at most 2048 label boundaries", K);
         return SQGR_ERR_UNSUPPORTED;
     }
     SQGR_HIP(hipSetDevice(ctx->device));
     sqgr_nhood* plan = nullptr;
     SQGR_TRY(nhood_build(ctx, nullptr, n, labels, K, nullptr, 0, &plan));
     *out = reinterpret_cast<LabelShuffler*>(plan);
+    return SQGR_OK;
+}
+
+bool label_shuffler_wide(const LabelShuffler* s) { return reinterpret_cast<const sqgr_nhood*>(s)->wide(); }
+
+size_t label_shuffler_key_words16() { return (size_t)key_words_per_row(16, 1); }
+
+int label_shuffler_philox16(LabelShuffler* s, uint64_t seed, int64_t perm0, int nb, uint32_t* keys_ws, uint16_t* slab16, hipStream_t st) {
+    sqgr_nhood* p = reinterpret_cast<sqgr_nhood*>(s);
+    if (!p->wide() || perm0 % FEISTEL_GROUP != 0) {
+        set_error("label_shuffler_philox16: needs more than 256 labels and perm0 (%lld) a multiple of %d", (long long)perm0, FEISTEL_GROUP);
+        return SQGR_ERR_INVALID;
+    }
+    {
+        LaunchTimer t(p->ctx, "ligrec_keygen", st);
+        const int64_t nk = (int64_t)nb * (16 / FEISTEL_GROUP + 16 / 2);
+        k_keygen<<<(unsigned)ceil_div(nk, 256), 256, 0, st>>>(seed, perm0, nb, 16, 1, keys_ws);
+        SQGR_HIP(hipGetLastError());
+    }
+    return launch_shuffle_raw(p, 16, nb, keys_ws, reinterpret_cast<uint8_t*>(slab16), st);
+}
+
+int label_shuffler_pcg64_16(LabelShuffler* s, const uint64_t* states_dev, int64_t pc, uint16_t* slab16, hipStream_t st) {
+    sqgr_nhood* p = reinterpret_cast<sqgr_nhood*>(s);
+    if (!p->wide() || !p->base16.p) {
+        set_error("label_shuffler_pcg64_16: needs more than 256 labels");
+        return SQGR_ERR_INVALID;
+    }
+    const int64_t n = p->n;
+    SQGR_TRY(p->perm_idx.ensure((size_t)pc * n));
+    SQGR_TRY(pcg_permutations_dev(p->ctx, p->pcg_ws, n, states_dev, pc, p->perm_idx.p, st));
+    const int nb = (int)ceil_div(pc, 16);
+    LaunchTimer t(p->ctx, "ligrec_gather_labels16", st);
+    k_gather_labels16<<<dim3((unsigned)ceil_div(n, 256), nb), 256, 0, st>>>(n, p->base16.p, p->perm_idx.p, 0, pc, slab16);
+    SQGR_HIP(hipGetLastError());
     return SQGR_OK;
 }
 

@@ -259,8 +259,8 @@ class PermutationTest:
         ``rng='philox'`` shuffles with the device generator keyed by ``(seed, permutation)``; ``rng='numpy'``
         reproduces the reference's PCG64 streams bit for bit, i.e. Squidpy's p-values for that ``seed``.
 
-        Limits of the GPU path: at most ``256`` clusters among the requested cluster pairs (``NotImplementedError`` beyond;
-        the reference has no limit); a subset that resolves to a single cluster is computed on the host like the reference does."""
+        Limits of the GPU path: at most ``2048`` clusters among the requested cluster pairs (``NotImplementedError`` beyond;
+        the reference has no limit; more than 256 run in cluster tiles of 255 on 16-bit labels); a subset that resolves to a single cluster is computed on the host like the reference does."""
         assert_positive(n_perms, name="n_perms")
         _assert_categorical_obs(self._adata, key=cluster_key)
         if rng not in ("philox", "numpy"):
@@ -372,10 +372,10 @@ class PermutationTest:
         means = np.where(nonzero, (m_rec + m_lig) / 2.0, 0.0)
         obs = m_rec + m_lig
 
-        if n_cls > 256:
+        if n_cls > 2048:
             raise NotImplementedError(
-                f"`{n_cls}` clusters: the ligand-receptor kernels keep `n_clusters x 64` float64 accumulators per gene in LDS and "
-                "uint8 labels, i.e. at most `256` clusters per call (there is no CPU fallback); restrict `clusters` to at most 256."
+                f"`{n_cls}` clusters: the label generators of the GPU path address at most `2048` clusters per call (there is no CPU "
+                "fallback); restrict `clusters` to at most 2048."
             )
         if n_cls == 1:
             # A cluster subset that resolves to ONE cluster (e.g. clusters=[("A", "A")]): the reference has no check here and

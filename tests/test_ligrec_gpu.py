@@ -86,6 +86,32 @@ def test_counts_device_generator_match_oracle(L, ctx):
     np.testing.assert_array_equal(groups, O.ligrec_group_means(data, labels[0], pre["inv_counts"]))
 
 
+def test_more_than_256_clusters_in_tiles(L, ctx):
+    """256 < K <= 2048: 16-bit labels from both generators, group sums in cluster tiles of <= 255 clusters sharing one
+    permutation, scores straight from global memory.  Counts and group means bit for bit like the small-K path."""
+    n, g, k = 1500, 6, 300
+    data, cl, inter, cp = _problem(n, g, k, seed=21, density=0.5, n_inter=12)
+    rng = np.random.default_rng(3)
+    cp = cp[rng.choice(len(cp), 700, replace=False)]
+    cp[:4] = [(0, 299), (299, 0), (254, 255), (150, 151)]  # pairs across and at the tile borders
+    pre = O.ligrec_prepare(data, cl, inter, cp, threshold=0.0)
+    # numpy streams
+    labels = O.ligrec_perm_labels_numpy(cl, 5, 40)
+    want = O.ligrec_score_permutations(data, labels, pre["inv_counts"], pre["mean_obs"], inter, cp, pre["valid"])
+    got, groups = _device_counts(L, ctx, data, cl, k, inter, cp, pre, pcg_states=pcg64_states(5, 40), perm_begin=0, perm_end=40, return_first_groups=True)
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(groups, O.ligrec_group_means(data, labels[0], pre["inv_counts"]))
+    assert want.sum() > 0
+    # device generator, a range that starts inside a group of 16, and its split
+    labels = O.ligrec_perm_labels_philox(cl, 99, 5, 5 + 50)
+    want = O.ligrec_score_permutations(data, labels, pre["inv_counts"], pre["mean_obs"], inter, cp, pre["valid"])
+    got, groups = _device_counts(L, ctx, data, cl, k, inter, cp, pre, seed=99, perm_begin=5, perm_end=55, return_first_groups=True)
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(groups, O.ligrec_group_means(data, labels[0], pre["inv_counts"]))
+    parts = [_device_counts(L, ctx, data, cl, k, inter, cp, pre, seed=99, perm_begin=a, perm_end=b) for a, b in [(5, 21), (21, 55)]]
+    np.testing.assert_array_equal(got, sum(parts))
+
+
 def test_permutation_ranges_add_up(L, ctx):
     """Sharding invariance: counts over [0, P) equal the sum over any split (what the multi-GPU path relies on)."""
     data, cl, inter, cp = _problem(350, 8, 6, seed=9)
@@ -150,6 +176,40 @@ def test_front_end_reproduces_reference_golden(gold, tag):
     assert list(res["pvalues"].columns) == [(f"c{a}", f"c{b}") for a, b in cp]
     np.testing.assert_array_equal(res["means"].to_numpy(), gold[f"{tag}_means"])
     np.testing.assert_array_equal(res["pvalues"].to_numpy(dtype=np.float64), gold[f"{tag}_pvalues"])  # NaN == NaN here
+
+
+def test_front_end_more_than_256_clusters():
+    """The reference has no cluster limit (gr/_ligrec.py:677-775); 300 clusters through the front end, rng='numpy': the
+    oracle's `_analysis` restatement for the same seed, exactly."""
+    import squidpy_amd as sq
+
+    k = 300
+    data, cl, inter, _ = _problem(1200, 5, k, seed=8, density=0.6, n_inter=6)
+    adata = _adata_from(data, cl)
+    pairs = [(a, b) for a in (0, 1, 150, 254, 255, 256, 299) for b in (2, 255, 256, 298)]
+    res = sq.gr.ligrec(
+        adata, "cluster", interactions=[(f"G{s}", f"G{t}") for s, t in inter], clusters=[(f"c{a}", f"c{b}") for a, b in pairs],
+        threshold=0.0, n_perms=30, seed=12, use_raw=False, copy=True, rng="numpy",
+    )
+    # the front end codes the clusters of the requested pairs in category order (strings: "c0", "c1", "c150", ...)
+    cats = sorted({f"c{c}" for ab in pairs for c in ab})
+    code = {c: i for i, c in enumerate(cats)}
+    sel = np.isin(cl, [int(c[1:]) for c in cats])
+    lab = np.array([code[f"c{c}"] for c in cl[sel]], dtype=np.int32)
+    cp = np.array([(code[f"c{a}"], code[f"c{b}"]) for a, b in pairs], dtype=np.int32)
+    assert len(cats) <= 256  # a subset: this call runs the small path; the full set below runs the tiles
+    _, pv = O.ligrec_analysis(data[sel], lab, inter, cp, threshold=0.0, n_perms=30, seed=12)
+    np.testing.assert_array_equal(res["pvalues"].to_numpy(dtype=np.float64), pv)
+    # all 300 clusters (90 000 pairs)
+    res = sq.gr.ligrec(adata, "cluster", interactions=[(f"G{s}", f"G{t}") for s, t in inter], threshold=0.0, n_perms=20, seed=4,
+                       use_raw=False, copy=True, rng="numpy")
+    cats = sorted(f"c{c}" for c in range(k))
+    code = {c: i for i, c in enumerate(cats)}
+    lab = np.array([code[f"c{c}"] for c in cl], dtype=np.int32)
+    cp = np.array([(a, b) for a in range(k) for b in range(k)], dtype=np.int32)
+    _, pv = O.ligrec_analysis(data, lab, inter, cp, threshold=0.0, n_perms=20, seed=4)
+    assert res["pvalues"].shape == (len(inter), k * k)
+    np.testing.assert_array_equal(res["pvalues"].to_numpy(dtype=np.float64), pv)
 
 
 def test_front_end_device_generator_statistics():
