@@ -146,10 +146,16 @@ __global__ __launch_bounds__(HALF_TILE) void k_half_scatter(const int2* __restri
 }
 
 // key of a list entry (16 * row, 16 * col): (row block, column block) of 2^sh spots
-__global__ __launch_bounds__(256) void k_tile_keys(const int2* __restrict__ list, int64_t m, int sh, uint64_t* __restrict__ keys) {
+__global__ __launch_bounds__(256) void k_tile_keys(const int2* __restrict__ list, int64_t m, int sh, int grid_w, uint64_t* __restrict__ keys) {
     const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (e >= m) return;
     const int2 rc = list[e];
+    if (grid_w > 0) {  // experiment: 2-D tiles of 2^sh x 2^sh spots of a row-major grid of width grid_w, keyed by the row endpoint
+        const uint32_t r = (uint32_t)rc.x >> 4;
+        const uint64_t ty = (r / (uint32_t)grid_w) >> sh, tx = (r % (uint32_t)grid_w) >> sh;
+        keys[e] = (ty << 31) | tx;
+        return;
+    }
     const uint64_t rb = ((uint32_t)rc.x >> 4) >> sh, cb = ((uint32_t)rc.y >> 4) >> sh;
     keys[e] = (rb << 31) | cb;
 }
@@ -172,7 +178,9 @@ static int tile_edge_list(sqgr_ctx* ctx, int2* list, int64_t m, int64_t n) {
     SQGR_TRY(keys_out.alloc((size_t)m));
     SQGR_TRY(vals_out.alloc((size_t)m));
     LaunchTimer t(ctx, "graph_tile_edges");
-    k_tile_keys<<<(unsigned)ceil_div(m, 256), 256, 0, st>>>(list, m, sh, keys.p);
+    int grid_w = 0;
+    if (const char* env = getenv("SQGR_TILE_GRID_W")) grid_w = atoi(env);
+    k_tile_keys<<<(unsigned)ceil_div(m, 256), 256, 0, st>>>(list, m, sh, grid_w, keys.p);
     SQGR_HIP(hipGetLastError());
     (void)n;
     const int bits = 31;  // key = row block << 31 | column block
