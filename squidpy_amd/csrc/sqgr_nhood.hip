@@ -953,13 +953,15 @@ int sqgr_nhood::resolve_tuning() {
     const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
     (void)cus;
     if (nbatch <= 0) {
-        // 64 batches (1024 permutations) per launch group, fewer when two slab buffers of that size would not fit a
-        // quarter of the free HBM (n up to 2^27 spots)
+        // 160 batches (2560 permutations) per launch group, fewer when two slab buffers of that size would not fit a
+        // quarter of the free HBM (n up to 2^27 spots).  Measured at 1e6 spots x 30 clusters (tools/tune_sweep.sh, late round 2):
+        // 64 batches 970 k permutations/s, 128: 1016 k, 160: 1020 k, 256: 1014 k, 320: 996 k — longer launches shorten the
+        // ramp and the tail of the count kernel (0.466 -> 0.443 ms per 1000 permutations), beyond 256 the shuffle slows down.
         size_t free_b = 0, total_b = 0;
-        nbatch = 64;
+        nbatch = 160;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && n > 0) {
             const int64_t fit = (int64_t)(free_b / 4) / (2 * n * B);
-            nbatch = (int)std::max<int64_t>(1, std::min<int64_t>(64, fit));
+            nbatch = (int)std::max<int64_t>(1, std::min<int64_t>(160, fit));
         }
     }
     return SQGR_OK;
