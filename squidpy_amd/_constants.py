@@ -69,6 +69,7 @@ class _Obsp:
 
 
 class _Uns:
+    spatial_neighs = staticmethod(lambda value=None: "spatial_neighbors" if value is None else f"{value}_neighbors")
     nhood_enrichment = staticmethod(lambda cluster: cluster + "_nhood_enrichment")
     interaction_matrix = staticmethod(lambda cluster: cluster + "_interactions")
     co_occurrence = staticmethod(lambda cluster: cluster + "_co_occurrence")

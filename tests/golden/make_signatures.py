@@ -5,7 +5,7 @@ import ast, json, os, re
 REF = "/root/reference/src/squidpy/gr"
 HERE = os.path.dirname(os.path.abspath(__file__))
 WANT = {"_nhood.py": ["nhood_enrichment", "interaction_matrix"], "_ppatterns.py": ["spatial_autocorr", "co_occurrence"], "_ripley.py": ["ripley"], "_ligrec.py": ["ligrec"],
-        "_build.py": ["spatial_neighbors", "spatial_neighbors_knn", "spatial_neighbors_radius", "spatial_neighbors_grid", "spatial_neighbors_delaunay", "spatial_neighbors_from_builder"]}
+        "_build.py": ["spatial_neighbors", "spatial_neighbors_knn", "spatial_neighbors_radius", "spatial_neighbors_grid", "spatial_neighbors_delaunay", "spatial_neighbors_from_builder", "mask_graph"]}
 out = {}
 for fn, names in WANT.items():
     src = open(os.path.join(REF, fn)).read()
