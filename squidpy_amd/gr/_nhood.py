@@ -97,7 +97,7 @@ def nhood_enrichment(
         ``"numpy"``: the reference's own streams (``SeedSequence(seed).spawn(n_perms)`` -> PCG64 ->
         ``Generator.shuffle``) are reproduced bit for bit *on the GPU* (one wave per permutation, LCG jump-ahead draws), and the z-score
         is formed with the reference's float64 ``perms.mean/std``: Squidpy's z-scores for that ``seed``, exactly
-        (1e6 spots: ~20 k permutations/s against ~300 k for ``"philox"``; the CPU does ~20/s per core).
+        (1e6 spots: ~25 k permutations/s against ~1 M for ``"philox"``; the CPU does ~20/s per core).
         ``"numpy-host"``: same streams drawn by numpy on the host and injected (cross-check path).
     device
         HIP device index (default: ``LOCAL_RANK`` or 0).
@@ -128,8 +128,10 @@ def nhood_enrichment(
     ctx = default_context(device)
     graph = cached_graph(ctx, adj, with_data=False)  # stays resident for the next statistic on the same matrix
     count = nhood_counts(ctx, graph, int_clust, n_cls)
-    if n_cls > MAX_DEVICE_SHUFFLE_CLUSTERS or (n_cls > 256 and rng == "numpy" and lib_codes is not None):
-        # (numpy streams + libraries + more than 256 clusters: per-library sub-shuffles of 16-bit labels are not on the device)
+    if n_cls > MAX_DEVICE_SHUFFLE_CLUSTERS or (n_cls > 256 and (rng == "numpy-host" or (rng == "numpy" and lib_codes is not None))):
+        # (numpy streams + libraries + more than 256 clusters: per-library sub-shuffles of 16-bit labels are not on the device;
+        #  the injected-permutation entry point `sqgr_nhood_counts_batch` takes uint8 labels, so host-drawn streams with more
+        #  than 256 clusters are counted one permutation at a time by the any-K kernel)
         zscore = _zscore_many_clusters(ctx, graph, int_clust, n_cls, lib_codes, n_libs, seed, n_perms, count)
     elif rng == "numpy-host":
         zscore = _zscore_numpy_streams(ctx, graph, int_clust, n_cls, lib_codes, n_libs, seed, n_perms, count)
