@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SQGR_ABI_VERSION 2
+#define SQGR_ABI_VERSION 3
 
 typedef enum sqgr_status {
     SQGR_OK = 0,
@@ -197,6 +197,21 @@ int sqgr_autocorr_create_cm(sqgr_ctx* ctx, const sqgr_graph* g, const double* va
  * per block at all (gr/_ppatterns.py:154-185 builds `vals = adata[:, genes].X.T` on the host). */
 typedef struct sqgr_matrix sqgr_matrix;
 int sqgr_matrix_create(sqgr_ctx* ctx, const double* x, int64_t n_rows, int64_t n_cols, sqgr_matrix** out);
+/* The same for float32 (AnnData's usual dtype; widened to float64 on the device, exactly) and / or a column range of a
+ * wider host matrix: x points at the first wanted element, rows are `ld` elements apart (ld >= n_cols); value_bytes 4 | 8. */
+int sqgr_matrix_create_dense(sqgr_ctx* ctx, const void* x, int32_t value_bytes, int64_t n_rows, int64_t n_cols, int64_t ld,
+                             sqgr_matrix** out);
+/* Sparse expression as scipy holds it — the input every real Visium / Xenium object has (`adata.X` CSR float32; the
+ * reference densifies `vals` feature block by feature block on the host, gr/_ppatterns.py:154-185 + scanpy's metrics):
+ * CSR (rows = cells: indptr[n_rows + 1], indices = columns) or CSC (columns = features: indptr[n_cols + 1], indices = rows),
+ * index arrays int32 or int64 (index_bytes 4 | 8, both arrays alike as in scipy), values float32 or float64
+ * (value_bytes 4 | 8), indices ascending inside every row / column (scipy's `has_sorted_indices`; duplicates are summed
+ * like `toarray()` does).  Feature blocks are expanded to dense float64 ON THE DEVICE by sqgr_autocorr_create_cols: the
+ * results are bit-identical to uploading `toarray().astype(float64)`. */
+int sqgr_matrix_create_csr(sqgr_ctx* ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const void* indptr, const void* indices,
+                           int32_t index_bytes, const void* values, int32_t value_bytes, sqgr_matrix** out);
+int sqgr_matrix_create_csc(sqgr_ctx* ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const void* indptr, const void* indices,
+                           int32_t index_bytes, const void* values, int32_t value_bytes, sqgr_matrix** out);
 int sqgr_matrix_destroy(sqgr_matrix* m);
 int sqgr_autocorr_create_cols(sqgr_ctx* ctx, const sqgr_graph* g, const sqgr_matrix* m, int64_t col0, int64_t G, sqgr_autocorr** out);
 int sqgr_autocorr_destroy(sqgr_autocorr* h);
@@ -215,6 +230,19 @@ int sqgr_autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_idx,
  * rows is bit for bit `generators[p].permutation(n)` (gr/_ppatterns.py:270-271).  Nothing but 32 bytes per permutation
  * crosses PCIe (injecting the same permutations through sqgr_autocorr_perms costs 4*n bytes each, per feature block). */
 int sqgr_autocorr_perms_pcg64(sqgr_autocorr* h, int32_t mode, const uint64_t* pcg_states, int64_t n_perms, double* out_sims);
+
+/* The permutation test REDUCED on the device: runs the permutations exactly like sqgr_autocorr_perms (perm_idx != NULL:
+ * injected; pcg_states != NULL: numpy streams as sqgr_autocorr_perms_pcg64, one row per permutation of the range; both
+ * NULL: the device generator for [perm_begin, perm_end)) but keeps the (P, G) scores on the device and returns, per
+ * feature, what `_p_value_calc` (gr/_ppatterns.py:474-492) takes out of them — so G x 4 numbers cross PCIe instead of
+ * P x G (160 MB at 20 000 features x 1000 permutations):
+ *   out_ge[g]  = #{p : sims[p][g] >= score[g]}       `(sims >= score).sum(axis=0)`            int64[G]
+ *   out_sum[g] = `sims.sum(axis=0)[g]`    out_std[g] = `sims.std(axis=0)[g]`    out_var[g] = `np.var(sims, axis=0)[g]`
+ * each in numpy's own evaluation order (sequential over the permutation axis, mean = sum / P, then the squared
+ * deviations summed the same way): bit-identical to numpy on the same scores.  score: float64[G], the observed statistic. */
+int sqgr_autocorr_perm_stats(sqgr_autocorr* h, int32_t mode, const int32_t* perm_idx, const uint64_t* pcg_states, uint64_t seed,
+                             int64_t perm_begin, int64_t perm_end, const double* score, int64_t* out_ge, double* out_sum,
+                             double* out_std, double* out_var);
 
 /* parity hook: the device generator's permutations, int32[perm_end-perm_begin][n] (<= 32768 per call) */
 int sqgr_autocorr_perm_indices(sqgr_ctx* ctx, int64_t n, uint64_t seed, int64_t perm_begin, int64_t perm_end,

@@ -62,12 +62,16 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "sqgr_autocorr_create": (C.c_int, [C.c_void_p, C.c_void_p, c_f64p, C.c_int64, C.POINTER(C.c_void_p)]),
     "sqgr_autocorr_create_cm": (C.c_int, [C.c_void_p, C.c_void_p, c_f64p, C.c_int64, C.POINTER(C.c_void_p)]),
     "sqgr_matrix_create": (C.c_int, [C.c_void_p, c_f64p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p)]),
+    "sqgr_matrix_create_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_void_p)]),
+    "sqgr_matrix_create_csr": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
+    "sqgr_matrix_create_csc": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
     "sqgr_matrix_destroy": (C.c_int, [C.c_void_p]),
     "sqgr_autocorr_create_cols": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p)]),
     "sqgr_autocorr_destroy": (C.c_int, [C.c_void_p]),
     "sqgr_autocorr_scores": (C.c_int, [C.c_void_p, C.c_int32, c_f64p]),
     "sqgr_autocorr_perms": (C.c_int, [C.c_void_p, C.c_int32, c_i32p, C.c_uint64, C.c_int64, C.c_int64, c_f64p]),
     "sqgr_autocorr_perms_pcg64": (C.c_int, [C.c_void_p, C.c_int32, c_u64p, C.c_int64, c_f64p]),
+    "sqgr_autocorr_perm_stats": (C.c_int, [C.c_void_p, C.c_int32, c_i32p, c_u64p, C.c_uint64, C.c_int64, C.c_int64, c_f64p, c_i64p, c_f64p, c_f64p, c_f64p]),
     "sqgr_autocorr_perm_indices": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_int64, C.c_int64, c_i32p]),
     "sqgr_pair_counts": (C.c_int, [C.c_void_p, c_f64p, C.c_int64, c_f64p, C.c_int32, C.c_int32, c_i64p]),
     "sqgr_knn_dist": (C.c_int, [C.c_void_p, c_f64p, C.c_int64, c_f64p, C.c_int64, C.c_int32, C.c_int32, c_f64p]),
@@ -88,7 +92,7 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
 }
 
 
-ABI_VERSION = 2  # SQGR_ABI_VERSION of include/sqgr.h
+ABI_VERSION = 3  # SQGR_ABI_VERSION of include/sqgr.h
 
 
 class SqgrError(RuntimeError):
@@ -525,15 +529,47 @@ def cooccur_counts(
 
 
 class DeviceMatrix:
-    """A dense row-major float64 matrix resident on the device (``sqgr_matrix``): ``adata.X`` uploaded once."""
+    """The (cells x features) expression matrix resident on the device (``sqgr_matrix``), uploaded once per call: a dense
+    row-major float64 / float32 array (also a column range of one, through its row pitch) or a scipy CSR / CSC matrix as it
+    is — index arrays int32 / int64, values float32 / float64; other value types are converted to float64 on the host.
+    Feature blocks are cut out of it (and sparse ones densified, float32 widened) on the device."""
 
-    def __init__(self, ctx: Context, x: np.ndarray):
-        x = np.asarray(x)
-        if x.ndim != 2 or x.dtype != np.float64 or not x.flags.c_contiguous:
-            raise ValueError("DeviceMatrix needs a C-contiguous 2-D float64 array.")
-        self.ctx, self.shape = ctx, x.shape
+    def __init__(self, ctx: Context, x: Any):
+        from scipy import sparse
+
+        self.ctx = ctx
         h = C.c_void_p()
-        _check(ctx.lib, ctx.lib.sqgr_matrix_create(ctx.h, _ptr(x, c_f64p), x.shape[0], x.shape[1], C.byref(h)))
+        if sparse.issparse(x):
+            if not (sparse.isspmatrix_csr(x) or sparse.isspmatrix_csc(x)):
+                x = sparse.csr_matrix(x)
+            if x.dtype not in (np.float32, np.float64):
+                x = x.astype(np.float64)
+            if not x.has_sorted_indices:
+                x = x.sorted_indices()
+            if x.indices.dtype != x.indptr.dtype or x.indices.dtype not in (np.int32, np.int64):
+                x = type(x)((x.data, x.indices.astype(np.int64), x.indptr.astype(np.int64)), shape=x.shape)
+            indptr, indices, data = np.ascontiguousarray(x.indptr), np.ascontiguousarray(x.indices), np.ascontiguousarray(x.data)
+            fn = ctx.lib.sqgr_matrix_create_csr if sparse.isspmatrix_csr(x) else ctx.lib.sqgr_matrix_create_csc
+            _check(
+                ctx.lib,
+                fn(ctx.h, x.shape[0], x.shape[1], int(x.nnz), indptr.ctypes.data_as(C.c_void_p), indices.ctypes.data_as(C.c_void_p),
+                   indices.dtype.itemsize, data.ctypes.data_as(C.c_void_p), data.dtype.itemsize, C.byref(h)),
+            )
+            self.kind = "csr" if sparse.isspmatrix_csr(x) else "csc"
+        else:
+            x = np.asarray(x)
+            if x.ndim != 2:
+                raise ValueError(f"DeviceMatrix needs a 2-D array, found shape `{x.shape}`.")
+            if x.dtype not in (np.float32, np.float64):
+                x = np.ascontiguousarray(x, dtype=np.float64)
+            if x.strides[1] != x.itemsize or x.strides[0] % x.itemsize or x.strides[0] < x.shape[1] * x.itemsize:
+                x = np.ascontiguousarray(x)  # not a row-major array or a column range of one
+            _check(
+                ctx.lib,
+                ctx.lib.sqgr_matrix_create_dense(ctx.h, x.ctypes.data_as(C.c_void_p), x.itemsize, x.shape[0], x.shape[1], x.strides[0] // x.itemsize, C.byref(h)),
+            )
+            self.kind = "dense"
+        self.shape, self.dtype = x.shape, x.dtype
         self.h = h
 
     def close(self) -> None:
@@ -610,6 +646,37 @@ class AutocorrPlan:
             self.ctx.lib.sqgr_autocorr_perms_pcg64(self.h, self.MODES[mode], _ptr(states, c_u64p), states.shape[0], _ptr(out, c_f64p)),
         )
         return out
+
+    def perm_stats(
+        self, mode: str, score: np.ndarray, *, perm_idx: np.ndarray | None = None, pcg_states: np.ndarray | None = None, seed: int = 0,
+        perm_begin: int = 0, perm_end: int = 0,
+    ) -> dict[str, np.ndarray]:
+        """The permutation test reduced on the device (``sqgr_autocorr_perm_stats``): per feature the number of permutation
+        scores ``>= score``, and numpy's ``sum`` / ``std`` / ``var`` of the scores over the permutation axis — the (P, G)
+        scores themselves never leave the GPU.  Permutations: injected (``perm_idx``), numpy streams (``pcg_states``) or the
+        device generator for ``[perm_begin, perm_end)``."""
+        score = _as(score, np.float64)
+        if score.shape != (self.G,):
+            raise ValueError(f"Expected `{self.G}` observed scores, found shape `{score.shape}`.")
+        states = None
+        if perm_idx is not None:
+            perm_idx = _as(perm_idx, np.int32)
+            if perm_idx.ndim != 2 or perm_idx.shape[1] != self.g.n:
+                raise ValueError(f"Expected perm_idx of shape (n_perms, {self.g.n}), found {perm_idx.shape}.")
+            perm_begin, perm_end = 0, perm_idx.shape[0]
+        elif pcg_states is not None:
+            states = _as(pcg_states, np.uint64).reshape(-1, 4)
+            perm_begin, perm_end = 0, states.shape[0]
+        ge = np.zeros(self.G, dtype=np.int64)
+        ssum, sstd, svar = (np.zeros(self.G, dtype=np.float64) for _ in range(3))
+        _check(
+            self.ctx.lib,
+            self.ctx.lib.sqgr_autocorr_perm_stats(
+                self.h, self.MODES[mode], _ptr(perm_idx, c_i32p), _ptr(states, c_u64p), C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF),
+                int(perm_begin), int(perm_end), _ptr(score, c_f64p), _ptr(ge, c_i64p), _ptr(ssum, c_f64p), _ptr(sstd, c_f64p), _ptr(svar, c_f64p),
+            ),
+        )
+        return {"n_ge": ge, "sum": ssum, "std": sstd, "var": svar}
 
     def close(self) -> None:
         if getattr(self, "h", None):

@@ -1,71 +1,72 @@
-"""Host-side O(P*G) statistics of ``spatial_autocorr``: analytic moments, permutation p-values and
-multiple-testing correction, restated from the reference (gr/_ppatterns.py:443-559) and from
-``statsmodels.stats.multitest.multipletests`` (third-party, absent in this image; call site gr/_ppatterns.py:239-245)."""
+"""Host-side arithmetic of ``spatial_autocorr``'s p-value columns, O(G) and O(nnz) only.
+
+The O(P*G) part of the reference's ``_p_value_calc`` (gr/_ppatterns.py:474-492: the exceedance counts and the sum / std /
+var of the permutation scores) is formed on the device next to the scores (``sqgr_autocorr_perm_stats``) and arrives
+here already reduced; what is left is the normal tail, the folding of the counts, the closed-form variance under
+normality (Cliff & Ord 1981, as pysal/esda and gr/_ppatterns.py:501-538 use it) and the multiple-testing correction
+(``statsmodels.stats.multitest.multipletests``, third party; call site gr/_ppatterns.py:239-245) — pinned to statsmodels
+0.12.2 itself by tests/golden/multipletests_golden.json."""
 
 from __future__ import annotations
 
-from typing import Any
+from typing import Any, NamedTuple
 
 import numpy as np
 from scipy import sparse, stats
 
 
-def g_moments(w: Any) -> tuple[float, float, float]:
-    """gr/_ppatterns.py:541-559 (pysal's s0, s1, s2)."""
-    s0 = w.sum()
-    t = w.transpose() + w
-    t2 = t.multiply(t) if sparse.issparse(t) else t * t
-    s1 = t2.sum() / 2.0
-    s2array = np.array(w.sum(1) + w.sum(0).transpose()) ** 2
-    s2 = s2array.sum()
-    return s0, s1, s2
+class WeightMoments(NamedTuple):
+    """pysal's S0, S1, S2 of a spatial weight matrix (gr/_ppatterns.py:541-559)."""
+
+    s0: float
+    s1: float
+    s2: float
 
 
-def analytic_pval(score: np.ndarray, g: Any, mode: str, expected: float, two_tailed: bool) -> tuple[np.ndarray, float]:
-    """gr/_ppatterns.py:501-538: Moran and Geary have different normality variances (Cliff & Ord 1981)."""
-    s0, s1, s2 = g_moments(g)
-    n = g.shape[0]
-    s02 = s0 * s0
+def weight_moments(w: Any) -> WeightMoments:
+    """``S0 = sum w_ij``, ``S1 = 1/2 sum (w_ij + w_ji)^2``, ``S2 = sum_i (w_i. + w_.i)^2``."""
+    sym = w.transpose() + w
+    squared = sym.multiply(sym) if sparse.issparse(sym) else sym * sym
+    # (row sums + column sums, kept in the shape and dtype the reference sums them in — (n, 1) for scipy matrices, whose
+    # weights are often float32: the float32 pairwise sums depend on it in the 7th digit)
+    margins = np.asarray(w.sum(axis=1) + w.sum(axis=0).transpose())
+    return WeightMoments(w.sum(), squared.sum() / 2.0, np.square(margins).sum())
+
+
+def variance_under_normality(mom: WeightMoments, n: int, mode: str) -> float:
+    """Sampling variance of the statistic under the normality assumption.  Moran's I and Geary's C differ
+    (gr/_ppatterns.py:513-526):  Var[I] = (n^2 S1 - n S2 + 3 S0^2) / ((n - 1)(n + 1) S0^2) - 1/(n - 1)^2,
+    Var[C] = ((2 S1 + S2)(n - 1) - 4 S0^2) / (2 (n + 1) S0^2)."""
+    s0sq = mom.s0 * mom.s0
+    if mode == "moran":
+        return (n * n * mom.s1 - n * mom.s2 + 3 * s0sq) / ((n - 1) * (n + 1) * s0sq) - (1.0 / (n - 1)) ** 2
     if mode == "geary":
-        v_norm = ((2 * s1 + s2) * (n - 1) - 4 * s02) / (2 * (n + 1) * s02)
-    elif mode == "moran":
-        n2 = n * n
-        v_num = n2 * s1 - n * s2 + 3 * s02
-        v_den = (n - 1) * (n + 1) * s02
-        v_norm = v_num / v_den - (1.0 / (n - 1)) ** 2
-    else:
-        raise AssertionError(f"Unexpected mode `{mode}`.")
-    se_norm = v_norm ** (1 / 2.0)
-    z_norm = (score - expected) / se_norm
-    p_norm = np.empty(score.shape)
-    p_norm[z_norm > 0] = 1 - stats.norm.cdf(z_norm[z_norm > 0])
-    p_norm[z_norm <= 0] = stats.norm.cdf(z_norm[z_norm <= 0])
-    if two_tailed:
-        p_norm *= 2.0
-    return p_norm, v_norm
+        return ((2 * mom.s1 + mom.s2) * (n - 1) - 4 * s0sq) / (2 * (n + 1) * s0sq)
+    raise AssertionError(f"Unexpected mode `{mode}`.")
 
 
-def p_value_calc(score: np.ndarray, sims: np.ndarray | None, g: Any, mode: str, expected: float, two_tailed: bool) -> dict[str, Any]:
-    """gr/_ppatterns.py:443-498."""
-    p_norm, var_norm = analytic_pval(score, g, mode, expected, two_tailed)
-    results: dict[str, Any] = {"pval_norm": p_norm, "var_norm": var_norm}
-    if sims is None:
-        return results
-    n_perms = sims.shape[0]
-    large_perm = (sims >= score).sum(axis=0)
-    sel = (n_perms - large_perm) < large_perm
-    large_perm[sel] = n_perms - large_perm[sel]
-    p_sim = (large_perm + 1) / (n_perms + 1)
-    e_score_sim = sims.sum(axis=0) / n_perms
-    se_score_sim = sims.std(axis=0)
-    z_sim = (score - e_score_sim) / se_score_sim
-    p_z_sim = np.empty(z_sim.shape)
-    p_z_sim[z_sim > 0] = 1 - stats.norm.cdf(z_sim[z_sim > 0])
-    p_z_sim[z_sim <= 0] = stats.norm.cdf(z_sim[z_sim <= 0])
-    results["pval_z_sim"] = p_z_sim
-    results["pval_sim"] = p_sim
-    results["var_sim"] = np.var(sims, axis=0)
-    return results
+def upper_or_lower_tail(z: np.ndarray) -> np.ndarray:
+    """One-sided normal p-value of a z-score, folded at 0 the way the reference folds it: ``1 - cdf(z)`` where ``z > 0``,
+    ``cdf(z)`` elsewhere (NaN stays NaN).  ``1 - cdf`` and not ``sf``: the reference's rounding is part of its result."""
+    z = np.asarray(z, dtype=np.float64)
+    cdf = stats.norm.cdf(z)
+    return np.where(z > 0, 1 - cdf, cdf)
+
+
+def analytic_columns(score: np.ndarray, w: Any, mode: str, expected: float, two_tailed: bool) -> dict[str, Any]:
+    """``pval_norm`` / ``var_norm`` (gr/_ppatterns.py:501-538)."""
+    var_norm = variance_under_normality(weight_moments(w), w.shape[0], mode)
+    p = upper_or_lower_tail((score - expected) / var_norm ** (1 / 2.0))
+    return {"pval_norm": p * 2.0 if two_tailed else p, "var_norm": var_norm}
+
+
+def permutation_columns(score: np.ndarray, n_perms: int, n_ge: np.ndarray, sim_sum: np.ndarray, sim_std: np.ndarray, sim_var: np.ndarray) -> dict[str, Any]:
+    """``pval_z_sim`` / ``pval_sim`` / ``var_sim`` (gr/_ppatterns.py:474-496) from the device's reductions of the permutation
+    scores: ``n_ge`` = #{scores >= observed} is folded to the smaller tail, ``(k + 1) / (P + 1)``; the z-score of the
+    observed statistic against the permutation mean ``sum / P`` and standard deviation goes through the normal tail."""
+    k = np.minimum(np.asarray(n_ge, dtype=np.int64), n_perms - np.asarray(n_ge, dtype=np.int64))
+    z = (score - sim_sum / n_perms) / sim_std
+    return {"pval_z_sim": upper_or_lower_tail(z), "pval_sim": (k + 1) / (n_perms + 1), "var_sim": sim_var}
 
 
 def _ecdf_adjust(ps: np.ndarray, factor: np.ndarray) -> np.ndarray:
@@ -85,13 +86,23 @@ def multipletests_pvals(pvals: np.ndarray, method: str = "fdr_bh") -> np.ndarray
     if m in ("bonferroni", "b"):
         corr = np.minimum(ps * float(n), 1.0)  # statsmodels clips at 1 at the end
     elif m in ("sidak", "s"):
-        corr = -np.expm1(n * np.log1p(-ps))
+        corr = 1 - np.power(1.0 - ps, n)  # the plain form statsmodels evaluates (for tiny p it rounds to 0; part of its result)
     elif m in ("holm", "h"):
         corr = np.maximum.accumulate(ps * np.arange(n, 0, -1))
     elif m in ("holm-sidak", "hs"):
-        corr = np.maximum.accumulate(-np.expm1(np.arange(n, 0, -1) * np.log1p(-ps)))
+        corr = np.maximum.accumulate(1 - np.power(1.0 - ps, np.arange(n, 0, -1)))
     elif m in ("simes-hochberg", "sh"):
         corr = np.minimum.accumulate((ps * np.arange(n, 0, -1))[::-1])[::-1]
+    elif m in ("hommel", "ho"):
+        corr = ps.copy()
+        for k in range(n, 1, -1):  # Hommel's step-up over the k largest p-values
+            cim = np.min(k * ps[-k:] / np.arange(1, k + 1.0))
+            corr[-k:] = np.maximum(corr[-k:], cim)
+            corr[:-k] = np.maximum(corr[:-k], np.minimum(k * ps[:-k], cim))
+    elif m == "fdr_gbs":
+        ii = np.arange(1, n + 1)
+        q = (n + 1.0 - ii) / ii * ps / (1.0 - ps)
+        corr = np.minimum.accumulate(np.maximum.accumulate(q)[::-1])[::-1]
     elif m in ("fdr_bh", "fdr_i", "fdr_p", "fdri", "fdrp"):
         corr = _ecdf_adjust(ps, np.arange(1, n + 1) / float(n))
     elif m in ("fdr_by", "fdr_n", "fdr_c", "fdrn", "fdrcorr"):

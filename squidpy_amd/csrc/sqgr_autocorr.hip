@@ -75,6 +75,84 @@ __global__ __launch_bounds__(256) void k_cells_to_genes(const double* __restrict
     }
 }
 
+// The same from a float32 matrix (AnnData's usual `X` dtype): widened to float64 on the way — exactly what
+// `.astype(float64)` does on the host, so everything downstream is bit-identical to the float64 upload.
+__global__ __launch_bounds__(256) void k_cells_to_genes_f32(const float* __restrict__ D, int64_t ld, int64_t n, int64_t g0, int gc,
+                                                            double* __restrict__ X) {
+    __shared__ double tile[GT][GT + 1];
+    const int64_t i0 = (int64_t)blockIdx.x * GT;
+    const int gb = blockIdx.y * GT;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < GT; r += 4) {
+        const int64_t i = i0 + r;
+        tile[r][tx] = (i < n && gb + tx < gc) ? (double)D[(size_t)i * ld + g0 + gb + tx] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < GT; r += 4) {
+        const int64_t i = i0 + tx;
+        if (gb + r < gc && i < n) X[(size_t)(gb + r) * n + i] = tile[tx][r];
+    }
+}
+
+// Sparse expression (scipy CSR / CSC of the cells x genes matrix, float32 or float64 values) -> the staged gene-major block
+// X[gl][i] of genes g0..g0+gc, which the caller has zeroed: the dense block `toarray()` would give, formed on the device.
+// Stored entries of one cell (CSR) / one gene (CSC) land in distinct cells of X unless the matrix holds duplicates, which
+// scipy sums — so does the atomic add (0 + v is exact: canonical matrices reproduce `toarray()` bit for bit).
+// CSR: one thread per cell, binary search of the first stored gene >= g0 in its (sorted) row.
+template <typename V>
+__global__ __launch_bounds__(256) void k_csr_to_genes(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                                      const V* __restrict__ values, int64_t n, int64_t g0, int gc, double* __restrict__ X) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t lo = indptr[i], hi = indptr[i + 1];
+    const int64_t end = hi;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (indices[mid] < g0) lo = mid + 1; else hi = mid;
+    }
+    for (int64_t e = lo; e < end; ++e) {
+        const int64_t c = indices[e] - g0;
+        if (c >= gc) break;
+        atomicAdd(&X[(size_t)c * n + i], (double)values[e]);
+    }
+}
+
+// CSC: block (x, gene): the gene's stored cells, strided over the block's threads and the blocks of grid.x
+template <typename V>
+__global__ __launch_bounds__(256) void k_csc_to_genes(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                                      const V* __restrict__ values, int64_t n, int64_t g0, double* __restrict__ X) {
+    const int64_t g = blockIdx.y;
+    const int64_t e0 = indptr[g0 + g], e1 = indptr[g0 + g + 1];
+    for (int64_t e = e0 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < e1; e += (int64_t)gridDim.x * blockDim.x)
+        atomicAdd(&X[(size_t)g * n + indices[e]], (double)values[e]);
+}
+
+// one wave per major slice: flags[0] an index outside [0, minor), flags[1] a slice that is not ascending
+__global__ __launch_bounds__(256) void k_check_sparse(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, int64_t nslices,
+                                                      int64_t minor, int* __restrict__ flags) {
+    const int64_t j = blockIdx.x * (int64_t)4 + (threadIdx.x >> 6);
+    if (j >= nslices) return;
+    const int64_t a = indptr[j], b = indptr[j + 1];
+    int bad_range = 0, bad_order = 0;
+    for (int64_t e = a + (threadIdx.x & 63); e < b; e += 64) {
+        const int32_t c = indices[e];
+        bad_range |= (c < 0 || c >= minor);
+        if (e > a) bad_order |= indices[e - 1] > c;
+    }
+    if (bad_range) flags[0] = 1;
+    if (bad_order) flags[1] = 1;
+}
+
+// int64 index arrays of a scipy matrix with more than 2^31 stored entries -> the library's layout
+__global__ void k_narrow_indices(const int64_t* __restrict__ src, int64_t count, int32_t* __restrict__ dst) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t < count) dst[t] = (int32_t)src[t];
+}
+__global__ void k_widen_indptr(const int32_t* __restrict__ src, int64_t count, int64_t* __restrict__ dst) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t < count) dst[t] = src[t];
+}
+
 // ---- Zt[tile][i][gl] = X[g][i] - mean[g]   (64 x 64 tile transpose through LDS; gc is a multiple of 64 or the tail)
 __global__ __launch_bounds__(256) void k_center_transpose(const double* __restrict__ X, int64_t n, int gc, int64_t g0,
                                                           const double* __restrict__ mean, double* __restrict__ Zt) {
@@ -623,6 +701,41 @@ __global__ __launch_bounds__(256) void k_perm_final_lds(const double* __restrict
     sims[(size_t)p * G + g] = isconst[g] ? __builtin_nan("") : v;
 }
 
+// What gr/_ppatterns.py:474-492 takes out of the (P, G) permutation scores, formed where they are: per feature g
+//   ge  = #{p : sims[p][g] >= score[g]}                                   `(sims >= score).sum(axis=0)`
+//   sum = sims[:, g].sum()                                                `sims.sum(axis=0)`
+//   var = mean(|x - sum / P|^2), std = sqrt(var)                          `np.var(sims, axis=0)`, `sims.std(axis=0)`
+// bit for bit: numpy reduces the leading axis of a C-contiguous array by one rounded add per row, in row order
+// (pairwise summation only applies along the contiguous axis), `_var` forms `arrmean = sum / P`, `x = arr - arrmean`,
+// `x * x`, sums the same way and divides by P.  One thread per feature; every operation rounded separately.
+__global__ __launch_bounds__(256) void k_perm_stats(const double* __restrict__ sims, int64_t P, int64_t G, const double* __restrict__ score,
+                                                    long long* __restrict__ ge, double* __restrict__ sum, double* __restrict__ sd,
+                                                    double* __restrict__ var) {
+    const int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const double sc = score[g];
+    double acc = 0.0;
+    long long cnt = 0;
+#pragma unroll 8
+    for (int64_t p = 0; p < P; ++p) {  // (the loads are independent of the add chain: eight in flight per thread)
+        const double x = sims[(size_t)p * G + g];
+        acc += x;
+        cnt += (x >= sc) ? 1 : 0;
+    }
+    const double m = acc / (double)P;
+    double acc2 = 0.0;
+#pragma unroll 8
+    for (int64_t p = 0; p < P; ++p) {
+        const double d = sims[(size_t)p * G + g] - m;
+        acc2 += d * d;
+    }
+    const double v = acc2 / (double)P;
+    ge[g] = cnt;
+    sum[g] = acc;
+    var[g] = v;
+    sd[g] = sqrt(v);
+}
+
 __global__ void k_scores(int mode, int64_t G, int64_t n, double W, const double* __restrict__ num, const double* __restrict__ z2ss,
                          const uint8_t* __restrict__ isconst, double* __restrict__ out) {
     int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -635,10 +748,18 @@ __global__ void k_scores(int mode, int64_t G, int64_t n, double W, const double*
 
 using namespace sqgr;
 
-struct sqgr_matrix {  // a dense row-major float64 matrix resident on the device (the expression matrix, uploaded once)
+// The expression matrix resident on the device (uploaded once per call): dense row-major float64 / float32, or scipy's
+// CSR / CSC arrays as they are (int64 indptr, int32 indices; values float32 or float64).
+struct sqgr_matrix {
     sqgr_ctx* ctx = nullptr;
-    int64_t n_rows = 0, n_cols = 0;
+    int64_t n_rows = 0, n_cols = 0, ld = 0;
+    int kind = 0;        // 0 dense, 1 CSR (rows = cells), 2 CSC (columns = features)
+    bool f32 = false;    // values are float32
     DevBuf<double> data;
+    DevBuf<float> data32;
+    DevBuf<int64_t> indptr;
+    DevBuf<int32_t> indices;
+    int64_t nnz = 0;
 };
 
 struct sqgr_autocorr {
@@ -652,6 +773,7 @@ struct sqgr_autocorr {
     // permutation workspace
     DevBuf<int32_t> idx;
     DevBuf<double> part1, part2, sims;
+    DevBuf<double> sims_all;  // [P][G] scores of a whole permutation test kept on the device (sqgr_autocorr_perm_stats)
     PcgWorkspace pcg_ws;          // numpy-stream permutations generated in place (sqgr_autocorr_perms_pcg64)
     DevBuf<uint64_t> pcg_states;
     // LDS-bucketed permutation dot: gene-pair layout of Z and Y, and the bucket lists of the permutations in flight
@@ -801,8 +923,10 @@ static int column_sum(sqgr_autocorr* h, int mode, const double* A, const double*
 // vals: host block (gene-major, or cell-major when `cell_major`), or NULL when the features are columns
 // [dev_col0, dev_col0 + G) of a matrix already resident on the device (dev_x[i * dev_ld + col])
 static int autocorr_create(sqgr_ctx* ctx, const sqgr_graph* g, const double* vals, int64_t G, bool cell_major, sqgr_autocorr** out,
-                           const double* dev_x = nullptr, int64_t dev_ld = 0, int64_t dev_col0 = 0) {
-    SQGR_REQUIRE(ctx && g && (vals || dev_x) && out, "null argument");
+                           const sqgr_matrix* dm = nullptr, int64_t dev_col0 = 0) {
+    const double* dev_x = (dm && dm->kind == 0 && !dm->f32) ? dm->data.p : nullptr;
+    const int64_t dev_ld = dm ? dm->ld : 0;
+    SQGR_REQUIRE(ctx && g && (vals || dm) && out, "null argument");
     *out = nullptr;
     SQGR_REQUIRE(g->ctx == ctx, "graph belongs to a different context");
     SQGR_REQUIRE(g->has_data || g->nnz == 0, "graph was uploaded without edge weights");
@@ -841,7 +965,25 @@ static int autocorr_create(sqgr_ctx* ctx, const sqgr_graph* g, const double* val
     }
     for (int64_t g0 = 0; g0 < G && e == hipSuccess; g0 += gc_max) {
         const int gc = (int)std::min<int64_t>(gc_max, G - g0);
-        if (cm_src) {
+        if (dm && !dev_x) {  // float32 and / or sparse resident matrix: the gene block is formed from it on the device
+            LaunchTimer t(ctx, "autocorr_expand");
+            const dim3 tgrid((unsigned)ceil_div(n, GT), (unsigned)ceil_div(gc, GT));
+            if (dm->kind == 0) {
+                k_cells_to_genes_f32<<<tgrid, 256, 0, st>>>(dm->data32.p + dev_col0, dm->ld, n, g0, gc, X.p);
+            } else {
+                e = hipMemsetAsync(X.p, 0, (size_t)gc * n * 8, st);
+                if (e != hipSuccess) break;
+                if (dm->kind == 1) {
+                    if (dm->f32) k_csr_to_genes<float><<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(dm->indptr.p, dm->indices.p, dm->data32.p, n, dev_col0 + g0, gc, X.p);
+                    else k_csr_to_genes<double><<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(dm->indptr.p, dm->indices.p, dm->data.p, n, dev_col0 + g0, gc, X.p);
+                } else {
+                    const dim3 cgrid(8, (unsigned)gc);
+                    if (dm->f32) k_csc_to_genes<float><<<cgrid, 256, 0, st>>>(dm->indptr.p, dm->indices.p, dm->data32.p, n, dev_col0 + g0, X.p);
+                    else k_csc_to_genes<double><<<cgrid, 256, 0, st>>>(dm->indptr.p, dm->indices.p, dm->data.p, n, dev_col0 + g0, X.p);
+                }
+            }
+            e = hipGetLastError();
+        } else if (cm_src) {
             k_cells_to_genes<<<dim3((unsigned)ceil_div(n, GT), (unsigned)ceil_div(gc, GT)), 256, 0, st>>>(cm_src, cm_ld, n, g0, gc, X.p);
             e = hipGetLastError();
         } else {
@@ -894,20 +1036,29 @@ int sqgr_autocorr_create_cm(sqgr_ctx* ctx, const sqgr_graph* g, const double* va
     return autocorr_create(ctx, g, vals, G, true, out);
 }
 
-int sqgr_matrix_create(sqgr_ctx* ctx, const double* x, int64_t n_rows, int64_t n_cols, sqgr_matrix** out) {
+int sqgr_matrix_create_dense(sqgr_ctx* ctx, const void* x, int32_t value_bytes, int64_t n_rows, int64_t n_cols, int64_t ld,
+                             sqgr_matrix** out) {
     SQGR_REQUIRE(ctx && x && out && n_rows > 0 && n_cols > 0, "null argument or empty matrix");
+    SQGR_REQUIRE(value_bytes == 4 || value_bytes == 8, "value_bytes must be 4 (float32) or 8 (float64), found %d", value_bytes);
+    SQGR_REQUIRE(ld >= n_cols, "row pitch %lld < %lld columns", (long long)ld, (long long)n_cols);
     *out = nullptr;
     SQGR_HIP(hipSetDevice(ctx->device));
     sqgr_matrix* m = new sqgr_matrix();
     m->ctx = ctx;
     m->n_rows = n_rows;
     m->n_cols = n_cols;
-    int rc = m->data.alloc((size_t)n_rows * n_cols);
+    m->ld = n_cols;  // stored densely whatever the pitch of the source
+    m->f32 = value_bytes == 4;
+    const size_t count = (size_t)n_rows * n_cols;
+    int rc = m->f32 ? m->data32.alloc(count) : m->data.alloc(count);
     if (rc != SQGR_OK) {
         delete m;
         return rc;
     }
-    hipError_t e = hipMemcpyAsync(m->data.p, x, (size_t)n_rows * n_cols * 8, hipMemcpyHostToDevice, ctx->stream);
+    void* dst = m->f32 ? (void*)m->data32.p : (void*)m->data.p;
+    hipError_t e = (ld == n_cols) ? hipMemcpyAsync(dst, x, count * value_bytes, hipMemcpyHostToDevice, ctx->stream)
+                                  : hipMemcpy2DAsync(dst, (size_t)n_cols * value_bytes, x, (size_t)ld * value_bytes, (size_t)n_cols * value_bytes,
+                                                     (size_t)n_rows, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         set_error("matrix upload failed: %s", hipGetErrorString(e));
@@ -916,6 +1067,95 @@ int sqgr_matrix_create(sqgr_ctx* ctx, const double* x, int64_t n_rows, int64_t n
     }
     *out = m;
     return SQGR_OK;
+}
+
+int sqgr_matrix_create(sqgr_ctx* ctx, const double* x, int64_t n_rows, int64_t n_cols, sqgr_matrix** out) {
+    return sqgr_matrix_create_dense(ctx, x, 8, n_rows, n_cols, n_cols, out);
+}
+
+// kind 1: CSR (indptr has n_rows + 1 entries, indices are columns), kind 2: CSC (n_cols + 1, rows)
+static int matrix_create_sparse(sqgr_ctx* ctx, int kind, int64_t n_rows, int64_t n_cols, int64_t nnz, const void* indptr, const void* indices,
+                                int32_t index_bytes, const void* values, int32_t value_bytes, sqgr_matrix** out) {
+    SQGR_REQUIRE(ctx && indptr && out && n_rows > 0 && n_cols > 0 && nnz >= 0, "null argument or empty matrix");
+    SQGR_REQUIRE((indices && values) || nnz == 0, "indices/values is NULL");
+    SQGR_REQUIRE(index_bytes == 4 || index_bytes == 8, "index_bytes must be 4 or 8, found %d", index_bytes);
+    SQGR_REQUIRE(value_bytes == 4 || value_bytes == 8, "value_bytes must be 4 (float32) or 8 (float64), found %d", value_bytes);
+    SQGR_REQUIRE(n_rows < (int64_t)0x7fffffff && n_cols < (int64_t)0x7fffffff, "more than 2^31 rows or columns");
+    *out = nullptr;
+    const int64_t nptr = (kind == 1 ? n_rows : n_cols) + 1, minor = kind == 1 ? n_cols : n_rows;
+    // host-side validation (the arrays are caller memory): monotone pointers ending at nnz, indices inside the minor axis,
+    // ascending inside every major slice (the CSR expansion bisects its rows)
+    auto at = [&](const void* a, int64_t i) -> int64_t {
+        return index_bytes == 4 ? (int64_t) static_cast<const int32_t*>(a)[i] : static_cast<const int64_t*>(a)[i];
+    };
+    SQGR_REQUIRE(at(indptr, 0) == 0 && at(indptr, nptr - 1) == nnz, "indptr must run from 0 to nnz=%lld", (long long)nnz);
+    for (int64_t j = 0; j + 1 < nptr; ++j)
+        SQGR_REQUIRE(at(indptr, j) <= at(indptr, j + 1) && at(indptr, j + 1) <= nnz, "indptr is not monotone at %lld", (long long)j);
+    SQGR_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    sqgr_matrix* m = new sqgr_matrix();
+    m->ctx = ctx;
+    m->n_rows = n_rows;
+    m->n_cols = n_cols;
+    m->ld = n_cols;
+    m->kind = kind;
+    m->f32 = value_bytes == 4;
+    m->nnz = nnz;
+    auto fail = [&](int code) {
+        delete m;
+        return code;
+    };
+    int rc = SQGR_OK;
+    const size_t cnt = (size_t)std::max<int64_t>(nnz, 1);
+    if ((rc = m->indptr.alloc((size_t)nptr)) || (rc = m->indices.alloc(cnt)) || (rc = m->f32 ? m->data32.alloc(cnt) : m->data.alloc(cnt))) return fail(rc);
+    hipError_t e = hipSuccess;
+    if (index_bytes == 8) {
+        DevBuf<int64_t> wide;
+        if ((rc = wide.alloc(cnt))) return fail(rc);
+        e = hipMemcpyAsync(m->indptr.p, indptr, (size_t)nptr * 8, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess && nnz > 0) e = hipMemcpyAsync(wide.p, indices, (size_t)nnz * 8, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess && nnz > 0) k_narrow_indices<<<(unsigned)ceil_div(nnz, 256), 256, 0, st>>>(wide.p, nnz, m->indices.p);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);  // `wide` is released on return
+    } else {
+        DevBuf<int32_t> narrow;
+        if ((rc = narrow.alloc((size_t)nptr))) return fail(rc);
+        e = hipMemcpyAsync(narrow.p, indptr, (size_t)nptr * 4, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) k_widen_indptr<<<(unsigned)ceil_div(nptr, 256), 256, 0, st>>>(narrow.p, nptr, m->indptr.p);
+        if (e == hipSuccess && nnz > 0) e = hipMemcpyAsync(m->indices.p, indices, (size_t)nnz * 4, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    if (e == hipSuccess && nnz > 0)
+        e = hipMemcpyAsync(m->f32 ? (void*)m->data32.p : (void*)m->data.p, values, (size_t)nnz * value_bytes, hipMemcpyHostToDevice, st);
+    // the indices are checked where they now are: inside the minor axis, ascending inside every slice
+    DevBuf<int> flags;
+    int hflags[2] = {0, 0};
+    if (e == hipSuccess && (rc = flags.alloc(2))) return fail(rc);
+    if (e == hipSuccess) e = hipMemsetAsync(flags.p, 0, 8, st);
+    if (e == hipSuccess && nnz > 0) k_check_sparse<<<(unsigned)ceil_div(nptr - 1, 4), 256, 0, st>>>(m->indptr.p, m->indices.p, nptr - 1, minor, flags.p);
+    if (e == hipSuccess) e = hipMemcpyAsync(hflags, flags.p, 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("sparse matrix upload failed: %s", hipGetErrorString(e));
+        return fail(SQGR_ERR_HIP);
+    }
+    if (hflags[0] || hflags[1]) {
+        set_error(hflags[0] ? "sparse matrix: an index lies outside [0,%lld)" : "sparse matrix: indices are not sorted inside a row/column (call .sort_indices())",
+                  (long long)minor);
+        return fail(SQGR_ERR_INVALID);
+    }
+    *out = m;
+    return SQGR_OK;
+}
+
+int sqgr_matrix_create_csr(sqgr_ctx* ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const void* indptr, const void* indices,
+                           int32_t index_bytes, const void* values, int32_t value_bytes, sqgr_matrix** out) {
+    return matrix_create_sparse(ctx, 1, n_rows, n_cols, nnz, indptr, indices, index_bytes, values, value_bytes, out);
+}
+
+int sqgr_matrix_create_csc(sqgr_ctx* ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const void* indptr, const void* indices,
+                           int32_t index_bytes, const void* values, int32_t value_bytes, sqgr_matrix** out) {
+    return matrix_create_sparse(ctx, 2, n_rows, n_cols, nnz, indptr, indices, index_bytes, values, value_bytes, out);
 }
 
 int sqgr_matrix_destroy(sqgr_matrix* m) {
@@ -931,7 +1171,7 @@ int sqgr_autocorr_create_cols(sqgr_ctx* ctx, const sqgr_graph* g, const sqgr_mat
     SQGR_REQUIRE(m->n_rows == g->n, "matrix has %lld rows, the graph %lld", (long long)m->n_rows, (long long)g->n);
     SQGR_REQUIRE(col0 >= 0 && G >= 1 && col0 + G <= m->n_cols, "columns [%lld, %lld) outside the matrix (%lld columns)", (long long)col0,
                  (long long)(col0 + G), (long long)m->n_cols);
-    return autocorr_create(ctx, g, nullptr, G, true, out, m->data.p, m->n_cols, col0);
+    return autocorr_create(ctx, g, nullptr, G, true, out, m, col0);
 }
 
 int sqgr_autocorr_destroy(sqgr_autocorr* h) {
@@ -962,8 +1202,8 @@ int sqgr_autocorr_scores(sqgr_autocorr* h, int32_t mode, double* out_scores) {
 // permutation scores for permutations [perm_begin, perm_end): row permutations injected from the host (perm_idx), drawn
 // from numpy's streams on the device (pcg_states, one row per permutation of the range) or from the device generator
 static int autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_idx, const uint64_t* pcg_states, uint64_t seed,
-                          int64_t perm_begin, int64_t perm_end, double* out_sims) {
-    SQGR_REQUIRE(h && out_sims, "null argument");
+                          int64_t perm_begin, int64_t perm_end, double* out_sims, double* dev_all = nullptr) {
+    SQGR_REQUIRE(h && (out_sims || dev_all), "null argument");
     SQGR_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (moran) or 1 (geary)");
     SQGR_REQUIRE(perm_begin >= 0 && perm_end >= perm_begin, "bad permutation range");
     sqgr_ctx* ctx = h->ctx;
@@ -1025,7 +1265,8 @@ static int autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_id
                 if (pcg_states) pl->states.assign(pcg_states + (size_t)c0 * 4, pcg_states + (size_t)(c0 + pc) * 4);
             }
             SQGR_TRY(perms_pass_lds(h, mode, pc, pl));
-            SQGR_HIP(hipMemcpyAsync(out_sims + (size_t)c0 * G, h->sims.p, (size_t)pc * G * 8, hipMemcpyDeviceToHost, st));
+            if (dev_all) SQGR_HIP(hipMemcpyAsync(dev_all + (size_t)c0 * G, h->sims.p, (size_t)pc * G * 8, hipMemcpyDeviceToDevice, st));
+            if (out_sims) SQGR_HIP(hipMemcpyAsync(out_sims + (size_t)c0 * G, h->sims.p, (size_t)pc * G * 8, hipMemcpyDeviceToHost, st));
             SQGR_HIP(hipStreamSynchronize(st));
             continue;
         }
@@ -1047,7 +1288,8 @@ static int autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_id
                 k_perm_final<false><<<g2, 256, 0, st>>>(h->part1.p, nullptr, R, pc, G, n, h->W, h->z2ss.p, h->qsum.p, h->isconst.p, h->sims.p);
             SQGR_HIP(hipGetLastError());
         }
-        SQGR_HIP(hipMemcpyAsync(out_sims + (size_t)c0 * G, h->sims.p, (size_t)pc * G * 8, hipMemcpyDeviceToHost, st));
+        if (dev_all) SQGR_HIP(hipMemcpyAsync(dev_all + (size_t)c0 * G, h->sims.p, (size_t)pc * G * 8, hipMemcpyDeviceToDevice, st));
+        if (out_sims) SQGR_HIP(hipMemcpyAsync(out_sims + (size_t)c0 * G, h->sims.p, (size_t)pc * G * 8, hipMemcpyDeviceToHost, st));
         SQGR_HIP(hipStreamSynchronize(st));
     }
     return SQGR_OK;
@@ -1061,6 +1303,38 @@ int sqgr_autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_idx,
 int sqgr_autocorr_perms_pcg64(sqgr_autocorr* h, int32_t mode, const uint64_t* pcg_states, int64_t n_perms, double* out_sims) {
     SQGR_REQUIRE(pcg_states && n_perms >= 0, "pcg_states is NULL or n_perms < 0");
     return autocorr_perms(h, mode, nullptr, pcg_states, 0, 0, n_perms, out_sims);
+}
+
+int sqgr_autocorr_perm_stats(sqgr_autocorr* h, int32_t mode, const int32_t* perm_idx, const uint64_t* pcg_states, uint64_t seed,
+                             int64_t perm_begin, int64_t perm_end, const double* score, int64_t* out_ge, double* out_sum,
+                             double* out_std, double* out_var) {
+    SQGR_REQUIRE(h && score && out_ge && out_sum && out_std && out_var, "null argument");
+    SQGR_REQUIRE(!(perm_idx && pcg_states), "perm_idx and pcg_states are mutually exclusive");
+    SQGR_REQUIRE(perm_begin >= 0 && perm_end > perm_begin, "bad permutation range");
+    sqgr_ctx* ctx = h->ctx;
+    SQGR_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int64_t G = h->G, P = perm_end - perm_begin;
+    SQGR_TRY(h->sims_all.ensure((size_t)P * G));
+    SQGR_TRY(autocorr_perms(h, mode, perm_idx, pcg_states, seed, (perm_idx || pcg_states) ? 0 : perm_begin, (perm_idx || pcg_states) ? P : perm_end,
+                            nullptr, h->sims_all.p));
+    DevBuf<double> d_score, d_out;  // d_out: sum | std | var
+    DevBuf<long long> d_ge;
+    SQGR_TRY(d_score.alloc((size_t)G));
+    SQGR_TRY(d_out.alloc((size_t)3 * G));
+    SQGR_TRY(d_ge.alloc((size_t)G));
+    SQGR_HIP(hipMemcpyAsync(d_score.p, score, (size_t)G * 8, hipMemcpyHostToDevice, st));
+    {
+        LaunchTimer t(ctx, "autocorr_perm_stats");
+        k_perm_stats<<<(unsigned)ceil_div(G, 256), 256, 0, st>>>(h->sims_all.p, P, G, d_score.p, d_ge.p, d_out.p, d_out.p + G, d_out.p + 2 * G);
+        SQGR_HIP(hipGetLastError());
+    }
+    SQGR_HIP(hipMemcpyAsync(out_ge, d_ge.p, (size_t)G * 8, hipMemcpyDeviceToHost, st));
+    SQGR_HIP(hipMemcpyAsync(out_sum, d_out.p, (size_t)G * 8, hipMemcpyDeviceToHost, st));
+    SQGR_HIP(hipMemcpyAsync(out_std, d_out.p + G, (size_t)G * 8, hipMemcpyDeviceToHost, st));
+    SQGR_HIP(hipMemcpyAsync(out_var, d_out.p + 2 * G, (size_t)G * 8, hipMemcpyDeviceToHost, st));
+    SQGR_HIP(hipStreamSynchronize(st));
+    return SQGR_OK;
 }
 
 /* the device generator's permutation indices (parity hook): int32[(perm_end-perm_begin)][n] */

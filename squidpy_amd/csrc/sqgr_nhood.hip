@@ -14,6 +14,12 @@
 //               histograms are written out as partials (plain coalesced stores, no global atomics).
 //   k_reduce  : thread per (pair, b): sums the partials over blocks -> exact per-permutation count,
 //               accumulates d=count-shift and d*d in 64-bit integers (order independent, deterministic).
+// Variants measured on MI355X and dropped (round 3, commit 652982d holds their code; profiles/r03_nhood_experiments.json):
+// a deferred exact route of k_shuffle (flagged words appended to lists by returning atomics and recomputed by a second
+// kernel: 1.19 -> 1.62 ms per launch, and skipping the route altogether would only save 5 %); k_count with two lanes per
+// label row (global_load_dwordx2, half the gather instructions: bit-exact, 1.11 -> 1.56 ms — 8- and 16-byte-per-lane
+// gathers cost 16 clk per wave instruction in the address/L1 path whatever they touch, tools/ubench_count_shape.hip);
+// k_shuffle and k_count of consecutive launch groups sharing the CUs on two streams (no gain with 1 or 2 count blocks per CU).
 #include "sqgr_common.h"
 #include "sqgr_rng.h"
 #include "sqgr_shuffle.h"
@@ -82,20 +88,6 @@ struct LibDom {
     uint32_t aoff;  // offset of this library's block table
 };
 
-// Deferred exact route of k_shuffle.  A 4-label word that meets a sentinel byte (a rank outside [0, n) after sigma, or a
-// block the two-field table cannot describe) needs the long exact route; one such lane made its whole wave walk that code
-// (at 1e6 spots 0.18 % of the words but 11 % of the wave-words).  Instead the lane appends (spot, group row, word) to one of
-// FIX_SUBLISTS lists — one returning atomic — and k_shuffle_fix recomputes those words afterwards, one thread per entry.
-// A full list (cap entries per sublist) falls back to the inline route, so correctness never depends on the capacity.
-constexpr int FIX_SUBLISTS = 256;
-struct FixList {
-    uint32_t* count;       // [FIX_SUBLISTS] entries appended (may exceed cap: the surplus took the inline route)
-    uint32_t* count_next;  // the counters of the NEXT launch (two sets alternate): zeroed by this launch's k_shuffle_fix
-    uint2* entries;        // [FIX_SUBLISTS][cap]  (spot, (group row << 2) | word)
-    uint32_t cap;          // 0: no deferral
-};
-constexpr int FIX_BLOCKS = 8;  // blocks of k_shuffle_fix per sublist
-
 // label byte J of `word` <- e.byte0 + (b.half H >= e.half1)
 template <int J, int H>
 __device__ __forceinline__ void put_label(uint32_t& word, uint32_t e, uint32_t bpk, uint32_t zero) {
@@ -118,7 +110,7 @@ template <int B, bool HAS_LIBS, bool SMALLK>
 __global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __restrict__ cum, int kpad, int blk_words, int K,
                                                  const uint32_t* __restrict__ keys, LibDom dom0, int n_libs, int nrows,
                                                  const int32_t* __restrict__ lib_of, const int32_t* __restrict__ rank_of,
-                                                 const LibDom* __restrict__ libdoms, FixList fix, uint8_t* __restrict__ slab_all) {
+                                                 const LibDom* __restrict__ libdoms, uint8_t* __restrict__ slab_all) {
     extern __shared__ uint32_t s_lds[];               // [blk_words] block table (byte offset 0), then [n_libs][kpad] boundaries
     uint32_t* s_cum = s_lds + blk_words;
     for (int t = threadIdx.x; t < n_libs * kpad; t += 256) s_cum[t] = cum[t];
@@ -176,7 +168,7 @@ __global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __re
         } while (need0 | need1);
     }
     // the 16 labels of one group: sigma_p on the group's image (in both halves), two permutations per packed evaluation
-    auto emit_group = [&](const u16x2 gsa, const u16x2 gsb, const uint32_t* ks, const uint32_t grow, uint32_t (&out)[4]) {
+    auto emit_group = [&](const u16x2 gsa, const u16x2 gsb, const uint32_t* ks, uint32_t (&out)[4]) {
 #pragma unroll
         for (int w = 0; w < FEISTEL_GROUP / 4; ++w) {
             uint32_t word = 0;
@@ -206,20 +198,7 @@ __global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __re
                 const uint32_t k = (uint32_t)K;
                 sentinel = k > 255u || (word & 0xFFu) >= k || ((word >> 8) & 0xFFu) >= k || ((word >> 16) & 0xFFu) >= k || (word >> 24) >= k;
             }
-            bool inline_route = sentinel;
-            if constexpr (SMALLK) {
-                if (sentinel && fix.cap && !fix.count) {
-                    inline_route = false;  // developer probe (SQGR_SHUFFLE_DEFER=2): the exact route is skipped, results are wrong
-                } else if (sentinel && fix.cap) {  // defer: k_shuffle_fix rewrites this word (the store below leaves the sentinel bytes)
-                    const uint32_t sub = (blockIdx.x + 37u * blockIdx.y) & (FIX_SUBLISTS - 1);
-                    const uint32_t slot = atomicAdd(&fix.count[sub], 1u);
-                    if (slot < fix.cap) {
-                        fix.entries[(size_t)sub * fix.cap + slot] = make_uint2((uint32_t)i, (grow << 2) | (uint32_t)w);
-                        inline_route = false;
-                    }
-                }
-            }
-            if (inline_route) {  // exact route (rare): re-walk sigma where the image left [0, n), then rank against the boundaries
+            if (sentinel) {  // exact route (rare): re-walk sigma where the image left [0, n), then rank against the boundaries
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (K <= 255 && ((word >> (8 * j)) & 0xFFu) < (uint32_t)K) continue;
@@ -248,8 +227,8 @@ __global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __re
         }
     };
     uint32_t outA[4], outB[4];
-    emit_group((u16x2)(ga.x), (u16x2)(gb.x), ksA, (uint32_t)(row0 * NG), outA);
-    if (store1) emit_group((u16x2)(ga.y), (u16x2)(gb.y), ksB, (uint32_t)(NG == 2 ? row0 * NG + 1 : row1), outB);
+    emit_group((u16x2)(ga.x), (u16x2)(gb.x), ksA, outA);
+    if (store1) emit_group((u16x2)(ga.y), (u16x2)(gb.y), ksB, outB);
     if constexpr (NG == 2) {
         uint4* dst = reinterpret_cast<uint4*>(slab_all + ((size_t)row0 * n + i) * B);
         dst[0] = make_uint4(outA[0], outA[1], outA[2], outA[3]);
@@ -258,64 +237,6 @@ __global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __re
         *reinterpret_cast<uint4*>(slab_all + ((size_t)row0 * n + i) * B) = make_uint4(outA[0], outA[1], outA[2], outA[3]);
         if (store1) *reinterpret_cast<uint4*>(slab_all + ((size_t)row1 * n + i) * B) = make_uint4(outB[0], outB[1], outB[2], outB[3]);
     }
-    }
-}
-
-// The words k_shuffle deferred (FixList): one thread per entry recomputes the word's four labels by the plain route —
-// pi_g, then sigma_p cycle-walked into [0, n), then the rank against the label boundaries — in scalar arithmetic (the same
-// functions: grouped_perm of sqgr_rng.h) and overwrites the word.  grid (FIX_BLOCKS, FIX_SUBLISTS).
-template <bool HAS_LIBS>
-__global__ __launch_bounds__(256) void k_shuffle_fix(int64_t n, const uint32_t* __restrict__ cum, int kpad, int B, const uint32_t* __restrict__ keys,
-                                                     LibDom dom0, int n_libs, const int32_t* __restrict__ lib_of,
-                                                     const int32_t* __restrict__ rank_of, const LibDom* __restrict__ libdoms, FixList fix,
-                                                     uint8_t* __restrict__ slab_all) {
-    const uint32_t sub = blockIdx.y;
-    const uint32_t cnt = min(fix.count[sub], fix.cap);
-    const int NG = B / FEISTEL_GROUP;
-    const size_t row_words = key_words_per_row(B, n_libs);
-    if (blockIdx.x == 0 && threadIdx.x == 0) fix.count_next[sub] = 0;
-    for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < cnt; t += FIX_BLOCKS * 256) {
-        const uint2 ent = fix.entries[(size_t)sub * fix.cap + t];
-        const int64_t i = ent.x;
-        const uint32_t w = ent.y & 3u, grow = ent.y >> 2, row = grow / (uint32_t)NG, g = grow % (uint32_t)NG;
-        LibDom ld = dom0;
-        uint32_t x0 = (uint32_t)i, lib = 0;
-        if (HAS_LIBS) {
-            lib = (uint32_t)lib_of[i];
-            ld = libdoms[lib];
-            x0 = (uint32_t)rank_of[i];
-        }
-        const FeistelDomain dom = ld.dom;
-        const uint32_t* tab = cum + lib * kpad + 1;  // tab[k] = cum[k + 1]; cum[K] = UINT_MAX stops the scan
-        const uint32_t* gk = keys + (size_t)row * row_words + ((size_t)g * n_libs + lib) * 8;  // both halves hold the group key
-        uint32_t ga = x0 / dom.B, gb = x0 - ga * dom.B;
-        do {
-            for (int r = 0; r < FEISTEL_ROUNDS; r += 2) {
-                ga = (ga + feistel_F1(gb, gk[r], dom.ash)) & (dom.A - 1u);
-                uint32_t u = gb + feistel_F1(ga, gk[r + 1], dom.bsh);
-                u = u >= dom.B ? u - dom.B : u;
-                gb = u >= dom.B ? u - dom.B : u;
-            }
-        } while (ga * dom.B + gb >= dom.n);
-        uint32_t word = 0;
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t tt = g * (FEISTEL_GROUP / 2) + w * 2 + (uint32_t)(j >> 1);  // pair of permutations inside the row
-            const uint32_t* sk = keys + (size_t)row * row_words + (size_t)NG * n_libs * 8 + ((size_t)tt * n_libs + lib) * 2;
-            const int sh = (j & 1) * 16;
-            const uint32_t k0 = (sk[0] >> sh) & 0xFFFFu, k1 = (sk[1] >> sh) & 0xFFFFu;
-            uint32_t a = ga, b = gb, x;
-            do {
-                uint32_t u = b + feistel_F1(a, k0, dom.bsh);
-                u = u >= dom.B ? u - dom.B : u;
-                b = u >= dom.B ? u - dom.B : u;
-                a = (a + feistel_F1(b, k1, dom.ash)) & (dom.A - 1u);
-                x = a * dom.B + b;
-            } while (x >= dom.n);
-            uint32_t l = 0;
-            while (x >= tab[l]) ++l;
-            word |= l << (8 * j);
-        }
-        *reinterpret_cast<uint32_t*>(slab_all + ((size_t)row * n + i) * B + g * FEISTEL_GROUP + w * 4) = word;
     }
 }
 
@@ -713,156 +634,6 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
     }
 }
 
-// The 16-permutation count kernel with TWO lanes per label row (8 bytes per lane, global_load_dwordx2) instead of four.
-// Why (tools/ubench_count_shape.hip, profiles/r03_ubench_count_shape.json): vector-memory instructions and LDS atomics are NOT
-// independent — their VGPR operands travel over one path to the TA / the LDS, 2 clk per operand dword and wave instruction
-// (MI355X_MICROARCH.md §LDS describes it for DS stores), so a stage of k_count costs 16 ds_add_u32 x 4.4 clk + 8 gathers x
-// 2 clk (one address dword each) + one 64-bit-address list load x 4 clk = 90 clk per CU — exactly what the kernel runs at.
-// The L1/TD side (lines per instruction) hides behind that.  Halving the gather INSTRUCTIONS per edge (32 rows per
-// instruction) and giving the list load a scalar base + 32-bit offset takes 10 clk out of the 90.
-// A pair of lanes shares 2 consecutive edges per stage; lane h of the pair owns permutations [8h, 8h + 8) of both.
-// Stagger: step (sh, sl) of pair `el` handles byte (sl + el) & 3 of dword (sh + (el >> 2)) & 1 of the lane's 8 bytes, so the
-// 16 lanes of one half of 16 consecutive pairs touch 16 different counters of a pair row twice over (never more than two
-// lanes per LDS bank: free).  The dword choice is a register swap per row (v_cndmask), the byte choice rides in the
-// v_perm_b32 selector as in k_count.
-template <int MIN_WAVES, bool SELF, int DBG = 0>
-__global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count_pair(uint32_t nnz, const int2* __restrict__ coo,
-                                                                         const uint8_t* __restrict__ slab_all, int64_t n, int K,
-                                                                         int hist_words, uint32_t edges_per_block, uint32_t self_begin,
-                                                                         int add_transposed, uint32_t* __restrict__ partial_all) {
-    extern __shared__ uint32_t hist[];
-    __builtin_amdgcn_s_setprio(3);
-    constexpr int B = 16, LOGW = 6, U = 2;
-    constexpr uint32_t STEP = (COUNT_THREADS / 2) * U;
-    static_assert(6 * STEP + U <= LIST_PAD, "look-ahead exceeds the padding of the edge lists");
-    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-    const int tid = threadIdx.x;
-    for (int i = tid; i < hist_words; i += COUNT_THREADS) hist[i] = 0;
-    __syncthreads();
-
-    const uint8_t* slab = slab_all + (size_t)blockIdx.y * n * B;
-    const uint32_t chunk = (uint32_t)xcd_chunk(blockIdx.x, gridDim.x);
-    const uint32_t e0 = chunk * edges_per_block;
-    const uint32_t e1 = min(nnz, e0 + edges_per_block);
-    const bool uniform_block = (e0 + edges_per_block <= nnz) && (!SELF || e0 + edges_per_block <= self_begin);
-    const uint32_t h = tid & 1, el = tid >> 1;
-    const bool swap = ((el >> 2) & 1u) != 0;
-    const uint32_t qoff = h * 8;  // this lane's 8 bytes of a 16-byte row
-    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)hist;
-    uint32_t sel[4], ofs[2][4];  // v_perm selectors (byte (sl + el) & 3 of both rows) and counter byte offsets per step
-#pragma unroll
-    for (int sl = 0; sl < 4; ++sl) {
-        const uint32_t by = (sl + el) & 3u;
-        sel[sl] = 0x0c000c00u | ((4u + by) << 16) | by;
-#pragma unroll
-        for (int sh = 0; sh < 2; ++sh) ofs[sh][sl] = lds_base + (8u * h + 4u * ((sh + (el >> 2)) & 1u) + by) * 4u;
-    }
-    const uint32_t dot_k = ((uint32_t)K << (LOGW + 16)) | (1u << LOGW);  // {hi: K << 6, lo: 64}
-    // the block's part of the list through a scalar base and 32-bit byte offsets (one address dword per load)
-    const char* lst = reinterpret_cast<const char*>(coo + e0);
-    auto load_pair = [&](uint32_t rel) {  // rel: entry index relative to e0 of the pair's first edge
-        if constexpr ((DBG & 4) != 0) {
-            int2 v = make_int2((int)(h * 64u), (int)(h * 64u + 16u));
-            asm volatile("" : "+v"(v.x), "+v"(v.y));
-            return v;
-        } else {
-            return *reinterpret_cast<const int2*>(lst + (size_t)((rel + h) * 8u));
-        }
-    };
-#define SQGR_ADD_DPP(dst, src, qp) asm("v_add_u32_dpp %0, %1, %2 quad_perm:[" qp "] row_mask:0xf bank_mask:0xf" : "=v"(dst) : "v"(src), "v"(qoff))
-    struct Pairs { uint32_t r[U], c[U]; };
-    auto spread = [&](const int2 mine) {
-        Pairs pr;
-        SQGR_ADD_DPP(pr.r[0], mine.x, "0,0,2,2"); SQGR_ADD_DPP(pr.c[0], mine.y, "0,0,2,2");
-        SQGR_ADD_DPP(pr.r[1], mine.x, "1,1,3,3"); SQGR_ADD_DPP(pr.c[1], mine.y, "1,1,3,3");
-        return pr;
-    };
-#undef SQGR_ADD_DPP
-    const uint32_t dbg_lin = (uint32_t)((((size_t)blockIdx.x * 40503u) % (size_t)(n - 4096)) * 16) + tid * 8;
-    auto gather_rows = [&](const Pairs& pr, uint2 (&ra)[U], uint2 (&rb)[U]) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if constexpr ((DBG & 2) != 0) {
-                ra[u] = *reinterpret_cast<const uint2*>(slab + dbg_lin + u * 16384);
-                rb[u] = *reinterpret_cast<const uint2*>(slab + dbg_lin + u * 16384 + 8192);
-            } else {
-                ra[u] = *reinterpret_cast<const uint2*>(slab + pr.r[u]);
-                rb[u] = *reinterpret_cast<const uint2*>(slab + pr.c[u]);
-            }
-        }
-    };
-    auto histogram = [&](const uint2 (&row_a)[U], const uint2 (&row_b)[U], uint32_t eb, auto general_tag) {
-        constexpr bool GENERAL = decltype(general_tag)::value;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            uint32_t inc = SELF ? 2u : 1u;
-            if constexpr (GENERAL) {  // branch-free tail: out-of-range edges add 0, self loops 1
-                inc = (eb + u < e1) ? 1u : 0u;
-                if constexpr (SELF) inc += (eb + u < min(e1, self_begin)) ? 1u : 0u;
-            }
-            const uint32_t a2[2] = {swap ? row_a[u].y : row_a[u].x, swap ? row_a[u].x : row_a[u].y};
-            const uint32_t b2[2] = {swap ? row_b[u].y : row_b[u].x, swap ? row_b[u].x : row_b[u].y};
-#pragma unroll
-            for (int sh = 0; sh < 2; ++sh) {
-                uint32_t addr[4];
-#pragma unroll
-                for (int sl = 0; sl < 4; ++sl)
-                    addr[sl] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(a2[sh], b2[sh], sel[sl])),
-                                                      __builtin_bit_cast(u16x2, dot_k), ofs[sh][sl], false);
-                if constexpr ((DBG & 1) != 0) {
-                    asm volatile("" : : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]) : "memory");
-                    continue;
-                }
-                asm volatile("ds_add_u32 %0, %4\n\tds_add_u32 %1, %4\n\tds_add_u32 %2, %4\n\tds_add_u32 %3, %4"
-                             :
-                             : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(inc)
-                             : "memory");
-            }
-        }
-    };
-    auto sweep = [&](auto general_tag) {
-        // three stages deep, one uniform loop (see k_count): pairs run two stages ahead of their gathers, rows two ahead of
-        // their histogram; the first two stages histogram nothing and two dummy gathers put a steady-state load count in flight
-        uint32_t rel = el * U;  // relative to e0
-        uint2 ra[3][U], rb[3][U];
-        int2 pr[3];
-        const uint32_t T = (e1 - e0 + STEP - 1) / STEP;
-        Pairs dummy;
-#pragma unroll
-        for (int u = 0; u < U; ++u) dummy.r[u] = dummy.c[u] = qoff;
-        pr[0] = load_pair(rel);
-        gather_rows(dummy, ra[1], rb[1]);
-        pr[1] = load_pair(rel + STEP);
-        gather_rows(dummy, ra[2], rb[2]);
-        for (uint32_t j = 0; j < T + 2; j += 3) {
-#pragma unroll
-            for (int st = 0; st < 3; ++st) {
-                pr[(st + 2) % 3] = load_pair(rel + (st + 2) * STEP);
-                gather_rows(spread(pr[st]), ra[st], rb[st]);
-                if (j + st >= 2 && j + st - 2 < T)
-                    histogram(ra[(st + 1) % 3], rb[(st + 1) % 3], e0 + rel + st * STEP - 2 * STEP, general_tag);
-            }
-            rel += 3 * STEP;
-        }
-    };
-    if (e0 < nnz) {
-        if (uniform_block)
-            sweep(std::false_type{});
-        else
-            sweep(std::true_type{});
-    }
-    __syncthreads();
-    uint32_t* dst = partial_all + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * hist_words;
-    if (add_transposed) {
-        for (int i = tid; i < hist_words; i += COUNT_THREADS) {
-            const int pair = i >> 4, la = pair / K, lb = pair - la * K;
-            dst[i] = hist[i] + hist[((lb * K + la) << 4) + (i & (B - 1))];
-        }
-    } else {
-        for (int i = tid; i < hist_words; i += COUNT_THREADS) dst[i] = hist[i];
-    }
-}
-
 // Large-K variants: BE (< 16) permutations [b0, b0+BE) of a 16-wide slab per pass; BE == 0: K*K does not
 // fit LDS at all -> device-scope atomics straight into the (single) partial.
 template <int BE>
@@ -1125,9 +896,6 @@ struct sqgr_nhood {
     int nblk = 0;
     int nbatch = 0;  // batches per launch group; 0: automatic (resolve_tuning)
     // workspace
-    DevBuf<uint32_t> fix_count;  // deferred exact route of k_shuffle (FixList): two sets of counters, used alternately
-    int fix_parity = 0;
-    DevBuf<uint2> fix_entries;
     DevBuf<uint32_t> keys;   // 2 buffers (ping-pong between the shuffle and the count stream)
     DevBuf<uint8_t> slab;    // 2 buffers
     hipEvent_t ev_shuffled[2] = {nullptr, nullptr}, ev_counted[2] = {nullptr, nullptr};
@@ -1251,10 +1019,7 @@ int sqgr_nhood::count_batches(int nb, int buf) {
         const bool self = half && g->n_self > 0;
         sym_launch = self ? 2 : 0;  // the blocks' partials already hold h + h^T; half lists with self loops are in doubled units
         const uint32_t epb = (uint32_t)(ceil_div(ceil_div((int64_t)m, nblk), 1024) * 1024);  // whole iterations of a block
-        // SQGR_COUNT_LDS_KB=<KiB>: claim more LDS than the histogram needs, so that fewer count blocks share a CU and the blocks
-        // of the (VALU-bound) shuffle kernel of the next launch group fit beside them (SQGR_NHOOD_STREAMS=2)
-        static const size_t lds_claim = [] { const char* e = getenv("SQGR_COUNT_LDS_KB"); return e ? (size_t)atoi(e) * 1024 : (size_t)0; }();
-        const size_t lds = std::min<size_t>(LDS_BUDGET, std::max<size_t>((size_t)hw * 4, lds_claim));
+        const size_t lds = (size_t)hw * 4;
         const dim3 grid(nblk, nb);
 #define SQGR_COUNT(BB, MW, SELF) \
     k_count<BB, MW, SELF><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, hw, epb, self_begin, half ? 1 : 0, partial.p)
@@ -1273,8 +1038,7 @@ int sqgr_nhood::count_batches(int nb, int buf) {
         } else {
             LaunchTimer t(ctx, half ? "nhood_count_b16_half" : "nhood_count_b16");
             static const int dbg = [] { const char* e = getenv("SQGR_COUNT_DEBUG"); return e ? atoi(e) : 0; }();
-            static const bool pair_rows = [] { const char* e = getenv("SQGR_COUNT_PAIR"); return !(e && atoi(e) == 0); }();
-            if (dot2 && !pair_rows && dbg && lds * 2 <= LDS_BUDGET && !self) {
+            if (dot2 && dbg && lds * 2 <= LDS_BUDGET && !self) {
 #define SQGR_COUNT_DBG(D) \
     case D: k_count<16, 8, false, true, D><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, hw, epb, self_begin, half ? 1 : 0, partial.p); break
                 switch (dbg) {
@@ -1282,40 +1046,9 @@ int sqgr_nhood::count_batches(int nb, int buf) {
                     default: k_count<16, 8, false, true, 7><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, hw, epb, self_begin, half ? 1 : 0, partial.p);
                 }
 #undef SQGR_COUNT_DBG
-            } else if (dot2 && pair_rows) {
-#define SQGR_COUNT_P(MW, SELF) \
-    k_count_pair<MW, SELF><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, hw, epb, self_begin, half ? 1 : 0, partial.p)
-                if ((size_t)hw * 4 * 2 <= LDS_BUDGET) {
-                    if (self) {
-                        SQGR_TRY(allow_lds(k_count_pair<8, true>, lds));
-                        SQGR_COUNT_P(8, true);
-                    } else if (dbg) {
-                        switch (dbg) {
-                            case 1: k_count_pair<8, false, 1><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, hw, epb, self_begin, half ? 1 : 0, partial.p); break;
-                            case 2: k_count_pair<8, false, 2><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, hw, epb, self_begin, half ? 1 : 0, partial.p); break;
-                            default: k_count_pair<8, false, 6><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, hw, epb, self_begin, half ? 1 : 0, partial.p); break;
-                        }
-                    } else {
-                        SQGR_TRY(allow_lds(k_count_pair<8, false>, lds));
-                        SQGR_COUNT_P(8, false);
-                    }
-                } else if (self) {
-                    SQGR_TRY(allow_lds(k_count_pair<4, true>, lds));
-                    SQGR_COUNT_P(4, true);
-                } else {
-                    SQGR_TRY(allow_lds(k_count_pair<4, false>, lds));
-                    SQGR_COUNT_P(4, false);
-                }
-#undef SQGR_COUNT_P
             } else if (dot2) {
-                if ((size_t)hw * 4 * 2 <= LDS_BUDGET) {
-                    if (self) {
-                        SQGR_TRY(allow_lds(k_count<16, 8, true, true>, lds));
-                        SQGR_COUNT_D(16, 8, true);
-                    } else {
-                        SQGR_TRY(allow_lds(k_count<16, 8, false, true>, lds));
-                        SQGR_COUNT_D(16, 8, false);
-                    }
+                if (lds * 2 <= LDS_BUDGET) {
+                    if (self) SQGR_COUNT_D(16, 8, true); else SQGR_COUNT_D(16, 8, false);
                 } else if (self) {
                     SQGR_TRY(allow_lds(k_count<16, 4, true, true>, lds));
                     SQGR_COUNT_D(16, 4, true);
@@ -1677,29 +1410,9 @@ static int launch_shuffle_raw(sqgr_nhood* p, int B, int nb, const uint32_t* keys
         return SQGR_OK;
     }
     const unsigned gy = (unsigned)(B == 32 ? nb : (nb + 1) / 2);  // 16-permutation rows are shuffled in pairs
-    // deferred exact route (FixList): ~4x the entries expected at large n (words with a sentinel: ~4 (A*B - n) / n of all words);
-    // lists that fill up send the surplus through the inline route.  SQGR_SHUFFLE_DEFER=0 keeps everything inline.
-    FixList fix{nullptr, nullptr, nullptr, 0};
-    // Measured (gpurun_out/r03_sweep1): 1.185 -> 1.62 ms per 2560-permutation launch — the returning atomics of 1.1e6 flagged
-    // words per launch cost far more than the divergent inline route saves; off by default (1: on, 2: probe that skips the route).
-    static const int defer = [] { const char* e = getenv("SQGR_SHUFFLE_DEFER"); return e ? atoi(e) : 0; }();
-    if (defer == 2 && p->K <= 126) {
-        fix = FixList{nullptr, nullptr, nullptr, 1};
-    } else if (defer == 1 && p->K <= 126) {
-        const int64_t words = p->n * (int64_t)nb * (B / 4);
-        const int64_t cap = std::max<int64_t>(64, std::min<int64_t>(ceil_div(words, 128 * FIX_SUBLISTS), (int64_t)1 << 20));
-        if (!p->fix_count.p) {
-            SQGR_TRY(p->fix_count.alloc(2 * FIX_SUBLISTS));
-            SQGR_HIP(hipMemsetAsync(p->fix_count.p, 0, 2 * FIX_SUBLISTS * 4, st));
-            p->fix_parity = 0;
-        }
-        SQGR_TRY(p->fix_entries.ensure((size_t)cap * FIX_SUBLISTS));
-        fix = FixList{p->fix_count.p + p->fix_parity * FIX_SUBLISTS, p->fix_count.p + (p->fix_parity ^ 1) * FIX_SUBLISTS, p->fix_entries.p, (uint32_t)cap};
-        p->fix_parity ^= 1;
-    }
 #define SQGR_SHUFFLE(BB, LIBS, SK)                                                                                               \
     k_shuffle<BB, LIBS, SK><<<dim3(gx, gy), 256, lds, st>>>(p->n, p->cum.p, p->kpad, p->blk_bytes, p->K, keys, p->dom0, p->n_libs, nb, \
-                                                            p->lib_of.p, p->rank_of.p, p->libs.p, fix, slab)
+                                                            p->lib_of.p, p->rank_of.p, p->libs.p, slab)
 #define SQGR_SHUFFLE_K(BB, LIBS) \
     if (p->K <= 126) SQGR_SHUFFLE(BB, LIBS, true); else SQGR_SHUFFLE(BB, LIBS, false)
     if (B == 32) {
@@ -1710,15 +1423,6 @@ static int launch_shuffle_raw(sqgr_nhood* p, int B, int nb, const uint32_t* keys
 #undef SQGR_SHUFFLE_K
 #undef SQGR_SHUFFLE
     SQGR_HIP(hipGetLastError());
-    if (fix.cap && fix.count) {
-        if (p->has_libs)
-            k_shuffle_fix<true><<<dim3(FIX_BLOCKS, FIX_SUBLISTS), 256, 0, st>>>(p->n, p->cum.p, p->kpad, B, keys, p->dom0, p->n_libs, p->lib_of.p, p->rank_of.p,
-                                                                      p->libs.p, fix, slab);
-        else
-            k_shuffle_fix<false><<<dim3(FIX_BLOCKS, FIX_SUBLISTS), 256, 0, st>>>(p->n, p->cum.p, p->kpad, B, keys, p->dom0, p->n_libs, p->lib_of.p, p->rank_of.p,
-                                                                       p->libs.p, fix, slab);
-        SQGR_HIP(hipGetLastError());
-    }
     return SQGR_OK;
 }
 

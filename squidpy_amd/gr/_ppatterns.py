@@ -18,7 +18,7 @@ from scipy import sparse
 
 from .._constants import SpatialAutocorr
 from .._lib import AutocorrPlan, DeviceMatrix, cached_graph, cooccur_counts, default_context
-from .._stats import multipletests_pvals, p_value_calc
+from .._stats import analytic_columns, multipletests_pvals, permutation_columns
 from .._utils import (
     _assert_categorical_obs,
     _assert_connectivity_key,
@@ -135,7 +135,10 @@ def _extract_vals(adata: Any, attr: str, genes: Any, layer: str | None, use_raw:
         elif isinstance(genes, str):
             genes = [genes]
         if not use_raw:
-            subset = adata[:, genes]
+            if len(genes) == adata.shape[1] and np.array_equal(np.asarray(genes), np.asarray(adata.var_names)):
+                subset = adata  # every feature, in order: no subsetting copy of a (possibly very large, sparse) matrix
+            else:
+                subset = adata[:, genes]
             return (subset.X if layer is None else subset.layers[layer]).T, genes
         if getattr(adata, "raw", None) is None:
             raise AttributeError("No `.raw` attribute found. Try specifying `use_raw=False`.")
@@ -243,31 +246,38 @@ def spatial_autocorr(
     graph = cached_graph(ctx, g, with_data=True)  # stays resident for the next call on the same (normalised) matrix
     rank, world = _dist.world()
     blocks = [(b0, min(n_feat, b0 + gene_block)) for b0 in range(0, n_feat, max(int(gene_block), 1))]
+    mine = [bi for bi in range(len(blocks)) if _block_owner(bi, len(blocks), world) == rank]  # a contiguous run of feature blocks
     score = np.full(n_feat, np.nan)
-    sims = np.full((n_perms, n_feat), np.nan) if n_perms is not None else None
-    # `vals` is usually the transposed view of a cell-major array (`adata.X[:, genes].T`): upload that array once and take
-    # the feature blocks as its columns on the device — no slicing / transposing copy on the host per block
-    resident = None
-    base = vals.T if isinstance(vals, np.ndarray) and vals.ndim == 2 else None
-    if base is not None and base.dtype == np.float64 and base.flags.c_contiguous and n_feat > 1 and world == 1:
-        if base.nbytes <= ctx.device_info()["hbm_bytes"] // 4:
-            resident = DeviceMatrix(ctx, base)
+    # the (n_perms, n_feat) permutation scores stay on the device; per feature their exceedance count, sum, std and var come back
+    red = None
+    if n_perms is not None:
+        red = {"n_ge": np.zeros(n_feat, dtype=np.int64), **{k: np.full(n_feat, np.nan) for k in ("sum", "std", "var")}}
+    # The expression matrix goes to the device ONCE, as it lies in memory — `adata.X` is usually scipy CSR float32, sometimes a
+    # dense row-major array — and the feature blocks are cut out of it (densified, widened to float64) there; every rank
+    # uploads the columns of its own blocks only.  Nothing is sliced, densified or transposed on the host per block.
+    resident, shift = (None, 0)
+    if mine:
+        resident, shift = _resident_features(ctx, vals, blocks[mine[0]][0], blocks[mine[-1]][1])
     try:
-        for bi, (b0, b1) in enumerate(blocks):
-            if bi % world != rank:
-                continue
+        for bi in mine:
+            b0, b1 = blocks[bi]
             if resident is not None:
-                plan = AutocorrPlan.from_columns(ctx, graph, resident, b0, b1 - b0)
-            else:
+                plan = AutocorrPlan.from_columns(ctx, graph, resident, b0 - shift, b1 - b0)
+            else:  # a gene-major host array (contiguous feature rows), or a matrix too large to keep resident
                 blk = vals[b0:b1]
                 blk = np.asarray(blk.toarray() if sparse.issparse(blk) else blk, dtype=np.float64)
                 plan = AutocorrPlan(ctx, graph, blk)
             try:
                 score[b0:b1] = plan.scores(mode.s)
-                if n_perms is not None and states is not None:
-                    sims[:, b0:b1] = plan.perms_pcg64(mode.s, states)
-                elif n_perms is not None:
-                    sims[:, b0:b1] = plan.perms(mode.s, perm_idx=perm_idx, seed=key, perm_begin=0, perm_end=n_perms)
+                if n_perms is not None:
+                    if states is not None:
+                        part = plan.perm_stats(mode.s, score[b0:b1], pcg_states=states)
+                    elif perm_idx is not None:
+                        part = plan.perm_stats(mode.s, score[b0:b1], perm_idx=perm_idx)
+                    else:
+                        part = plan.perm_stats(mode.s, score[b0:b1], seed=key, perm_begin=0, perm_end=n_perms)
+                    for k, v in part.items():
+                        red[k][b0:b1] = v
             finally:
                 plan.close()
     finally:
@@ -275,15 +285,17 @@ def spatial_autocorr(
             resident.close()
     if world > 1:
         score = _merge_blocks(score, blocks, world, axis=0)
-        if sims is not None:
-            sims = _merge_blocks(sims, blocks, world, axis=1)
+        if red is not None:
+            red = {k: _merge_blocks(v, blocks, world, axis=0) for k, v in red.items()}
     if np.isnan(score).any():
         import warnings
 
         warnings.warn("Some features are constant or contain NaN: their statistic is NaN.", UserWarning, stacklevel=2)
 
     with np.errstate(divide="ignore", invalid="ignore"):
-        pval_results = p_value_calc(score, sims, g, mode.s, expected, two_tailed)
+        pval_results = analytic_columns(score, g, mode.s, expected, two_tailed)
+        if red is not None:
+            pval_results.update(permutation_columns(score, n_perms, red["n_ge"], red["sum"], red["std"], red["var"]))
 
     df = pd.DataFrame({stat: score, **pval_results}, index=index)
     if corr_method is not None:
@@ -297,12 +309,41 @@ def spatial_autocorr(
     return None
 
 
+def _block_owner(bi: int, n_blocks: int, world: int) -> int:
+    """Feature blocks go to the ranks in contiguous runs (so that a rank's features are one column range of the matrix)."""
+    return bi * world // max(n_blocks, 1)
+
+
+def _resident_features(ctx: Any, vals: Any, c0: int, c1: int) -> tuple[DeviceMatrix | None, int]:
+    """Columns ``[c0, c1)`` of the (cells x features) matrix behind ``vals`` (features x cells, gr/_ppatterns.py:154-185)
+    uploaded as they lie in memory -> (device matrix, index of its first column), or ``(None, 0)`` when the feature rows are
+    contiguous on the host anyway (gene-major array: plain block uploads) or the matrix would not fit a quarter of the HBM."""
+    budget = ctx.device_info()["hbm_bytes"] // 4
+    if sparse.issparse(vals):
+        base = vals.T  # CSR <-> CSC view of the same arrays, (cells x features)
+        if not (sparse.isspmatrix_csr(base) or sparse.isspmatrix_csc(base)):
+            base = sparse.csr_matrix(base)
+        shift = 0
+        if sparse.isspmatrix_csc(base) and (c0 > 0 or c1 < base.shape[1]):
+            base, shift = base[:, c0:c1], c0  # a slice of the column pointer array; CSR keeps all columns (no cheap cut)
+        if base.data.nbytes + base.indices.nbytes + base.indptr.nbytes > budget:
+            return None, 0
+        return DeviceMatrix(ctx, base), shift
+    if isinstance(vals, np.ndarray) and vals.ndim == 2:
+        base = vals.T
+        if base.strides[1] == base.itemsize and base.shape[1] > 0 and base.strides[0] >= base.shape[1] * base.itemsize:
+            view = base[:, c0:c1]  # row-major (cells x features): a column range through the row pitch
+            if view.shape[0] * view.shape[1] * max(view.itemsize, 4) <= budget:
+                return DeviceMatrix(ctx, view), c0
+    return None, 0
+
+
 def _merge_blocks(a: np.ndarray, blocks: list[tuple[int, int]], world: int, axis: int) -> np.ndarray:
     """Every rank filled only its own feature blocks (NaN elsewhere): gather and take each block from its owner."""
     parts = _dist.allgather_object(a)
     out = a.copy()
     for bi, (b0, b1) in enumerate(blocks):
-        src = parts[bi % world]
+        src = parts[_block_owner(bi, len(blocks), world)]
         if axis == 0:
             out[b0:b1] = src[b0:b1]
         else:

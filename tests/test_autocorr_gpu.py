@@ -268,3 +268,89 @@ def test_moran_geary_exact_rational_known_answers_on_the_device(L, ctx):
         np.testing.assert_allclose(plan.perms("geary", perm_idx=idx)[0], want["C"], rtol=1e-12, atol=1e-15, equal_nan=True)
         plan.close()
         graph.close()
+
+
+@pytest.mark.parametrize("mode", ["moran", "geary"])
+def test_permutation_reductions_on_the_device_are_numpys(L, ctx, mode):
+    """`sqgr_autocorr_perm_stats` keeps the (P, G) scores on the device and returns what gr/_ppatterns.py:474-492 takes
+    out of them: the exceedance counts and numpy's sum / std / var over the permutation axis — bit for bit numpy's own
+    results on the scores of `perms()`, for all three permutation sources, incl. a constant (NaN) feature."""
+    from squidpy_amd._utils import pcg64_states
+
+    rng = np.random.default_rng(17)
+    n, G, P = 1500, 70, 97
+    g = knn_graph(rng.random((n, 2)), 6)
+    g.data = rng.random(g.nnz).astype(np.float32) + 0.1
+    vals = rng.gamma(2.0, 1.0, size=(G, n))
+    vals[3] = 0.5
+    graph = L.Graph(ctx, g)
+    plan = L.AutocorrPlan(ctx, graph, vals)
+    score = plan.scores(mode)
+    states = pcg64_states(5, P)
+    idx = O.autocorr_perm_indices(n, 8, P)
+    for kw, sims in (
+        (dict(seed=3, perm_begin=4, perm_end=4 + P), plan.perms(mode, seed=3, perm_begin=4, perm_end=4 + P)),
+        (dict(pcg_states=states), plan.perms_pcg64(mode, states)),
+        (dict(perm_idx=idx), plan.perms(mode, perm_idx=idx)),
+    ):
+        red = plan.perm_stats(mode, score, **kw)
+        with np.errstate(invalid="ignore"):
+            np.testing.assert_array_equal(red["n_ge"], (sims >= score).sum(axis=0))
+            np.testing.assert_array_equal(red["sum"], sims.sum(axis=0))
+            np.testing.assert_array_equal(red["std"], sims.std(axis=0))
+            np.testing.assert_array_equal(red["var"], np.var(sims, axis=0))
+        assert np.isnan(red["sum"][3]) and red["n_ge"][3] == 0
+    plan.close()
+    graph.close()
+
+
+@pytest.mark.parametrize("fmt,dtype,itype", [("csr", np.float32, np.int32), ("csc", np.float32, np.int64), ("csr", np.float64, np.int64),
+                                               ("csc", np.float64, np.int32), ("dense", np.float32, None), ("coo", np.int32, None)])
+def test_sparse_and_float32_expression_resident_on_the_device(L, fmt, dtype, itype):
+    """`adata.X` as real objects hold it — scipy CSR / CSC, float32, int32 or int64 index arrays; also dense float32 and an
+    integer COO matrix — is uploaded as it is and densified / widened on the device (`sqgr_matrix_create_csr/_csc/_dense`):
+    the result frame is IDENTICAL (every bit) to the one of the dense float64 matrix with the same values, for all features
+    and for a feature subset, over several feature blocks."""
+    import squidpy_amd as sq
+
+    adata = _adata(n=700, G=53, seed=4)
+    rng = np.random.default_rng(9)
+    X = np.where(rng.random(adata.X.shape) < 0.15, np.round(adata.X * 4), 0.0)  # sparse counts, exactly representable in float32
+    X[:, 7] = 0.0  # an all-zero (constant) feature
+    dense = adata.copy()
+    dense.X = X.astype(np.float64)
+    if fmt == "dense":
+        other_X = X.astype(dtype)
+    else:
+        m = getattr(sp, fmt + "_matrix")(X.astype(dtype))
+        if itype is not None:
+            m = type(m)((m.data, m.indices.astype(itype), m.indptr.astype(itype)), shape=m.shape)
+        other_X = m
+    other = adata.copy()
+    other.X = other_X
+    with pytest.warns(UserWarning, match="constant"):
+        a = sq.gr.spatial_autocorr(dense, genes=list(dense.var_names), n_perms=40, seed=2, copy=True, gene_block=16)
+    with pytest.warns(UserWarning, match="constant"):
+        b = sq.gr.spatial_autocorr(other, genes=list(other.var_names), n_perms=40, seed=2, copy=True, gene_block=16)
+    pd.testing.assert_frame_equal(a, b, check_exact=True)
+    sub = ["gene40", "gene3", "gene12", "gene13"]
+    pd.testing.assert_frame_equal(sq.gr.spatial_autocorr(dense, genes=sub, n_perms=20, seed=2, copy=True, mode="geary"),
+                                  sq.gr.spatial_autocorr(other, genes=sub, n_perms=20, seed=2, copy=True, mode="geary"), check_exact=True)
+
+
+def test_sparse_matrix_argument_checks(L, ctx):
+    m = sp.random(50, 20, density=0.2, format="csr", random_state=1, dtype=np.float32)
+    dm = L.DeviceMatrix(ctx, m)
+    assert dm.kind == "csr" and dm.shape == (50, 20)
+    dm.close()
+    bad = m.copy()
+    bad.indices = bad.indices[::-1].copy()  # rows no longer ascending; has_sorted_indices is stale on purpose
+    bad.has_sorted_indices = True
+    with pytest.raises(L.SqgrError, match="not sorted|outside"):
+        L.DeviceMatrix(ctx, bad)
+    bad2 = m.copy()
+    bad2.indices = bad2.indices.copy()
+    bad2.indices[0] = 25
+    bad2.has_sorted_indices = True
+    with pytest.raises(L.SqgrError, match="outside|not sorted"):
+        L.DeviceMatrix(ctx, bad2)

@@ -55,6 +55,18 @@ def test_interaction_matrix_known_answers(L, ctx, golden):
     cats[0] = -1
     ref = O.interaction_matrix(adj[1:, :][:, 1:].tocsr().data, adj[1:, :][:, 1:].tocsr().indices, adj[1:, :][:, 1:].tocsr().indptr, cats[1:], 2, True)
     np.testing.assert_array_equal(L.interaction_matrix(ctx, g, cats, 2, True), ref)
+    # ... and the reference's literal values for it (tests/graph/test_nhood.py:165-173), also through the front end
+    np.testing.assert_array_equal(L.interaction_matrix(ctx, g, cats, 2, True), [[2, 1], [2, 3]])
+    np.testing.assert_array_equal(L.interaction_matrix(ctx, g, cats, 2, False), [[1, 1], [2, 2]])
+    import pandas as pd
+
+    import squidpy_amd as sq
+
+    adata = sq.AnnDataLite(X=np.zeros((5, 5)), obs={"cat": pd.Categorical.from_codes(golden["intmat_cats"], ("a", "b"))},
+                           obsp={"spatial_connectivities": sp.csr_matrix(adj, dtype=np.int64)})
+    adata.obs.loc["0", "cat"] = np.nan
+    np.testing.assert_array_equal(sq.gr.interaction_matrix(adata, "cat", weights=True, copy=True), [[2, 1], [2, 3]])
+    np.testing.assert_array_equal(sq.gr.interaction_matrix(adata, "cat", weights=False, copy=True), [[1, 1], [2, 2]])
 
 
 @pytest.mark.parametrize("k", [3, 30, 60, 150])
@@ -409,6 +421,9 @@ def test_more_than_256_clusters_run_batched_on_the_device(L, ctx):
     ok = np.isfinite(want)
     res3 = sq.gr.nhood_enrichment(adata, "cluster", library_key="library", n_perms=6, seed=3, copy=True, rng="numpy")
     np.testing.assert_array_equal(res3.zscore[ok], want[ok])
+    # rng="numpy-host" with more than 256 clusters (the uint8 injection path must not be taken): the same z-scores
+    res4 = sq.gr.nhood_enrichment(adata, "cluster", n_perms=12, seed=3, copy=True, rng="numpy-host")
+    np.testing.assert_array_equal(res4.zscore[np.isfinite(res2.zscore)], res2.zscore[np.isfinite(res2.zscore)])
 
 
 def test_300_clusters_at_1e5_spots_is_a_device_path(L, ctx):

@@ -16,18 +16,50 @@ def _g(golden):
 
 
 @pytest.mark.parametrize("mode", ["moran", "geary"])
-def test_p_value_calc_matches_reference_source(golden, mode):
+def test_p_value_columns_match_reference_source(golden, mode):
+    """`_stats` takes the permutation scores already reduced (the device forms the reductions, tests/test_autocorr_gpu.py
+    checks those against numpy): fed with numpy's reductions of the golden scores it must give the columns of the
+    reference's literal `_p_value_calc` / `_analytic_pval` / `_g_moments` (tests/golden/make_golden.py)."""
     g = _g(golden)
     n = g.shape[0]
     expected = -1.0 / (n - 1) if mode == "moran" else 1.0
-    res = _stats.p_value_calc(golden[f"unpinned_{mode}_score"], golden[f"unpinned_{mode}_sims"], g, mode, expected, False)
+    score, sims = golden[f"unpinned_{mode}_score"], golden[f"unpinned_{mode}_sims"]
+    res = _stats.analytic_columns(score, g, mode, expected, False)
+    res.update(_stats.permutation_columns(score, sims.shape[0], (sims >= score).sum(axis=0), sims.sum(axis=0), sims.std(axis=0), np.var(sims, axis=0)))
     for key in ("pval_norm", "pval_z_sim", "pval_sim", "var_sim"):
         np.testing.assert_allclose(res[key], golden[f"autocorr_{mode}_{key}"], rtol=1e-13)
     np.testing.assert_allclose(res["var_norm"], golden[f"autocorr_{mode}_var_norm"], rtol=1e-13)
-    np.testing.assert_allclose(_stats.g_moments(g), golden["autocorr_moments"], rtol=1e-13)
-    two = _stats.p_value_calc(golden[f"unpinned_{mode}_score"], None, g, mode, expected, True)
+    np.testing.assert_allclose(_stats.weight_moments(g), golden["autocorr_moments"], rtol=1e-13)
+    np.testing.assert_allclose(_stats.weight_moments(g.toarray()), golden["autocorr_moments"], rtol=1e-6)  # dense float32 weights: other summation order
+    two = _stats.analytic_columns(score, g, mode, expected, True)
     np.testing.assert_allclose(two["pval_norm"], 2 * golden[f"autocorr_{mode}_pval_norm"], rtol=1e-13)
     assert set(two) == {"pval_norm", "var_norm"}
+    with pytest.raises(AssertionError, match="Unexpected mode"):
+        _stats.variance_under_normality(_stats.weight_moments(g), n, "foo")
+
+
+def test_multipletests_equals_statsmodels():
+    """Pinned to statsmodels 0.12.2 itself (tests/golden/make_multipletests_golden.py, run with the image's conda python):
+    every method squidpy_amd implements, on ties / zeros / ones / tiny values / a 400-vector / a NaN."""
+    import json
+    import os
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "multipletests_golden.json")) as fh:
+        gold = json.load(fh)
+    assert gold["statsmodels"] == "0.12.2"
+    for name, case in gold["cases"].items():
+        p = np.array(case["pvals"], dtype=float)
+        for method, want in case["corrected"].items():
+            want = np.array([np.nan if v is None else v for v in want], dtype=float)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                got = _stats.multipletests_pvals(p, method)
+            if name == "with_nan":
+                # statsmodels sorts the NaN to the end and lets it poison what the method accumulates over it; the reference feeds
+                # NaN p-values (constant features) straight in, so this behaviour is part of the contract
+                np.testing.assert_allclose(got, want, rtol=1e-12, equal_nan=True, err_msg=f"{name}/{method}")
+            else:
+                # (atol: `1 - (1 - p)**n` cancels, and np.power differs by an ulp between the numpy that made the golden and this one)
+                np.testing.assert_allclose(got, want, rtol=1e-13, atol=1e-15 if "sidak" in method else 0, err_msg=f"{name}/{method}")
 
 
 def test_multipletests_methods():
