@@ -15,20 +15,26 @@ the all-reduce of the exact integer moments, done ON THE DEVICE by RCCL inside l
 * ``--scaling strong``: a step is BASELINE config 5 as specified — ``--total-perms`` (100 000) permutations split
   1/N over the ranks.
 
-Rank 0 prints ONE JSON line.  Every ``frac`` in it is a fraction of a ceiling the kernel can actually reach:
+Rank 0 prints ONE JSON line:
 
-* ``roofline``            the CSR-gather kernel (``nhood_count*``): LDS-atomic issue — one ``ds_add_u32`` lane-operation
-                          per (edge of the list, permutation) against the chip's measured ``ds_add_u32`` rate
-                          (profiles/r02_ubench_ops.json, tools/ubench_ops.hip); its HBM side (algorithmic bytes,
-                          PMC traffic) is reported next to it, the ratio of the two is ``algorithmic_reuse``.
-* ``kernels``             the same for every kernel of the step (label shuffle: VALU issue; reduce: HBM).
-* ``secondary``           Moran's I genes/s on the config-3 shape, gather-bound out of L2 / Infinity Cache.
-* ``legs``                co_occurrence and Ripley L on the config-4 shape (pairs/s, VALU issue).
+* ``roofline``            the CSR-gather kernel (``nhood_count*``) against HBM: measured memory-side traffic per launch (PMC
+                          of this build and workload, 2 x FETCH_SIZE + WRITE_SIZE as calibrated in
+                          profiles/r03_fetch_calibration.json) / its HIP-event time / 8 TB/s.  SURVEY §8d's algorithmic
+                          bytes exceed the traffic by ``algorithmic_reuse`` (16 permutations per pass over the edge list).
+                          ``issue_limits``: what actually limits the kernel — the L1 access rate of its label-row gathers,
+                          the ``ds_add_u32`` rate of its LDS atomics, VALU issue — each against a rate measured on this chip.
+* ``kernels``             the same for the other kernels of the step (label shuffle: VALU issue; reduce: HBM).
+* ``secondary``           Moran's I genes/s on the config-3 shape (LDS-read bound; p-value reductions on the device).
+* ``legs``                co_occurrence / Ripley L / Ripley G on the config-4 shape, Geary's C on the config-3 shape, and
+                          config 3 IN FULL through the front end (20 000 genes, upload included); every leg with its own
+                          ``roofline`` and ``cpu_baseline`` (Ripley: the reference's own sklearn calls).
+* ``numpy_stream_mode``   the test with numpy's own PCG64 streams reproduced bit for bit on the GPU.
 * ``cpu_baseline``        the oracle's C restatement of Squidpy's numba kernel driven by numpy's PCG64 shuffles, timed
                           on this box's host cores on a bounded sample (N=1, rank 0 only).
+* ``emulated_ranks``      (``--emulate-ranks N``) the N shards of config 5 run one after the other on this GPU: a projection.
 PMC-derived inputs (HBM traffic, instruction counts per launch) cannot be collected inside this process; they come from
-``profiles/r02_counters.json``, written by ``tools/profile_round.sh`` from rocprofv3 ``--pmc`` passes of THIS command,
-and are used only when that file's workload (spots, permutations per launch, list length) matches the run."""
+``profiles/r03_counters.json``, written by ``tools/profile_round.sh`` from rocprofv3 ``--pmc`` passes of THIS command, and
+are used only when that file was taken from this build of the kernels (``source_sha16``) on this workload."""
 
 from __future__ import annotations
 
@@ -50,13 +56,13 @@ PERMS_PER_STEP = 10_000
 HBM_PEAK = 8.0e12   # B/s, MI355X_MICROARCH.md
 L2_PEAK = 34.5e12   # B/s aggregate L2 bandwidth, MI355X_MICROARCH.md §L2
 LDS_READ_PEAK = 256 * 256 * 2.4e9  # B/s: 256 B/clk/CU (ds_read_b64/b128, MI355X_MICROARCH.md §LDS) x 256 CUs x 2.4 GHz
-PROFILE_TAG = "r02"
+PROFILE_TAG = "r03"
 
 
 # --------------------------------------------------------------------------------------------- measured ceilings
 def load_ceilings() -> dict:
     """Issue-rate ceilings measured by tools/ubench_ops.hip on an MI355X (committed: profiles/r02_ubench_ops.json)."""
-    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_ubench_ops.json")
+    path = os.path.join(ROOT, "profiles", "r02_ubench_ops.json")  # (instruction rates of the chip: not re-measured every round)
     out = {"source": os.path.relpath(path, ROOT), "valu_simple": None, "valu_complex": None, "lds_add": None, "lds_add_pattern": None}
     try:
         with open(path) as fh:
@@ -75,19 +81,41 @@ def load_ceilings() -> dict:
 
 
 def load_counters() -> dict:
+    """PMC averages written by tools/profile_round.sh.  They are used only if they come from THIS build of the kernels
+    (`source_sha16` = squidpy_amd._build.source_fingerprint()) — and, per kernel, from this workload (kernel_counters)."""
+    from squidpy_amd._build import source_fingerprint
+
     path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_counters.json")
     try:
         with open(path) as fh:
             d = json.load(fh)
-        d["_source"] = os.path.relpath(path, ROOT)
-        return d
     except Exception:
-        return {}
+        return {"_status": f"no {os.path.relpath(path, ROOT)}"}
+    if d.get("source_sha16") != source_fingerprint():
+        return {"_status": f"{os.path.relpath(path, ROOT)} was taken from another build of the kernels (source_sha16 {d.get('source_sha16')} != "
+                           f"{source_fingerprint()}): PMC fields left null; re-run tools/profile_round.sh"}
+    d["_source"] = os.path.relpath(path, ROOT)
+    d["_status"] = "ok"
+    return d
+
+
+def load_f64_ceilings() -> dict:
+    """float64 VALU issue rates measured by tools/ubench_f64.hip (committed: profiles/r03_ubench_f64.json), clk per wave
+    instruction per SIMD at the nominal 2.4 GHz."""
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_ubench_f64.json")
+    out = {"source": os.path.relpath(path, ROOT)}
+    try:
+        with open(path) as fh:
+            for r in json.load(fh)["valu"]:
+                out[r["op"]] = r["clk_per_wave_instr_per_simd"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return out
 
 
 def load_lds_read_ceilings() -> dict:
     """LDS read rates measured by tools/ubench_lds_read.hip on an MI355X (committed: profiles/r02_ubench_lds_read.json)."""
-    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_ubench_lds_read.json")
+    path = os.path.join(ROOT, "profiles", "r02_ubench_lds_read.json")
     out = {"source": os.path.relpath(path, ROOT), "random_b128_bytes_per_s": None, "linear_b128_bytes_per_s": None}
     try:
         with open(path) as fh:
@@ -261,9 +289,10 @@ def gather_roofline(kernels: dict, counters: dict, n: int, G: int, P: int, steps
     return roof
 
 
-def moran_secondary(ctx, world: int, fence, reduce_max, steps: int, with_cpu: bool, counters: dict) -> dict:
-    """Second half of BASELINE.json's metric: Moran's I genes/sec on the C3 shape (1e5 spots, k=6 CSR graph,
-    n_perms=1000); one step = observed score + 1000 permuted scores for a resident block of 2048 genes per GPU."""
+def autocorr_leg(ctx, mode: str, world: int, fence, reduce_max, steps: int, with_cpu: bool, counters: dict) -> dict:
+    """Second half of BASELINE.json's metric: Moran's I (``mode="moran"``; ``"geary"``: Geary's C) genes/sec on the C3 shape
+    (1e5 spots, k=6 CSR graph, n_perms=1000); one step = observed score + 1000 permuted scores for a resident block of 2048
+    genes per GPU, the p-value reductions formed on the device (``sqgr_autocorr_perm_stats``)."""
     from sklearn.preprocessing import normalize
 
     from squidpy_amd import _lib
@@ -276,29 +305,31 @@ def moran_secondary(ctx, world: int, fence, reduce_max, steps: int, with_cpu: bo
     vals = np.random.default_rng(1 + rank).gamma(2.0, 1.0, size=(G, n))
     graph = _lib.Graph(ctx, g, with_data=True)
     plan = _lib.AutocorrPlan(ctx, graph, vals)  # resident from here on
-    plan.perms("moran", seed=1, perm_begin=0, perm_end=32)
+    plan.perms(mode, seed=1, perm_begin=0, perm_end=32)
     fence()
     ctx.timer_enable(True)
     ctx.timer_reset()
     t0 = time.perf_counter()
     for i in range(steps):
-        score = plan.scores("moran")
-        sims = plan.perms("moran", seed=7, perm_begin=i * P, perm_end=(i + 1) * P)
+        score = plan.scores(mode)
+        red = plan.perm_stats(mode, score, seed=7, perm_begin=i * P, perm_end=(i + 1) * P)
     fence()
     elapsed = reduce_max(time.perf_counter() - t0)
     kernels = ctx.timer_report()
     ctx.timer_enable(False)
-    assert np.isfinite(score).all() and np.isfinite(sims).all()
-    lds_cnt, lds_ms = kernels.get("autocorr_perm_dot_lds_moran", (0, 0.0))
-    cnt, ms = kernels.get("autocorr_perm_dot_moran", (0, 0.0))
+    assert np.isfinite(score).all() and np.isfinite(red["std"]).all() and (red["n_ge"] <= P).all()
+    kname = f"autocorr_perm_dot_lds_{mode}"
+    lds_cnt, lds_ms = kernels.get(kname, (0, 0.0))
+    geary = mode == "geary"
     b_gene = (P + 1) * 8 * n
+    per = 24.0 if geary else 16.0  # LDS bytes per (spot, permutation, gene): z and y[idx] (and r[idx] for Geary's C)
     if lds_cnt:  # the LDS-bucketed kernel (n_perms >= 512): both operands of every z*y product are read from LDS
         avg_ms = lds_ms / lds_cnt
-        lds_bytes = 16.0 * n * P * G  # two float64 operands per (spot, permutation, gene): what the statistic needs
+        lds_bytes = per * n * P * G
         achieved = lds_bytes * lds_cnt / (lds_ms * 1e-3)
         ceil = load_lds_read_ceilings()
         roof = {
-            "kernel": "autocorr_perm_dot_lds_moran",
+            "kernel": kname,
             "bound": "lds_read",
             "achieved": achieved / 1e9,
             "peak": LDS_READ_PEAK / 1e9,
@@ -311,18 +342,19 @@ def moran_secondary(ctx, world: int, fence, reduce_max, steps: int, with_cpu: bo
             "algorithmic_bytes_per_gene": b_gene,
             "algorithmic_GBps": b_gene * G * lds_cnt / (lds_ms * 1e-3) / 1e9,
             "list_build_ms_per_launch": kernels.get("autocorr_bucket_lists", (0, 0.0))[1] / max(lds_cnt, 1),
+            "perm_stats_ms_per_launch": kernels.get("autocorr_perm_stats", (0, 0.0))[1] / max(lds_cnt, 1),
             "note": "spots are cut into chunks, the pairs (i, idx_p(i)) of every permutation are bucketed by (chunk of i, chunk of idx_p(i)) once "
             "per gene block; a workgroup keeps Z[chunk a] and Y[chunk b] of two genes in LDS and every lane walks the list of its own "
-            "permutation: two random ds_read_b128 per pair, no global gather.  `achieved` = 16 B x spots x permutations x genes / time "
-            "(padding pairs not counted) against the LDS read peak of the guide (256 B/clk/CU); random 16-byte rows conflict ~3-way inside a "
-            "16-lane group, `frac_of_pattern_ceiling` prices it against the measured rate of exactly that pattern "
-            "(tools/ubench_lds_read.hip).  HBM side: lists + chunks, `traffic` from PMC when the committed profile matches",
+            "permutation: two random ds_read_b128 per pair (Geary's C: + one ds_read_b64 of the row sum), no global gather.  `achieved` = "
+            f"{per:.0f} B x spots x permutations x genes / time (padding pairs not counted) against the LDS read peak of the guide (256 B/clk/CU); "
+            "random 16-byte rows conflict ~3-way inside a 16-lane group, `frac_of_pattern_ceiling` prices it against the measured rate of "
+            "exactly that pattern (tools/ubench_lds_read.hip).  HBM side: lists + chunks, `traffic` from PMC when the committed profile matches",
         }
         if ceil.get("random_b128_bytes_per_s"):
             roof["pattern_ceiling_GBps"] = ceil["random_b128_bytes_per_s"] / 1e9
             roof["frac_of_pattern_ceiling"] = achieved / ceil["random_b128_bytes_per_s"]
             roof["ceiling_source"] = ceil["source"]
-        pmc = kernel_counters(counters.get("moran", {}), "k_perm_dot_lds<", {"spots": n, "genes": G, "perms": P})
+        pmc = kernel_counters(counters.get(mode, {}), "k_perm_dot_lds<", {"spots": n, "genes": G, "perms": P})
         if pmc and pmc.get("FETCH_SIZE_bytes") is not None and pmc.get("WRITE_SIZE_bytes") is not None:
             roof["traffic"] = 2.0 * pmc["FETCH_SIZE_bytes"] + pmc["WRITE_SIZE_bytes"]
             roof["traffic_source"] = counters.get("_source")
@@ -334,13 +366,16 @@ def moran_secondary(ctx, world: int, fence, reduce_max, steps: int, with_cpu: bo
                 roof["lds_conflict_cycle_share"] = pmc["SQ_LDS_BANK_CONFLICT"] / pmc["SQ_LDS_IDX_ACTIVE"]
     else:
         roof = gather_roofline(kernels, counters, n, G, P, steps, b_gene)
+    stat = "Geary's C" if geary else "Moran's I"
     out = {
-        "metric": "Moran's I genes/sec (1e5 spots, CSR k=6, n_perms=1000)",
+        "metric": f"{stat} genes/sec (1e5 spots, CSR k=6, n_perms=1000)",
         "value": steps * G * world / elapsed,
         "unit": "genes/s",
         "ms_per_step": elapsed / steps * 1e3,
         "dtype": "f64",
-        "config": {"workload": f"spatial_autocorr moran: {n} spots, {G} genes per GPU per step, {P} permutations, device permutations"},
+        "config": {"workload": f"spatial_autocorr {mode}: {n} spots, {G} genes per GPU per step, {P} permutations, device permutations, "
+                               "p-value reductions on the device (G x 4 numbers leave the GPU per step)"},
+        "kernel_time_share": {k: round(v[1] / max(sum(x[1] for x in kernels.values()), 1e-9), 3) for k, v in kernels.items() if v[0] > 0},
         "roofline": roof,
     }
     if with_cpu:
@@ -349,12 +384,13 @@ def moran_secondary(ctx, world: int, fence, reduce_max, steps: int, with_cpu: bo
         gsub, evals = 64, 0
         gens = [np.random.default_rng(s) for s in np.random.SeedSequence(0).spawn(64)]
         g64 = g.astype(np.float64)
+        func = cport.gearys_c if geary else cport.morans_i
         t0 = time.perf_counter()
         while evals < len(gens):
             idx = gens[evals].permutation(n)
-            cport.morans_i(g64[idx, :], vals[:gsub], parallel=False, native=True)  # gr/_ppatterns.py:271-272
+            func(g64[idx, :], vals[:gsub], parallel=False, native=True)  # gr/_ppatterns.py:271-272
             evals += 1
-            if time.perf_counter() - t0 > 6.0 and evals >= 2:
+            if time.perf_counter() - t0 > (3.0 if geary else 6.0) and evals >= 2:
                 break
         per_eval_gene = (time.perf_counter() - t0) / (evals * gsub)
         out["cpu_baseline"] = {
@@ -363,19 +399,58 @@ def moran_secondary(ctx, world: int, fence, reduce_max, steps: int, with_cpu: bo
             "cores": 1,
             "kind": "port",
             "sample": f"{evals} permutations x {gsub} genes (scipy row permutation g[idx,:] + C restatement of scanpy's per-gene "
-            f"Moran loop), scaled to {P + 1} evaluations per gene",
+            f"{stat} loop), scaled to {P + 1} evaluations per gene",
         }
     plan.close()
     graph.close()
     return out
 
 
+def config3_full_leg(with_cpu_value: float | None) -> dict:
+    """BASELINE config 3 IN FULL through the front end: `spatial_autocorr` on 1e5 spots x 20 000 genes (16 GB of float64
+    expression handed over as a host array), 1000 permutations, both statistics — upload, graph normalisation, p-values, FDR
+    and the sorted frame included; what README quotes as "config 3 end to end"."""
+    import warnings
+
+    import pandas as pd
+
+    import squidpy_amd as sq
+    from squidpy_amd._synthetic import hex_grid_graph
+
+    rows, cols, G, P = 250, 400, 20_000, 1000
+    n = rows * cols
+    t0 = time.perf_counter()
+    base = np.random.default_rng(3).gamma(2.0, 1.0, size=(n, 2000))
+    X = np.empty((n, G), dtype=np.float64)
+    for j in range(G // 2000):  # ten shifted copies of a 2000-gene block: cheap to build, no two columns equal
+        np.add(base, 0.01 * j, out=X[:, j * 2000 : (j + 1) * 2000])
+    del base
+    adata = sq.AnnDataLite(X=X, obs=pd.DataFrame(index=[f"s{i}" for i in range(n)]), obsp={"spatial_connectivities": hex_grid_graph(rows, cols)})
+    build_s = time.perf_counter() - t0
+    out = {"metric": "spatial_autocorr end to end, BASELINE config 3 in full (1e5 spots x 20 000 genes, n_perms=1000)", "unit": "s",
+           "input": "dense float64 host array (16 GB), uploaded once inside the call", "synthetic_input_build_s": build_s}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sq.gr.spatial_autocorr(adata, genes=list(adata.var_names[:256]), mode="moran", n_perms=64, seed=1, copy=True)  # warm-up (module load)
+        for mode in ("moran", "geary"):
+            t0 = time.perf_counter()
+            df = sq.gr.spatial_autocorr(adata, mode=mode, n_perms=P, seed=1, copy=True)
+            dt = time.perf_counter() - t0
+            assert df.shape == (G, 9) and np.isfinite(df.iloc[:, 0]).all()
+            out[mode] = {"seconds": dt, "genes_per_s": G / dt}
+    if with_cpu_value:
+        out["cpu_baseline"] = {"value": G / with_cpu_value, "unit": "s", "cores": 1, "kind": "port",
+                               "sample": "config 3 (Moran) at the per-gene rate of the secondary leg's CPU baseline (C restatement, 1 core): 20 000 genes / that rate"}
+    return out
+
+
 # --------------------------------------------------------------------------------------------- config-4 legs
-def config4_legs(ctx, ceil: dict, with_cpu: bool) -> dict:
-    """co_occurrence and Ripley L on BASELINE config 4's shape: 1e6 points (hex grid + N(0,5) jitter), 30 clusters,
-    50 interval edges (49 thresholds) / 50 Ripley radii.  Unit of work = one ORDERED pair evaluation (SURVEY §8d);
-    both kernels are VALU-issue bound (no HBM or MFMA roofline applies): 15 VALU wave-instructions per 64 unordered
-    pairs in the branch-free inner loop, priced against the measured rate of that instruction class."""
+def config4_legs(ctx, ceil: dict, with_cpu: bool, counters: dict) -> dict:
+    """co_occurrence, Ripley L and Ripley G on BASELINE config 4's shape: 1e6 points (hex grid + N(0,5) jitter), 30 clusters,
+    50 interval edges (49 thresholds) / 50 Ripley radii.  Unit of work = one ORDERED pair evaluation.  Neither HBM
+    nor MFMA bounds these kernels: the pair kernels are VALU-issue bound, priced against the measured issue rate of their own
+    instruction mix — the mix per 64 unordered pairs is read off the hot loop's ISA (tools/isa_mix.py) and, when the committed
+    profile matches, cross-checked by the PMC instruction counts of the same launch."""
     from squidpy_amd import _lib
     from squidpy_amd._synthetic import hex_grid
     from squidpy_amd.gr._ppatterns import _find_min_max
@@ -385,6 +460,7 @@ def config4_legs(ctx, ceil: dict, with_cpu: bool) -> dict:
     xy = hex_grid(ROWS, COLS) + rng.normal(0, 5, (n, 2))
     labels = rng.integers(0, N_CLS, n).astype(np.int32)
     out = {}
+    wkey = {"points": n, "clusters": N_CLS}
     # ---- co_occurrence (gr/_ppatterns.py:283-310): float32 coordinates, 49 squared thresholds
     sp = xy.astype(np.float32)
     lo, hi = _find_min_max(sp)
@@ -402,17 +478,26 @@ def config4_legs(ctx, ceil: dict, with_cpu: bool) -> dict:
     kms = sum(v[1] for name, v in k.items() if name.startswith("cooccur_pairs"))
     pairs = n * (n - 1)
     assert int(counts[:, :, -1].sum()) <= pairs
-    valu_per_pair = 15.0 / 2.0 / 64.0   # wave-instructions per ORDERED pair (15 per 64 unordered pairs)
+    valu_per_pair = 15.0 / 2.0 / 64.0   # wave-instructions per ORDERED pair: 15 VALU per 64 unordered pairs in the hot loop (tools/isa_mix.py)
     peak = valu_mix_peak(ceil, 0.5)
+    roof = {"kernel": "cooccur_pairs_fast", "bound": "valu_issue", "achieved": pairs * valu_per_pair / (kms * 1e-3) if kms > 0 else None,
+            "peak": peak, "unit": "wave-instr/s", "frac": (pairs * valu_per_pair / (kms * 1e-3) / peak) if kms > 0 and peak else None,
+            "traffic": None, "workload_key": wkey, "algorithmic_hbm_bytes": (n / 256.0) * n * 8.0, "isa_mix_per_64_unordered_pairs": {"valu_32": 15, "lds": 3},
+            "note": "15 VALU + 3 LDS wave-instructions per 64 unordered pairs (hot loop of k_cooccur_fast<false>, tools/isa_mix.py: 120 VALU + 24 DS per "
+            "8 pairs per lane; every unordered pair evaluated once and credited to (a,b) and (b,a)); HBM side negligible: (N/256)*N*8 B of tile re-reads"}
+    pmc = kernel_counters(counters.get("legs", {}), "k_cooccur_fast", wkey)
+    if pmc and pmc.get("SQ_INSTS_VALU") is not None and kms > 0:
+        launches = max(sum(v[0] for name, v in k.items() if name.startswith("cooccur_pairs")), 1)
+        vi, li = pmc["SQ_INSTS_VALU"] * launches, (pmc.get("SQ_INSTS_LDS") or 0.0) * launches
+        roof["pmc"] = {"valu_wave_instr": vi, "lds_wave_instr": li, "valu_per_64_unordered_pairs": vi / (pairs / 2 / 64.0), "lds_per_64_unordered_pairs": li / (pairs / 2 / 64.0),
+                       "achieved_valu_wave_instr_per_s": vi / (kms * 1e-3), "frac_of_mix_peak": vi / (kms * 1e-3) / peak if peak else None, "source": counters.get("_source")}
+        roof["frac"] = roof["pmc"]["frac_of_mix_peak"]
+        roof["achieved"] = roof["pmc"]["achieved_valu_wave_instr_per_s"]
+        if pmc.get("FETCH_SIZE_bytes") is not None and pmc.get("WRITE_SIZE_bytes") is not None:
+            roof["traffic"] = (2.0 * pmc["FETCH_SIZE_bytes"] + pmc["WRITE_SIZE_bytes"]) * launches
     out["co_occurrence"] = {
         "metric": "co_occurrence ordered pair evaluations/sec (1e6 points x 30 clusters x 49 thresholds)",
-        "value": pairs / wall, "unit": "pairs/s", "wall_s": wall, "kernel_ms": kms,
-        "roofline": {"kernel": "cooccur_pairs_fast", "bound": "valu_issue", "achieved": pairs * valu_per_pair / (kms * 1e-3) if kms > 0 else None,
-                     "peak": peak, "unit": "wave-instr/s", "frac": (pairs * valu_per_pair / (kms * 1e-3) / peak) if kms > 0 and peak else None,
-                     "traffic": None,
-                     "algorithmic_hbm_bytes": (n / 256.0) * n * 8.0,
-                     "note": "15 VALU + 3 LDS wave-instructions per 64 unordered pairs (branch-free loop, every unordered pair evaluated once "
-                     "and credited to (a,b) and (b,a)); HBM side negligible: (N/256)*N*8 B of tile re-reads"},
+        "value": pairs / wall, "unit": "pairs/s", "wall_s": wall, "kernel_ms": kms, "roofline": roof,
     }
     # ---- Ripley L (gr/_ripley.py:212-227): float64 pair counts per cluster, 50 radii
     from scipy.spatial import ConvexHull
@@ -427,20 +512,63 @@ def config4_legs(ctx, ceil: dict, with_cpu: bool) -> dict:
     ctx.timer_reset()
     t0 = time.perf_counter()
     tot = 0
+    first_counts = None
     for pts in by_cluster:
-        tot += int(_lib.pair_counts(ctx, pts, support)[-1])
+        c = _lib.pair_counts(ctx, pts, support)
+        first_counts = c if first_counts is None else first_counts
+        tot += int(c[-1])
     wall = time.perf_counter() - t0
     k = ctx.timer_report()
     ctx.timer_enable(False)
     kms = sum(v[1] for name, v in k.items() if name.startswith("ripley_pair_hist"))
     rp = sum(len(p) * (len(p) - 1) for p in by_cluster)
+    f64 = load_f64_ceilings()
+    # hot loop of k_pair_hist_fast<0> (tools/isa_mix.py): per lane and unordered pair 2 v_add_f64 (dx, dy) + 2 v_mul_f64 + 1 v_add_f64 (d2)
+    # + 1 v_mul_f64 (cell) + 1 v_cvt_i32_f64 + 2 v_cmp_f64 = 9 float64 VALU, 6 32-bit VALU, 3 DS (table read, two thresholds in one
+    # ds_read2_b64, one ds_add_u32)
+    mix = {"v_add_f64": 3, "v_mul_f64": 3, "v_cvt_i32_f64": 1, "v_cmp_le_f64": 2}
+    clk = None
+    if all(op in f64 for op in mix) and ceil.get("valu_complex"):
+        cu = ctx.device_info().get("cu_count") or 256
+        clk32 = cu * 4 * 2.4e9 / valu_mix_peak(ceil, 0.5)   # clk per 32-bit wave-instruction per SIMD of a half simple / half complex mix
+        clk = sum(cnt * f64[op] for op, cnt in mix.items()) + 6 * clk32   # SIMD clk per 64 unordered pairs
+        peak_pairs = cu * 4 * 2.4e9 / clk * 64 * 2                       # ORDERED pairs/s at which the VALU mix saturates
     out["ripley_L"] = {
         "metric": "ripley L ordered pair evaluations/sec (1e6 points in 30 clusters, 50 radii, float64)",
         "value": rp / wall, "unit": "pairs/s", "wall_s": wall, "kernel_ms": kms, "pairs": rp,
-        "roofline": {"kernel": "ripley_pair_hist_fast", "bound": "valu_issue",
-                     "achieved": rp / (kms * 1e-3) if kms > 0 else None, "peak": None, "unit": "pairs/s", "frac": None, "traffic": None,
-                     "note": "float64 VALU (v_fma_f64 / v_mul_f64 issue at quarter to half the f32 rate on gfx950 — not yet in tools/ubench_ops.hip), "
-                     "so no ceiling is claimed; reported as pairs/s of kernel time and of wall time"},
+        "roofline": {"kernel": "ripley_pair_hist_fast", "bound": "valu_f64_issue",
+                     "achieved": rp / (kms * 1e-3) if kms > 0 else None, "peak": peak_pairs if clk else None, "unit": "ordered pairs/s",
+                     "frac": (rp / (kms * 1e-3) / peak_pairs) if clk and kms > 0 else None, "traffic": None,
+                     "isa_mix_per_64_unordered_pairs": {**mix, "valu_32": 6, "lds": 3}, "simd_clk_per_64_unordered_pairs": clk, "ceiling_source": f64.get("source"),
+                     "note": "float64 VALU issue: the hot loop spends 9 float64 instructions per pair (4 clk class) beside 6 32-bit ones; `peak` = pair rate at which "
+                     "that mix saturates the four SIMDs of every CU at the issue rates of tools/ubench_f64.hip.  30 separate launches of ~650 workgroups "
+                     "each (one per cluster): launch ramp and tail are inside `kernel_ms`"},
+    }
+    # ---- Ripley G (gr/_ripley.py:163-169): for every cluster, the 2 nearest cluster points of every point NOT in it, histogram of the distances
+    pts_dev = _lib.DevicePoints(ctx, xy, labels)
+    edges = np.linspace(0, (area / 2) ** 0.5, 50)
+    pts_dev.knn_hist(by_cluster[0], 2, edges, exclude_label=0)
+    ctx.sync()
+    ctx.timer_enable(True)
+    ctx.timer_reset()
+    t0 = time.perf_counter()
+    gq = 0
+    for c in range(N_CLS):
+        h = pts_dev.knn_hist(by_cluster[c], 2, edges, exclude_label=c)
+        gq += n - len(by_cluster[c])
+    wall_g = time.perf_counter() - t0
+    kg = ctx.timer_report()
+    ctx.timer_enable(False)
+    pts_dev.close()
+    kms_g = sum(v[1] for name, v in kg.items() if name.startswith("ripley_knn_hist"))
+    brute = sum((n - len(p)) * len(p) for p in by_cluster)
+    out["ripley_G"] = {
+        "metric": "ripley G nearest-neighbour queries/sec (1e6 points, 30 clusters, n_neigh=2)",
+        "value": gq / wall_g, "unit": "queries/s", "wall_s": wall_g, "kernel_ms": kms_g, "queries": gq,
+        "roofline": {"kernel": "ripley_knn_hist_cells", "bound": "latency (cell-list walk)", "achieved": gq / (kms_g * 1e-3) if kms_g > 0 else None, "peak": None,
+                     "unit": "queries/s", "frac": None, "traffic": None, "brute_force_distance_evaluations_avoided": brute,
+                     "note": "one thread per query walks ~9-25 cells of ~2 reference points each (divergent, dependent loads): no throughput roofline applies; "
+                     f"the brute-force sweep this replaces evaluates {brute:.3g} distances (round 2: 0.60 s at this shape)"},
     }
     if with_cpu:
         from oracle import cport  # checker code: cpu_baseline leg only
@@ -451,7 +579,74 @@ def config4_legs(ctx, ceil: dict, with_cpu: bool) -> dict:
         dt = time.perf_counter() - t0
         out["co_occurrence"]["cpu_baseline"] = {"value": m * (m - 1) / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
                                                 "sample": f"C restatement of _occur_count on the first {m} points ({dt:.1f} s, 1 core); cost scales with N^2"}
+        # Ripley L: the reference's own call (gr/_ripley.py:220-222) — sklearn is installed here, so this is the reference, not a port
+        from sklearn.neighbors import KDTree, NearestNeighbors
+
+        t0 = time.perf_counter()
+        done, pr = 0, 0
+        for pts in by_cluster:
+            cnt = KDTree(pts).two_point_correlation(pts, support, dualtree=True) - len(pts)
+            if done == 0:
+                assert np.array_equal(cnt, first_counts), "sklearn and the device disagree on cluster 0"
+            done += 1
+            pr += len(pts) * (len(pts) - 1)
+            if time.perf_counter() - t0 > 12.0:
+                break
+        dt = time.perf_counter() - t0
+        out["ripley_L"]["cpu_baseline"] = {"value": pr / dt, "unit": "pairs/s", "cores": 1, "kind": "reference",
+                                           "sample": f"sklearn KDTree.two_point_correlation(dualtree=True) on {done} of the {N_CLS} clusters at full size ({dt:.1f} s, 1 core; "
+                                           "counts of cluster 0 asserted equal to the device's)"}
+        t0 = time.perf_counter()
+        done, qs = 0, 0
+        for c in range(N_CLS):
+            nn = NearestNeighbors(n_neighbors=2).fit(by_cluster[c])
+            sample = xy[labels != c][:: 8]  # every 8th query point
+            nn.kneighbors(sample, n_neighbors=2)
+            done += 1
+            qs += len(sample)
+            if time.perf_counter() - t0 > 8.0:
+                break
+        dt = time.perf_counter() - t0
+        out["ripley_G"]["cpu_baseline"] = {"value": qs / dt, "unit": "queries/s", "cores": 1, "kind": "reference",
+                                           "sample": f"sklearn NearestNeighbors(n_neighbors=2).kneighbors on every 8th query point of {done} clusters ({dt:.1f} s, 1 core)"}
     return out
+
+
+def numpy_stream_leg(ctx, plan, shift, n: int) -> dict:
+    """The test with numpy's own PCG64 streams reproduced bit for bit on the GPU (`rng="numpy"` — the mode whose z-scores ARE
+    Squidpy's for a seed).  One wave per permutation replays `Generator.shuffle`'s n - 1 dependent swap steps; the bound is
+    that serial chain, priced as swap steps per second per resident wave."""
+    from squidpy_amd._utils import pcg64_states
+
+    res, kern = {}, {}
+    for n_exact in (1000, 8192):  # Squidpy's default n_perms, and a throughput-sized batch
+        states = pcg64_states(0, n_exact)
+        plan.run_pcg64(states, shift)  # warm-up at full size: the workspaces are allocated (and first touched) here
+        ctx.timer_enable(True)
+        ctx.timer_reset()
+        t1 = time.perf_counter()
+        plan.run_pcg64(states, shift)
+        res[n_exact] = n_exact / (time.perf_counter() - t1)
+        kern[n_exact] = ctx.timer_report()
+        ctx.timer_enable(False)
+    k = kern[8192]
+    ms_shuffle = sum(v[1] for name, v in k.items() if "pcg64" in name)
+    ms_all = sum(v[1] for v in k.values())
+    cu = ctx.device_info().get("cu_count") or 256
+    steps_per_s = 8192 * (n - 1) / (ms_shuffle * 1e-3) if ms_shuffle > 0 else None
+    return {
+        "value": res[8192], "unit": "permutations/s", "at_n_perms_1000": res[1000],
+        "kernel_ms": {name: round(v[1], 3) for name, v in k.items() if v[0] > 0}, "shuffle_share_of_gpu_time": ms_shuffle / ms_all if ms_all > 0 else None,
+        "roofline": {"kernel": "nhood_pcg64_shuffle", "bound": "serial dependency chain (Fisher-Yates, one wave per permutation)",
+                     "achieved": steps_per_s, "unit": "swap steps/s", "peak": None, "frac": None, "traffic": None,
+                     "swap_steps_per_s_per_cu": steps_per_s / cu if steps_per_s else None,
+                     "clk_per_swap_step_per_wave_at_32_waves_per_cu": (cu * 32 * 2.4e9 / steps_per_s) if steps_per_s else None,
+                     "note": "numpy's shuffle is n - 1 swaps, each depending on the array state the previous ones left: a permutation cannot be split over "
+                     "lanes without replaying conflicts.  The kernel draws a wave-wide batch of swap targets with LCG jump-ahead, applies the "
+                     "non-conflicting ones in parallel and replays the rest in order (csrc/sqgr_pcg.hip); what bounds it is the dependent "
+                     "LDS/global round trip per batch, not a throughput unit — `clk_per_swap_step_per_wave` is the figure to lower"},
+        "note": "rng='numpy': z-scores equal Squidpy's for the same seed bit for bit",
+    }
 
 
 # --------------------------------------------------------------------------------------------- main
@@ -475,6 +670,10 @@ def main() -> None:
     ap.add_argument("--no-secondary", action="store_true", help="skip the Moran's I genes/sec leg")
     ap.add_argument("--no-legs", action="store_true", help="skip the co_occurrence / Ripley L legs (config 4)")
     ap.add_argument("--no-numpy-leg", action="store_true", help="skip the bit-compatible numpy-stream leg")
+    ap.add_argument("--no-config3-full", action="store_true", help="skip BASELINE config 3 in full through the front end (builds a 16 GB host matrix)")
+    ap.add_argument("--emulate-ranks", type=int, default=0,
+                    help="projection for a node this box does not have: run the N rank shards of BASELINE config 5 (--total-perms permutations, strong "
+                    "scaling) one after the other on this GPU and print per-shard times; no collective runs, labelled as a projection")
     ap.add_argument("--tune", type=str, default="", help="perms_per_pass,blocks_per_batch,batches_per_launch")
     args = ap.parse_args()
 
@@ -555,13 +754,45 @@ def main() -> None:
 
     ceil = load_ceilings()
     counters = load_counters()
-    secondary = None
+    secondary = geary = None
+    with_cpu = world == 1 and rank == 0 and not args.no_cpu_baseline
     if not args.no_secondary:
-        secondary = moran_secondary(ctx, world, fence, reduce_max, max(1, min(args.steps, 3)), world == 1 and rank == 0 and not args.no_cpu_baseline,
-                                    counters)
+        secondary = autocorr_leg(ctx, "moran", world, fence, reduce_max, max(1, min(args.steps, 3)), with_cpu, counters)
+        if world == 1:
+            geary = autocorr_leg(ctx, "geary", world, fence, reduce_max, max(1, min(args.steps, 3)), with_cpu, counters)
     legs = None
     if world == 1 and not args.no_legs:
-        legs = config4_legs(ctx, ceil, not args.no_cpu_baseline)
+        legs = config4_legs(ctx, ceil, not args.no_cpu_baseline, counters)
+        if geary is not None:
+            legs["geary_c"] = geary
+        if not args.no_secondary and not args.no_config3_full:
+            try:
+                legs["config3_full"] = config3_full_leg(secondary.get("cpu_baseline", {}).get("value") if secondary else None)
+            except MemoryError as exc:  # pragma: no cover  (a host without 20 GB of free memory)
+                legs["config3_full"] = {"error": repr(exc)}
+    emulated = None
+    if world == 1 and args.emulate_ranks > 1:
+        # the N shards of config 5 (strong scaling) as they would run on N GPUs, one after the other on this one: per-shard wall time
+        # = plan.run over the shard's permutation range incl. its launch ramp/tail and the 14 KB copy-out; the all-reduce of 2*K*K
+        # int64 moments (< 15 KB, latency-bound) is NOT included
+        N = args.emulate_ranks
+        times = []
+        for r in range(N):
+            lo, hi = _dist.shard_range(args.total_perms, r, N)
+            plan.run(777, lo, hi, shift)  # warm
+            ctx.sync()
+            t1 = time.perf_counter()
+            plan.run(777, lo, hi, shift)
+            ctx.sync()
+            times.append(time.perf_counter() - t1)
+        t1 = time.perf_counter()
+        plan.run(777, 0, args.total_perms, shift)
+        ctx.sync()
+        t_all = time.perf_counter() - t1
+        emulated = {"PROJECTION": f"the {N} rank shards of BASELINE config 5 run sequentially on ONE GPU; no multi-GPU hardware was used",
+                    "total_perms": args.total_perms, "ranks": N, "shard_seconds": times, "one_gpu_seconds": t_all,
+                    "projected_speedup_if_ranks_ran_concurrently": t_all / max(times), "fixed_cost_per_shard_s": max(0.0, (sum(times) - t_all) / N),
+                    "not_included": "RCCL all-reduce of int64[2*K*K] (14.4 KB) per call; process start-up; PCIe contention"}
 
     if rank == 0:
         total_perms = args.steps * (P if strong else P * world)
@@ -655,6 +886,28 @@ def main() -> None:
                             "frac": vi / (avg_count_ms * 1e-3) / valu_mix_peak(ceil, 0.8) if valu_mix_peak(ceil, 0.8) else None,
                             "note": "VALU side of the same kernel (v_perm_b32 + v_dot2_u32_u16 address, DPP offset spread; ~90 % complex class): "
                             "the VALU-only skeleton of the kernel takes 0.24 ms per 1024 permutations (profiles/r02_count_probes.json)"}
+        # ---- the line's `roofline` object: HBM (SURVEY §8d names HBM for this kernel; VERDICT r2 asks for the measured-traffic fraction).
+        # What limits the kernel in practice — the issue rate of its label-row gathers / LDS atomics — stays beside it as `issue_limits`.
+        issue = roof
+        roof = {
+            "kernel": issue["kernel"], "bound": "hbm",
+            "achieved": side.get("traffic_GBps"), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": side.get("traffic_frac_of_hbm_peak"),
+            "traffic": side["traffic_bytes_per_launch"], "traffic_source": side.get("traffic_source"),
+            "traffic_formula": "2 x FETCH_SIZE + WRITE_SIZE: calibrated on this kernel's own access patterns (4 B/lane row gathers, 8 B/lane list loads, "
+            "4 B/lane stores) over 512 MiB each — FETCH_SIZE reports exactly 0.5, WRITE_SIZE 1.0 (profiles/r03_fetch_calibration.json)",
+            "launches": launches, "avg_launch_ms": avg_count_ms, "perms_per_launch": perms_per_launch, "list_edges": list_edges,
+            "symmetric_half_list": info["symmetric"], "workload_key": workload,
+            "algorithmic_bytes_per_launch": side["algorithmic_bytes_per_launch"], "algorithmic_GBps": side["algorithmic_GBps"],
+            "algorithmic_reuse": side.get("algorithmic_reuse"),
+            "issue_limits": issue,
+            "note": "`achieved` = measured memory-side traffic of the CSR-gather kernel per launch (PMC, same build, same workload) / its HIP-event time on the "
+            "library's stream.  SURVEY §8d's ALGORITHMIC bytes (4*nnz + 4*(N+1) + N per permutation) are `algorithmic_reuse` times the traffic, because one "
+            "pass over the edge list serves 16 permutations — that ratio is reuse, not a roofline fraction.  The kernel is not HBM-bound: `issue_limits` "
+            "prices it against the L1 access rate of its gathers and the LDS-atomic rate (probe variants: profiles/r02_count_probes.json; "
+            "round-3 experiments: profiles/r03_nhood_experiments.json, profiles/r03_ubench_count_shape.json)",
+        }
+        if roof["frac"] is None:
+            roof["note"] += ".  No PMC profile of THIS build and workload is committed (" + str(counters.get("_status")) + "): traffic / achieved / frac are null"
         # ---- label shuffle: VALU issue
         avg_shuf_ms = ms_shuf / max(shuf_launch, 1)
         side_s, rec_s = hbm_side("k_shuffle", n * perms_per_launch, avg_shuf_ms)
@@ -701,7 +954,7 @@ def main() -> None:
                 "collective": collective,
             },
             "roofline": roof,
-            "kernels": {"nhood_shuffle": shuf, "nhood_count": {k: roof.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "lds_atomic")}, "nhood_reduce": red},
+            "kernels": {"nhood_shuffle": shuf, "nhood_count": {k: issue.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "lds_atomic")}, "nhood_reduce": red},
             "pipeline": {
                 "algorithmic_bytes_per_perm": b_perm,
                 "gpu_ms_all_kernels": gpu_ms,
@@ -718,29 +971,21 @@ def main() -> None:
             out["secondary"] = secondary
         if legs is not None:
             out["legs"] = legs
-        if world == 1 and not args.no_numpy_leg:  # bonus leg: the same test with numpy's own PCG64 streams reproduced bit for bit on the GPU
-            from squidpy_amd._utils import pcg64_states
-
-            res = {}
-            for n_exact in (1000, 8192):  # Squidpy's default n_perms, and a throughput-sized batch
-                states = pcg64_states(0, n_exact)
-                plan.run_pcg64(states, shift)  # warm-up at full size: the workspaces are allocated (and first touched) here
-                t1 = time.perf_counter()
-                plan.run_pcg64(states, shift)
-                res[n_exact] = n_exact / (time.perf_counter() - t1)
-            out["numpy_stream_mode"] = {
-                "value": res[8192],
-                "unit": "permutations/s",
-                "at_n_perms_1000": res[1000],
-                "note": "rng='numpy': PCG64 + Generator.shuffle reproduced on the device, one wave per permutation (LCG "
-                "jump-ahead draws, parallel swaps, exact replay of conflicting steps); z-scores equal Squidpy's for the same "
-                "seed bit for bit",
-            }
+        elif geary is not None:
+            out["geary_c"] = geary
+        if emulated is not None:
+            out["emulated_ranks"] = emulated
+        if world == 1 and not args.no_numpy_leg:  # the same test with numpy's own PCG64 streams reproduced bit for bit on the GPU
+            out["numpy_stream_mode"] = numpy_stream_leg(ctx, plan, shift, n)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(adj, labels)
             out["speedup_vs_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"]
             if "value" in out["cpu_baseline"].get("all_cores", {}):
                 out["speedup_vs_cpu_all_cores"] = out["value"] / out["cpu_baseline"]["all_cores"]["value"]
+            if "numpy_stream_mode" in out:  # the CPU path draws exactly these streams: the like-for-like ratio
+                out["numpy_stream_mode"]["cpu_baseline"] = {k: out["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind", "sample")}
+                out["numpy_stream_mode"]["speedup_vs_cpu_1core"] = out["numpy_stream_mode"]["value"] / out["cpu_baseline"]["value"]
+        out["pmc_profile"] = counters.get("_status")
         print(json.dumps(out))
     if world > 1:
         _dist.barrier()

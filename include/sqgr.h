@@ -205,8 +205,8 @@ int sqgr_matrix_create_dense(sqgr_ctx* ctx, const void* x, int32_t value_bytes, 
  * reference densifies `vals` feature block by feature block on the host, gr/_ppatterns.py:154-185 + scanpy's metrics):
  * CSR (rows = cells: indptr[n_rows + 1], indices = columns) or CSC (columns = features: indptr[n_cols + 1], indices = rows),
  * index arrays int32 or int64 (index_bytes 4 | 8, both arrays alike as in scipy), values float32 or float64
- * (value_bytes 4 | 8), indices ascending inside every row / column (scipy's `has_sorted_indices`; duplicates are summed
- * like `toarray()` does).  Feature blocks are expanded to dense float64 ON THE DEVICE by sqgr_autocorr_create_cols: the
+ * (value_bytes 4 | 8), in scipy's canonical format: indices ascending inside every row / column, no repeated entries
+ * (checked on the device; SQGR_ERR_INVALID names which — `sort_indices()` / `sum_duplicates()` fix it).  Feature blocks are expanded to dense float64 ON THE DEVICE by sqgr_autocorr_create_cols: the
  * results are bit-identical to uploading `toarray().astype(float64)`. */
 int sqgr_matrix_create_csr(sqgr_ctx* ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const void* indptr, const void* indices,
                            int32_t index_bytes, const void* values, int32_t value_bytes, sqgr_matrix** out);

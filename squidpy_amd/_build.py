@@ -24,6 +24,20 @@ def sources() -> list[str]:
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def source_fingerprint() -> str:
+    """sha256 (16 hex digits) over the kernel sources and the C ABI header: stamps profiles taken from a build, so that
+    bench.py never prices one build's timings with another build's counters."""
+    import hashlib
+
+    h = hashlib.sha256()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for path in sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(root, "include", "sqgr.h")]:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True

@@ -544,17 +544,25 @@ class DeviceMatrix:
                 x = sparse.csr_matrix(x)
             if x.dtype not in (np.float32, np.float64):
                 x = x.astype(np.float64)
-            if not x.has_sorted_indices:
-                x = x.sorted_indices()
             if x.indices.dtype != x.indptr.dtype or x.indices.dtype not in (np.int32, np.int64):
                 x = type(x)((x.data, x.indices.astype(np.int64), x.indptr.astype(np.int64)), shape=x.shape)
-            indptr, indices, data = np.ascontiguousarray(x.indptr), np.ascontiguousarray(x.indices), np.ascontiguousarray(x.data)
             fn = ctx.lib.sqgr_matrix_create_csr if sparse.isspmatrix_csr(x) else ctx.lib.sqgr_matrix_create_csc
-            _check(
-                ctx.lib,
-                fn(ctx.h, x.shape[0], x.shape[1], int(x.nnz), indptr.ctypes.data_as(C.c_void_p), indices.ctypes.data_as(C.c_void_p),
-                   indices.dtype.itemsize, data.ctypes.data_as(C.c_void_p), data.dtype.itemsize, C.byref(h)),
-            )
+            for attempt in range(2):
+                indptr, indices, data = np.ascontiguousarray(x.indptr), np.ascontiguousarray(x.indices), np.ascontiguousarray(x.data)
+                try:
+                    _check(
+                        ctx.lib,
+                        fn(ctx.h, x.shape[0], x.shape[1], int(x.nnz), indptr.ctypes.data_as(C.c_void_p), indices.ctypes.data_as(C.c_void_p),
+                           indices.dtype.itemsize, data.ctypes.data_as(C.c_void_p), data.dtype.itemsize, C.byref(h)),
+                    )
+                    break
+                except SqgrError as exc:
+                    # the library checks the canonical format where the arrays land (no O(nnz) pass on the host for the usual,
+                    # canonical, matrix); a matrix that is not is brought into it here the way `toarray()` would read it
+                    if attempt or not ("not sorted" in str(exc) or "duplicate" in str(exc)):
+                        raise
+                    x = x.copy()
+                    x.sum_duplicates()  # sorts the indices as well
             self.kind = "csr" if sparse.isspmatrix_csr(x) else "csc"
         else:
             x = np.asarray(x)

@@ -127,20 +127,24 @@ __global__ __launch_bounds__(256) void k_csc_to_genes(const int64_t* __restrict_
         atomicAdd(&X[(size_t)g * n + indices[e]], (double)values[e]);
 }
 
-// one wave per major slice: flags[0] an index outside [0, minor), flags[1] a slice that is not ascending
+// one wave per major slice: flags[0] an index outside [0, minor), flags[1] a slice that is not ascending, flags[2] a repeated index
 __global__ __launch_bounds__(256) void k_check_sparse(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, int64_t nslices,
                                                       int64_t minor, int* __restrict__ flags) {
     const int64_t j = blockIdx.x * (int64_t)4 + (threadIdx.x >> 6);
     if (j >= nslices) return;
     const int64_t a = indptr[j], b = indptr[j + 1];
-    int bad_range = 0, bad_order = 0;
+    int bad_range = 0, bad_order = 0, dup = 0;
     for (int64_t e = a + (threadIdx.x & 63); e < b; e += 64) {
         const int32_t c = indices[e];
         bad_range |= (c < 0 || c >= minor);
-        if (e > a) bad_order |= indices[e - 1] > c;
+        if (e > a) {
+            bad_order |= indices[e - 1] > c;
+            dup |= indices[e - 1] == c;
+        }
     }
     if (bad_range) flags[0] = 1;
     if (bad_order) flags[1] = 1;
+    if (dup) flags[2] = 1;
 }
 
 // int64 index arrays of a scipy matrix with more than 2^31 stored entries -> the library's layout
@@ -958,7 +962,7 @@ static int autocorr_create(sqgr_ctx* ctx, const sqgr_graph* g, const double* val
     hipError_t e = hipSuccess;
     const double* cm_src = dev_x ? dev_x + dev_col0 : nullptr;  // cell-major source on the device and its row pitch
     int64_t cm_ld = dev_x ? dev_ld : G;
-    if (cell_major && !dev_x) {  // one contiguous upload of vals[n][G]; the gene blocks are cut out of it on the device
+    if (cell_major && !dm) {  // one contiguous upload of vals[n][G]; the gene blocks are cut out of it on the device
         if ((rc = D.alloc((size_t)n * G))) return fail(rc);
         e = hipMemcpyAsync(D.p, vals, (size_t)n * G * 8, hipMemcpyHostToDevice, st);
         cm_src = D.p;
@@ -1128,19 +1132,23 @@ static int matrix_create_sparse(sqgr_ctx* ctx, int kind, int64_t n_rows, int64_t
         e = hipMemcpyAsync(m->f32 ? (void*)m->data32.p : (void*)m->data.p, values, (size_t)nnz * value_bytes, hipMemcpyHostToDevice, st);
     // the indices are checked where they now are: inside the minor axis, ascending inside every slice
     DevBuf<int> flags;
-    int hflags[2] = {0, 0};
-    if (e == hipSuccess && (rc = flags.alloc(2))) return fail(rc);
-    if (e == hipSuccess) e = hipMemsetAsync(flags.p, 0, 8, st);
+    int hflags[3] = {0, 0, 0};
+    if (e == hipSuccess && (rc = flags.alloc(3))) return fail(rc);
+    if (e == hipSuccess) e = hipMemsetAsync(flags.p, 0, 12, st);
     if (e == hipSuccess && nnz > 0) k_check_sparse<<<(unsigned)ceil_div(nptr - 1, 4), 256, 0, st>>>(m->indptr.p, m->indices.p, nptr - 1, minor, flags.p);
-    if (e == hipSuccess) e = hipMemcpyAsync(hflags, flags.p, 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(hflags, flags.p, 12, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("sparse matrix upload failed: %s", hipGetErrorString(e));
         return fail(SQGR_ERR_HIP);
     }
-    if (hflags[0] || hflags[1]) {
-        set_error(hflags[0] ? "sparse matrix: an index lies outside [0,%lld)" : "sparse matrix: indices are not sorted inside a row/column (call .sort_indices())",
+    if (hflags[0] || hflags[1] || hflags[2]) {
+        // (repeated indices: scipy's `toarray()` sums them in the matrix dtype, which a float64 accumulation would not reproduce
+        //  for float32 values — the caller sums them first)
+        set_error(hflags[0] ? "sparse matrix: an index lies outside [0,%lld)"
+                            : (hflags[1] ? "sparse matrix: indices are not sorted inside a row/column (call .sort_indices())"
+                                         : "sparse matrix: duplicate entries (call .sum_duplicates())"),
                   (long long)minor);
         return fail(SQGR_ERR_INVALID);
     }

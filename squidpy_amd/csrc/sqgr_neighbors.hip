@@ -13,25 +13,16 @@
 // best (d2, index) pairs in registers, and stops as soon as the k-th best is strictly closer than the unexplored
 // region.  Exact (not approximate) and deterministic: ties are broken by the smaller sample index.
 #include "sqgr_common.h"
+#include "sqgr_grid.h"
 
 #include <algorithm>
 #include <cmath>
 
 namespace sqgr {
 
-struct CellGrid {
-    double x0, y0, inv_h, h;
-    int gx, gy;
-};
-
 __device__ __forceinline__ double sqdist(double ax, double ay, double bx, double by) {
     const double dx = ax - bx, dy = ay - by;
     return __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));  // -ffp-contract=off: never fused
-}
-
-__device__ __forceinline__ void cell_of(const CellGrid& g, double x, double y, int& cx, int& cy) {
-    cx = min(max((int)floor((x - g.x0) * g.inv_h), 0), g.gx - 1);
-    cy = min(max((int)floor((y - g.y0) * g.inv_h), 0), g.gy - 1);
 }
 
 // lexicographic (d2, index) order
@@ -135,14 +126,8 @@ __global__ __launch_bounds__(128) void k_radius_grid(CellGrid g, const double* _
     if (COUNT) counts[qid] = cnt;
 }
 
-struct HostGrid {
-    CellGrid g;
-    std::vector<double> sx, sy;
-    std::vector<int32_t> sid, cell_start;
-};
-
 // counting sort of the points into ~n/target cells
-static int build_grid(const double* xy, int64_t n, double target_per_cell, double min_h, HostGrid& out) {
+int build_grid(const double* xy, int64_t n, double target_per_cell, double min_h, HostGrid& out) {
     double x0 = xy[0], x1 = xy[0], y0 = xy[1], y1 = xy[1];
     for (int64_t i = 0; i < n; ++i) {
         const double x = xy[2 * i], y = xy[2 * i + 1];
@@ -183,22 +168,6 @@ static int build_grid(const double* xy, int64_t n, double target_per_cell, doubl
     }
     return SQGR_OK;
 }
-
-struct DevGrid {
-    DevBuf<double> sx, sy;
-    DevBuf<int32_t> sid, cell_start;
-    int upload(const HostGrid& h, hipStream_t st) {
-        SQGR_TRY(sx.alloc(h.sx.size()));
-        SQGR_TRY(sy.alloc(h.sy.size()));
-        SQGR_TRY(sid.alloc(h.sid.size()));
-        SQGR_TRY(cell_start.alloc(h.cell_start.size()));
-        SQGR_HIP(hipMemcpyAsync(sx.p, h.sx.data(), h.sx.size() * 8, hipMemcpyHostToDevice, st));
-        SQGR_HIP(hipMemcpyAsync(sy.p, h.sy.data(), h.sy.size() * 8, hipMemcpyHostToDevice, st));
-        SQGR_HIP(hipMemcpyAsync(sid.p, h.sid.data(), h.sid.size() * 4, hipMemcpyHostToDevice, st));
-        SQGR_HIP(hipMemcpyAsync(cell_start.p, h.cell_start.data(), h.cell_start.size() * 4, hipMemcpyHostToDevice, st));
-        return SQGR_OK;
-    }
-};
 
 }  // namespace sqgr
 

@@ -13,8 +13,10 @@
 // `sqrt(d2) <= r` is decided WITHOUT a square root: the caller passes, per radius, the largest float64 t with
 // fl(sqrt(t)) <= r, so `d2 <= t` is the same predicate bit for bit.
 #include "sqgr_common.h"
+#include "sqgr_grid.h"
 
 #include <algorithm>
+#include <cmath>
 
 namespace sqgr {
 
@@ -79,6 +81,9 @@ __global__ __launch_bounds__(RP_TILE) void k_pair_hist(const double* __restrict_
 // Branch-free variant (same scheme as k_cooccur_fast): a lookup table over the metric value gives a lower bound g of the
 // bin with true bin <= g + 2; two compares against the adjacent thresholds finish it.  Full batches of off-diagonal
 // tiles with finite coordinates skip all validity tests (out-of-range pairs land in RP_TRASH write-only rows).
+// Histogram columns are per LANE (64), shared by the block's four waves through the LDS atomics they are anyway: 13 KB
+// instead of 54 KB at 50 radii, so five blocks instead of two share a CU (round 3: the kernel was latency-bound at
+// 8 waves per CU — a cluster of config 4 is only 650 blocks).  A column receives at most 4 waves x 32 tiles x 256 x 2 counts.
 constexpr int RP_BATCH = 8;
 constexpr int RP_TRASH = 3;
 constexpr int RP_CELLS_MIN = 1024;
@@ -91,22 +96,23 @@ __global__ __launch_bounds__(RP_TILE) void k_pair_hist_fast(const double* __rest
                                                             int finite, unsigned long long* __restrict__ out) {
     extern __shared__ unsigned char smem_raw[];
     double* s_thr = reinterpret_cast<double*>(smem_raw);                       // [S + 2], two +inf sentinels
-    uint32_t* hist = reinterpret_cast<uint32_t*>(s_thr + S + 2);               // [S + RP_TRASH][256]
-    uint16_t* s_cell = reinterpret_cast<uint16_t*>(hist + (S + RP_TRASH) * RP_TILE);  // [ncells]
+    constexpr int HC = 64;                                                     // histogram columns
+    uint32_t* hist = reinterpret_cast<uint32_t*>(s_thr + S + 2);               // [S + RP_TRASH][HC]
+    uint16_t* s_cell = reinterpret_cast<uint16_t*>(hist + (S + RP_TRASH) * HC);  // [ncells]
     const int t = threadIdx.x;
     const int ti = blockIdx.x;
     const int tj0 = max(ti, (int)blockIdx.y * RP_CHUNK);
     const int tj1 = min(T, ((int)blockIdx.y + 1) * RP_CHUNK);
     if (tj0 >= tj1) return;
     for (int i = t; i < S + 2; i += RP_TILE) s_thr[i] = i < S ? thr[i] : __builtin_inf();
-    for (int i = t; i < (S + RP_TRASH) * RP_TILE; i += RP_TILE) hist[i] = 0;
+    for (int i = t; i < (S + RP_TRASH) * HC; i += RP_TILE) hist[i] = 0;
     for (int i = t; i < ncells; i += RP_TILE) s_cell[i] = cell[i];
     __syncthreads();
     const int64_t gi = (int64_t)ti * RP_TILE + t;
     const bool active = gi < m;
     const double xi = active ? xs[gi] : 0.0, yi = active ? ys[gi] : 0.0;
     const int cmax = ncells - 1;
-    uint32_t* my = hist + t;
+    uint32_t* my = hist + (t & (HC - 1));
     for (int tj = tj0; tj < tj1; ++tj) {
         const int64_t j0g = (int64_t)tj * RP_TILE;
         const int vj = (int)min<int64_t>(RP_TILE, m - j0g);
@@ -137,9 +143,9 @@ __global__ __launch_bounds__(RP_TILE) void k_pair_hist_fast(const double* __rest
                 const int gg = g[u] + c0 + c1;
                 if constexpr (CHECKED) {
                     const bool ok = (gg < S) & (j0 + u < vj) & !(diag && j0 + u == t) & (d[u] == d[u]);
-                    atomicAdd(my + min(gg, S - 1) * RP_TILE, ok ? w : 0u);
+                    atomicAdd(my + min(gg, S - 1) * HC, ok ? w : 0u);
                 } else {
-                    atomicAdd(my + gg * RP_TILE, w);
+                    atomicAdd(my + gg * HC, w);
                 }
             }
         };
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(RP_TILE) void k_pair_hist_fast(const double* __rest
     __syncthreads();
     for (int g = t; g < S; g += RP_TILE) {
         unsigned long long s = 0;
-        for (int k = 0; k < RP_TILE; ++k) s += hist[g * RP_TILE + ((k + t) & (RP_TILE - 1))];
+        for (int k = 0; k < HC; ++k) s += hist[g * HC + ((k + t) & (HC - 1))];
         if (s) atomicAdd(&out[g], s);
     }
 }
@@ -264,6 +270,124 @@ __global__ __launch_bounds__(256) void k_knn_hist(const double* __restrict__ qx,
         if (s_hist[i]) atomicAdd(&out[i], (unsigned long long)s_hist[i]);
 }
 
+// The same two sweeps through a CELL LIST of the reference points (round 3; the brute-force kernels above cost
+// n_queries x n_refs distance evaluations — 1e12 for Ripley's G at 1e6 points).  One thread per query walks the cells of
+// the reference grid ring by ring around the query's own cell, keeps the k best metric values in registers and stops as
+// soon as the k-th best is strictly closer than anything outside the block of cells visited so far; for all three
+// metrics a point outside the block [xl, xh] x [yl, yh] is at least m = (distance from the query to the block's boundary)
+// away (L2 and L1 >= Linf >= m).  Queries may lie outside the grid (F draws them in the convex hull of ALL points): their
+// cell is the clamped one, m is negative until the block reaches them, and the walk ends at the latest when every cell has
+// been seen.  The k smallest values are the same multiset whatever the visiting order, so the result equals the brute-force
+// sweep bit for bit.  HIST: numpy's histogram of the distances instead of the distances (see k_knn_hist).
+template <int METRIC, int KMAX, bool HIST>
+__global__ __launch_bounds__(128) void k_knn_cells(CellGrid g, const double* __restrict__ sx, const double* __restrict__ sy,
+                                                   const int32_t* __restrict__ cell_start, const double* __restrict__ qx,
+                                                   const double* __restrict__ qy, const int32_t* __restrict__ qlabel, int exclude,
+                                                   int64_t nq, int k, double* __restrict__ out, const double* __restrict__ edges, int S,
+                                                   unsigned long long* __restrict__ hist_out) {
+    extern __shared__ unsigned char knn_smem[];
+    double* s_edges = reinterpret_cast<double*>(knn_smem);        // [S]      (HIST only)
+    uint32_t* s_hist = reinterpret_cast<uint32_t*>(s_edges + S);  // [S - 1]
+    if constexpr (HIST) {
+        for (int i = threadIdx.x; i < S; i += blockDim.x) s_edges[i] = edges[i];
+        for (int i = threadIdx.x; i < S - 1; i += blockDim.x) s_hist[i] = 0;
+        __syncthreads();
+    }
+    const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const bool active = q < nq && (!HIST || exclude < 0 || qlabel[q] != exclude);
+    double best[KMAX];
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) best[s] = __builtin_inf();
+    if (active) {
+        const double xi = qx[q], yi = qy[q];
+        int cx, cy;
+        cell_of(g, xi, yi, cx, cy);
+        const int rmax = max(max(cx, g.gx - 1 - cx), max(cy, g.gy - 1 - cy));
+        for (int r = 0; r <= rmax; ++r) {
+            const int ylo = cy - r, yhi = cy + r;
+            for (int yy = max(ylo, 0); yy <= min(yhi, g.gy - 1); ++yy) {
+                const bool edge_row = (yy == ylo) || (yy == yhi);
+                const int step = edge_row ? 1 : 2 * r;  // interior rows of the ring: only the two end cells
+                for (int xx = cx - r; xx <= cx + r; xx += (step > 0 ? step : 1)) {
+                    if (xx < 0 || xx >= g.gx) continue;
+                    const int c = yy * g.gx + xx;
+                    for (int p = cell_start[c]; p < cell_start[c + 1]; ++p) {
+                        double d = metric_dist<METRIC>(xi, yi, sx[p], sy[p]);
+                        if (d < best[KMAX - 1]) {
+#pragma unroll
+                            for (int s = 0; s < KMAX; ++s) {
+                                const double lo = fmin(best[s], d), hi = fmax(best[s], d);
+                                best[s] = lo;
+                                d = hi;
+                            }
+                        }
+                    }
+                }
+            }
+            const double xl = g.x0 + (double)(cx - r) * g.h, xh = g.x0 + (double)(cx + r + 1) * g.h;
+            const double yl = g.y0 + (double)(cy - r) * g.h, yh = g.y0 + (double)(cy + r + 1) * g.h;
+            const double m = fmin(fmin(xi - xl, xh - xi), fmin(yi - yl, yh - yi)) - 1e-9 * g.h;  // slack for cell rounding
+            double kth = __builtin_inf();
+#pragma unroll
+            for (int s = 0; s < KMAX; ++s) kth = (s == k - 1) ? best[s] : kth;
+            if (m > 0.0 && kth < (METRIC == 0 ? m * m : m)) break;  // strict: ties at the k-th distance are harmless either way
+        }
+        if constexpr (!HIST) {
+#pragma unroll
+            for (int s = 0; s < KMAX; ++s)
+                if (s < k) out[(size_t)q * k + s] = best[s];
+        } else {
+            const double e_first = s_edges[0], e_last = s_edges[S - 1];
+#pragma unroll
+            for (int s = 0; s < KMAX; ++s) {
+                if (s < k) {
+                    const double v = (METRIC == 0) ? __dsqrt_rn(best[s]) : best[s];
+                    if (v >= e_first && v <= e_last) {
+                        int lo = 0, hi = S - 1;
+                        while (hi - lo > 1) {
+                            const int mid = (lo + hi) >> 1;
+                            if (s_edges[mid] <= v) lo = mid; else hi = mid;
+                        }
+                        atomicAdd(&s_hist[lo], 1u);
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (HIST) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < S - 1; i += blockDim.x)
+            if (s_hist[i]) atomicAdd(&hist_out[i], (unsigned long long)s_hist[i]);
+    }
+}
+
+// reference sets from this size on go through the cell list (below it the brute-force sweep is as fast and needs no grid)
+constexpr int64_t KNN_GRID_MIN_REFS = 512;
+
+template <int METRIC, bool HIST>
+static int launch_knn_cells(sqgr_ctx* ctx, const HostGrid& hg, const DevGrid& dg, const double* qx, const double* qy, const int32_t* qlabel,
+                            int exclude, int64_t nq, int k, double* out, const double* edges, int S, unsigned long long* hist_out) {
+    const unsigned grid = (unsigned)ceil_div(nq, 128);
+    const size_t lds = HIST ? (size_t)S * 8 + (size_t)S * 4 : 0;
+    hipStream_t st = ctx->stream;
+#define SQGR_KC(KM) \
+    k_knn_cells<METRIC, KM, HIST><<<grid, 128, lds, st>>>(hg.g, dg.sx.p, dg.sy.p, dg.cell_start.p, qx, qy, qlabel, exclude, nq, k, out, edges, S, hist_out)
+    if (k <= 1) SQGR_KC(1);
+    else if (k <= 2) SQGR_KC(2);
+    else if (k <= 4) SQGR_KC(4);
+    else if (k <= 8) SQGR_KC(8);
+    else SQGR_KC(16);
+#undef SQGR_KC
+    SQGR_HIP(hipGetLastError());
+    return SQGR_OK;
+}
+
+static bool all_finite(const double* xy, int64_t n) {
+    for (int64_t i = 0; i < 2 * n; ++i)
+        if (!std::isfinite(xy[i])) return false;
+    return true;
+}
+
 template <int METRIC>
 static int launch_knn(sqgr_ctx* ctx, const double* qx, const double* qy, int64_t nq, const double* rx, const double* ry, int64_t nr,
                       int k, double* out) {
@@ -329,7 +453,7 @@ int sqgr_pair_counts(sqgr_ctx* ctx, const double* xy, int64_t m, const double* t
     int ncells = RP_CELLS_MIN;
     double inv_cell = 0.0;
     bool fast = false;
-    const size_t lds_fast_fixed = (size_t)(S + 2) * 8 + (size_t)(S + RP_TRASH) * RP_TILE * 4;
+    const size_t lds_fast_fixed = (size_t)(S + 2) * 8 + (size_t)(S + RP_TRASH) * 64 * 4;
     if (tmax > 0.0 && S < 65000) {
         for (;; ncells *= 2) {
             inv_cell = (double)ncells / tmax;
@@ -420,6 +544,28 @@ int sqgr_knn_dist(sqgr_ctx* ctx, const double* query, int64_t nq, const double* 
     SQGR_HIP(hipSetDevice(ctx->device));
     std::vector<double> qx, qy, rx, ry;
     split_xy(query, nq, qx, qy);
+    if (nr >= KNN_GRID_MIN_REFS && all_finite(ref, nr)) {  // cell list over the reference points
+        HostGrid hg;
+        SQGR_TRY(build_grid(ref, nr, 2.0, 0.0, hg));
+        DevGrid dg;
+        hipStream_t st = ctx->stream;
+        SQGR_TRY(dg.upload(hg, st));
+        struct { double* p; } dqx, dqy, dout;
+        SQGR_TRY(ctx->scratch_get(0, (size_t)nq * 8, reinterpret_cast<void**>(&dqx.p)));
+        SQGR_TRY(ctx->scratch_get(1, (size_t)nq * 8, reinterpret_cast<void**>(&dqy.p)));
+        SQGR_TRY(ctx->scratch_get(4, (size_t)nq * k * 8, reinterpret_cast<void**>(&dout.p)));
+        SQGR_HIP(hipMemcpyAsync(dqx.p, qx.data(), (size_t)nq * 8, hipMemcpyHostToDevice, st));
+        SQGR_HIP(hipMemcpyAsync(dqy.p, qy.data(), (size_t)nq * 8, hipMemcpyHostToDevice, st));
+        {
+            LaunchTimer t(ctx, "ripley_knn_cells");
+            if (metric == 0) SQGR_TRY((launch_knn_cells<0, false>(ctx, hg, dg, dqx.p, dqy.p, nullptr, -1, nq, k, dout.p, nullptr, 0, nullptr)));
+            else if (metric == 1) SQGR_TRY((launch_knn_cells<1, false>(ctx, hg, dg, dqx.p, dqy.p, nullptr, -1, nq, k, dout.p, nullptr, 0, nullptr)));
+            else SQGR_TRY((launch_knn_cells<2, false>(ctx, hg, dg, dqx.p, dqy.p, nullptr, -1, nq, k, dout.p, nullptr, 0, nullptr)));
+        }
+        SQGR_HIP(hipMemcpyAsync(out, dout.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
+        SQGR_HIP(hipStreamSynchronize(st));  // also keeps `dg` alive until the kernel is done
+        return SQGR_OK;
+    }
     split_xy(ref, nr, rx, ry);
     struct { double* p; } dqx, dqy, drx, dry, dout;  // context scratch (see sqgr_pair_counts)
     SQGR_TRY(ctx->scratch_get(0, (size_t)nq * 8, reinterpret_cast<void**>(&dqx.p)));
@@ -491,6 +637,31 @@ int sqgr_knn_hist(sqgr_ctx* ctx, const sqgr_points* queries, int32_t exclude_lab
         return SQGR_ERR_UNSUPPORTED;
     }
     SQGR_HIP(hipSetDevice(ctx->device));
+    if (nr >= KNN_GRID_MIN_REFS && all_finite(ref, nr)) {  // cell list over the reference points
+        HostGrid hg;
+        SQGR_TRY(build_grid(ref, nr, 2.0, 0.0, hg));
+        DevGrid dg;
+        hipStream_t st = ctx->stream;
+        SQGR_TRY(dg.upload(hg, st));
+        struct { double* p; } dedges;
+        struct { unsigned long long* p; } dout;
+        SQGR_TRY(ctx->scratch_get(2, (size_t)S * 8, reinterpret_cast<void**>(&dedges.p)));
+        SQGR_TRY(ctx->scratch_get(3, (size_t)S * 8, reinterpret_cast<void**>(&dout.p)));
+        SQGR_HIP(hipMemcpyAsync(dedges.p, edges, (size_t)S * 8, hipMemcpyHostToDevice, st));
+        SQGR_HIP(hipMemsetAsync(dout.p, 0, (size_t)S * 8, st));
+        {
+            LaunchTimer t(ctx, "ripley_knn_hist_cells");
+            const sqgr_points* qs = queries;
+            if (metric == 0) SQGR_TRY((launch_knn_cells<0, true>(ctx, hg, dg, qs->x.p, qs->y.p, qs->label.p, exclude_label, qs->n, k, nullptr, dedges.p, S, dout.p)));
+            else if (metric == 1) SQGR_TRY((launch_knn_cells<1, true>(ctx, hg, dg, qs->x.p, qs->y.p, qs->label.p, exclude_label, qs->n, k, nullptr, dedges.p, S, dout.p)));
+            else SQGR_TRY((launch_knn_cells<2, true>(ctx, hg, dg, qs->x.p, qs->y.p, qs->label.p, exclude_label, qs->n, k, nullptr, dedges.p, S, dout.p)));
+        }
+        std::vector<unsigned long long> hc((size_t)S);
+        SQGR_HIP(hipMemcpyAsync(hc.data(), dout.p, (size_t)(S - 1) * 8, hipMemcpyDeviceToHost, st));
+        SQGR_HIP(hipStreamSynchronize(st));
+        for (int s2 = 0; s2 < S - 1; ++s2) out_counts[s2] = (int64_t)hc[s2];
+        return SQGR_OK;
+    }
     std::vector<double> rx, ry;
     split_xy(ref, nr, rx, ry);
     struct { double* p; } drx, dry, dedges;

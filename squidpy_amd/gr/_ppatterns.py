@@ -79,6 +79,7 @@ def co_occurrence(
     table_key: str | None = None,
     fma: bool = False,
     device: int | None = None,
+    shard: str = "tiles",
 ) -> tuple[np.ndarray, np.ndarray] | None:
     """Compute co-occurrence probability of clusters (drop-in for ``squidpy.gr.co_occurrence``).
 
@@ -88,7 +89,10 @@ def co_occurrence(
 
     Extra keyword-only parameters: ``fma`` — evaluate ``d2`` as ``fma(dx, dx, dy*dy)`` instead of separately rounded
     products (only matters for pairs lying exactly on a threshold; default matches numpy semantics); ``device``.
-    With a ``torch.distributed`` process group the row tiles are split across ranks and the int64 counts all-reduced.
+    With a process group the work is split across ranks and the int64 counts all-reduced: ``shard="tiles"`` (default) gives
+    every rank a share of the row tiles of the N x N sweep (each pair evaluated once overall), ``shard="intervals"`` gives
+    every rank all pairs and a contiguous batch of the radius intervals (the partition BASELINE's north star names; it
+    repeats the distance work on every rank and is kept as the alternative).  The counts are identical either way.
 
     Note: the number of clusters is the number of *categories* of ``adata.obs[cluster_key]``; the reference takes
     ``len(np.unique(labels))`` and indexes out of bounds when a category is empty (gr/_ppatterns.py:337-338).
@@ -109,11 +113,21 @@ def co_occurrence(
         raise ValueError(f"Expected interval to be of length `>= 2`, found `{len(interval)}`.")
 
     thresholds = (interval[1:]) ** 2  # float32, as in gr/_ppatterns.py:341
+    if shard not in ("tiles", "intervals"):
+        raise ValueError(f"Invalid option `{shard}` for `shard`. Valid options are: `['tiles', 'intervals']`.")
     ctx = default_context(device)
     rank, world = _dist.world()
-    counts = cooccur_counts(
-        ctx, spatial[:, 0], spatial[:, 1], labs.astype(ip), n_cls, thresholds, fma=fma, shard_index=rank, shard_count=world
-    )
+    if shard == "intervals" and world > 1:
+        # a cumulative count at threshold r only needs the thresholds of the rank's own batch: pairs below its first
+        # threshold all fall into its first bin
+        lo, hi = _dist.shard_range(len(thresholds), rank, world)
+        counts = np.zeros((n_cls, n_cls, len(thresholds)), dtype=np.int64)
+        if hi > lo:
+            counts[:, :, lo:hi] = cooccur_counts(ctx, spatial[:, 0], spatial[:, 1], labs.astype(ip), n_cls, thresholds[lo:hi], fma=fma)
+    else:
+        counts = cooccur_counts(
+            ctx, spatial[:, 0], spatial[:, 1], labs.astype(ip), n_cls, thresholds, fma=fma, shard_index=rank, shard_count=world
+        )
     (counts,) = _dist.allreduce_sum_([counts])
     out = _occ_from_counts(counts)
 

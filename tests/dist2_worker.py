@@ -34,11 +34,20 @@ def main():
     occ, _ = sq.gr.co_occurrence(adata, "cluster", interval=8, copy=True)
     occ_ref, _ = O.co_occurrence(adata.obsm["spatial"], lab, interval=8)
     np.testing.assert_allclose(occ, occ_ref, rtol=1e-12)
-    # autocorr: feature blocks round-robin (3 blocks over 2 ranks), gathered
+    # the other shard axis (BASELINE north star: radius-interval batches per rank): identical result
+    occ_iv, _ = sq.gr.co_occurrence(adata, "cluster", interval=8, copy=True, shard="intervals")
+    np.testing.assert_array_equal(occ_iv, occ)
+    # autocorr: contiguous runs of feature blocks per rank (3 blocks over 2 ranks), each rank uploads its columns only; gathered
     df = sq.gr.spatial_autocorr(adata, mode="geary", n_perms=12, seed=5, copy=True, rng="numpy", gene_block=64)
     want = O.spatial_autocorr(adj, adata.X.T, adata.var_names, mode="geary", n_perms=12, seed=5)
     for c in df.columns:
         np.testing.assert_allclose(df[c].to_numpy(), want[c].to_numpy(), rtol=1e-6, atol=1e-12, err_msg=c)
+    ad_sp = adata.copy()
+    ad_sp.X = sp.csr_matrix(np.asarray(adata.X, dtype=np.float32))  # sparse float32 expression, resident per rank
+    df_sp = sq.gr.spatial_autocorr(ad_sp, mode="geary", n_perms=12, seed=5, copy=True, rng="numpy", gene_block=64)
+    want32 = O.spatial_autocorr(adj, np.asarray(adata.X, dtype=np.float32).astype(np.float64).T, adata.var_names, mode="geary", n_perms=12, seed=5)
+    for c in df_sp.columns:
+        np.testing.assert_allclose(df_sp[c].to_numpy(), want32[c].to_numpy(), rtol=1e-6, atol=1e-12, err_msg=c)
     # ligrec: permutation ranges, all-reduce of the indicator counts
     genes = list(adata.var_names[:6])
     inter = [(a, b) for a in genes for b in genes if a != b]

@@ -82,13 +82,26 @@ def main() -> None:
     (summed,) = _dist.allreduce_sum_([part])
     assert np.array_equal(summed, fullc)
 
-    # ---- autocorr: feature blocks owned round-robin, merged by gather
+    # ---- co-occurrence, the other shard axis (radius-interval batches per rank, all pairs): a rank's cumulative counts need
+    # its own thresholds only; zero elsewhere, the all-reduce assembles the full array
+    lo, hi = _dist.shard_range(len(thr), rank, world)
+    part_iv = np.zeros_like(fullc)
+    if hi > lo:
+        part_iv[:, :, lo:hi] = O.occur_count(x, y, thr[lo:hi], labs, 3)
+    (summed_iv,) = _dist.allreduce_sum_([part_iv])
+    assert np.array_equal(summed_iv, fullc)
+
+    # ---- autocorr: contiguous runs of feature blocks per rank (a rank's features are one column range), merged by gather
+    from squidpy_amd.gr._ppatterns import _block_owner
+
     G = 10
     blocks = [(b0, min(G, b0 + 3)) for b0 in range(0, G, 3)]
+    owners = [_block_owner(bi, len(blocks), world) for bi in range(len(blocks))]
+    assert owners == sorted(owners) and set(owners) <= set(range(world)) and (world > len(blocks) or set(owners) == set(range(world)))
     score = np.full(G, np.nan)
     sims = np.full((4, G), np.nan)
     for bi, (b0, b1) in enumerate(blocks):
-        if bi % world == rank:
+        if owners[bi] == rank:
             score[b0:b1] = np.arange(b0, b1)
             sims[:, b0:b1] = np.arange(b0, b1)[None, :] + 100 * np.arange(4)[:, None]
     score = _merge_blocks(score, blocks, world, axis=0)

@@ -339,18 +339,28 @@ def test_sparse_and_float32_expression_resident_on_the_device(L, fmt, dtype, ity
 
 
 def test_sparse_matrix_argument_checks(L, ctx):
+    """The library checks scipy's canonical format where the arrays land (no host pass for the usual canonical matrix); a
+    matrix with unsorted rows and repeated entries is repaired on the host (`sum_duplicates`, float32 sums like `toarray()`)
+    and gives the frame of its dense form; an index outside the matrix is an error."""
+    import squidpy_amd as sq
+
     m = sp.random(50, 20, density=0.2, format="csr", random_state=1, dtype=np.float32)
     dm = L.DeviceMatrix(ctx, m)
     assert dm.kind == "csr" and dm.shape == (50, 20)
     dm.close()
-    bad = m.copy()
-    bad.indices = bad.indices[::-1].copy()  # rows no longer ascending; has_sorted_indices is stale on purpose
-    bad.has_sorted_indices = True
-    with pytest.raises(L.SqgrError, match="not sorted|outside"):
+    adata = _adata(n=300, G=12, seed=6)
+    rng = np.random.default_rng(1)
+    rows = np.repeat(np.arange(300), 5)
+    cols = rng.integers(0, 12, rows.size)  # unsorted inside the rows, with repeats
+    vals = rng.integers(1, 9, rows.size).astype(np.float32) / 3
+    indptr = np.arange(0, rows.size + 1, 5)
+    messy = sp.csr_matrix((vals, cols, indptr), shape=(300, 12))
+    dense = adata.copy()
+    dense.X = messy.toarray().astype(np.float64)
+    other = adata.copy()
+    other.X = sp.csr_matrix((vals.copy(), cols.copy(), indptr.copy()), shape=(300, 12))
+    pd.testing.assert_frame_equal(sq.gr.spatial_autocorr(dense, genes=list(dense.var_names), n_perms=16, seed=1, copy=True),
+                                  sq.gr.spatial_autocorr(other, genes=list(other.var_names), n_perms=16, seed=1, copy=True), check_exact=True)
+    bad = sp.csr_matrix((vals[:5], np.array([0, 3, 5, 7, 25]), np.array([0, 5] + [5] * 299)), shape=(300, 12), copy=True)
+    with pytest.raises(L.SqgrError, match="outside"):
         L.DeviceMatrix(ctx, bad)
-    bad2 = m.copy()
-    bad2.indices = bad2.indices.copy()
-    bad2.indices[0] = 25
-    bad2.has_sorted_indices = True
-    with pytest.raises(L.SqgrError, match="outside|not sorted"):
-        L.DeviceMatrix(ctx, bad2)

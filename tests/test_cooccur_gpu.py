@@ -119,3 +119,21 @@ def test_many_thresholds_are_swept_in_chunks(L, ctx):
     labs = rng.integers(0, k, n).astype(np.int32)
     thr = rng.permutation(np.linspace(0.5, 120, 300, dtype=np.float32) ** 2)  # also unsorted
     np.testing.assert_array_equal(L.cooccur_counts(ctx, x, y, labs, k, thr), O.occur_count(x, y, thr, labs, k))
+
+
+def test_interval_batches_reproduce_the_full_counts(L, ctx):
+    """The other shard axis of config 4 (radius-interval batches, all pairs per batch): a cumulative count at threshold r
+    needs only the thresholds of its own batch, so the slices of `sqgr_cooccur_counts` over threshold ranges ARE the
+    corresponding slices of the full result — what `co_occurrence(..., shard="intervals")` relies on."""
+    rng = np.random.default_rng(3)
+    n, k = 5000, 7
+    xy = (rng.random((n, 2)) * 300).astype(np.float32)
+    xy[:1000] = np.round(xy[:1000])  # lattice part: exact ties with thresholds
+    lab = rng.integers(0, k, n).astype(np.int32)
+    thr = (np.linspace(1, 150, 23, dtype=np.float32)) ** 2
+    thr[5] = np.float32(25.0)
+    thr.sort()
+    full = L.cooccur_counts(ctx, xy[:, 0], xy[:, 1], lab, k, thr)
+    for cuts in ((0, 8, 23), (0, 1, 2, 11, 22, 23)):
+        parts = [L.cooccur_counts(ctx, xy[:, 0], xy[:, 1], lab, k, thr[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+        np.testing.assert_array_equal(np.concatenate(parts, axis=2), full)

@@ -134,3 +134,32 @@ def test_resident_knn_histogram_equals_numpy_histogram(metric):
         dropped.append(int(dist.size - got.sum()))
     assert max(dropped) > 0  # at least one setting has distances outside its edges
     pts.close()
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "manhattan", "chebyshev"])
+def test_knn_cell_list_outside_queries_duplicates_clusters(L, ctx, metric):
+    """Reference sets of 512 points or more go through the cell list (k_knn_cells): two far-apart blobs with duplicated
+    points and lattice ties as references, queries spread over a box three times as wide (most of them OUTSIDE the grid,
+    like Ripley's F draws them), every register tier of k; equal to sklearn's KD-tree, distance for distance.  The
+    resident-query histogram (Ripley's G) goes through the same kernel."""
+    from sklearn.neighbors import NearestNeighbors
+
+    rng = np.random.default_rng(11)
+    blob = lambda c, m: np.round(rng.normal(c, 3.0, (m, 2)), 1)
+    ref = np.concatenate([blob((0, 0), 900), blob((200, 50), 700), np.repeat(blob((100, 100), 20), 3, axis=0)])
+    qry = np.concatenate([rng.uniform(-300, 500, (1500, 2)), ref[:200], np.round(rng.uniform(-10, 10, (300, 2)))])
+    for k in (1, 2, 4, 7, 16):
+        exp, _ = NearestNeighbors(metric=metric, n_neighbors=k).fit(ref).kneighbors(qry, n_neighbors=k)
+        np.testing.assert_array_equal(L.knn_dist(ctx, qry, ref, k, metric), exp)
+    # a single row / column of cells (degenerate bounding box) and fewer points than one cell's target
+    line = np.stack([np.linspace(0, 100, 600), np.zeros(600)], axis=1)
+    exp, _ = NearestNeighbors(metric=metric, n_neighbors=3).fit(line).kneighbors(qry, n_neighbors=3)
+    np.testing.assert_array_equal(L.knn_dist(ctx, qry, line, 3, metric), exp)
+    lab = rng.integers(0, 3, len(qry)).astype(np.int32)
+    pts = L.DevicePoints(ctx, qry, lab)
+    edges = np.linspace(0.0, 120.0, 33)
+    for k, excl in ((1, -1), (2, 1)):
+        keep = np.ones(len(qry), bool) if excl < 0 else lab != excl
+        dist = L.knn_dist(ctx, qry[keep], ref, k, metric)
+        np.testing.assert_array_equal(pts.knn_hist(ref, k, edges, metric, exclude_label=excl), np.histogram(dist.ravel(), bins=edges)[0])
+    pts.close()

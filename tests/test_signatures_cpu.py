@@ -16,7 +16,7 @@ import squidpy_amd as sq
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = json.load(open(os.path.join(HERE, "golden", "reference_signatures.json")))
-EXTRA = {"rng", "device", "fma", "gene_block"}
+EXTRA = {"rng", "device", "fma", "gene_block", "shard"}
 # defaults the reference spells through its constants
 SPECIAL = {
     "Key.obsp.spatial_conn()": "spatial_connectivities",

@@ -1,19 +1,23 @@
 #!/bin/bash
 # rocprofv3 evidence for bench.py's JSON line, taken on the GPU box in ONE lease:
-#   1. --kernel-trace --stats                      -> profiles/<tag>_rocprofv3_summary.txt
+#   1. --kernel-trace --stats of the bench command       -> profiles/<tag>_rocprofv3_summary.txt
 #   2. separate --pmc passes (never combined with a trace): FETCH_SIZE | WRITE_SIZE | SQ instruction counts |
-#      SQ LDS/busy counters | TCC hit/miss            -> profiles/<tag>_counters.json (per kernel, per launch)
-# bench.py reads <tag>_counters.json for `traffic` and the VALU instruction counts and uses it only when the workload key
-# (spots, list edges, permutations per launch) equals its own.
-#   usage: tools/profile_round.sh [tag]          (default tag r02; outputs under gpurun_out/prof_<tag>/ and profiles/)
+#      SQ LDS/busy counters | TCC hit/miss | L1 (TCP/TD/TA)  -> profiles/<tag>_counters.json (per kernel, per launch),
+#      for the nhood + Moran + Geary kernels and (FETCH/WRITE/SQ instruction counts) for the config-4 legs
+#   3. FETCH_SIZE / WRITE_SIZE calibration on known byte counts (tools/ubench_fetch_calib.hip) -> profiles/<tag>_fetch_calibration.json
+#   4. micro-benchmarks: float64 issue rates, gathers beside LDS atomics
+# <tag>_counters.json is stamped with the kernel sources' fingerprint; bench.py uses it only for that build and for the
+# workload key (spots, list edges, permutations per launch) it was taken on.
+#   usage: tools/profile_round.sh [tag]          (default tag r03; outputs under gpurun_out/prof_<tag>/ and profiles/)
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT $REPO/profiles
 cd /tmp && export TMPDIR=/tmp
 CMD="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-numpy-leg --no-legs"
 PMC="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-numpy-leg --no-legs"
+LEGS="python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-numpy-leg --no-secondary"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/stats.log 2>&1
 timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $PMC > $OUT/fetch.log 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $PMC > $OUT/write.log 2>&1
@@ -21,5 +25,17 @@ timeout 900 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VM
 timeout 900 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/sqb -- $PMC > $OUT/sqb.log 2>&1
 timeout 900 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/tcc -- $PMC > $OUT/tcc.log 2>&1
 timeout 900 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TD_TD_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum --output-format csv -d $OUT/tcp -- $PMC > $OUT/tcp.log 2>&1
-python $REPO/tools/summarize_round.py $OUT $TAG "$CMD" "$PMC" && cp $OUT/${TAG}_rocprofv3_summary.txt $OUT/${TAG}_counters.json $REPO/profiles/
+# the config-4 legs (co-occurrence, Ripley L / G): kernel trace + instruction counts + traffic
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/legs_stats -- $LEGS > $OUT/legs_stats.log 2>&1
+timeout 900 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAVES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES --output-format csv -d $OUT/legs_sqa -- $LEGS > $OUT/legs_sqa.log 2>&1
+timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/legs_fetch -- $LEGS > $OUT/legs_fetch.log 2>&1
+timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/legs_write -- $LEGS > $OUT/legs_write.log 2>&1
+# calibration of FETCH_SIZE / WRITE_SIZE on known byte counts, in the nhood kernels' access patterns
+if [ -x $REPO/tools/ubench_fetch_calib.bin ]; then
+  timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/calib_fetch -- $REPO/tools/ubench_fetch_calib.bin > $OUT/calib_fetch.log 2>&1
+  timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/calib_write -- $REPO/tools/ubench_fetch_calib.bin > $OUT/calib_write.log 2>&1
+fi
+[ -x $REPO/tools/ubench_f64.bin ] && timeout 300 $REPO/tools/ubench_f64.bin $OUT/${TAG}_ubench_f64.json > $OUT/ubench_f64.log 2>&1
+[ -x $REPO/tools/ubench_count_shape.bin ] && timeout 300 $REPO/tools/ubench_count_shape.bin > $OUT/${TAG}_ubench_count_shape.json 2> $OUT/ubench_count_shape.err
+python $REPO/tools/summarize_round.py $OUT $TAG "$CMD" "$PMC" "$LEGS" && cp $OUT/${TAG}_*.txt $OUT/${TAG}_*.json $REPO/profiles/
 tail -2 $OUT/stats.log | cut -c1-600
