@@ -100,14 +100,14 @@ def load_counters() -> dict:
 
 
 def load_f64_ceilings() -> dict:
-    """float64 VALU issue rates measured by tools/ubench_f64.hip (committed: profiles/r03_ubench_f64.json), clk per wave
-    instruction per SIMD at the nominal 2.4 GHz."""
+    """float64 VALU issue costs measured by tools/ubench_f64.hip (committed: profiles/r03_ubench_f64.json) as multiples of
+    v_fma_f32 measured in the same process — the ratio does not depend on the clock the chip sustained during the run."""
     path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_ubench_f64.json")
     out = {"source": os.path.relpath(path, ROOT)}
     try:
         with open(path) as fh:
             for r in json.load(fh)["valu"]:
-                out[r["op"]] = r["clk_per_wave_instr_per_simd"]
+                out[r["op"]] = r["cost_vs_v_fma_f32"]
     except (OSError, ValueError, KeyError):
         pass
     return out
@@ -486,15 +486,15 @@ def config4_legs(ctx, ceil: dict, with_cpu: bool, counters: dict) -> dict:
             "note": "15 VALU + 3 LDS wave-instructions per 64 unordered pairs (hot loop of k_cooccur_fast<false>, tools/isa_mix.py: 120 VALU + 24 DS per "
             "8 pairs per lane; every unordered pair evaluated once and credited to (a,b) and (b,a)); HBM side negligible: (N/256)*N*8 B of tile re-reads"}
     pmc = kernel_counters(counters.get("legs", {}), "k_cooccur_fast", wkey)
-    if pmc and pmc.get("SQ_INSTS_VALU") is not None and kms > 0:
-        launches = max(sum(v[0] for name, v in k.items() if name.startswith("cooccur_pairs")), 1)
-        vi, li = pmc["SQ_INSTS_VALU"] * launches, (pmc.get("SQ_INSTS_LDS") or 0.0) * launches
+    if pmc and pmc.get("SQ_INSTS_VALU_timed_total") is not None and kms > 0:
+        # (totals over the timed launches of the profiled run: its first dispatch is the small warm-up call above)
+        vi, li = pmc["SQ_INSTS_VALU_timed_total"], pmc.get("SQ_INSTS_LDS_timed_total") or 0.0
         roof["pmc"] = {"valu_wave_instr": vi, "lds_wave_instr": li, "valu_per_64_unordered_pairs": vi / (pairs / 2 / 64.0), "lds_per_64_unordered_pairs": li / (pairs / 2 / 64.0),
                        "achieved_valu_wave_instr_per_s": vi / (kms * 1e-3), "frac_of_mix_peak": vi / (kms * 1e-3) / peak if peak else None, "source": counters.get("_source")}
         roof["frac"] = roof["pmc"]["frac_of_mix_peak"]
         roof["achieved"] = roof["pmc"]["achieved_valu_wave_instr_per_s"]
-        if pmc.get("FETCH_SIZE_bytes") is not None and pmc.get("WRITE_SIZE_bytes") is not None:
-            roof["traffic"] = (2.0 * pmc["FETCH_SIZE_bytes"] + pmc["WRITE_SIZE_bytes"]) * launches
+        if pmc.get("FETCH_SIZE_bytes_timed_total") is not None and pmc.get("WRITE_SIZE_bytes_timed_total") is not None:
+            roof["traffic"] = 2.0 * pmc["FETCH_SIZE_bytes_timed_total"] + pmc["WRITE_SIZE_bytes_timed_total"]
     out["co_occurrence"] = {
         "metric": "co_occurrence ordered pair evaluations/sec (1e6 points x 30 clusters x 49 thresholds)",
         "value": pairs / wall, "unit": "pairs/s", "wall_s": wall, "kernel_ms": kms, "roofline": roof,
@@ -528,11 +528,11 @@ def config4_legs(ctx, ceil: dict, with_cpu: bool, counters: dict) -> dict:
     # ds_read2_b64, one ds_add_u32)
     mix = {"v_add_f64": 3, "v_mul_f64": 3, "v_cvt_i32_f64": 1, "v_cmp_le_f64": 2}
     clk = None
-    if all(op in f64 for op in mix) and ceil.get("valu_complex"):
-        cu = ctx.device_info().get("cu_count") or 256
-        clk32 = cu * 4 * 2.4e9 / valu_mix_peak(ceil, 0.5)   # clk per 32-bit wave-instruction per SIMD of a half simple / half complex mix
-        clk = sum(cnt * f64[op] for op, cnt in mix.items()) + 6 * clk32   # SIMD clk per 64 unordered pairs
-        peak_pairs = cu * 4 * 2.4e9 / clk * 64 * 2                       # ORDERED pairs/s at which the VALU mix saturates
+    if all(op in f64 for op in mix) and ceil.get("valu_complex") and ceil.get("valu_simple"):
+        # issue time of the mix in units of one v_fma_f32 (= the simple class of tools/ubench_ops.hip), then in wave-instructions/s
+        fma_units = sum(cnt * f64[op] for op, cnt in mix.items()) + 6 * (ceil["valu_simple"] / valu_mix_peak(ceil, 0.5))
+        clk = fma_units * (ctx.device_info().get("cu_count") or 256) * 4 * 2.4e9 / ceil["valu_simple"]  # SIMD clk per 64 unordered pairs at 2.4 GHz
+        peak_pairs = ceil["valu_simple"] / fma_units * 64 * 2                                          # ORDERED pairs/s at which the VALU mix saturates
     out["ripley_L"] = {
         "metric": "ripley L ordered pair evaluations/sec (1e6 points in 30 clusters, 50 radii, float64)",
         "value": rp / wall, "unit": "pairs/s", "wall_s": wall, "kernel_ms": kms, "pairs": rp,
@@ -544,6 +544,13 @@ def config4_legs(ctx, ceil: dict, with_cpu: bool, counters: dict) -> dict:
                      "that mix saturates the four SIMDs of every CU at the issue rates of tools/ubench_f64.hip.  30 separate launches of ~650 workgroups "
                      "each (one per cluster): launch ramp and tail are inside `kernel_ms`"},
     }
+    pmc = kernel_counters(counters.get("legs", {}), "k_pair_hist_fast", wkey)
+    if pmc and pmc.get("SQ_INSTS_VALU_timed_total") is not None and kms > 0:
+        out["ripley_L"]["roofline"]["pmc"] = {
+            "valu_wave_instr": pmc["SQ_INSTS_VALU_timed_total"], "lds_wave_instr": pmc.get("SQ_INSTS_LDS_timed_total"),
+            "valu_per_64_unordered_pairs": pmc["SQ_INSTS_VALU_timed_total"] / (rp / 2 / 64.0),
+            "lds_per_64_unordered_pairs": (pmc.get("SQ_INSTS_LDS_timed_total") or 0.0) / (rp / 2 / 64.0), "source": counters.get("_source"),
+            "note": "PMC instruction counts of the 30 cluster launches of the profiled run / pairs: the ISA count (15 VALU, 3 DS) plus tile set-up and the diagonal tiles' checked path"}
     # ---- Ripley G (gr/_ripley.py:163-169): for every cluster, the 2 nearest cluster points of every point NOT in it, histogram of the distances
     pts_dev = _lib.DevicePoints(ctx, xy, labels)
     edges = np.linspace(0, (area / 2) ** 0.5, 50)

@@ -19,9 +19,12 @@ torch process group is already initialised (also one created programmatically wi
 
 from __future__ import annotations
 
+import hmac
+import io
 import os
-import pickle
+import secrets
 import socket
+import stat
 import struct
 import sys
 import tempfile
@@ -54,43 +57,148 @@ def _recv_msg(sock: socket.socket) -> bytes:
     return _recv_exact(sock, n)
 
 
-class SocketGroup:
-    """All ranks of ONE node connected to rank 0 over TCP (loopback or ``MASTER_ADDR``).
+# Host objects that cross the side channel (a seed, result blocks, a timing) are encoded by a small DATA-ONLY codec — no
+# pickle: nothing a peer sends is ever executed.  None / bool / int / float / str / bytes / numpy arrays (the .npy format,
+# allow_pickle=False) / list / tuple / dict of those.
+def _enc(obj: Any, out: io.BytesIO) -> None:
+    if obj is None:
+        out.write(b"N")
+    elif isinstance(obj, (bool, np.bool_)):
+        out.write(b"T" if obj else b"f")
+    elif isinstance(obj, (int, np.integer)):
+        b = str(int(obj)).encode()
+        out.write(b"I" + struct.pack("<I", len(b)) + b)
+    elif isinstance(obj, (float, np.floating)):
+        out.write(b"F" + struct.pack("<d", float(obj)))
+    elif isinstance(obj, str):
+        b = obj.encode()
+        out.write(b"S" + struct.pack("<Q", len(b)) + b)
+    elif isinstance(obj, (bytes, bytearray)):
+        out.write(b"B" + struct.pack("<Q", len(obj)) + bytes(obj))
+    elif isinstance(obj, np.ndarray):
+        if obj.dtype.hasobject:
+            raise TypeError("object arrays do not cross the side channel")
+        buf = io.BytesIO()
+        np.lib.format.write_array(buf, obj, allow_pickle=False)
+        out.write(b"A" + struct.pack("<Q", buf.tell()) + buf.getvalue())
+    elif isinstance(obj, (list, tuple)):
+        out.write((b"L" if isinstance(obj, list) else b"U") + struct.pack("<Q", len(obj)))
+        for item in obj:
+            _enc(item, out)
+    elif isinstance(obj, dict):
+        out.write(b"D" + struct.pack("<Q", len(obj)))
+        for k, v in obj.items():
+            _enc(k, out)
+            _enc(v, out)
+    else:
+        raise TypeError(f"cannot send a {type(obj).__name__} through the side channel")
 
-    Rank 0 listens on an ephemeral port and publishes it in ``$TMPDIR/sqgr_rdzv_<MASTER_PORT>_<launcher pid>``
-    (``MASTER_PORT`` itself belongs to the launcher's own store); the others poll that file and connect.  Every
-    collective is an all-gather through the hub — the payloads on this path are a unique id, a seed, a few result
-    blocks."""
+
+def _dec(buf: io.BytesIO) -> Any:
+    tag = buf.read(1)
+    if tag == b"N":
+        return None
+    if tag in (b"T", b"f"):
+        return tag == b"T"
+    if tag == b"I":
+        (n,) = struct.unpack("<I", buf.read(4))
+        return int(buf.read(n).decode())
+    if tag == b"F":
+        return struct.unpack("<d", buf.read(8))[0]
+    if tag in (b"S", b"B", b"A"):
+        (n,) = struct.unpack("<Q", buf.read(8))
+        raw = buf.read(n)
+        if len(raw) != n:
+            raise ValueError("truncated side-channel message")
+        if tag == b"S":
+            return raw.decode()
+        if tag == b"B":
+            return raw
+        return np.lib.format.read_array(io.BytesIO(raw), allow_pickle=False)
+    if tag in (b"L", b"U"):
+        (n,) = struct.unpack("<Q", buf.read(8))
+        items = [_dec(buf) for _ in range(n)]
+        return items if tag == b"L" else tuple(items)
+    if tag == b"D":
+        (n,) = struct.unpack("<Q", buf.read(8))
+        return {_dec(buf): _dec(buf) for _ in range(n)}
+    raise ValueError(f"unknown tag {tag!r} in a side-channel message")
+
+
+def encode_object(obj: Any) -> bytes:
+    out = io.BytesIO()
+    _enc(obj, out)
+    return out.getvalue()
+
+
+def decode_object(payload: bytes) -> Any:
+    return _dec(io.BytesIO(payload))
+
+
+def _rendezvous_dir() -> str:
+    """A directory only this user can enter (0700, owned by us, not a symlink): the rendezvous file and the group's secret
+    live there, so another local user can neither pre-create the file (redirecting ranks to a server of theirs) nor read it."""
+    path = os.path.join(tempfile.gettempdir(), f"sqgr-{os.getuid()}")
+    try:
+        os.mkdir(path, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(path)
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise PermissionError(f"{path} must be a directory owned by uid {os.getuid()} with mode 0700 (found mode {oct(st.st_mode & 0o7777)}, uid {st.st_uid})")
+    return path
+
+
+class SocketGroup:
+    """All ranks of ONE node connected to rank 0 over loopback TCP.
+
+    Rank 0 listens on an ephemeral loopback port and publishes ``port`` and a fresh 32-byte secret in
+    ``$TMPDIR/sqgr-<uid>/rdzv_<MASTER_PORT>_<launcher pid>`` (a 0700 directory, a 0600 file created exclusively;
+    ``MASTER_PORT`` itself belongs to the launcher's own store); the others poll that file, connect and present the secret —
+    a peer without it is dropped.  Every collective is an all-gather of byte strings through the hub, framed by lengths;
+    nothing received is unpickled or otherwise executed.  The payloads on this path are a unique id, a seed, a few result blocks."""
 
     kind = "socket"
 
     def __init__(self, rank: int, world: int, addr: str = "127.0.0.1", key: str | None = None):
         self.rank, self.world = int(rank), int(world)
+        if addr not in ("127.0.0.1", "localhost", "::1", socket.gethostname()) and os.environ.get("SQGR_DIST_ALLOW_REMOTE") != "1":
+            # a single-node group: the hub never listens on a routable address
+            addr = "127.0.0.1"
         key = key or f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
-        self._path = os.path.join(tempfile.gettempdir(), f"sqgr_rdzv_{key}")
+        self._path = os.path.join(_rendezvous_dir(), f"rdzv_{key}")
         self._peers: list[socket.socket] = []
         self._hub: socket.socket | None = None
         deadline = time.monotonic() + _TIMEOUT_S
         if self.rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            try:
-                srv.bind((addr, 0))
-            except OSError:
-                srv.bind(("127.0.0.1", 0))
+            srv.bind(("127.0.0.1", 0))
             srv.listen(self.world)
             srv.settimeout(_TIMEOUT_S)
-            tmp = f"{self._path}.{os.getpid()}.tmp"
-            with open(tmp, "w") as fh:
-                fh.write(f"{srv.getsockname()[0]} {srv.getsockname()[1]}")
-            os.replace(tmp, self._path)
+            token = secrets.token_bytes(32)
+            try:
+                os.remove(self._path)  # a stale file of an earlier launch with the same key (ours: the directory is private)
+            except OSError:
+                pass
+            fd = os.open(self._path, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+            with os.fdopen(fd, "w") as fh:
+                fh.write(f"{srv.getsockname()[1]} {token.hex()}")
             by_rank: dict[int, socket.socket] = {}
             try:
                 while len(by_rank) < self.world - 1:
                     conn, _ = srv.accept()
                     conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                     conn.settimeout(_TIMEOUT_S)
-                    r, w = struct.unpack("<ii", _recv_exact(conn, 8))
+                    try:
+                        r, w = struct.unpack("<ii", _recv_exact(conn, 8))
+                        ok = hmac.compare_digest(_recv_exact(conn, 32), token)
+                    except (ConnectionError, OSError, struct.error):
+                        conn.close()
+                        continue
+                    if not ok:  # not one of ours: drop it and keep waiting for the real ranks
+                        conn.close()
+                        continue
                     if w != self.world or not 0 < r < self.world or r in by_rank:
                         conn.close()
                         raise RuntimeError(f"rendezvous: unexpected peer (rank {r} of {w}) for a {self.world}-rank group")
@@ -107,11 +215,11 @@ class SocketGroup:
             while time.monotonic() < deadline:
                 try:
                     with open(self._path) as fh:
-                        host, port = fh.read().split()
-                    s = socket.create_connection((host, int(port)), timeout=5.0)
+                        port, token_hex = fh.read().split()
+                    s = socket.create_connection(("127.0.0.1", int(port)), timeout=5.0)
                     s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                     s.settimeout(_TIMEOUT_S)
-                    s.sendall(struct.pack("<ii", self.rank, self.world))
+                    s.sendall(struct.pack("<ii", self.rank, self.world) + bytes.fromhex(token_hex))
                     self._hub = s
                     break
                 except (OSError, ValueError) as exc:  # file not there yet / stale port of an earlier run
@@ -126,13 +234,23 @@ class SocketGroup:
             return [payload]
         if self.rank == 0:
             parts = [payload] + [_recv_msg(p) for p in self._peers]
-            blob = pickle.dumps(parts, protocol=pickle.HIGHEST_PROTOCOL)
+            blob = struct.pack("<Q", len(parts)) + b"".join(struct.pack("<Q", len(x)) + x for x in parts)
             for p in self._peers:
                 _send_msg(p, blob)
             return parts
         assert self._hub is not None
         _send_msg(self._hub, payload)
-        return pickle.loads(_recv_msg(self._hub))
+        blob = _recv_msg(self._hub)
+        (count,) = struct.unpack_from("<Q", blob, 0)
+        if count != self.world:
+            raise ValueError("malformed all-gather reply from the hub")
+        parts, off = [], 8
+        for _ in range(count):
+            (n,) = struct.unpack_from("<Q", blob, off)
+            off += 8
+            parts.append(blob[off : off + n])
+            off += n
+        return parts
 
     def barrier(self) -> None:
         self.allgather_bytes(b"")
@@ -333,7 +451,7 @@ def allgather_object(a: Any) -> list[Any]:
         return [a]
     g = group()
     assert g is not None
-    return [pickle.loads(b) for b in g.allgather_bytes(pickle.dumps(a, protocol=pickle.HIGHEST_PROTOCOL))]
+    return [decode_object(b) for b in g.allgather_bytes(encode_object(a))]
 
 
 def broadcast_object(a: Any, src: int = 0) -> Any:

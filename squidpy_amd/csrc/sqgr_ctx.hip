@@ -451,11 +451,6 @@ int sqgr_timer_report(sqgr_ctx* ctx, char* buf, int len) {
 static int graph_create_impl(sqgr_ctx* ctx, int64_t n, int64_t nnz, const int64_t* indptr, const int32_t* indices,
                              const float* data32, const double* data, sqgr_graph** out_graph) {
     SQGR_REQUIRE(ctx && out_graph, "ctx/out_graph is NULL");
-    std::vector<double> widened;
-    if (data32) {  // float32 weights are widened exactly; every kernel computes with float64 weights like the reference
-        widened.assign(data32, data32 + nnz);
-        data = widened.data();
-    }
     *out_graph = nullptr;
     SQGR_REQUIRE(n > 0 && n < (int64_t)0x7fffffff, "n=%lld out of range", (long long)n);
     SQGR_REQUIRE(nnz >= 0, "nnz=%lld negative", (long long)nnz);
@@ -467,6 +462,11 @@ static int graph_create_impl(sqgr_ctx* ctx, int64_t n, int64_t nnz, const int64_
     for (int64_t e = 0; e < nnz; ++e)
         SQGR_REQUIRE(indices[e] >= 0 && indices[e] < n, "indices[%lld]=%d out of [0,%lld)", (long long)e, indices[e],
                      (long long)n);
+    std::vector<double> widened;
+    if (data32) {  // float32 weights are widened exactly (after the arguments have been checked); every kernel computes with
+        widened.assign(data32, data32 + nnz);  // float64 weights like the reference
+        data = widened.data();
+    }
     SQGR_HIP(hipSetDevice(ctx->device));
     sqgr_graph* g = new sqgr_graph();
     g->ctx = ctx;

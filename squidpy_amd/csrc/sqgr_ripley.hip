@@ -21,7 +21,7 @@
 namespace sqgr {
 
 constexpr int RP_TILE = 256;
-constexpr int RP_CHUNK = 32;
+constexpr int RP_CHUNK = 8;  // tj tiles per block (round 3: 32 -> 8: four times the blocks per launch — a cluster of config 4 is 131 tiles)
 
 template <int METRIC>
 __device__ __forceinline__ double metric_dist(double xi, double yi, double xj, double yj) {
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(RP_TILE) void k_pair_hist(const double* __restrict_
 // tiles with finite coordinates skip all validity tests (out-of-range pairs land in RP_TRASH write-only rows).
 // Histogram columns are per LANE (64), shared by the block's four waves through the LDS atomics they are anyway: 13 KB
 // instead of 54 KB at 50 radii, so five blocks instead of two share a CU (round 3: the kernel was latency-bound at
-// 8 waves per CU — a cluster of config 4 is only 650 blocks).  A column receives at most 4 waves x 32 tiles x 256 x 2 counts.
+// 8 waves per CU — a cluster of config 4 is only 650 blocks).  A column receives at most 4 waves x RP_CHUNK tiles x 256 x 2 counts.
 constexpr int RP_BATCH = 8;
 constexpr int RP_TRASH = 3;
 constexpr int RP_CELLS_MIN = 1024;

@@ -127,3 +127,38 @@ def test_ripley_cluster_assignment_is_balanced_and_deterministic():
         assert np.array_equal(own, _assign_by_cost(cost, world)) and own.min() >= 0 and own.max() < world
         load = np.bincount(own, weights=cost, minlength=world)
         assert load.max() <= cost.sum() / world + cost.max()  # LPT bound
+
+
+def test_side_channel_codec_is_data_only_and_round_trips(tmp_path, monkeypatch):
+    """nothing that arrives over the socket side channel is unpickled.  The codec round-trips what the front ends
+    send (arrays incl. 0-d / non-contiguous / NaN, big ints, nested containers), refuses object arrays and arbitrary classes,
+    and a pickle payload is rejected as an unknown tag instead of being executed."""
+    import pickle
+
+    import numpy as np
+
+    from squidpy_amd import _dist as D
+
+    a = np.arange(12, dtype=np.float64).reshape(3, 4)[:, ::2]
+    obj = (a, {"r": 3, "x": [1.5, None, True, "s", b"b", 2**70]}, np.array([np.nan, 1.0]), np.uint64(2**63 + 5), np.array(7.0))
+    back = D.decode_object(D.encode_object(obj))
+    assert np.array_equal(back[0], a) and back[1] == obj[1] and np.array_equal(back[2], obj[2], equal_nan=True)
+    assert back[3] == 2**63 + 5 and back[4].shape == () and back[4] == 7.0
+    import pytest
+
+    with pytest.raises(TypeError):
+        D.encode_object(np.array([object()], dtype=object))
+    with pytest.raises(TypeError):
+        D.encode_object(lambda: 0)
+    with pytest.raises(ValueError, match="unknown tag"):
+        D.decode_object(pickle.dumps({"a": 1}))
+    # the rendezvous directory is private to the user; a directory someone else could write to is refused
+    monkeypatch.setattr(D.tempfile, "gettempdir", lambda: str(tmp_path))
+    d = D._rendezvous_dir()
+    import os
+    import stat
+
+    assert stat.S_IMODE(os.lstat(d).st_mode) == 0o700
+    os.chmod(d, 0o777)
+    with pytest.raises(PermissionError):
+        D._rendezvous_dir()

@@ -56,28 +56,33 @@ print("\n".join(lines))
 
 
 def collect(subs) -> dict:
-    agg = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))  # kernel -> counter -> [dispatches, total]
+    agg = defaultdict(lambda: defaultdict(lambda: [0, 0.0, None, None]))  # kernel -> counter -> [dispatches, total, first dispatch id, its value]
     for sub in subs:
         for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
                 a = agg[short(r["Kernel_Name"])][r["Counter_Name"]]
                 a[0] += 1
                 a[1] += float(r["Counter_Value"])
+                did = int(r["Dispatch_Id"])
+                if a[2] is None or did < a[2]:
+                    a[2], a[3] = did, float(r["Counter_Value"])
     return agg
 
 
-def section(agg, match) -> dict:
+def section(agg, match, after_first: bool = False) -> dict:
+    """Per-launch averages per kernel.  after_first: the first dispatch of a kernel is the bench's small warm-up call, the others
+    are the timed ones — report TOTALS over the others (`*_timed_total`), which is what bench.py's timed region ran."""
     ks = {}
     for k, cs in agg.items():
         if not match(k):
             continue
         rec = {"dispatches": max(v[0] for v in cs.values())}
-        for c, (n, tot) in cs.items():
-            per = tot / max(n, 1)
-            if c in ("FETCH_SIZE", "WRITE_SIZE"):
-                rec[c + "_bytes"] = per * 1024.0  # reported in KiB; FETCH_SIZE still to be doubled (see <tag>_fetch_calibration.json)
-            else:
-                rec[c] = per
+        for c, (n, tot, _, first) in cs.items():
+            scale = 1024.0 if c in ("FETCH_SIZE", "WRITE_SIZE") else 1.0  # reported in KiB; FETCH_SIZE still to be doubled (see <tag>_fetch_calibration.json)
+            name = c + "_bytes" if scale != 1.0 else c
+            rec[name] = tot / max(n, 1) * scale
+            if after_first:
+                rec[name + "_timed_total"] = (tot - (first or 0.0)) * scale
         ks[k] = rec
     return ks
 
@@ -101,7 +106,7 @@ rep = {
 lagg = collect(("legs_sqa", "legs_fetch", "legs_write"))
 lb = bench_line("legs_sqa.log") or legs_bench or {}
 rep["legs"] = {"command": legs_cmd, "workload": (((lb.get("legs") or {}).get("co_occurrence") or {}).get("roofline") or {}).get("workload_key"),
-               "kernels": section(lagg, lambda k: "k_cooccur" in k or "k_pair_hist" in k or "k_knn" in k)}
+               "kernels": section(lagg, lambda k: "k_cooccur" in k or "k_pair_hist" in k or "k_knn" in k, after_first=True)}
 json.dump(rep, open(os.path.join(out, f"{tag}_counters.json"), "w"), indent=1)
 print(json.dumps({k: (list(v["kernels"]) if isinstance(v, dict) and "kernels" in v else v) for k, v in rep.items() if k != "note"}, indent=1)[:3000])
 
@@ -111,7 +116,7 @@ if cagg:
     true_bytes = 512 << 20
     cal = {"tool": "tools/ubench_fetch_calib.hip under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (tools/profile_round.sh)", "bytes_moved_per_launch": true_bytes, "kernels": {}}
     for k, cs in sorted(cagg.items()):
-        for c, (n, tot) in cs.items():
+        for c, (n, tot, _, _) in cs.items():
             cal["kernels"].setdefault(k, {})[c + "_reported_bytes"] = tot / n * 1024
             cal["kernels"][k][c + "_ratio_to_true"] = tot / n * 1024 / true_bytes
     cal["conclusion"] = ("FETCH_SIZE reports 0.5 of the bytes read for 16 B/lane streaming reads, for the count kernel's 4 B/lane quad-per-row gathers and for its "
