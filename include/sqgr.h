@@ -249,7 +249,9 @@ int sqgr_autocorr_perm_indices(sqgr_ctx* ctx, int64_t n, uint64_t seed, int64_t 
                                int32_t* out_idx);
 
 /* ------------------------------------------------------------------ ripley (K/L pair counts, F/G kNN distances)
- * metric: 0 euclidean, 1 manhattan, 2 chebyshev (sklearn KDTree arithmetic: per-coordinate accumulation, no FMA).
+ * metric: 0 euclidean, 1 manhattan, 2 chebyshev (sklearn KDTree arithmetic: per-coordinate accumulation, no FMA); the
+ * nearest-neighbour entry points also take 3 canberra (sklearn's BallTree metric without parameters; brute-force sweep,
+ * no cell list) — sqgr_pair_counts does not: KDTree.valid_metrics ends at chebyshev (gr/_ripley.py:213).
  *
  * sqgr_pair_counts replaces `KDTree(points).two_point_correlation(points, support, dualtree=True) - m`
  * (gr/_ripley.py:220-222): out[s] = #{ordered i != j : dist_ij <= r_s}.  xy: float64[m][2]; thr: float64[S]

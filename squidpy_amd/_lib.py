@@ -721,6 +721,7 @@ METRICS = {
     "euclidean": 0, "l2": 0, "minkowski": 0, "p": 0,  # sklearn's default minkowski p=2
     "manhattan": 1, "cityblock": 1, "l1": 1,
     "chebyshev": 2, "infinity": 2,
+    "canberra": 3,  # nearest-neighbour statistics only (a BallTree metric; KDTree / Ripley's L do not take it)
 }
 
 

@@ -149,3 +149,33 @@ def pcg64_states(seed: int | None, n: int, begin: int = 0, end: int | None = Non
         st = np.random.PCG64(s).state["state"]
         out[k] = (st["state"] >> 64, st["state"] & mask, st["inc"] >> 64, st["inc"] & mask)
     return out
+
+
+class progress:
+    """The reference's progress bar (`show_progress_bar`, _utils.py:168-197 drives tqdm from its worker processes): here the
+    host loop over permutation batches / feature blocks / clusters advances it.  Silent when disabled, when tqdm is missing,
+    when stderr is not a terminal (logs, tests, batch jobs) or on ranks other than 0."""
+
+    def __init__(self, total: int, unit: str, enabled: bool = True):
+        self._bar = None
+        if enabled and total > 0:
+            try:
+                import sys
+
+                from tqdm.auto import tqdm
+
+                if sys.stderr.isatty() and os.environ.get("RANK", "0") == "0":
+                    self._bar = tqdm(total=int(total), unit=unit)
+            except Exception:  # tqdm missing or unusable: the reference degrades the same way (`tqdm = None`)
+                self._bar = None
+
+    def update(self, n: int = 1) -> None:
+        if self._bar is not None:
+            self._bar.update(n)
+
+    def __enter__(self) -> "progress":
+        return self
+
+    def __exit__(self, *exc: Any) -> None:
+        if self._bar is not None:
+            self._bar.close()

@@ -102,6 +102,36 @@ int comm_allgather_dev(sqgr_comm* c, const void* dev_send, void* dev_recv, size_
     return SQGR_OK;
 }
 
+// Before a data collective every rank tells the others whether its own part succeeded (one all-reduce(max) of a flag): a
+// rank that failed — an invalid argument, an allocation — does not enter the data collective and must not leave its peers
+// waiting in it.  Returns local_rc if that is an error, SQGR_ERR_HIP if a peer failed, SQGR_OK otherwise.
+int comm_agree(sqgr_comm* c, int local_rc, hipStream_t st) {
+    if (!c || c->world <= 1) return local_rc;
+    int64_t flag = local_rc != SQGR_OK ? 1 : 0;
+    const char* keep = nullptr;
+    std::string msg;
+    if (local_rc != SQGR_OK) msg = sqgr_last_error();  // the agreement below must not overwrite the rank's own message
+    int rc = c->stage.ensure(1);
+    if (rc == SQGR_OK) {
+        hipError_t e = hipMemcpyAsync(c->stage.p, &flag, 8, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) rc = comm_allreduce_i64_dev(c, c->stage.p, 1, true, st);
+        if (e == hipSuccess && rc == SQGR_OK) e = hipMemcpyAsync(&flag, c->stage.p, 8, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && rc == SQGR_OK) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = SQGR_ERR_HIP;
+    }
+    (void)keep;
+    if (local_rc != SQGR_OK) {
+        set_error("%s", msg.c_str());
+        return local_rc;
+    }
+    if (rc != SQGR_OK) return rc;
+    if (flag) {
+        set_error("rank %d: another rank failed before the collective (its own error message says why)", c->rank);
+        return SQGR_ERR_HIP;
+    }
+    return SQGR_OK;
+}
+
 int comm_rank(const sqgr_comm* c) { return c ? c->rank : 0; }
 int comm_world(const sqgr_comm* c) { return c ? c->world : 1; }
 

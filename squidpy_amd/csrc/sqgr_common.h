@@ -132,6 +132,7 @@ constexpr int LIST_PAD = 6400;
 // device-side collectives of an sqgr_comm (sqgr_comm.hip); no-ops for a NULL communicator or a single rank
 int comm_allreduce_i64_dev(sqgr_comm* c, int64_t* dev_buf, size_t count, bool op_max, hipStream_t st);
 int comm_allgather_dev(sqgr_comm* c, const void* dev_send, void* dev_recv, size_t bytes_per_rank, hipStream_t st);
+int comm_agree(sqgr_comm* c, int local_rc, hipStream_t st);  // error agreement in front of a data collective (sqgr_comm.hip)
 int comm_rank(const sqgr_comm* c);
 int comm_world(const sqgr_comm* c);
 

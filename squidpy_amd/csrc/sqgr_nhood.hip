@@ -1438,10 +1438,14 @@ int sqgr_nhood_run(sqgr_nhood* plan, uint64_t seed, int64_t perm_begin, int64_t 
     sqgr_nhood* p = plan;
     sqgr_ctx* ctx = p->ctx;
     SQGR_HIP(hipSetDevice(ctx->device));
-    SQGR_TRY(p->ensure_workspace(out_perms != nullptr));
     hipStream_t st = ctx->stream;
-    const int B = p->B, K2 = p->K2, hw = p->hist_words();
+    const int K2 = p->K2;
     const int64_t nperm = perm_end - perm_begin;
+    // this rank's own part (everything in front of the collective); with a communicator its outcome is agreed on first, so
+    // that a rank that fails here never leaves its peers waiting inside the all-reduce
+    auto local = [&]() -> int {
+    SQGR_TRY(p->ensure_workspace(out_perms != nullptr));
+    const int B = p->B, hw = p->hist_words();
     const int64_t per_launch = (int64_t)p->nbatch * B;
     if (shift)
         SQGR_HIP(hipMemcpyAsync(p->shift.p, shift, (size_t)K2 * 8, hipMemcpyHostToDevice, st));
@@ -1483,6 +1487,9 @@ int sqgr_nhood_run(sqgr_nhood* plan, uint64_t seed, int64_t perm_begin, int64_t 
                                                 reinterpret_cast<uint64_t*>(p->fin.p + K2));
         SQGR_HIP(hipGetLastError());
     }
+    return SQGR_OK;
+    };
+    SQGR_TRY(comm_agree(p->comm, local(), st));
     // multi-GPU: the ranks ran disjoint permutation ranges; one RCCL all-reduce of the 2*K*K exact integer moments on the
     // device, then every rank copies out the global sums
     SQGR_TRY(comm_allreduce_i64_dev(p->comm, p->fin.p, (size_t)2 * K2, false, st));
@@ -1574,9 +1581,11 @@ static int run_pcg64_impl(sqgr_nhood* plan, const uint64_t* pcg_states, int64_t 
     SQGR_REQUIRE(p->has_labels, "plan was created without labels");
     sqgr_ctx* ctx = p->ctx;
     SQGR_HIP(hipSetDevice(ctx->device));
-    SQGR_TRY(p->ensure_workspace(keep_perms));
     hipStream_t st = ctx->stream;
-    const int B = p->B, K2 = p->K2, hw = p->hist_words();
+    const int K2 = p->K2;
+    auto local = [&]() -> int {  // this rank's own part; its outcome is agreed on in front of the collective (see sqgr_nhood_run)
+    SQGR_TRY(p->ensure_workspace(keep_perms));
+    const int B = p->B, hw = p->hist_words();
     const int64_t n = p->n;
     if (shift)
         SQGR_HIP(hipMemcpyAsync(p->shift.p, shift, (size_t)K2 * 8, hipMemcpyHostToDevice, st));
@@ -1658,6 +1667,9 @@ static int run_pcg64_impl(sqgr_nhood* plan, const uint64_t* pcg_states, int64_t 
                                                 reinterpret_cast<uint64_t*>(p->fin.p + K2));
         SQGR_HIP(hipGetLastError());
     }
+    return SQGR_OK;
+    };
+    SQGR_TRY(comm_agree(p->comm, local(), st));
     // multi-GPU: the ranks ran disjoint permutation ranges; one RCCL all-reduce of the 2*K*K exact integer moments on the
     // device, then every rank copies out the global sums
     SQGR_TRY(comm_allreduce_i64_dev(p->comm, p->fin.p, (size_t)2 * K2, false, st));
@@ -1690,9 +1702,9 @@ int sqgr_nhood_run_pcg64_stats(sqgr_nhood* plan, const uint64_t* pcg_states, int
     plan->comm = nullptr;  // the moments of the slice are not what is wanted here: no all-reduce inside the run
     const int rc = run_pcg64_impl(plan, pcg_states + (size_t)lo * 4, mine, nullptr, s1.data(), s2.data(), nullptr, true);
     plan->comm = comm;
-    SQGR_TRY(rc);
     sqgr_ctx* ctx = plan->ctx;
     hipStream_t st = ctx->stream;
+    SQGR_TRY(comm_agree(comm, rc, st));  // a rank whose slice failed does not leave the others waiting in the all-gather
     const uint32_t* perms = plan->perms_dev.p;
     int64_t rank_stride = 0, kbase = n_perms, krem = 0;
     if (world > 1) {

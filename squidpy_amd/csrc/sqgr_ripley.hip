@@ -28,7 +28,16 @@ __device__ __forceinline__ double metric_dist(double xi, double yi, double xj, d
     const double dx = xi - xj, dy = yi - yj;
     if (METRIC == 0) return __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));  // reduced euclidean, every op rounded
     if (METRIC == 1) return fabs(dx) + fabs(dy);                               // manhattan
-    return fmax(fabs(dx), fabs(dy));                                           // chebyshev
+    if (METRIC == 2) return fmax(fabs(dx), fabs(dy));                          // chebyshev
+    // canberra — the parameter-free BallTree metric a metric STRING can also name (the reference hands `metric` straight to
+    // NearestNeighbors, gr/_ripley.py:144,148): sum |x - y| / (|x| + |y|), 0/0 terms skipped, sklearn's per-coordinate loop.
+    // (braycurtis was tried too: it is not a metric, sklearn's ball tree prunes with the triangle inequality anyway and returns
+    //  neighbours an exact search does not — nothing to be bit-compatible with.)
+    const double ex = fabs(xi) + fabs(xj), ey = fabs(yi) + fabs(yj);
+    double d = 0.0;
+    if (ex > 0.0) d += fabs(dx) / ex;
+    if (ey > 0.0) d += fabs(dy) / ey;
+    return d;
 }
 
 template <int METRIC>
@@ -533,7 +542,7 @@ int sqgr_pair_counts(sqgr_ctx* ctx, const double* xy, int64_t m, const double* t
 int sqgr_knn_dist(sqgr_ctx* ctx, const double* query, int64_t nq, const double* ref, int64_t nr, int32_t k, int32_t metric,
                   double* out) {
     SQGR_REQUIRE(ctx && out && (query || nq == 0) && (ref || nr == 0), "null argument");
-    SQGR_REQUIRE(nq >= 0 && nr >= 0 && metric >= 0 && metric <= 2, "bad argument");
+    SQGR_REQUIRE(nq >= 0 && nr >= 0 && metric >= 0 && metric <= 3, "bad argument");
     SQGR_REQUIRE(k >= 1 && k <= nr, "Expected n_neighbors <= n_samples_fit, but n_neighbors = %d, n_samples_fit = %lld, n_samples = %lld",
                  k, (long long)nr, (long long)nq);
     if (k > 16) {
@@ -544,7 +553,7 @@ int sqgr_knn_dist(sqgr_ctx* ctx, const double* query, int64_t nq, const double* 
     SQGR_HIP(hipSetDevice(ctx->device));
     std::vector<double> qx, qy, rx, ry;
     split_xy(query, nq, qx, qy);
-    if (nr >= KNN_GRID_MIN_REFS && all_finite(ref, nr)) {  // cell list over the reference points
+    if (metric <= 2 && nr >= KNN_GRID_MIN_REFS && all_finite(ref, nr)) {  // cell list over the reference points (the Lp metrics)
         HostGrid hg;
         SQGR_TRY(build_grid(ref, nr, 2.0, 0.0, hg));
         DevGrid dg;
@@ -582,7 +591,8 @@ int sqgr_knn_dist(sqgr_ctx* ctx, const double* query, int64_t nq, const double* 
         LaunchTimer t(ctx, "ripley_knn");
         if (metric == 0) SQGR_TRY(launch_knn<0>(ctx, dqx.p, dqy.p, nq, drx.p, dry.p, nr, k, dout.p));
         else if (metric == 1) SQGR_TRY(launch_knn<1>(ctx, dqx.p, dqy.p, nq, drx.p, dry.p, nr, k, dout.p));
-        else SQGR_TRY(launch_knn<2>(ctx, dqx.p, dqy.p, nq, drx.p, dry.p, nr, k, dout.p));
+        else if (metric == 2) SQGR_TRY(launch_knn<2>(ctx, dqx.p, dqy.p, nq, drx.p, dry.p, nr, k, dout.p));
+        else SQGR_TRY(launch_knn<3>(ctx, dqx.p, dqy.p, nq, drx.p, dry.p, nr, k, dout.p));
     }
     SQGR_HIP(hipMemcpyAsync(out, dout.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
     SQGR_HIP(hipStreamSynchronize(st));
@@ -627,7 +637,7 @@ int sqgr_knn_hist(sqgr_ctx* ctx, const sqgr_points* queries, int32_t exclude_lab
                   int32_t metric, const double* edges, int32_t S, int64_t* out_counts) {
     SQGR_REQUIRE(ctx && queries && ref && edges && out_counts, "null argument");
     SQGR_REQUIRE(queries->ctx == ctx, "points belong to a different context");
-    SQGR_REQUIRE(S >= 2 && S <= 8192 && metric >= 0 && metric <= 2, "bad argument S=%d metric=%d", S, metric);
+    SQGR_REQUIRE(S >= 2 && S <= 8192 && metric >= 0 && metric <= 3, "bad argument S=%d metric=%d", S, metric);
     SQGR_REQUIRE(exclude_label < 0 || queries->has_label, "points were created without labels");
     SQGR_REQUIRE(k >= 1 && k <= nr, "Expected n_neighbors <= n_samples_fit, but n_neighbors = %d, n_samples_fit = %lld, n_samples = %lld", k,
                  (long long)nr, (long long)queries->n);
@@ -637,7 +647,7 @@ int sqgr_knn_hist(sqgr_ctx* ctx, const sqgr_points* queries, int32_t exclude_lab
         return SQGR_ERR_UNSUPPORTED;
     }
     SQGR_HIP(hipSetDevice(ctx->device));
-    if (nr >= KNN_GRID_MIN_REFS && all_finite(ref, nr)) {  // cell list over the reference points
+    if (metric <= 2 && nr >= KNN_GRID_MIN_REFS && all_finite(ref, nr)) {  // cell list over the reference points (the Lp metrics)
         HostGrid hg;
         SQGR_TRY(build_grid(ref, nr, 2.0, 0.0, hg));
         DevGrid dg;
@@ -688,7 +698,7 @@ int sqgr_knn_hist(sqgr_ctx* ctx, const sqgr_points* queries, int32_t exclude_lab
         else if (k <= 8) SQGR_KH(M, 8);            \
         else SQGR_KH(M, 16);                       \
     } while (0)
-        if (metric == 0) SQGR_KHM(0); else if (metric == 1) SQGR_KHM(1); else SQGR_KHM(2);
+        if (metric == 0) SQGR_KHM(0); else if (metric == 1) SQGR_KHM(1); else if (metric == 2) SQGR_KHM(2); else SQGR_KHM(3);
 #undef SQGR_KHM
 #undef SQGR_KH
         SQGR_HIP(hipGetLastError());

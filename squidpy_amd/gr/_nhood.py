@@ -25,6 +25,7 @@ from .._utils import (
     get_n_processes,
     logg,
     pcg64_states,
+    progress,
     resolve_seed,
     spawn_generators,
 )
@@ -85,8 +86,8 @@ def nhood_enrichment(
     """Compute neighborhood enrichment by permutation test (drop-in for ``squidpy.gr.nhood_enrichment``).
 
     Same positional parameters, defaults, validation errors and ``adata.uns`` slots as the reference.
-    ``numba_parallel``, ``n_jobs``, ``backend`` and ``show_progress_bar`` are accepted (and ``n_jobs``
-    validated) but do not influence the GPU path.
+    ``numba_parallel``, ``n_jobs`` and ``backend`` are accepted (and ``n_jobs`` validated) but do not influence the GPU path;
+    ``show_progress_bar`` drives a tqdm bar over permutation batches (on a terminal, rank 0 only).
 
     Extra keyword-only parameters
     -----------------------------
@@ -167,7 +168,20 @@ def nhood_enrichment(
         try:
             key = _broadcast_seed(resolve_seed(seed))
             plan.set_comm(comm)  # the exact integer moments are all-reduced on the device (RCCL inside libsqgr)
-            s1, s2, _ = plan.run(key, lo, hi, shift)
+            # the permutation range in a few pieces (whole launch groups each): the exact integer moments add up, the generator is
+            # keyed by the global index, so the result does not depend on the split — it only lets the progress bar move
+            longest = -(-n_perms // world)  # every rank enters the same number of collectives: pieces are cut from the longest range
+            step = max(PROGRESS_STEP, -(-longest // 20) // PROGRESS_STEP * PROGRESS_STEP) if show_progress_bar else max(longest, 1)
+            s1 = np.zeros((n_cls, n_cls), dtype=np.int64)
+            s2 = np.zeros((n_cls, n_cls), dtype=np.uint64)
+            n_pieces = -(-longest // step)
+            with progress(hi - lo, "perm", show_progress_bar) as bar:
+                for q in range(max(n_pieces, 1)):
+                    a, b = min(hi, lo + q * step), min(hi, lo + (q + 1) * step)
+                    p1, p2, _ = plan.run(key, a, b, shift)
+                    s1 += p1
+                    s2 += p2
+                    bar.update(b - a)
         finally:
             plan.close()
         if comm is None:
@@ -195,6 +209,7 @@ def _broadcast_seed(key: int) -> int:
     return int(_dist.broadcast_object(int(key), src=0))
 
 
+PROGRESS_STEP = 40_960  # permutations per progress update: 16 launch groups of 2560
 MAX_DEVICE_SHUFFLE_CLUSTERS = 2048  # batched permutation kernels: uint8 labels + LDS counters up to 256 clusters, uint16 labels + device-scope
 # counters up to 2048 (K*K*16 counters per batch); beyond that the any-K edge-pair kernel counts host-drawn numpy shuffles
 

@@ -31,6 +31,7 @@ from .._utils import (
     extract_adata_if_sdata,
     get_n_processes,
     pcg64_states,
+    progress,
     resolve_seed,
     spawn_generators,
 )
@@ -272,6 +273,7 @@ def spatial_autocorr(
     resident, shift = (None, 0)
     if mine:
         resident, shift = _resident_features(ctx, vals, blocks[mine[0]][0], blocks[mine[-1]][1])
+    bar = progress(sum(blocks[bi][1] - blocks[bi][0] for bi in mine), "feature", show_progress_bar and n_perms is not None)
     try:
         for bi in mine:
             b0, b1 = blocks[bi]
@@ -292,9 +294,11 @@ def spatial_autocorr(
                         part = plan.perm_stats(mode.s, score[b0:b1], seed=key, perm_begin=0, perm_end=n_perms)
                     for k, v in part.items():
                         red[k][b0:b1] = v
+                bar.update(b1 - b0)
             finally:
                 plan.close()
     finally:
+        bar.__exit__()
         if resident is not None:
             resident.close()
     if world > 1:

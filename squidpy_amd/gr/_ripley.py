@@ -154,8 +154,13 @@ def ripley(
 
     Same parameters, numpy random streams (``spawn_generators(seed, n_simulations + 1)``: the first generator draws the
     observed-mode Poisson patterns, the others one simulation each), result keys (``'{mode}_stat'``, ``'sims_stat'``,
-    ``'bins'``, ``'pvalues'``) and ``adata.uns['{cluster_key}_ripley_{mode}']`` slot as the reference.  Supported metrics
-    on the GPU: euclidean / manhattan / chebyshev (and their sklearn aliases).
+    ``'bins'``, ``'pvalues'``) and ``adata.uns['{cluster_key}_ripley_{mode}']`` slot as the reference.  Metrics on the GPU:
+    euclidean / manhattan / chebyshev and their sklearn aliases (``l2``, ``minkowski`` / ``p`` at sklearn's default p = 2,
+    ``cityblock``, ``l1``, ``infinity``) for every mode; ``canberra`` for F and G (Ripley's L takes
+    :class:`sklearn.neighbors.KDTree` metrics only, as in the reference).  Metrics that need parameters a metric string
+    cannot carry (``seuclidean``, ``mahalanobis``, ``minkowski`` with another p), libm transcendentals (``haversine``) or
+    that are not metrics, so that sklearn's ball tree itself returns inexact neighbours for them (``braycurtis``), raise
+    ``NotImplementedError`` naming the supported set.
     """
     from scipy.spatial import ConvexHull
     from sklearn.preprocessing import LabelEncoder

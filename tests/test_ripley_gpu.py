@@ -163,3 +163,30 @@ def test_knn_cell_list_outside_queries_duplicates_clusters(L, ctx, metric):
         dist = L.knn_dist(ctx, qry[keep], ref, k, metric)
         np.testing.assert_array_equal(pts.knn_hist(ref, k, edges, metric, exclude_label=excl), np.histogram(dist.ravel(), bins=edges)[0])
     pts.close()
+
+
+@pytest.mark.parametrize("metric", ["canberra"])
+def test_ball_tree_metrics_without_parameters(L, ctx, metric):
+    """The reference hands `metric` straight to NearestNeighbors (gr/_ripley.py:144,148): canberra — the BallTree metric a bare
+    string can name that IS a metric — runs on the device for F / G (sklearn's per-coordinate arithmetic, incl. points on the
+    axes and at the origin, where 0/0 terms are skipped), and stays invalid for L like in the reference."""
+    from sklearn.neighbors import NearestNeighbors
+
+    import squidpy_amd as sq
+
+    rng = np.random.default_rng(5)
+    ref = np.round(rng.normal(0, 30, (900, 2)), 1)
+    ref[:5] = [[0, 0], [0, 3], [4, 0], [0, 0], [-2, 0]]
+    qry = np.concatenate([np.round(rng.normal(0, 40, (400, 2)), 1), [[0, 0], [0, 5], [3, 0]]])
+    for k in (1, 2, 5):
+        exp, _ = NearestNeighbors(metric=metric, n_neighbors=k).fit(ref).kneighbors(qry, n_neighbors=k)
+        np.testing.assert_array_equal(L.knn_dist(ctx, qry, ref, k, metric), exp)
+    adata = _adata()
+    res = sq.gr.ripley(adata, "cl", mode="G", metric=metric, n_simulations=4, n_observations=60, n_steps=9, seed=0, copy=True, max_dist=2.0)
+    ref_res = O.ripley(adata.obsm["spatial"], adata.obs["cl"].values, mode="G", metric=metric, n_simulations=4, n_observations=60, n_steps=9, seed=0, max_dist=2.0)
+    np.testing.assert_allclose(res["G_stat"]["stats"].to_numpy().reshape(3, 9), ref_res["obs"], rtol=1e-12)
+    np.testing.assert_array_equal(res["pvalues"], ref_res["pvalues"])
+    with pytest.raises(ValueError, match="Unsupported metric"):
+        sq.gr.ripley(adata, "cl", mode="L", metric=metric)
+    with pytest.raises(NotImplementedError, match="not implemented on the GPU path"):
+        sq.gr.ripley(adata, "cl", mode="F", metric="haversine")
