@@ -619,10 +619,13 @@ def config4_legs(ctx, ceil: dict, with_cpu: bool, counters: dict) -> dict:
     return out
 
 
-def numpy_stream_leg(ctx, plan, shift, n: int) -> dict:
+def numpy_stream_leg(ctx, plan, shift, n: int, counters: dict) -> dict:
     """The test with numpy's own PCG64 streams reproduced bit for bit on the GPU (`rng="numpy"` — the mode whose z-scores ARE
-    Squidpy's for a seed).  One wave per permutation replays `Generator.shuffle`'s n - 1 dependent swap steps; the bound is
-    that serial chain, priced as swap steps per second per resident wave."""
+    Squidpy's for a seed).  One wave per permutation replays `Generator.shuffle`: n - 1 swaps of position i with a uniformly
+    drawn j <= i in the permutation's own 1-byte-per-spot row.  At 1e6 spots thousands of 1 MB rows are in flight, so every j
+    side of a swap is a random 1-byte read AND a random 1-byte write in HBM — a 64-byte sector each: the kernel is bound by
+    HBM's random-sector rate, priced as 2 (n - 1) x 64 B per permutation against the 8 TB/s peak, and by the measured
+    traffic when the committed profile matches."""
     from squidpy_amd._utils import pcg64_states
 
     res, kern = {}, {}
@@ -639,19 +642,27 @@ def numpy_stream_leg(ctx, plan, shift, n: int) -> dict:
     k = kern[8192]
     ms_shuffle = sum(v[1] for name, v in k.items() if "pcg64" in name)
     ms_all = sum(v[1] for v in k.values())
-    cu = ctx.device_info().get("cu_count") or 256
-    steps_per_s = 8192 * (n - 1) / (ms_shuffle * 1e-3) if ms_shuffle > 0 else None
+    sector_bytes = 8192 * 2.0 * (n - 1) * 64.0  # one 64-byte sector read and one written per swap (the i side streams)
+    roof = {"kernel": "nhood_pcg64_shuffle (k_pcg_shuffle_wave)", "bound": "hbm",
+            "achieved": sector_bytes / (ms_shuffle * 1e-3) / 1e9 if ms_shuffle > 0 else None, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": sector_bytes / (ms_shuffle * 1e-3) / HBM_PEAK if ms_shuffle > 0 else None, "traffic": None,
+            "algorithmic_sector_bytes_per_launch": sector_bytes, "workload_key": {"spots": n, "perms": 8192},
+            "swap_steps_per_s": 8192 * (n - 1) / (ms_shuffle * 1e-3) if ms_shuffle > 0 else None,
+            "note": "random 1-byte read + 1-byte write per swap, each moving a 64-byte sector of HBM (rows of thousands of permutations in flight do "
+            "not fit any cache); `achieved` = 2 (n - 1) x 64 B x permutations / kernel time — an ALGORITHMIC sector count, the measured traffic "
+            "(`traffic`, `traffic_frac`) replaces it when the committed PMC profile matches"}
+    pmc = kernel_counters(counters.get("numpy", {}), "k_pcg_shuffle_wave", {"spots": n, "perms": 8192})
+    if pmc and pmc.get("FETCH_SIZE_bytes_timed_total") is not None and pmc.get("WRITE_SIZE_bytes_timed_total") is not None and ms_shuffle > 0:
+        # totals of the profiled run minus its first dispatch (the n_perms = 1000 warm-up): 1000 timed + 2 x 8192
+        share = 8192.0 / (1000 + 2 * 8192)
+        roof["traffic"] = (2.0 * pmc["FETCH_SIZE_bytes_timed_total"] + pmc["WRITE_SIZE_bytes_timed_total"]) * share
+        roof["traffic_source"] = counters.get("_source")
+        roof["traffic_GBps"] = roof["traffic"] / (ms_shuffle * 1e-3) / 1e9
+        roof["traffic_frac"] = roof["traffic"] / (ms_shuffle * 1e-3) / HBM_PEAK
     return {
         "value": res[8192], "unit": "permutations/s", "at_n_perms_1000": res[1000],
         "kernel_ms": {name: round(v[1], 3) for name, v in k.items() if v[0] > 0}, "shuffle_share_of_gpu_time": ms_shuffle / ms_all if ms_all > 0 else None,
-        "roofline": {"kernel": "nhood_pcg64_shuffle", "bound": "serial dependency chain (Fisher-Yates, one wave per permutation)",
-                     "achieved": steps_per_s, "unit": "swap steps/s", "peak": None, "frac": None, "traffic": None,
-                     "swap_steps_per_s_per_cu": steps_per_s / cu if steps_per_s else None,
-                     "clk_per_swap_step_per_wave_at_32_waves_per_cu": (cu * 32 * 2.4e9 / steps_per_s) if steps_per_s else None,
-                     "note": "numpy's shuffle is n - 1 swaps, each depending on the array state the previous ones left: a permutation cannot be split over "
-                     "lanes without replaying conflicts.  The kernel draws a wave-wide batch of swap targets with LCG jump-ahead, applies the "
-                     "non-conflicting ones in parallel and replays the rest in order (csrc/sqgr_pcg.hip); what bounds it is the dependent "
-                     "LDS/global round trip per batch, not a throughput unit — `clk_per_swap_step_per_wave` is the figure to lower"},
+        "roofline": roof,
         "note": "rng='numpy': z-scores equal Squidpy's for the same seed bit for bit",
     }
 
@@ -983,7 +994,7 @@ def main() -> None:
         if emulated is not None:
             out["emulated_ranks"] = emulated
         if world == 1 and not args.no_numpy_leg:  # the same test with numpy's own PCG64 streams reproduced bit for bit on the GPU
-            out["numpy_stream_mode"] = numpy_stream_leg(ctx, plan, shift, n)
+            out["numpy_stream_mode"] = numpy_stream_leg(ctx, plan, shift, n, counters)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(adj, labels)
             out["speedup_vs_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"]

@@ -761,10 +761,12 @@ __global__ __launch_bounds__(256) void k_edge_pairs(int64_t nnz, const int32_t* 
         atomicAdd(&out_u64[la * K + lb], 1ull);
 }
 
-// Weighted edge sums (gr/_nhood.py:412-429 sums float64 weights serially), run-to-run reproducible: every WAVE owns a
-// contiguous run of edges and a private K*K float64 accumulator in LDS.  A wave's LDS operations complete in program order
-// and the lanes of one ds_add_f64 that meet in a cell are applied in a fixed hardware order, so a wave's partial sums are a
-// pure function of its inputs (no cross-wave atomics anywhere); k_sum_partials adds the partials in wave order.
+// Weighted edge sums (gr/_nhood.py:412-429 sums float64 weights serially), bit-reproducible BY CONSTRUCTION: every WAVE owns
+// a contiguous run of edges and a private K*K float64 accumulator in LDS, and adds its edges to it in EDGE ORDER — the 64
+// edges of a trip are grouped by target cell with ballots, the lanes of a group are read out in lane (= edge) order by
+// readlane and added one after the other to the cell's running value by the group's first lane.  No floating-point atomic,
+// no assumption about the order in which the hardware applies conflicting LDS operations (round 2 relied on that); a wave's
+// partial sums are a pure function of its inputs and k_sum_partials adds the partials in wave order.
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void k_edge_weight_partials(int64_t nnz, const int32_t* __restrict__ erow,
                                                                       const int32_t* __restrict__ indices, const double* __restrict__ data,
@@ -779,10 +781,29 @@ __global__ __launch_bounds__(WAVES * 64) void k_edge_weight_partials(int64_t nnz
     const int64_t e0 = w * edges_per_wave, e1 = e0 + edges_per_wave < nnz ? e0 + edges_per_wave : nnz;
     for (int64_t base = e0; base < e1; base += 64) {
         const int64_t e = base + lane;
+        int cell = -1;
+        double wt = 0.0;
         if (e < e1) {
             const int la = labels[erow[e]], lb = labels[indices[e]];
-            if (la >= 0 && lb >= 0)
-                __hip_atomic_fetch_add(&acc[la * K + lb], data[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (la >= 0 && lb >= 0) {
+                cell = la * K + lb;
+                wt = data[e];
+            }
+        }
+        unsigned long long todo = __ballot(cell >= 0);
+        while (todo) {  // wave-uniform: one target cell per turn, first pending lane first
+            const int leader = __ffsll((long long)todo) - 1;
+            const int lc = __shfl(cell, leader, 64);
+            unsigned long long grp = __ballot(cell == lc) & todo;
+            todo &= ~grp;
+            double run = (lane == leader) ? acc[lc] : 0.0;
+            while (grp) {  // the group's weights in lane order = edge order
+                const int l = __ffsll((long long)grp) - 1;
+                run += __shfl(wt, l, 64);
+                grp &= grp - 1;
+            }
+            if (lane == leader) acc[lc] = run;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the next turn may read what this one wrote
         }
     }
     __builtin_amdgcn_s_waitcnt(0);

@@ -30,6 +30,10 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/legs_st
 timeout 900 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAVES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES --output-format csv -d $OUT/legs_sqa -- $LEGS > $OUT/legs_sqa.log 2>&1
 timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/legs_fetch -- $LEGS > $OUT/legs_fetch.log 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/legs_write -- $LEGS > $OUT/legs_write.log 2>&1
+# the numpy-stream shuffle (rng="numpy"): traffic of k_pcg_shuffle_wave
+NPY="python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --no-legs"
+timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/npy_fetch -- $NPY > $OUT/npy_fetch.log 2>&1
+timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/npy_write -- $NPY > $OUT/npy_write.log 2>&1
 # calibration of FETCH_SIZE / WRITE_SIZE on known byte counts, in the nhood kernels' access patterns
 if [ -x $REPO/tools/ubench_fetch_calib.bin ]; then
   timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/calib_fetch -- $REPO/tools/ubench_fetch_calib.bin > $OUT/calib_fetch.log 2>&1

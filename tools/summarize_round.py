@@ -107,6 +107,10 @@ lagg = collect(("legs_sqa", "legs_fetch", "legs_write"))
 lb = bench_line("legs_sqa.log") or legs_bench or {}
 rep["legs"] = {"command": legs_cmd, "workload": (((lb.get("legs") or {}).get("co_occurrence") or {}).get("roofline") or {}).get("workload_key"),
                "kernels": section(lagg, lambda k: "k_cooccur" in k or "k_pair_hist" in k or "k_knn" in k, after_first=True)}
+nagg = collect(("npy_fetch", "npy_write"))
+nb = bench_line("npy_fetch.log") or {}
+rep["numpy"] = {"workload": (((nb.get("numpy_stream_mode") or {}).get("roofline")) or {}).get("workload_key"),
+                "kernels": section(nagg, lambda k: "k_pcg_shuffle" in k or "k_rows_to_columns" in k or "k_columns_to_slab" in k, after_first=True)}
 json.dump(rep, open(os.path.join(out, f"{tag}_counters.json"), "w"), indent=1)
 print(json.dumps({k: (list(v["kernels"]) if isinstance(v, dict) and "kernels" in v else v) for k, v in rep.items() if k != "note"}, indent=1)[:3000])
 
