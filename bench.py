@@ -511,12 +511,8 @@ def config4_legs(ctx, ceil: dict, with_cpu: bool, counters: dict) -> dict:
     ctx.timer_enable(True)
     ctx.timer_reset()
     t0 = time.perf_counter()
-    tot = 0
-    first_counts = None
-    for pts in by_cluster:
-        c = _lib.pair_counts(ctx, pts, support)
-        first_counts = c if first_counts is None else first_counts
-        tot += int(c[-1])
+    all_counts = _lib.pair_counts_batch(ctx, by_cluster, support)  # one launch for the 30 clusters, as `sq.gr.ripley(mode="L")` issues it
+    first_counts = all_counts[0]
     wall = time.perf_counter() - t0
     k = ctx.timer_report()
     ctx.timer_enable(False)
@@ -541,8 +537,8 @@ def config4_legs(ctx, ceil: dict, with_cpu: bool, counters: dict) -> dict:
                      "frac": (rp / (kms * 1e-3) / peak_pairs) if clk and kms > 0 else None, "traffic": None,
                      "isa_mix_per_64_unordered_pairs": {**mix, "valu_32": 6, "lds": 3}, "simd_clk_per_64_unordered_pairs": clk, "ceiling_source": f64.get("source"),
                      "note": "float64 VALU issue: the hot loop spends 9 float64 instructions per pair (4 clk class) beside 6 32-bit ones; `peak` = pair rate at which "
-                     "that mix saturates the four SIMDs of every CU at the issue rates of tools/ubench_f64.hip.  30 separate launches of ~650 workgroups "
-                     "each (one per cluster): launch ramp and tail are inside `kernel_ms`"},
+                     "that mix saturates the four SIMDs of every CU at the issue rates of tools/ubench_f64.hip.  One launch for the 30 clusters "
+                     "(sqgr_pair_counts_batch), as the front end issues it"},
     }
     pmc = kernel_counters(counters.get("legs", {}), "k_pair_hist_fast", wkey)
     if pmc and pmc.get("SQ_INSTS_VALU_timed_total") is not None and kms > 0:
@@ -550,7 +546,7 @@ def config4_legs(ctx, ceil: dict, with_cpu: bool, counters: dict) -> dict:
             "valu_wave_instr": pmc["SQ_INSTS_VALU_timed_total"], "lds_wave_instr": pmc.get("SQ_INSTS_LDS_timed_total"),
             "valu_per_64_unordered_pairs": pmc["SQ_INSTS_VALU_timed_total"] / (rp / 2 / 64.0),
             "lds_per_64_unordered_pairs": (pmc.get("SQ_INSTS_LDS_timed_total") or 0.0) / (rp / 2 / 64.0), "source": counters.get("_source"),
-            "note": "PMC instruction counts of the 30 cluster launches of the profiled run / pairs: the ISA count (15 VALU, 3 DS) plus tile set-up and the diagonal tiles' checked path"}
+            "note": "PMC instruction counts of the timed launch of the profiled run / pairs: the ISA count (15 VALU, 3 DS) plus tile set-up and the diagonal tiles' checked path"}
     # ---- Ripley G (gr/_ripley.py:163-169): for every cluster, the 2 nearest cluster points of every point NOT in it, histogram of the distances
     pts_dev = _lib.DevicePoints(ctx, xy, labels)
     edges = np.linspace(0, (area / 2) ** 0.5, 50)

@@ -259,6 +259,10 @@ int sqgr_autocorr_perm_indices(sqgr_ctx* ctx, int64_t n, uint64_t seed, int64_t 
  * fl(sqrt(t)) <= r_s (so that `d2 <= t` == `sqrt(d2) <= r_s` bit for bit); for metrics 1/2 pass the radii. */
 int sqgr_pair_counts(sqgr_ctx* ctx, const double* xy, int64_t m, const double* thr, int32_t S, int32_t metric,
                      int64_t* out_counts);
+/* The same for n_sets point sets in ONE launch (Ripley's L evaluates one set per cluster and one per simulation,
+ * gr/_ripley.py:152,171): set z = points xy[offsets[z] .. offsets[z+1]), out_counts int64[n_sets][S].  n_sets <= 65535. */
+int sqgr_pair_counts_batch(sqgr_ctx* ctx, const double* xy, const int64_t* offsets, int32_t n_sets, const double* thr, int32_t S,
+                           int32_t metric, int64_t* out_counts);
 /* sqgr_knn_dist replaces `NearestNeighbors(n_neighbors=k).fit(ref).kneighbors(query)[0]` (gr/_ripley.py:144-150,
  * 163-169): out float64[nq][k] ascending; for metric 0 the SQUARED distances (caller applies sqrt). 1 <= k <= 16. */
 int sqgr_knn_dist(sqgr_ctx* ctx, const double* query, int64_t nq, const double* ref, int64_t nr, int32_t k, int32_t metric,

@@ -74,6 +74,7 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "sqgr_autocorr_perm_stats": (C.c_int, [C.c_void_p, C.c_int32, c_i32p, c_u64p, C.c_uint64, C.c_int64, C.c_int64, c_f64p, c_i64p, c_f64p, c_f64p, c_f64p]),
     "sqgr_autocorr_perm_indices": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_int64, C.c_int64, c_i32p]),
     "sqgr_pair_counts": (C.c_int, [C.c_void_p, c_f64p, C.c_int64, c_f64p, C.c_int32, C.c_int32, c_i64p]),
+    "sqgr_pair_counts_batch": (C.c_int, [C.c_void_p, c_f64p, c_i64p, C.c_int32, c_f64p, C.c_int32, C.c_int32, c_i64p]),
     "sqgr_knn_dist": (C.c_int, [C.c_void_p, c_f64p, C.c_int64, c_f64p, C.c_int64, C.c_int32, C.c_int32, c_f64p]),
     "sqgr_points_create": (C.c_int, [C.c_void_p, c_f64p, c_i32p, C.c_int64, C.POINTER(C.c_void_p)]),
     "sqgr_points_destroy": (C.c_int, [C.c_void_p]),
@@ -751,6 +752,22 @@ def pair_counts(ctx: Context, xy: np.ndarray, support: np.ndarray, metric: str =
     thr = sqrt_thresholds(support) if m == 0 else support
     out = np.zeros(len(support), dtype=np.int64)
     _check(ctx.lib, ctx.lib.sqgr_pair_counts(ctx.h, _ptr(xy, c_f64p), xy.shape[0], _ptr(thr, c_f64p), len(thr), m, _ptr(out, c_i64p)))
+    return out
+
+
+def pair_counts_batch(ctx: Context, sets: "list[np.ndarray]", support: np.ndarray, metric: str = "euclidean") -> np.ndarray:
+    """:func:`pair_counts` of several point sets in one launch -> int64 (n_sets, S)."""
+    support = _as(support, np.float64)
+    m = METRICS[metric]
+    thr = sqrt_thresholds(support) if m == 0 else support
+    out = np.zeros((len(sets), len(support)), dtype=np.int64)
+    if not sets:
+        return out
+    arrs = [_as(a, np.float64).reshape(-1, 2) for a in sets]
+    offsets = np.zeros(len(arrs) + 1, dtype=np.int64)
+    np.cumsum([len(a) for a in arrs], out=offsets[1:])
+    xy = np.ascontiguousarray(np.concatenate(arrs, axis=0)) if offsets[-1] else np.zeros((1, 2))
+    _check(ctx.lib, ctx.lib.sqgr_pair_counts_batch(ctx.h, _ptr(xy, c_f64p), _ptr(offsets, c_i64p), len(arrs), _ptr(thr, c_f64p), len(thr), m, _ptr(out, c_i64p)))
     return out
 
 

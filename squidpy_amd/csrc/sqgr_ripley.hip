@@ -40,15 +40,29 @@ __device__ __forceinline__ double metric_dist(double xi, double yi, double xj, d
     return d;
 }
 
+// Point sets of one launch (blockIdx.z): set z has set_m[z] points stored from tile set_tile0[z] on in the packed, tile-padded
+// coordinate arrays; its counts go to out + z * S.  (Ripley's L evaluates one set per cluster and per simulation: one launch for
+// all of them instead of 30 + 100 small ones.)
+struct PairSets {
+    const int64_t* m;
+    const int32_t* tile0;
+};
+
 template <int METRIC>
-__global__ __launch_bounds__(RP_TILE) void k_pair_hist(const double* __restrict__ xs, const double* __restrict__ ys, int64_t m,
-                                                       const double* __restrict__ thr, int S, int T,
-                                                       unsigned long long* __restrict__ out) {
+__global__ __launch_bounds__(RP_TILE) void k_pair_hist(const double* __restrict__ xs_all, const double* __restrict__ ys_all, PairSets sets,
+                                                       const double* __restrict__ thr, int S,
+                                                       unsigned long long* __restrict__ out_all) {
     extern __shared__ unsigned char smem_raw[];
     double* s_thr = reinterpret_cast<double*>(smem_raw);                 // [S]
     uint32_t* hist = reinterpret_cast<uint32_t*>(s_thr + S);             // [S][256]
     const int t = threadIdx.x;
+    const int64_t m = sets.m[blockIdx.z];
+    const int T = (int)((m + RP_TILE - 1) / RP_TILE);
+    const double* xs = xs_all + (size_t)sets.tile0[blockIdx.z] * RP_TILE;
+    const double* ys = ys_all + (size_t)sets.tile0[blockIdx.z] * RP_TILE;
+    unsigned long long* out = out_all + (size_t)blockIdx.z * S;
     const int ti = blockIdx.x;
+    if (ti >= T) return;
     const int tj0 = max(ti, (int)blockIdx.y * RP_CHUNK);
     const int tj1 = min(T, ((int)blockIdx.y + 1) * RP_CHUNK);
     if (tj0 >= tj1) return;
@@ -99,17 +113,23 @@ constexpr int RP_CELLS_MIN = 1024;
 constexpr int RP_CELLS_MAX = 32768;
 
 template <int METRIC>
-__global__ __launch_bounds__(RP_TILE) void k_pair_hist_fast(const double* __restrict__ xs, const double* __restrict__ ys, int64_t m,
-                                                            const double* __restrict__ thr, int S, int T,
+__global__ __launch_bounds__(RP_TILE) void k_pair_hist_fast(const double* __restrict__ xs_all, const double* __restrict__ ys_all,
+                                                            PairSets sets, const double* __restrict__ thr, int S,
                                                             const uint16_t* __restrict__ cell, int ncells, double inv_cell,
-                                                            int finite, unsigned long long* __restrict__ out) {
+                                                            int finite, unsigned long long* __restrict__ out_all) {
     extern __shared__ unsigned char smem_raw[];
     double* s_thr = reinterpret_cast<double*>(smem_raw);                       // [S + 2], two +inf sentinels
     constexpr int HC = 64;                                                     // histogram columns
     uint32_t* hist = reinterpret_cast<uint32_t*>(s_thr + S + 2);               // [S + RP_TRASH][HC]
     uint16_t* s_cell = reinterpret_cast<uint16_t*>(hist + (S + RP_TRASH) * HC);  // [ncells]
     const int t = threadIdx.x;
+    const int64_t m = sets.m[blockIdx.z];
+    const int T = (int)((m + RP_TILE - 1) / RP_TILE);
+    const double* xs = xs_all + (size_t)sets.tile0[blockIdx.z] * RP_TILE;
+    const double* ys = ys_all + (size_t)sets.tile0[blockIdx.z] * RP_TILE;
+    unsigned long long* out = out_all + (size_t)blockIdx.z * S;
     const int ti = blockIdx.x;
+    if (ti >= T) return;
     const int tj0 = max(ti, (int)blockIdx.y * RP_CHUNK);
     const int tj1 = min(T, ((int)blockIdx.y + 1) * RP_CHUNK);
     if (tj0 >= tj1) return;
@@ -436,24 +456,46 @@ struct sqgr_points {  // a point set resident on the device (coordinates split i
 
 extern "C" {
 
-int sqgr_pair_counts(sqgr_ctx* ctx, const double* xy, int64_t m, const double* thr, int32_t S, int32_t metric,
-                     int64_t* out_counts) {
-    SQGR_REQUIRE(ctx && thr && out_counts && (xy || m == 0), "null argument");
-    SQGR_REQUIRE(m >= 0 && S >= 1 && metric >= 0 && metric <= 2, "bad argument m=%lld S=%d metric=%d", (long long)m, S, metric);
+int sqgr_pair_counts_batch(sqgr_ctx* ctx, const double* xy, const int64_t* offsets, int32_t n_sets, const double* thr, int32_t S,
+                           int32_t metric, int64_t* out_counts) {
+    SQGR_REQUIRE(ctx && thr && out_counts && offsets && n_sets >= 0, "null argument or n_sets < 0");
+    SQGR_REQUIRE(S >= 1 && metric >= 0 && metric <= 2, "bad argument S=%d metric=%d", S, metric);
     for (int s = 1; s < S; ++s) SQGR_REQUIRE(thr[s - 1] <= thr[s], "thresholds must be ascending");
+    SQGR_REQUIRE(offsets[0] == 0, "offsets[0] must be 0");
+    for (int z = 0; z < n_sets; ++z) SQGR_REQUIRE(offsets[z] <= offsets[z + 1], "offsets are not ascending at set %d", z);
+    SQGR_REQUIRE(n_sets <= 65535, "at most 65535 point sets per call, found %d", n_sets);
+    const int64_t total = n_sets ? offsets[n_sets] : 0;
+    SQGR_REQUIRE(xy || total == 0, "xy is NULL");
     const size_t lds = (size_t)S * 8 + (size_t)S * RP_TILE * 4;
     if (lds > 160 * 1024) {
         set_error("S=%d radii need %zu bytes of LDS (> 160 KiB)", S, lds);
         return SQGR_ERR_UNSUPPORTED;
     }
-    for (int s = 0; s < S; ++s) out_counts[s] = 0;
-    if (m < 2) return SQGR_OK;
+    for (int64_t i = 0; i < (int64_t)n_sets * S; ++i) out_counts[i] = 0;
+    if (n_sets == 0 || total == 0) return SQGR_OK;
     SQGR_HIP(hipSetDevice(ctx->device));
-    std::vector<double> x, y;
-    split_xy(xy, m, x, y);
+    // pack: every set padded with zeros to whole tiles
+    std::vector<int64_t> set_m((size_t)n_sets);
+    std::vector<int32_t> tile0((size_t)n_sets + 1, 0);
+    int64_t max_m = 0;
+    for (int z = 0; z < n_sets; ++z) {
+        set_m[z] = offsets[z + 1] - offsets[z];
+        tile0[z + 1] = tile0[z] + (int32_t)ceil_div(std::max<int64_t>(set_m[z], 1), RP_TILE);
+        max_m = std::max(max_m, set_m[z]);
+    }
+    if (max_m < 2) return SQGR_OK;
+    const size_t mp = (size_t)tile0[n_sets] * RP_TILE;
+    std::vector<double> x(mp, 0.0), y(mp, 0.0);
     bool finite = true;
-    for (int64_t i = 0; i < 2 * m; ++i) finite = finite && std::isfinite(xy[i]);
-    const size_t mp = x.size();  // padded length
+    for (int z = 0; z < n_sets; ++z) {
+        const size_t base = (size_t)tile0[z] * RP_TILE;
+        for (int64_t i = 0; i < set_m[z]; ++i) {
+            const double px = xy[2 * (offsets[z] + i)], py = xy[2 * (offsets[z] + i) + 1];
+            x[base + i] = px;
+            y[base + i] = py;
+            finite = finite && std::isfinite(px) && std::isfinite(py);
+        }
+    }
     // lookup table over the metric value for the branch-free kernel: cell c -> lower bound of the bin of every value in it
     double tmax = 0.0;
     for (int s2 = 0; s2 < S; ++s2)
@@ -488,22 +530,29 @@ int sqgr_pair_counts(sqgr_ctx* ctx, const double* xy, int64_t m, const double* t
             if (ncells * 2 > RP_CELLS_MAX) break;
         }
     }
-    struct { double* p; } dx, dy, dthr;  // context scratch: this entry point runs once per cluster and per simulation
+    struct { double* p; } dx, dy, dthr;  // context scratch: this entry point may run once per cluster and per simulation
     struct { unsigned long long* p; } dout;
     struct { uint16_t* p; } dcell;
+    struct { int64_t* p; } dm;
+    struct { int32_t* p; } dt0;
     SQGR_TRY(ctx->scratch_get(0, mp * 8, reinterpret_cast<void**>(&dx.p)));
     SQGR_TRY(ctx->scratch_get(1, mp * 8, reinterpret_cast<void**>(&dy.p)));
     SQGR_TRY(ctx->scratch_get(4, (size_t)RP_CELLS_MAX * 2, reinterpret_cast<void**>(&dcell.p)));
     SQGR_TRY(ctx->scratch_get(2, (size_t)S * 8, reinterpret_cast<void**>(&dthr.p)));
-    SQGR_TRY(ctx->scratch_get(3, (size_t)S * 8, reinterpret_cast<void**>(&dout.p)));
+    SQGR_TRY(ctx->scratch_get(3, (size_t)n_sets * S * 8, reinterpret_cast<void**>(&dout.p)));
+    SQGR_TRY(ctx->scratch_get(5, (size_t)n_sets * 8, reinterpret_cast<void**>(&dm.p)));
+    SQGR_TRY(ctx->scratch_get(6, ((size_t)n_sets + 1) * 4, reinterpret_cast<void**>(&dt0.p)));
     hipStream_t st = ctx->stream;
     SQGR_HIP(hipMemcpyAsync(dx.p, x.data(), mp * 8, hipMemcpyHostToDevice, st));
     SQGR_HIP(hipMemcpyAsync(dy.p, y.data(), mp * 8, hipMemcpyHostToDevice, st));
     SQGR_HIP(hipMemcpyAsync(dthr.p, thr, (size_t)S * 8, hipMemcpyHostToDevice, st));
+    SQGR_HIP(hipMemcpyAsync(dm.p, set_m.data(), (size_t)n_sets * 8, hipMemcpyHostToDevice, st));
+    SQGR_HIP(hipMemcpyAsync(dt0.p, tile0.data(), ((size_t)n_sets + 1) * 4, hipMemcpyHostToDevice, st));
     if (fast) SQGR_HIP(hipMemcpyAsync(dcell.p, cell.data(), (size_t)ncells * 2, hipMemcpyHostToDevice, st));
-    SQGR_HIP(hipMemsetAsync(dout.p, 0, (size_t)S * 8, st));
-    const int T = (int)ceil_div(m, RP_TILE);
-    dim3 grid((unsigned)T, (unsigned)ceil_div(T, RP_CHUNK));
+    SQGR_HIP(hipMemsetAsync(dout.p, 0, (size_t)n_sets * S * 8, st));
+    const int T = (int)ceil_div(max_m, RP_TILE);
+    const dim3 grid((unsigned)T, (unsigned)ceil_div(T, RP_CHUNK), (unsigned)n_sets);
+    const PairSets sets{dm.p, dt0.p};
     if (fast) {
         LaunchTimer t(ctx, "ripley_pair_hist_fast");
         const size_t lds_fast = lds_fast_fixed + (size_t)ncells * 2;
@@ -511,7 +560,7 @@ int sqgr_pair_counts(sqgr_ctx* ctx, const double* xy, int64_t m, const double* t
     do {                                                                                                                    \
         if (lds_fast > 64 * 1024)                                                                                           \
             SQGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_hist_fast<M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast)); \
-        k_pair_hist_fast<M><<<grid, RP_TILE, lds_fast, st>>>(dx.p, dy.p, m, dthr.p, S, T, dcell.p, ncells, inv_cell, finite ? 1 : 0, dout.p); \
+        k_pair_hist_fast<M><<<grid, RP_TILE, lds_fast, st>>>(dx.p, dy.p, sets, dthr.p, S, dcell.p, ncells, inv_cell, finite ? 1 : 0, dout.p); \
     } while (0)
         if (metric == 0) SQGR_PHF(0); else if (metric == 1) SQGR_PHF(1); else SQGR_PHF(2);
 #undef SQGR_PHF
@@ -522,21 +571,31 @@ int sqgr_pair_counts(sqgr_ctx* ctx, const double* xy, int64_t m, const double* t
     do {                                                                                                                    \
         if (lds > 64 * 1024)                                                                                                \
             SQGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_hist<M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        k_pair_hist<M><<<grid, RP_TILE, lds, st>>>(dx.p, dy.p, m, dthr.p, S, T, dout.p);                                   \
+        k_pair_hist<M><<<grid, RP_TILE, lds, st>>>(dx.p, dy.p, sets, dthr.p, S, dout.p);                                   \
     } while (0)
         if (metric == 0) SQGR_PH(0); else if (metric == 1) SQGR_PH(1); else SQGR_PH(2);
 #undef SQGR_PH
         SQGR_HIP(hipGetLastError());
     }
-    std::vector<unsigned long long> h((size_t)S);
-    SQGR_HIP(hipMemcpyAsync(h.data(), dout.p, (size_t)S * 8, hipMemcpyDeviceToHost, st));
+    std::vector<unsigned long long> h((size_t)n_sets * S);
+    SQGR_HIP(hipMemcpyAsync(h.data(), dout.p, (size_t)n_sets * S * 8, hipMemcpyDeviceToHost, st));
     SQGR_HIP(hipStreamSynchronize(st));
-    unsigned long long run = 0;
-    for (int s = 0; s < S; ++s) {
-        run += h[s];
-        out_counts[s] = (int64_t)run;
+    for (int z = 0; z < n_sets; ++z) {
+        unsigned long long run = 0;
+        for (int s = 0; s < S; ++s) {
+            run += h[(size_t)z * S + s];
+            out_counts[(size_t)z * S + s] = (int64_t)run;
+        }
     }
     return SQGR_OK;
+}
+
+int sqgr_pair_counts(sqgr_ctx* ctx, const double* xy, int64_t m, const double* thr, int32_t S, int32_t metric,
+                     int64_t* out_counts) {
+    SQGR_REQUIRE(m >= 0, "bad argument m=%lld", (long long)m);
+    SQGR_REQUIRE(xy || m == 0, "null argument");
+    const int64_t offsets[2] = {0, m};
+    return sqgr_pair_counts_batch(ctx, xy, offsets, 1, thr, S, metric, out_counts);
 }
 
 int sqgr_knn_dist(sqgr_ctx* ctx, const double* query, int64_t nq, const double* ref, int64_t nr, int32_t k, int32_t metric,

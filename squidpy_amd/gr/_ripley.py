@@ -13,7 +13,7 @@ import pandas as pd
 
 from .._constants import Key, RipleyStat
 from .. import _dist
-from .._lib import METRICS, Context, DevicePoints, default_context, knn_dist, pair_counts
+from .._lib import METRICS, Context, DevicePoints, default_context, knn_dist, pair_counts, pair_counts_batch
 from .._utils import _assert_categorical_obs, _assert_spatial_basis, _save_data, extract_adata_if_sdata, spawn_generators
 
 __all__ = ["ripley"]
@@ -99,6 +99,15 @@ class _Engine:
 
     def l_stat(self, points: np.ndarray) -> np.ndarray:
         return _l_function(self.ctx, points, self.support, self.n_total, self.area, self.metric)[1]
+
+    def l_stat_many(self, point_sets: "list[np.ndarray]") -> np.ndarray:
+        """`_l_function` (gr/_ripley.py:212-227) of several point sets — one per cluster, or one per simulation — with their
+        pair counts taken in ONE launch (`sqgr_pair_counts_batch`); row k = `l_stat(point_sets[k])`."""
+        if self.metric not in KDTREE_VALID_METRICS:
+            raise ValueError(f"Unsupported metric '{self.metric}'. Ripley's L supports {KDTREE_VALID_METRICS}")
+        n_pairs = pair_counts_batch(self.ctx, point_sets, self.support, self.metric)
+        k_estimate = (n_pairs / self.n_total) / (self.n_total / self.area)
+        return np.sqrt(k_estimate / np.pi)
 
     def nn_stat(self, queries: np.ndarray, refs: np.ndarray, k: int) -> np.ndarray:
         dist = knn_dist(self.ctx, queries, refs, k, self.metric)
@@ -204,24 +213,32 @@ def ripley(
             continue
         members = xy64[codes == gidx]
         if stat == RipleyStat.L:
-            observed[gidx] = engine.l_stat(members)
+            pass  # the clusters this rank owns are counted together below
         elif stat == RipleyStat.G:
             observed[gidx] = engine.nn_stat_resident(everyone, members, n_neigh, exclude_label=gidx)
         else:
             observed[gidx] = engine.nn_stat(probe, members, n_neigh)
 
+    if stat == RipleyStat.L:
+        mine = [gidx for gidx in range(int(codes.max()) + 1) if owner[gidx] == rank]
+        if mine:
+            observed[mine] = engine.l_stat_many([xy64[codes == gidx] for gidx in mine])
+
     # null distribution: complete spatial randomness inside the hull, one pattern per generator
     simulated = np.full((n_simulations, n_steps), np.nan)
+    l_patterns: list[tuple[int, np.ndarray]] = []
     for s_idx, rng in enumerate(other_rngs):
         if s_idx % world != rank:
             continue
         pattern = _ppp(hull, n_simulations=1, n_observations=n_observations, rng=rng)
         if stat == RipleyStat.L:
-            simulated[s_idx] = engine.l_stat(pattern)
+            l_patterns.append((s_idx, pattern))  # all of this rank's simulations in one launch below
         elif stat == RipleyStat.G:
             simulated[s_idx] = engine.nn_stat_resident(everyone, pattern, 1)
         else:  # the reference reuses the probe pattern of the LAST cluster here (gr/_ripley.py:163-165)
             simulated[s_idx] = engine.nn_stat(probe, pattern, 1)
+    if l_patterns:
+        simulated[[k for k, _ in l_patterns]] = engine.l_stat_many([pat for _, pat in l_patterns])
     if world > 1:  # rows are owned by exactly one rank: gather and take each from its owner (int64[n_steps]-sized rows)
         parts = _dist.allgather_object((observed, simulated))
         for gidx in range(n_groups):

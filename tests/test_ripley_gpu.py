@@ -190,3 +190,22 @@ def test_ball_tree_metrics_without_parameters(L, ctx, metric):
         sq.gr.ripley(adata, "cl", mode="L", metric=metric)
     with pytest.raises(NotImplementedError, match="not implemented on the GPU path"):
         sq.gr.ripley(adata, "cl", mode="F", metric="haversine")
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "chebyshev"])
+def test_pair_counts_of_many_sets_in_one_launch(L, ctx, metric):
+    """`sqgr_pair_counts_batch` (one launch for all clusters / all simulations of Ripley's L) == the per-set call == sklearn,
+    for sets of very different sizes incl. empty, one-point and exactly-one-tile sets."""
+    from sklearn.neighbors import KDTree
+
+    rng = np.random.default_rng(21)
+    sizes = [0, 1, 2, 255, 256, 257, 1000, 3001, 17]
+    sets = [np.round(rng.random((m, 2)) * 30, 1) for m in sizes]
+    support = np.linspace(0, 20, 37)
+    got = L.pair_counts_batch(ctx, sets, support, metric)
+    assert got.shape == (len(sizes), 37)
+    for k, pts in enumerate(sets):
+        np.testing.assert_array_equal(got[k], L.pair_counts(ctx, pts, support, metric))
+        if len(pts) >= 2:
+            np.testing.assert_array_equal(got[k], KDTree(pts, metric=metric).two_point_correlation(pts, support, dualtree=True) - len(pts))
+    assert L.pair_counts_batch(ctx, [], support).shape == (0, 37)
