@@ -113,6 +113,18 @@ def load_f64_ceilings() -> dict:
     return out
 
 
+def load_ds_mix(name: str) -> dict | None:
+    """DS wave-instructions/s of a named LDS instruction mix at full occupancy (tools/ubench_ds_mix.hip, profiles/r03_ubench_ds_mix.json)."""
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_ubench_ds_mix.json")
+    try:
+        with open(path) as fh:
+            rows = [r for r in json.load(fh)["ds_mix"] if r["mix"] == name]
+        best = max(rows, key=lambda r: r["ds_wave_instr_per_s"])
+        return {"rate": best["ds_wave_instr_per_s"], "source": os.path.relpath(path, ROOT)}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def load_lds_read_ceilings() -> dict:
     """LDS read rates measured by tools/ubench_lds_read.hip on an MI355X (committed: profiles/r02_ubench_lds_read.json)."""
     path = os.path.join(ROOT, "profiles", "r02_ubench_lds_read.json")
@@ -495,6 +507,11 @@ def config4_legs(ctx, ceil: dict, with_cpu: bool, counters: dict) -> dict:
         roof["achieved"] = roof["pmc"]["achieved_valu_wave_instr_per_s"]
         if pmc.get("FETCH_SIZE_bytes_timed_total") is not None and pmc.get("WRITE_SIZE_bytes_timed_total") is not None:
             roof["traffic"] = 2.0 * pmc["FETCH_SIZE_bytes_timed_total"] + pmc["WRITE_SIZE_bytes_timed_total"]
+        ds = load_ds_mix("co_occurrence: ds_read_u16 + ds_read2_b32 + ds_add_u32")
+        if ds and li > 0:  # the LDS side: DS wave-instructions per second against the rate of exactly this triple (tools/ubench_ds_mix.hip)
+            roof["lds_issue"] = {"achieved": li / (kms * 1e-3), "peak": ds["rate"], "unit": "DS wave-instr/s", "frac": li / (kms * 1e-3) / ds["rate"],
+                                 "ceiling_source": ds["source"], "note": "table look-up + two thresholds (bank-staggered copies) + histogram add per pair: the kernel sits "
+                                 "close to BOTH its VALU and its LDS issue limit"}
     out["co_occurrence"] = {
         "metric": "co_occurrence ordered pair evaluations/sec (1e6 points x 30 clusters x 49 thresholds)",
         "value": pairs / wall, "unit": "pairs/s", "wall_s": wall, "kernel_ms": kms, "roofline": roof,

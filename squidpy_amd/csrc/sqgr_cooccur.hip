@@ -28,6 +28,9 @@ constexpr int CO_LMAX = 120;          // thresholds per sweep: (L+?)*1 KiB of pr
 constexpr int CO_BATCH = 8;           // pairs in flight per thread in the branch-free kernel
 constexpr int CO_CHUNK_TILES = 64;
 constexpr int CO_TRASH = 3;           // overflow rows behind the L bins of the branch-free kernel (bin <= L + 2)
+constexpr int CO_HC = 64;             // histogram columns of the branch-free kernel: one per LANE, shared by the block's four waves through
+                                      // the LDS atomics they are anyway (round 3: 14 KB instead of 53 KB at 49 thresholds: 7 instead of 2 blocks per CU);
+                                      // a column receives at most 4 waves x CO_CHUNK_TILES x 256 counts between two flushes
 
 struct CoParams {
     float inv_cell;
@@ -45,15 +48,16 @@ __device__ __forceinline__ float dist2(float xi, float yi, float xj, float yj) {
     return __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));  // numpy / un-contracted semantics: every op rounded
 }
 
-// sum every bin's 256 private columns and credit (a,b) [and (b,a)]; leaves the histogram zeroed.
+// sum every bin's HC histogram columns and credit (a,b) [and (b,a)]; leaves the histogram zeroed.
+template <int HC>
 __device__ void co_flush(uint32_t* hist, int L, int K, int a, int b, bool mirror, unsigned long long* out) {
     __syncthreads();
     const int t = threadIdx.x;
     for (int g = t; g < L; g += CO_TILE) {
         unsigned long long s = 0;
-        uint32_t* row = hist + g * CO_TILE;
-        for (int k = 0; k < CO_TILE; ++k) {
-            const int kk = (k + t) & (CO_TILE - 1);  // rotate: lanes of a wave walk distinct banks
+        uint32_t* row = hist + g * HC;
+        for (int k = 0; k < HC; ++k) {
+            const int kk = (k + t) & (HC - 1);  // rotate: lanes of a wave walk distinct banks
             s += row[kk];
             row[kk] = 0;
         }
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(CO_TILE) void k_cooccur(const float* __restrict__ x
     for (int tj = tj0; tj < tj1; ++tj) {
         const int b = tile_label[tj];
         if (b != cur_b) {
-            if (cur_b >= 0) co_flush(hist, L, p.K, a, cur_b, true, p.out);
+            if (cur_b >= 0) co_flush<CO_TILE>(hist, L, p.K, a, cur_b, true, p.out);
             cur_b = b;
         }
         const int vj = tile_valid[tj];
@@ -121,10 +125,10 @@ __global__ __launch_bounds__(CO_TILE) void k_cooccur(const float* __restrict__ x
             }
         }
         if (diag) {  // ordered pairs of the diagonal tile are complete on their own: credit (a,a) once
-            co_flush(hist, L, p.K, a, a, false, p.out);
+            co_flush<CO_TILE>(hist, L, p.K, a, a, false, p.out);
         }
     }
-    co_flush(hist, L, p.K, a, cur_b, true, p.out);
+    co_flush<CO_TILE>(hist, L, p.K, a, cur_b, true, p.out);
 }
 
 // Branch-free variant used whenever the lookup table is fine enough that the true bin is at most 2 above the
@@ -137,9 +141,11 @@ __global__ __launch_bounds__(CO_TILE) void k_cooccur_fast(const float* __restric
                                                           const uint16_t* __restrict__ cell, CoParams p) {
     extern __shared__ uint32_t smem[];
     const int L = p.L;
-    uint32_t* hist = smem;                                          // [L + CO_TRASH][256]: bins, then write-only overflow rows
-    float* s_thr = reinterpret_cast<float*>(smem + (L + CO_TRASH) * CO_TILE);  // [L + 2], two +inf sentinels
-    uint16_t* s_cell = reinterpret_cast<uint16_t*>(s_thr + L + 2);  // [ncells]
+    uint32_t* hist = smem;                                          // [L + CO_TRASH][CO_HC]: bins, then write-only overflow rows
+    // [L + 2][32]: every threshold (and two +inf sentinels) 32 times, copy c in bank c — lane l reads copy l & 31, so the 64 lanes'
+    // threshold reads (random g) never meet in a bank (tools/ubench_ds_mix.hip: the plain [L] array cost ~8 clk per ds_read2_b32)
+    float* s_thr = reinterpret_cast<float*>(smem + (L + CO_TRASH) * CO_HC);
+    uint16_t* s_cell = reinterpret_cast<uint16_t*>(s_thr + (L + 2) * 32);  // [ncells]
     const int t = threadIdx.x;
 
     const int ti = blockIdx.x * p.shard_count + p.shard_index;
@@ -148,8 +154,8 @@ __global__ __launch_bounds__(CO_TILE) void k_cooccur_fast(const float* __restric
     const int tj1 = min(p.T, ((int)blockIdx.y + 1) * CO_CHUNK_TILES);
     if (tj0 >= tj1) return;
 
-    for (int i = t; i < (L + CO_TRASH) * CO_TILE; i += CO_TILE) hist[i] = 0;
-    for (int i = t; i < L + 2; i += CO_TILE) s_thr[i] = i < L ? thr[i] : __builtin_inff();
+    for (int i = t; i < (L + CO_TRASH) * CO_HC; i += CO_TILE) hist[i] = 0;
+    for (int i = t; i < (L + 2) * 32; i += CO_TILE) s_thr[i] = (i >> 5) < L ? thr[i >> 5] : __builtin_inff();
     for (int i = t; i < p.ncells; i += CO_TILE) s_cell[i] = cell[i];
     __syncthreads();
 
@@ -159,13 +165,14 @@ __global__ __launch_bounds__(CO_TILE) void k_cooccur_fast(const float* __restric
     const float yi = ys[(size_t)ti * CO_TILE + t];
     const float inv_cell = p.inv_cell;
     const int cmax = p.ncells - 1;
-    uint32_t* my = hist + t;
+    uint32_t* my = hist + (t & (CO_HC - 1));
+    const int l32 = t & 31;
 
     int cur_b = -1;
     for (int tj = tj0; tj < tj1; ++tj) {
         const int b = tile_label[tj];
         if (b != cur_b) {
-            if (cur_b >= 0) co_flush(hist, L, p.K, a, cur_b, true, p.out);
+            if (cur_b >= 0) co_flush<CO_HC>(hist, L, p.K, a, cur_b, true, p.out);
             cur_b = b;
         }
         const int vj = tile_valid[tj];
@@ -192,8 +199,8 @@ __global__ __launch_bounds__(CO_TILE) void k_cooccur_fast(const float* __restric
             float t0[CO_BATCH], t1[CO_BATCH];
 #pragma unroll
             for (int u = 0; u < CO_BATCH; ++u) {
-                t0[u] = s_thr[g[u]];  // adjacent: one ds_read2_b32
-                t1[u] = s_thr[g[u] + 1];
+                t0[u] = s_thr[g[u] * 32 + l32];  // 32 words apart: one ds_read2_b32
+                t1[u] = s_thr[g[u] * 32 + 32 + l32];
             }
 #pragma unroll
             for (int u = 0; u < CO_BATCH; ++u) {
@@ -202,9 +209,9 @@ __global__ __launch_bounds__(CO_TILE) void k_cooccur_fast(const float* __restric
                 const int gg = g[u] + c0 + c1;
                 if constexpr (CHECKED) {
                     const int ok = (int)(gg < L) & (int)(j0 + u < vj) & (int)(j0 + u != self) & (int)(d2[u] == d2[u]);
-                    atomicAdd(my + min(gg, L - 1) * CO_TILE, (uint32_t)ok);
+                    atomicAdd(my + min(gg, L - 1) * CO_HC, (uint32_t)ok);
                 } else {
-                    atomicAdd(my + gg * CO_TILE, 1u);
+                    atomicAdd(my + gg * CO_HC, 1u);
                 }
             }
         };
@@ -217,9 +224,9 @@ __global__ __launch_bounds__(CO_TILE) void k_cooccur_fast(const float* __restric
                 if (jfull < vj) batch(jfull, std::true_type{});
             }
         }
-        if (tj == ti) co_flush(hist, L, p.K, a, a, false, p.out);  // diagonal tile: ordered pairs complete, credit (a,a) once
+        if (tj == ti) co_flush<CO_HC>(hist, L, p.K, a, a, false, p.out);  // diagonal tile: ordered pairs complete, credit (a,a) once
     }
-    co_flush(hist, L, p.K, a, cur_b, true, p.out);
+    co_flush<CO_HC>(hist, L, p.K, a, cur_b, true, p.out);
 }
 
 }  // namespace sqgr
@@ -350,7 +357,7 @@ extern "C" int sqgr_cooccur_counts(sqgr_ctx* ctx, const float* x, const float* y
         SQGR_HIP(hipMemcpyAsync(d_cell.p, cell.data(), (size_t)ncells * 2, hipMemcpyHostToDevice, st));
         SQGR_HIP(hipMemsetAsync(d_out.p, 0, (size_t)K * K * L_eff * 8, st));
         CoParams p{inv_cell, ncells, (int)T, L_eff, K, shard_index, shard_count, all_finite ? 1 : 0, d_out.p};
-        const size_t lds_eff = lds_fixed + (size_t)ncells * 2;
+        const size_t lds_eff = fast ? (size_t)(L_eff + CO_TRASH) * CO_HC * 4 + (size_t)(L_eff + 2) * 32 * 4 + (size_t)ncells * 2 : lds_fixed + (size_t)ncells * 2;
         dim3 grid((unsigned)ceil_div(T, shard_count), (unsigned)ceil_div(T, CO_CHUNK_TILES));
         {
             LaunchTimer tm(ctx, fast ? (fma ? "cooccur_pairs_fast_fma" : "cooccur_pairs_fast") : (fma ? "cooccur_pairs_fma" : "cooccur_pairs"));

@@ -118,9 +118,11 @@ __global__ __launch_bounds__(RP_TILE) void k_pair_hist_fast(const double* __rest
                                                             const uint16_t* __restrict__ cell, int ncells, double inv_cell,
                                                             int finite, unsigned long long* __restrict__ out_all) {
     extern __shared__ unsigned char smem_raw[];
-    double* s_thr = reinterpret_cast<double*>(smem_raw);                       // [S + 2], two +inf sentinels
+    // [S + 2][32]: every threshold (and two +inf sentinels) 32 times, copy c in bank pair c — lane l reads copy l & 31, so the
+    // threshold reads of a wave (random bins) never meet in a bank (tools/ubench_ds_mix.hip: ds_read2_b64 of the plain array ~11 clk)
+    double* s_thr = reinterpret_cast<double*>(smem_raw);
     constexpr int HC = 64;                                                     // histogram columns
-    uint32_t* hist = reinterpret_cast<uint32_t*>(s_thr + S + 2);               // [S + RP_TRASH][HC]
+    uint32_t* hist = reinterpret_cast<uint32_t*>(s_thr + (S + 2) * 32);        // [S + RP_TRASH][HC]
     uint16_t* s_cell = reinterpret_cast<uint16_t*>(hist + (S + RP_TRASH) * HC);  // [ncells]
     const int t = threadIdx.x;
     const int64_t m = sets.m[blockIdx.z];
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(RP_TILE) void k_pair_hist_fast(const double* __rest
     const int tj0 = max(ti, (int)blockIdx.y * RP_CHUNK);
     const int tj1 = min(T, ((int)blockIdx.y + 1) * RP_CHUNK);
     if (tj0 >= tj1) return;
-    for (int i = t; i < S + 2; i += RP_TILE) s_thr[i] = i < S ? thr[i] : __builtin_inf();
+    for (int i = t; i < (S + 2) * 32; i += RP_TILE) s_thr[i] = (i >> 5) < S ? thr[i >> 5] : __builtin_inf();
     for (int i = t; i < (S + RP_TRASH) * HC; i += RP_TILE) hist[i] = 0;
     for (int i = t; i < ncells; i += RP_TILE) s_cell[i] = cell[i];
     __syncthreads();
@@ -142,6 +144,7 @@ __global__ __launch_bounds__(RP_TILE) void k_pair_hist_fast(const double* __rest
     const double xi = active ? xs[gi] : 0.0, yi = active ? ys[gi] : 0.0;
     const int cmax = ncells - 1;
     uint32_t* my = hist + (t & (HC - 1));
+    const int l32 = t & 31;
     for (int tj = tj0; tj < tj1; ++tj) {
         const int64_t j0g = (int64_t)tj * RP_TILE;
         const int vj = (int)min<int64_t>(RP_TILE, m - j0g);
@@ -163,8 +166,8 @@ __global__ __launch_bounds__(RP_TILE) void k_pair_hist_fast(const double* __rest
             double t0[RP_BATCH], t1[RP_BATCH];  // fetched before the first LDS atomic (reads cannot move across it)
 #pragma unroll
             for (int u = 0; u < RP_BATCH; ++u) {
-                t0[u] = s_thr[g[u]];
-                t1[u] = s_thr[g[u] + 1];
+                t0[u] = s_thr[g[u] * 32 + l32];
+                t1[u] = s_thr[g[u] * 32 + 32 + l32];
             }
 #pragma unroll
             for (int u = 0; u < RP_BATCH; ++u) {
@@ -504,7 +507,7 @@ int sqgr_pair_counts_batch(sqgr_ctx* ctx, const double* xy, const int64_t* offse
     int ncells = RP_CELLS_MIN;
     double inv_cell = 0.0;
     bool fast = false;
-    const size_t lds_fast_fixed = (size_t)(S + 2) * 8 + (size_t)(S + RP_TRASH) * 64 * 4;
+    const size_t lds_fast_fixed = (size_t)(S + 2) * 32 * 8 + (size_t)(S + RP_TRASH) * 64 * 4;
     if (tmax > 0.0 && S < 65000) {
         for (;; ncells *= 2) {
             inv_cell = (double)ncells / tmax;

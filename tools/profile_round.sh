@@ -40,6 +40,7 @@ if [ -x $REPO/tools/ubench_fetch_calib.bin ]; then
   timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/calib_write -- $REPO/tools/ubench_fetch_calib.bin > $OUT/calib_write.log 2>&1
 fi
 [ -x $REPO/tools/ubench_f64.bin ] && timeout 300 $REPO/tools/ubench_f64.bin $OUT/${TAG}_ubench_f64.json > $OUT/ubench_f64.log 2>&1
+[ -x $REPO/tools/ubench_ds_mix.bin ] && timeout 300 $REPO/tools/ubench_ds_mix.bin $OUT/${TAG}_ubench_ds_mix.json > $OUT/ubench_ds_mix.log 2>&1
 [ -x $REPO/tools/ubench_count_shape.bin ] && timeout 300 $REPO/tools/ubench_count_shape.bin > $OUT/${TAG}_ubench_count_shape.json 2> $OUT/ubench_count_shape.err
 python $REPO/tools/summarize_round.py $OUT $TAG "$CMD" "$PMC" "$LEGS" && cp $OUT/${TAG}_*.txt $OUT/${TAG}_*.json $REPO/profiles/
 tail -2 $OUT/stats.log | cut -c1-600
