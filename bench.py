@@ -509,9 +509,11 @@ def config4_legs(ctx, ceil: dict, with_cpu: bool, counters: dict) -> dict:
             roof["traffic"] = 2.0 * pmc["FETCH_SIZE_bytes_timed_total"] + pmc["WRITE_SIZE_bytes_timed_total"]
         ds = load_ds_mix("co_occurrence: ds_read_u16 + ds_read2_b32 + ds_add_u32")
         if ds and li > 0:  # the LDS side: DS wave-instructions per second against the rate of exactly this triple (tools/ubench_ds_mix.hip)
-            roof["lds_issue"] = {"achieved": li / (kms * 1e-3), "peak": ds["rate"], "unit": "DS wave-instr/s", "frac": li / (kms * 1e-3) / ds["rate"],
-                                 "ceiling_source": ds["source"], "note": "table look-up + two thresholds (bank-staggered copies) + histogram add per pair: the kernel sits "
-                                 "close to BOTH its VALU and its LDS issue limit"}
+            roof["lds_issue"] = {"achieved": li / (kms * 1e-3), "peak": ds["rate"], "unit": "DS wave-instr/s", "frac": min(1.0, li / (kms * 1e-3) / ds["rate"]),
+                                 "achieved_over_microbenchmark": li / (kms * 1e-3) / ds["rate"],
+                                 "ceiling_source": ds["source"], "note": "table look-up + two thresholds (bank-staggered copies) + histogram add per pair, against the rate the same three DS "
+                                 "instructions reach alone in tools/ubench_ds_mix.hip (its best occupancy; the kernel matches it to within the run-to-run clock, "
+                                 "`frac` is capped at 1): co-occurrence is LDS-issue bound, with VALU issue (`frac` above) close behind"}
     out["co_occurrence"] = {
         "metric": "co_occurrence ordered pair evaluations/sec (1e6 points x 30 clusters x 49 thresholds)",
         "value": pairs / wall, "unit": "pairs/s", "wall_s": wall, "kernel_ms": kms, "roofline": roof,

@@ -28,12 +28,15 @@ template <int MODE, bool WIDE, bool STAG = true>
 __global__ __launch_bounds__(256) void k_ds(uint32_t* out, int iters) {
     extern __shared__ uint32_t smem[];
     uint32_t* hist = smem;                                                   // [L + TRASH][HC]
-    double* thr = reinterpret_cast<double*>(smem + (L + TRASH) * HC);        // [L + 2][32] (floats use the low half of the space)
-    uint16_t* cell = reinterpret_cast<uint16_t*>(thr + (L + 2) * 32);        // [NCELLS]
+    double* thr = reinterpret_cast<double*>(smem + (L + TRASH) * HC);        // [L + 2][32] doubles (WIDE) or floats
+    uint16_t* cell = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(thr) + (size_t)(L + 2) * 32 * (WIDE ? 8 : 4));  // [NCELLS]
     const int t = threadIdx.x;
     const int TS = STAG ? 32 : 1, tl = STAG ? (t & 31) : 0;
     for (int i = t; i < (L + TRASH) * HC; i += 256) hist[i] = 0;
-    for (int i = t; i < (L + 2) * 32; i += 256) thr[i] = (double)i;
+    for (int i = t; i < (L + 2) * 32; i += 256) {
+        if (WIDE) thr[i] = (double)i;
+        else reinterpret_cast<float*>(thr)[i] = (float)i;
+    }
     for (int i = t; i < NCELLS; i += 256) cell[i] = (uint16_t)((i * (L - 2)) / NCELLS);
     __syncthreads();
     uint32_t h = (blockIdx.x * 256u + t) * 2654435761u + 7u, acc = 0;
@@ -78,11 +81,14 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    const size_t lds = (size_t)(L + TRASH) * HC * 4 + (size_t)(L + 2) * 32 * 8 + NCELLS * 2;
+    const size_t lds_narrow = (size_t)(L + TRASH) * HC * 4 + (size_t)(L + 2) * 32 * 4 + NCELLS * 2;
+    const size_t lds_wide = (size_t)(L + TRASH) * HC * 4 + (size_t)(L + 2) * 32 * 8 + NCELLS * 2;
     std::string js = "{\n  \"device\": \"" + std::string(prop.gcnArchName) + "\", \"cus\": " + std::to_string(cus) +
                      ",\n  \"note\": \"clk at the nominal 2.4 GHz per PAIR STEP of one wave (the DS instructions named) per CU\",\n  \"ds_mix\": [\n";
     bool first = true;
-    auto run = [&](const char* name, void (*kern)(uint32_t*, int), int blocks_per_cu, int n_ds) {
+    auto run = [&](const char* name, void (*kern)(uint32_t*, int), int blocks_per_cu, int n_ds, bool wide = false) {
+        const size_t lds = wide ? lds_wide : lds_narrow;
+        if ((size_t)blocks_per_cu * lds > 160 * 1024) return;
         const int iters = 4096, blocks = cus * blocks_per_cu;
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, 0, out, 16);
         CHECK(hipDeviceSynchronize());
@@ -106,13 +112,13 @@ int main(int argc, char** argv) {
         printf("%-70s %2d waves/CU  %.2f clk per step per CU\n", name, blocks_per_cu * 4, clk);
         first = false;
     };
-    for (int bpc : {2, 5}) {
+    for (int bpc : {2, 4, 5}) {
         run("ds_add_u32 (per-lane column)", k_ds<4, false>, bpc, 1);
         run("ds_read_u16 (random table cell)", k_ds<1, false>, bpc, 1);
         run("co_occurrence: ds_read_u16 + ds_read2_b32 + ds_add_u32, plain threshold array (round 2)", k_ds<7, false, false>, bpc, 3);
         run("co_occurrence: ds_read_u16 + ds_read2_b32 + ds_add_u32", k_ds<7, false, true>, bpc, 3);
-        run("ripley L: ds_read_u16 + ds_read2_b64 + ds_add_u32, plain threshold array (round 2)", k_ds<7, true, false>, bpc, 3);
-        run("ripley L: ds_read_u16 + ds_read2_b64 + ds_add_u32", k_ds<7, true, true>, bpc, 3);
+        run("ripley L: ds_read_u16 + ds_read2_b64 + ds_add_u32, plain threshold array (round 2)", k_ds<7, true, false>, bpc, 3, true);
+        run("ripley L: ds_read_u16 + ds_read2_b64 + ds_add_u32", k_ds<7, true, true>, bpc, 3, true);
     }
     js += "\n  ]\n}\n";
     if (argc > 1) {
