@@ -214,6 +214,12 @@ int sqgr_matrix_create_csc(sqgr_ctx* ctx, int64_t n_rows, int64_t n_cols, int64_
                            int32_t index_bytes, const void* values, int32_t value_bytes, sqgr_matrix** out);
 int sqgr_matrix_destroy(sqgr_matrix* m);
 int sqgr_autocorr_create_cols(sqgr_ctx* ctx, const sqgr_graph* g, const sqgr_matrix* m, int64_t col0, int64_t G, sqgr_autocorr** out);
+/* Features = the columns cols[0 .. G) of the resident matrix, in that order (any subset, any order): the reference's default —
+ * the highly variable genes — and explicit `genes` lists select columns with `adata[:, genes].X` on the host
+ * (gr/_ppatterns.py:156-166), an O(nnz) copy that costs more than the whole statistic at 1e5 cells; here the matrix is uploaded
+ * once as it is and the selection happens on the device (a CSR matrix gets a by-column twin there the first time). */
+int sqgr_autocorr_create_colidx(sqgr_ctx* ctx, const sqgr_graph* g, const sqgr_matrix* m, const int32_t* cols, int64_t G,
+                                sqgr_autocorr** out);
 int sqgr_autocorr_destroy(sqgr_autocorr* h);
 /* observed statistic: replaces `score = func(g, vals)` (gr/_ppatterns.py:216; scanpy.metrics.morans_i/gearys_c);
  * constant features -> NaN.  out_scores: float64[G]. */

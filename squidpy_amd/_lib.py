@@ -67,6 +67,7 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "sqgr_matrix_create_csc": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
     "sqgr_matrix_destroy": (C.c_int, [C.c_void_p]),
     "sqgr_autocorr_create_cols": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p)]),
+    "sqgr_autocorr_create_colidx": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_i32p, C.c_int64, C.POINTER(C.c_void_p)]),
     "sqgr_autocorr_destroy": (C.c_int, [C.c_void_p]),
     "sqgr_autocorr_scores": (C.c_int, [C.c_void_p, C.c_int32, c_f64p]),
     "sqgr_autocorr_perms": (C.c_int, [C.c_void_p, C.c_int32, c_i32p, C.c_uint64, C.c_int64, C.c_int64, c_f64p]),
@@ -615,6 +616,17 @@ class AutocorrPlan:
         self.ctx, self.g, self.G = ctx, g, int(n_features)
         h = C.c_void_p()
         _check(ctx.lib, ctx.lib.sqgr_autocorr_create_cols(ctx.h, g.h, matrix.h, int(col0), int(n_features), C.byref(h)))
+        self.h = h
+        return self
+
+    @classmethod
+    def from_column_list(cls, ctx: Context, g: Graph, matrix: "DeviceMatrix", cols: np.ndarray) -> "AutocorrPlan":
+        """Features = columns ``cols`` (any subset, any order) of a device-resident (cells x genes) matrix."""
+        self = cls.__new__(cls)
+        cols = _as(cols, np.int32)
+        self.ctx, self.g, self.G = ctx, g, int(len(cols))
+        h = C.c_void_p()
+        _check(ctx.lib, ctx.lib.sqgr_autocorr_create_colidx(ctx.h, g.h, matrix.h, _ptr(cols, c_i32p), self.G, C.byref(h)))
         self.h = h
         return self
 

@@ -147,6 +147,59 @@ __global__ __launch_bounds__(256) void k_check_sparse(const int64_t* __restrict_
     if (dup) flags[2] = 1;
 }
 
+// Feature blocks given as a LIST of columns (the reference's HVG default and explicit `genes` subsets, gr/_ppatterns.py:156-166:
+// `adata[:, genes].X` — a copy of the selected columns on the host; here the selection happens on the device).
+// Dense rows: the 64 x 64 LDS transpose with gathered columns.
+template <typename T>
+__global__ __launch_bounds__(256) void k_cells_to_genes_idx(const T* __restrict__ D, int64_t ld, int64_t n, const int32_t* __restrict__ cols, int gc,
+                                                            double* __restrict__ X) {
+    __shared__ double tile[GT][GT + 1];
+    const int64_t i0 = (int64_t)blockIdx.x * GT;
+    const int gb = blockIdx.y * GT;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t c = (gb + tx < gc) ? cols[gb + tx] : -1;
+    for (int r = ty; r < GT; r += 4) {
+        const int64_t i = i0 + r;
+        tile[r][tx] = (i < n && c >= 0) ? (double)D[(size_t)i * ld + c] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < GT; r += 4) {
+        const int64_t i = i0 + tx;
+        if (gb + r < gc && i < n) X[(size_t)(gb + r) * n + i] = tile[tx][r];
+    }
+}
+
+// CSC: block (x, g) expands column cols[g]
+template <typename V>
+__global__ __launch_bounds__(256) void k_csc_to_genes_idx(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                                          const V* __restrict__ values, int64_t n, const int32_t* __restrict__ cols,
+                                                          double* __restrict__ X) {
+    const int64_t g = blockIdx.y, c = cols[g];
+    const int64_t e0 = indptr[c], e1 = indptr[c + 1];
+    for (int64_t e = e0 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < e1; e += (int64_t)gridDim.x * blockDim.x)
+        atomicAdd(&X[(size_t)g * n + indices[e]], (double)values[e]);
+}
+
+// CSR -> CSC on the device (once per matrix, when a column LIST is asked for): column histogram, exclusive scan (host: n_cols + 1
+// numbers), scatter through per-column cursors.  The order inside a column is whatever the atomics give — the expansion adds
+// every stored entry into its own cell of a zeroed block, so it does not matter (a canonical matrix has one entry per cell).
+__global__ void k_count_columns(const int32_t* __restrict__ indices, int64_t nnz, unsigned long long* __restrict__ cnt) {
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e < nnz) atomicAdd(&cnt[indices[e]], 1ull);
+}
+template <typename V>
+__global__ __launch_bounds__(256) void k_scatter_to_columns(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                                            const V* __restrict__ values, int64_t n_rows, unsigned long long* __restrict__ cursor,
+                                                            int32_t* __restrict__ out_rows, V* __restrict__ out_vals) {
+    const int64_t i = blockIdx.x * (int64_t)4 + (threadIdx.x >> 6);  // one wave per row
+    if (i >= n_rows) return;
+    for (int64_t e = indptr[i] + (threadIdx.x & 63); e < indptr[i + 1]; e += 64) {
+        const unsigned long long pos = atomicAdd(&cursor[indices[e]], 1ull);
+        out_rows[pos] = (int32_t)i;
+        out_vals[pos] = values[e];
+    }
+}
+
 // int64 index arrays of a scipy matrix with more than 2^31 stored entries -> the library's layout
 __global__ void k_narrow_indices(const int64_t* __restrict__ src, int64_t count, int32_t* __restrict__ dst) {
     const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -764,7 +817,49 @@ struct sqgr_matrix {
     DevBuf<int64_t> indptr;
     DevBuf<int32_t> indices;
     int64_t nnz = 0;
+    // CSR matrices: the same entries by column, built on the device the first time a column LIST is asked for (ensure_by_column)
+    mutable bool by_col_ready = false;
+    mutable DevBuf<int64_t> c_indptr;
+    mutable DevBuf<int32_t> c_rows;
+    mutable DevBuf<double> c_data;
+    mutable DevBuf<float> c_data32;
+    int ensure_by_column() const;
 };
+
+int sqgr_matrix::ensure_by_column() const {
+    if (kind != 1 || by_col_ready) return SQGR_OK;
+    hipStream_t st = ctx->stream;
+    DevBuf<unsigned long long> cnt;
+    SQGR_TRY(cnt.alloc((size_t)n_cols + 1));
+    SQGR_HIP(hipMemsetAsync(cnt.p, 0, ((size_t)n_cols + 1) * 8, st));
+    const size_t count = (size_t)std::max<int64_t>(nnz, 1);
+    SQGR_TRY(c_indptr.alloc((size_t)n_cols + 1));
+    SQGR_TRY(c_rows.alloc(count));
+    SQGR_TRY(f32 ? c_data32.alloc(count) : c_data.alloc(count));
+    LaunchTimer t(ctx, "autocorr_csr_to_csc");
+    if (nnz > 0) k_count_columns<<<(unsigned)ceil_div(nnz, 256), 256, 0, st>>>(indices.p, nnz, cnt.p);
+    std::vector<unsigned long long> h((size_t)n_cols + 1);
+    SQGR_HIP(hipMemcpyAsync(h.data(), cnt.p, ((size_t)n_cols + 1) * 8, hipMemcpyDeviceToHost, st));
+    SQGR_HIP(hipStreamSynchronize(st));
+    std::vector<int64_t> ptr((size_t)n_cols + 1);
+    unsigned long long run = 0;
+    for (int64_t c = 0; c <= n_cols; ++c) {  // exclusive scan; the cursors start at the column starts
+        const unsigned long long v = c < n_cols ? h[c] : 0;
+        ptr[c] = (int64_t)run;
+        h[c] = run;
+        run += v;
+    }
+    SQGR_HIP(hipMemcpyAsync(c_indptr.p, ptr.data(), ((size_t)n_cols + 1) * 8, hipMemcpyHostToDevice, st));
+    SQGR_HIP(hipMemcpyAsync(cnt.p, h.data(), ((size_t)n_cols + 1) * 8, hipMemcpyHostToDevice, st));
+    if (nnz > 0) {
+        if (f32) k_scatter_to_columns<float><<<(unsigned)ceil_div(n_rows, 4), 256, 0, st>>>(indptr.p, indices.p, data32.p, n_rows, cnt.p, c_rows.p, c_data32.p);
+        else k_scatter_to_columns<double><<<(unsigned)ceil_div(n_rows, 4), 256, 0, st>>>(indptr.p, indices.p, data.p, n_rows, cnt.p, c_rows.p, c_data.p);
+    }
+    SQGR_HIP(hipGetLastError());
+    SQGR_HIP(hipStreamSynchronize(st));  // `cnt`, `h`, `ptr` are released on return
+    by_col_ready = true;
+    return SQGR_OK;
+}
 
 struct sqgr_autocorr {
     sqgr_ctx* ctx = nullptr;
@@ -927,8 +1022,9 @@ static int column_sum(sqgr_autocorr* h, int mode, const double* A, const double*
 // vals: host block (gene-major, or cell-major when `cell_major`), or NULL when the features are columns
 // [dev_col0, dev_col0 + G) of a matrix already resident on the device (dev_x[i * dev_ld + col])
 static int autocorr_create(sqgr_ctx* ctx, const sqgr_graph* g, const double* vals, int64_t G, bool cell_major, sqgr_autocorr** out,
-                           const sqgr_matrix* dm = nullptr, int64_t dev_col0 = 0) {
-    const double* dev_x = (dm && dm->kind == 0 && !dm->f32) ? dm->data.p : nullptr;
+                           const sqgr_matrix* dm = nullptr, int64_t dev_col0 = 0, const int32_t* dev_cols = nullptr) {
+    // dev_cols != NULL: the features are columns dev_cols[0 .. G) of the resident matrix (a device array), else [dev_col0, dev_col0 + G)
+    const double* dev_x = (dm && dm->kind == 0 && !dm->f32 && !dev_cols) ? dm->data.p : nullptr;
     const int64_t dev_ld = dm ? dm->ld : 0;
     SQGR_REQUIRE(ctx && g && (vals || dm) && out, "null argument");
     *out = nullptr;
@@ -969,7 +1065,24 @@ static int autocorr_create(sqgr_ctx* ctx, const sqgr_graph* g, const double* val
     }
     for (int64_t g0 = 0; g0 < G && e == hipSuccess; g0 += gc_max) {
         const int gc = (int)std::min<int64_t>(gc_max, G - g0);
-        if (dm && !dev_x) {  // float32 and / or sparse resident matrix: the gene block is formed from it on the device
+        if (dm && dev_cols) {  // a LIST of columns of the resident matrix
+            LaunchTimer t(ctx, "autocorr_expand");
+            const dim3 tgrid((unsigned)ceil_div(n, GT), (unsigned)ceil_div(gc, GT));
+            if (dm->kind == 0) {
+                if (dm->f32) k_cells_to_genes_idx<float><<<tgrid, 256, 0, st>>>(dm->data32.p, dm->ld, n, dev_cols + g0, gc, X.p);
+                else k_cells_to_genes_idx<double><<<tgrid, 256, 0, st>>>(dm->data.p, dm->ld, n, dev_cols + g0, gc, X.p);
+            } else {
+                e = hipMemsetAsync(X.p, 0, (size_t)gc * n * 8, st);
+                if (e != hipSuccess) break;
+                const bool twin = dm->kind == 1;  // CSR: its by-column twin (built by the caller of this function)
+                const int64_t* cp = twin ? dm->c_indptr.p : dm->indptr.p;
+                const int32_t* cr = twin ? dm->c_rows.p : dm->indices.p;
+                const dim3 cgrid(8, (unsigned)gc);
+                if (dm->f32) k_csc_to_genes_idx<float><<<cgrid, 256, 0, st>>>(cp, cr, twin ? dm->c_data32.p : dm->data32.p, n, dev_cols + g0, X.p);
+                else k_csc_to_genes_idx<double><<<cgrid, 256, 0, st>>>(cp, cr, twin ? dm->c_data.p : dm->data.p, n, dev_cols + g0, X.p);
+            }
+            e = hipGetLastError();
+        } else if (dm && !dev_x) {  // float32 and / or sparse resident matrix: the gene block is formed from it on the device
             LaunchTimer t(ctx, "autocorr_expand");
             const dim3 tgrid((unsigned)ceil_div(n, GT), (unsigned)ceil_div(gc, GT));
             if (dm->kind == 0) {
@@ -1180,6 +1293,22 @@ int sqgr_autocorr_create_cols(sqgr_ctx* ctx, const sqgr_graph* g, const sqgr_mat
     SQGR_REQUIRE(col0 >= 0 && G >= 1 && col0 + G <= m->n_cols, "columns [%lld, %lld) outside the matrix (%lld columns)", (long long)col0,
                  (long long)(col0 + G), (long long)m->n_cols);
     return autocorr_create(ctx, g, nullptr, G, true, out, m, col0);
+}
+
+int sqgr_autocorr_create_colidx(sqgr_ctx* ctx, const sqgr_graph* g, const sqgr_matrix* m, const int32_t* cols, int64_t G,
+                                sqgr_autocorr** out) {
+    SQGR_REQUIRE(ctx && g && m && cols && out, "null argument");
+    SQGR_REQUIRE(m->ctx == ctx, "matrix belongs to a different context");
+    SQGR_REQUIRE(m->n_rows == g->n, "matrix has %lld rows, the graph %lld", (long long)m->n_rows, (long long)g->n);
+    SQGR_REQUIRE(G >= 1, "G=%lld", (long long)G);
+    for (int64_t k = 0; k < G; ++k)
+        SQGR_REQUIRE(cols[k] >= 0 && cols[k] < m->n_cols, "cols[%lld]=%d outside the matrix (%lld columns)", (long long)k, cols[k], (long long)m->n_cols);
+    SQGR_HIP(hipSetDevice(ctx->device));
+    SQGR_TRY(m->ensure_by_column());
+    DevBuf<int32_t> d_cols;
+    SQGR_TRY(d_cols.alloc((size_t)G));
+    SQGR_HIP(hipMemcpyAsync(d_cols.p, cols, (size_t)G * 4, hipMemcpyHostToDevice, ctx->stream));
+    return autocorr_create(ctx, g, nullptr, G, true, out, m, 0, d_cols.p);  // synchronous on return: d_cols may go
 }
 
 int sqgr_autocorr_destroy(sqgr_autocorr* h) {

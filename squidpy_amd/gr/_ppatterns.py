@@ -138,13 +138,49 @@ def co_occurrence(
     return None
 
 
+class _ColumnSelection:
+    """``base[:, cols].T`` not yet formed: the reference selects the features with ``adata[:, genes].X`` (gr/_ppatterns.py:156-166),
+    an O(nnz) host copy; here ``base`` goes to the device as it is and ``cols`` select there (``sqgr_autocorr_create_colidx``)."""
+
+    def __init__(self, base: Any, cols: np.ndarray):
+        self.base, self.cols = base, np.ascontiguousarray(cols, dtype=np.int32)
+        self.shape = (len(self.cols), base.shape[0])
+
+    def on_host(self) -> Any:
+        return self.base[:, self.cols].T
+
+    def device_bytes(self) -> int:
+        b = self.base
+        if sparse.issparse(b):  # a CSR matrix gets a by-column twin on the device
+            return (b.data.nbytes + b.indices.nbytes + b.indptr.nbytes) * (2 if sparse.isspmatrix_csr(b) else 1)
+        return int(b.shape[0]) * int(b.shape[1]) * max(b.itemsize, 4)
+
+    @staticmethod
+    def worthwhile(base: Any, cols: np.ndarray) -> bool:
+        if sparse.issparse(base):
+            return sparse.isspmatrix_csr(base) or sparse.isspmatrix_csc(base)
+        # dense rows: the whole matrix is uploaded, which only pays when a good part of it is asked for
+        return isinstance(base, np.ndarray) and base.ndim == 2 and base.dtype in (np.float32, np.float64) and 4 * len(cols) >= base.shape[1]
+
+
+def _column_selection(var_names: Any, genes: Any, matrix: Any) -> _ColumnSelection | None:
+    try:
+        cols = var_names.get_indexer(np.asarray(genes))
+    except Exception:  # non-unique var_names and the like: AnnData's own indexing decides what that means
+        return None
+    if len(cols) == 0 or (cols < 0).any() or not _ColumnSelection.worthwhile(matrix, cols):
+        return None
+    return _ColumnSelection(matrix, cols)
+
+
 def _extract_vals(adata: Any, attr: str, genes: Any, layer: str | None, use_raw: bool) -> tuple[Any, Any]:
-    """gr/_ppatterns.py:154-194: ``vals`` as (n_features, N) plus the feature index."""
+    """gr/_ppatterns.py:154-194: ``vals`` as (n_features, N) — or a `_ColumnSelection` standing for it — plus the feature index."""
 
     def extract_X(genes: Any) -> tuple[Any, Any]:
         if genes is None:
             if "highly_variable" in adata.var:
-                genes = adata[:, adata.var["highly_variable"]].var_names.values
+                # = adata[:, adata.var["highly_variable"]].var_names.values, without forming the subset object
+                genes = adata.var_names[np.asarray(adata.var["highly_variable"], dtype=bool)].values
             else:
                 genes = adata.var_names.values
         elif isinstance(genes, str):
@@ -153,11 +189,17 @@ def _extract_vals(adata: Any, attr: str, genes: Any, layer: str | None, use_raw:
             if len(genes) == adata.shape[1] and np.array_equal(np.asarray(genes), np.asarray(adata.var_names)):
                 subset = adata  # every feature, in order: no subsetting copy of a (possibly very large, sparse) matrix
             else:
+                lazy = _column_selection(adata.var_names, genes, adata.X if layer is None else adata.layers[layer])
+                if lazy is not None:
+                    return lazy, genes
                 subset = adata[:, genes]
             return (subset.X if layer is None else subset.layers[layer]).T, genes
         if getattr(adata, "raw", None) is None:
             raise AttributeError("No `.raw` attribute found. Try specifying `use_raw=False`.")
         genes = list(set(genes) & set(adata.raw.var_names))
+        lazy = _column_selection(adata.raw.var_names, genes, adata.raw.X)
+        if lazy is not None:
+            return lazy, genes
         return adata.raw[:, genes].X.T, genes
 
     def extract_obs(cols: Any) -> tuple[Any, Any]:
@@ -271,13 +313,21 @@ def spatial_autocorr(
     # dense row-major array — and the feature blocks are cut out of it (densified, widened to float64) there; every rank
     # uploads the columns of its own blocks only.  Nothing is sliced, densified or transposed on the host per block.
     resident, shift = (None, 0)
-    if mine:
+    cols = None
+    if isinstance(vals, _ColumnSelection):  # a gene subset (the HVG default, an explicit list): selected on the device
+        if mine and vals.device_bytes() <= ctx.device_info()["hbm_bytes"] // 4:
+            resident, cols = DeviceMatrix(ctx, vals.base), vals.cols
+        elif mine:
+            vals = vals.on_host()
+    if mine and cols is None:
         resident, shift = _resident_features(ctx, vals, blocks[mine[0]][0], blocks[mine[-1]][1])
     bar = progress(sum(blocks[bi][1] - blocks[bi][0] for bi in mine), "feature", show_progress_bar and n_perms is not None)
     try:
         for bi in mine:
             b0, b1 = blocks[bi]
-            if resident is not None:
+            if cols is not None:
+                plan = AutocorrPlan.from_column_list(ctx, graph, resident, cols[b0:b1])
+            elif resident is not None:
                 plan = AutocorrPlan.from_columns(ctx, graph, resident, b0 - shift, b1 - b0)
             else:  # a gene-major host array (contiguous feature rows), or a matrix too large to keep resident
                 blk = vals[b0:b1]

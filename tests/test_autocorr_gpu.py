@@ -364,3 +364,57 @@ def test_sparse_matrix_argument_checks(L, ctx):
     bad = sp.csr_matrix((vals[:5], np.array([0, 3, 5, 7, 25]), np.array([0, 5] + [5] * 299)), shape=(300, 12), copy=True)
     with pytest.raises(L.SqgrError, match="outside"):
         L.DeviceMatrix(ctx, bad)
+
+
+@pytest.mark.parametrize("fmt,dtype", [("csr", np.float32), ("csr", np.float64), ("csc", np.float32), ("dense", np.float64), ("dense", np.float32)])
+def test_gene_subsets_are_selected_on_the_device(L, ctx, fmt, dtype, monkeypatch):
+    """The reference's default (the highly variable genes) and explicit `genes` lists are `adata[:, genes].X` on the host
+    (gr/_ppatterns.py:156-166); here the matrix is uploaded whole and `sqgr_autocorr_create_colidx` picks the columns on the
+    device (a CSR matrix gets a by-column twin there): frames identical to the host-subset path, for any order, repeats,
+    `use_raw`, over several feature blocks; a column outside the matrix is an error."""
+    import squidpy_amd as sq
+    from squidpy_amd.gr import _ppatterns as pp
+
+    adata = _adata(n=900, G=61, seed=8)
+    rng = np.random.default_rng(3)
+    X = np.where(rng.random(adata.X.shape) < 0.2, np.round(adata.X * 4), 0.0)
+    host = adata.copy()
+    host.X = X.astype(np.float64)
+    dev = adata.copy()
+    dev.X = X.astype(dtype) if fmt == "dense" else getattr(sp, fmt + "_matrix")(X.astype(dtype))
+    dev.raw = dev.copy()
+    host.raw = host.copy()
+    calls = []
+    real = L.AutocorrPlan.from_column_list.__func__
+    monkeypatch.setattr(pp.AutocorrPlan, "from_column_list", classmethod(lambda cls, *a: (calls.append(len(a[3])), real(cls, *a))[1]))
+    monkeypatch.setattr(pp._ColumnSelection, "worthwhile", staticmethod(lambda base, cols: base is not host.X and base is not host.raw.X))
+    picks = [list(adata.var_names[::-1][:33]), ["gene5", "gene60", "gene5", "gene0"], None]
+    for genes in picks:
+        calls.clear()
+        a = sq.gr.spatial_autocorr(host, genes=genes, n_perms=24, seed=5, copy=True, gene_block=8)
+        assert not calls
+        b = sq.gr.spatial_autocorr(dev, genes=genes, n_perms=24, seed=5, copy=True, gene_block=8)
+        assert calls and sum(calls) == len(b)
+        pd.testing.assert_frame_equal(a, b, check_exact=True)
+    calls.clear()
+    a = sq.gr.spatial_autocorr(host, genes=["gene9", "gene1", "nope"], use_raw=True, mode="geary", copy=True)
+    b = sq.gr.spatial_autocorr(dev, genes=["gene9", "gene1", "nope"], use_raw=True, mode="geary", copy=True)
+    assert calls
+    pd.testing.assert_frame_equal(a.sort_index(), b.sort_index(), check_exact=True)  # `set` order decides ties of the sort
+    monkeypatch.undo()
+    # the library call itself
+    g = sp.csr_matrix(adata.obsp["spatial_connectivities"]).astype(np.float64)
+    graph = L.Graph(ctx, g, with_data=True)
+    dm = L.DeviceMatrix(ctx, dev.X)
+    cols = np.array([60, 0, 17, 17, 33], dtype=np.int32)
+    p1 = L.AutocorrPlan.from_column_list(ctx, graph, dm, cols)
+    p2 = L.AutocorrPlan(ctx, graph, np.ascontiguousarray(X[:, cols].T))
+    np.testing.assert_array_equal(p1.scores("moran"), p2.scores("moran"))
+    np.testing.assert_array_equal(p1.scores("geary"), p2.scores("geary"))
+    p1.close(), p2.close()
+    with pytest.raises(L.SqgrError, match="outside"):
+        L.AutocorrPlan.from_column_list(ctx, graph, dm, np.array([3, 61], dtype=np.int32))
+    with pytest.raises(L.SqgrError, match="outside"):
+        L.AutocorrPlan.from_column_list(ctx, graph, dm, np.array([-1], dtype=np.int32))
+    dm.close()
+    graph.close()
