@@ -245,10 +245,13 @@ int sqgr_autocorr_perms_pcg64(sqgr_autocorr* h, int32_t mode, const uint64_t* pc
  *   out_ge[g]  = #{p : sims[p][g] >= score[g]}       `(sims >= score).sum(axis=0)`            int64[G]
  *   out_sum[g] = `sims.sum(axis=0)[g]`    out_std[g] = `sims.std(axis=0)[g]`    out_var[g] = `np.var(sims, axis=0)[g]`
  * each in numpy's own evaluation order (sequential over the permutation axis, mean = sum / P, then the squared
- * deviations summed the same way): bit-identical to numpy on the same scores.  score: float64[G], the observed statistic. */
+ * deviations summed the same way): bit-identical to numpy on the same scores.  score: float64[G], the observed statistic.
+ * only_feature != 0 (G must be 1): this block is the ONLY feature of the call — the reference's (P, 1) array is contiguous
+ * along the permutation axis as well and numpy reduces it in its other order (pairwise sums of 8192-element runs); set it
+ * when the call scores a single feature, never for a one-feature block of a larger call. */
 int sqgr_autocorr_perm_stats(sqgr_autocorr* h, int32_t mode, const int32_t* perm_idx, const uint64_t* pcg_states, uint64_t seed,
                              int64_t perm_begin, int64_t perm_end, const double* score, int64_t* out_ge, double* out_sum,
-                             double* out_std, double* out_var);
+                             double* out_std, double* out_var, int32_t only_feature);
 
 /* parity hook: the device generator's permutations, int32[perm_end-perm_begin][n] (<= 32768 per call) */
 int sqgr_autocorr_perm_indices(sqgr_ctx* ctx, int64_t n, uint64_t seed, int64_t perm_begin, int64_t perm_end,

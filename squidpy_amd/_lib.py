@@ -72,7 +72,7 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "sqgr_autocorr_scores": (C.c_int, [C.c_void_p, C.c_int32, c_f64p]),
     "sqgr_autocorr_perms": (C.c_int, [C.c_void_p, C.c_int32, c_i32p, C.c_uint64, C.c_int64, C.c_int64, c_f64p]),
     "sqgr_autocorr_perms_pcg64": (C.c_int, [C.c_void_p, C.c_int32, c_u64p, C.c_int64, c_f64p]),
-    "sqgr_autocorr_perm_stats": (C.c_int, [C.c_void_p, C.c_int32, c_i32p, c_u64p, C.c_uint64, C.c_int64, C.c_int64, c_f64p, c_i64p, c_f64p, c_f64p, c_f64p]),
+    "sqgr_autocorr_perm_stats": (C.c_int, [C.c_void_p, C.c_int32, c_i32p, c_u64p, C.c_uint64, C.c_int64, C.c_int64, c_f64p, c_i64p, c_f64p, c_f64p, c_f64p, C.c_int32]),
     "sqgr_autocorr_perm_indices": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_int64, C.c_int64, c_i32p]),
     "sqgr_pair_counts": (C.c_int, [C.c_void_p, c_f64p, C.c_int64, c_f64p, C.c_int32, C.c_int32, c_i64p]),
     "sqgr_pair_counts_batch": (C.c_int, [C.c_void_p, c_f64p, c_i64p, C.c_int32, c_f64p, C.c_int32, C.c_int32, c_i64p]),
@@ -680,12 +680,13 @@ class AutocorrPlan:
 
     def perm_stats(
         self, mode: str, score: np.ndarray, *, perm_idx: np.ndarray | None = None, pcg_states: np.ndarray | None = None, seed: int = 0,
-        perm_begin: int = 0, perm_end: int = 0,
+        perm_begin: int = 0, perm_end: int = 0, only_feature: bool = False,
     ) -> dict[str, np.ndarray]:
         """The permutation test reduced on the device (``sqgr_autocorr_perm_stats``): per feature the number of permutation
         scores ``>= score``, and numpy's ``sum`` / ``std`` / ``var`` of the scores over the permutation axis — the (P, G)
         scores themselves never leave the GPU.  Permutations: injected (``perm_idx``), numpy streams (``pcg_states``) or the
-        device generator for ``[perm_begin, perm_end)``."""
+        device generator for ``[perm_begin, perm_end)``.  ``only_feature``: the plan's single feature is the only one of the
+        whole call — numpy reduces a (P, 1) array in its contiguous (pairwise) order, not row by row."""
         score = _as(score, np.float64)
         if score.shape != (self.G,):
             raise ValueError(f"Expected `{self.G}` observed scores, found shape `{score.shape}`.")
@@ -705,6 +706,7 @@ class AutocorrPlan:
             self.ctx.lib.sqgr_autocorr_perm_stats(
                 self.h, self.MODES[mode], _ptr(perm_idx, c_i32p), _ptr(states, c_u64p), C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF),
                 int(perm_begin), int(perm_end), _ptr(score, c_f64p), _ptr(ge, c_i64p), _ptr(ssum, c_f64p), _ptr(sstd, c_f64p), _ptr(svar, c_f64p),
+                1 if only_feature else 0,
             ),
         )
         return {"n_ge": ge, "sum": ssum, "std": sstd, "var": svar}

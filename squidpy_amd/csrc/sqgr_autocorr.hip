@@ -765,12 +765,57 @@ __global__ __launch_bounds__(256) void k_perm_final_lds(const double* __restrict
 // bit for bit: numpy reduces the leading axis of a C-contiguous array by one rounded add per row, in row order
 // (pairwise summation only applies along the contiguous axis), `_var` forms `arrmean = sum / P`, `x = arr - arrmean`,
 // `x * x`, sums the same way and divides by P.  One thread per feature; every operation rounded separately.
+//
+// ONE feature in the whole call (`genes="x"`): the (P, 1) array is contiguous along the reduced axis too and numpy takes its
+// other route — `pairwise_sum` of umath/loops_utils.h (fewer than 8 elements: in order; up to 128: eight interleaved partial
+// sums combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the tail in order; longer: split at n/2 rounded down to a multiple
+// of 8), applied to every buffer-sized run of 8192 elements, the runs added in order.  np_contiguous_sum restates that.
+template <typename F>
+__device__ double np_pairwise(int64_t lo, int64_t n, const F& at) {
+    if (n < 8) {
+        double res = 0.0;
+        for (int64_t i = 0; i < n; ++i) res += at(lo + i);
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; ++j) r[j] = at(lo + j);
+        int64_t i = 8;
+        for (; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += at(lo + i + j);
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += at(lo + i);
+        return res;
+    }
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise(lo, n2, at) + np_pairwise(lo + n2, n - n2, at);
+}
+template <typename F>
+__device__ double np_contiguous_sum(int64_t n, const F& at) {
+    double res = 0.0;
+    for (int64_t c = 0; c < n; c += 8192) res += np_pairwise(c, (n - c < 8192) ? n - c : 8192, at);
+    return res;
+}
+
 __global__ __launch_bounds__(256) void k_perm_stats(const double* __restrict__ sims, int64_t P, int64_t G, const double* __restrict__ score,
                                                     long long* __restrict__ ge, double* __restrict__ sum, double* __restrict__ sd,
-                                                    double* __restrict__ var) {
+                                                    double* __restrict__ var, int contiguous_column) {
     const int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (g >= G) return;
     const double sc = score[g];
+    if (contiguous_column) {  // G == 1 here
+        long long cnt = 0;
+        for (int64_t p = 0; p < P; ++p) cnt += (sims[p] >= sc) ? 1 : 0;
+        const double total = np_contiguous_sum(P, [&](int64_t p) { return sims[p]; });
+        const double m = total / (double)P;
+        const double v = np_contiguous_sum(P, [&](int64_t p) { const double d = sims[p] - m; return d * d; }) / (double)P;
+        ge[g] = cnt;
+        sum[g] = total;
+        var[g] = v;
+        sd[g] = sqrt(v);
+        return;
+    }
     double acc = 0.0;
     long long cnt = 0;
 #pragma unroll 8
@@ -1444,8 +1489,9 @@ int sqgr_autocorr_perms_pcg64(sqgr_autocorr* h, int32_t mode, const uint64_t* pc
 
 int sqgr_autocorr_perm_stats(sqgr_autocorr* h, int32_t mode, const int32_t* perm_idx, const uint64_t* pcg_states, uint64_t seed,
                              int64_t perm_begin, int64_t perm_end, const double* score, int64_t* out_ge, double* out_sum,
-                             double* out_std, double* out_var) {
+                             double* out_std, double* out_var, int32_t only_feature) {
     SQGR_REQUIRE(h && score && out_ge && out_sum && out_std && out_var, "null argument");
+    SQGR_REQUIRE(!only_feature || h->G == 1, "only_feature is set for a block of %lld features", (long long)h->G);
     SQGR_REQUIRE(!(perm_idx && pcg_states), "perm_idx and pcg_states are mutually exclusive");
     SQGR_REQUIRE(perm_begin >= 0 && perm_end > perm_begin, "bad permutation range");
     sqgr_ctx* ctx = h->ctx;
@@ -1463,7 +1509,7 @@ int sqgr_autocorr_perm_stats(sqgr_autocorr* h, int32_t mode, const int32_t* perm
     SQGR_HIP(hipMemcpyAsync(d_score.p, score, (size_t)G * 8, hipMemcpyHostToDevice, st));
     {
         LaunchTimer t(ctx, "autocorr_perm_stats");
-        k_perm_stats<<<(unsigned)ceil_div(G, 256), 256, 0, st>>>(h->sims_all.p, P, G, d_score.p, d_ge.p, d_out.p, d_out.p + G, d_out.p + 2 * G);
+        k_perm_stats<<<(unsigned)ceil_div(G, 256), 256, 0, st>>>(h->sims_all.p, P, G, d_score.p, d_ge.p, d_out.p, d_out.p + G, d_out.p + 2 * G, only_feature ? 1 : 0);
         SQGR_HIP(hipGetLastError());
     }
     SQGR_HIP(hipMemcpyAsync(out_ge, d_ge.p, (size_t)G * 8, hipMemcpyDeviceToHost, st));

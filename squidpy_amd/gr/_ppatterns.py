@@ -336,12 +336,13 @@ def spatial_autocorr(
             try:
                 score[b0:b1] = plan.scores(mode.s)
                 if n_perms is not None:
+                    only = n_feat == 1  # a (n_perms, 1) score array: numpy reduces it in its contiguous order
                     if states is not None:
-                        part = plan.perm_stats(mode.s, score[b0:b1], pcg_states=states)
+                        part = plan.perm_stats(mode.s, score[b0:b1], pcg_states=states, only_feature=only)
                     elif perm_idx is not None:
-                        part = plan.perm_stats(mode.s, score[b0:b1], perm_idx=perm_idx)
+                        part = plan.perm_stats(mode.s, score[b0:b1], perm_idx=perm_idx, only_feature=only)
                     else:
-                        part = plan.perm_stats(mode.s, score[b0:b1], seed=key, perm_begin=0, perm_end=n_perms)
+                        part = plan.perm_stats(mode.s, score[b0:b1], seed=key, perm_begin=0, perm_end=n_perms, only_feature=only)
                     for k, v in part.items():
                         red[k][b0:b1] = v
                 bar.update(b1 - b0)

@@ -202,6 +202,13 @@ def ripley(
     sizes = np.bincount(codes, minlength=n_groups).astype(np.float64)
     owner = _assign_by_cost(sizes * sizes if stat == RipleyStat.L else sizes, world)
 
+    # the clusters' points, each in obs order (= `xy[codes == gidx]`), from ONE stable sort instead of a mask per cluster
+    by_cluster = xy64[np.argsort(codes, kind="stable")]
+    starts = np.concatenate([[0], np.cumsum(np.bincount(codes, minlength=n_groups))])
+
+    def members_of(gidx: int) -> np.ndarray:
+        return by_cluster[starts[gidx] : starts[gidx + 1]]
+
     # observed statistic per cluster (F: each cluster is probed with its own Poisson pattern drawn from `first_rng`)
     observed = np.full((n_groups, n_steps), np.nan)
     probe = None
@@ -211,7 +218,7 @@ def ripley(
             probe = _ppp(hull, n_simulations=1, n_observations=n_observations, rng=first_rng)
         if owner[gidx] != rank:
             continue
-        members = xy64[codes == gidx]
+        members = members_of(gidx)
         if stat == RipleyStat.L:
             pass  # the clusters this rank owns are counted together below
         elif stat == RipleyStat.G:
@@ -222,7 +229,7 @@ def ripley(
     if stat == RipleyStat.L:
         mine = [gidx for gidx in range(int(codes.max()) + 1) if owner[gidx] == rank]
         if mine:
-            observed[mine] = engine.l_stat_many([xy64[codes == gidx] for gidx in mine])
+            observed[mine] = engine.l_stat_many([members_of(gidx) for gidx in mine])
 
     # null distribution: complete spatial randomness inside the hull, one pattern per generator
     simulated = np.full((n_simulations, n_steps), np.nan)

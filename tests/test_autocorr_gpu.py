@@ -304,6 +304,62 @@ def test_permutation_reductions_on_the_device_are_numpys(L, ctx, mode):
     graph.close()
 
 
+@pytest.mark.parametrize("P", [5, 8, 39, 128, 129, 1000, 8192, 8200, 20000])
+def test_single_feature_reductions_follow_numpys_contiguous_order(L, ctx, P):
+    """One feature in the whole call (`genes="x"`): the reference's score array is (P, 1), contiguous along the permutation
+    axis, and numpy reduces it pairwise in 8192-element runs instead of row by row (it differs from the sequential sum from
+    ~30 permutations on).  `only_feature=1` follows that order — bit for bit — and the front end sets it exactly when the call
+    has one feature; a one-feature BLOCK of a larger call keeps the row-by-row order."""
+    import squidpy_amd as sq
+
+    rng = np.random.default_rng(P)
+    n = 400
+    g = knn_graph(rng.random((n, 2)), 6)
+    g.data = rng.random(g.nnz) + 0.1
+    graph = L.Graph(ctx, g)
+    vals = rng.gamma(2.0, 1.0, size=(1, n))
+    plan = L.AutocorrPlan(ctx, graph, vals)
+    for mode in ("moran", "geary"):
+        score = plan.scores(mode)
+        sims = plan.perms(mode, seed=9, perm_begin=0, perm_end=P)
+        assert sims.shape == (P, 1) and sims.flags.c_contiguous
+        red = plan.perm_stats(mode, score, seed=9, perm_begin=0, perm_end=P, only_feature=True)
+        np.testing.assert_array_equal(red["n_ge"], (sims >= score).sum(axis=0))
+        np.testing.assert_array_equal(red["sum"], sims.sum(axis=0))
+        np.testing.assert_array_equal(red["std"], sims.std(axis=0))
+        np.testing.assert_array_equal(red["var"], np.var(sims, axis=0))
+        wide = np.hstack([sims, sims])  # the same column inside a (P, 2) array: row by row
+        red = plan.perm_stats(mode, score, seed=9, perm_begin=0, perm_end=P)
+        np.testing.assert_array_equal(red["sum"], wide.sum(axis=0)[:1])
+        np.testing.assert_array_equal(red["std"], wide.std(axis=0)[:1])
+    plan.close()
+    with pytest.raises(L.SqgrError, match="only_feature"):
+        two = L.AutocorrPlan(ctx, graph, np.vstack([vals, vals]))
+        try:
+            two.perm_stats("moran", two.scores("moran"), seed=1, perm_begin=0, perm_end=4, only_feature=True)
+        finally:
+            two.close()
+    graph.close()
+    if P == 1000:  # the front end sets the flag exactly when the call has one feature
+        from squidpy_amd.gr import _ppatterns as pp
+
+        seen = []
+        real = pp.AutocorrPlan.perm_stats
+
+        def spy(self, *a, **kw):
+            seen.append((self.G, kw.get("only_feature")))
+            return real(self, *a, **kw)
+
+        adata = _adata(n=300, G=12, seed=2)
+        try:
+            pp.AutocorrPlan.perm_stats = spy
+            sq.gr.spatial_autocorr(adata, genes="gene1", n_perms=40, seed=3, copy=True)
+            sq.gr.spatial_autocorr(adata, genes=["gene1", "gene2", "gene3"], n_perms=40, seed=3, copy=True, gene_block=2)
+        finally:
+            pp.AutocorrPlan.perm_stats = real
+        assert seen == [(1, True), (2, False), (1, False)]
+
+
 @pytest.mark.parametrize("fmt,dtype,itype", [("csr", np.float32, np.int32), ("csc", np.float32, np.int64), ("csr", np.float64, np.int64),
                                                ("csc", np.float64, np.int32), ("dense", np.float32, None), ("coo", np.int32, None)])
 def test_sparse_and_float32_expression_resident_on_the_device(L, fmt, dtype, itype):

@@ -93,4 +93,81 @@ while (it < ITERS) if ITERS else (time.time() - t0 < budget):
                           seed=sd, perm_begin=lo, perm_end=lo + Pl)
     want = O.ligrec_score_permutations(data, O.ligrec_perm_labels_philox(cl, sd, lo, lo + Pl), pre["inv_counts"], pre["mean_obs"], inter, cp, pre["valid"])
     assert np.array_equal(got, want), ("ligrec philox", nc, ng, kc)
+    # ---- round-3 surfaces
+    # pair counts of several point sets in one launch (empty and single-point sets included), the three KDTree metrics
+    metric = str(rng.choice(["euclidean", "manhattan", "chebyshev"]))
+    sets = [np.round(rng.random((int(rng.choice([0, 1, 2, 65, 300, 1500])), 2)) * rng.choice([1.0, 50.0]), int(rng.integers(0, 4))) for _ in range(int(rng.integers(1, 6)))]
+    note('  pair batch', [len(a) for a in sets], metric)
+    got = L.pair_counts_batch(ctx, sets, sup, metric)
+    for a, row in zip(sets, got):
+        if len(a) >= 2:
+            from sklearn.neighbors import KDTree
+            assert np.array_equal(row, KDTree(a, metric=metric).two_point_correlation(a, sup) - len(a)), ("pair batch", len(a), metric)  # gr/_ripley.py:220-222
+        else:
+            assert np.array_equal(row, np.zeros(len(sup), dtype=np.int64)), ("pair batch tiny", len(a))
+    # k nearest neighbours: brute force below 512 reference points, the cell list above; ties from rounded coordinates
+    from sklearn.neighbors import NearestNeighbors
+    nr = int(rng.choice([1, 5, 511, 512, 3000, 20000])); nq = int(rng.choice([1, 64, 1000])); kq = int(rng.integers(1, min(nr, 16) + 1))
+    metric = str(rng.choice(["euclidean", "manhattan", "chebyshev", "canberra"]))
+    refs = rng.random((nr, 2)) * np.array([rng.choice([1.0, 1000.0]), rng.choice([1.0, 1000.0])])
+    if rng.random() < 0.3: refs = np.round(refs, 1)
+    if rng.random() < 0.3: refs[:, 0] = refs[0, 0]  # degenerate: all on a line
+    qs = rng.random((nq, 2)) * refs.max(0) * 1.2 - 0.1
+    note('  knn nr', nr, 'nq', nq, 'k', kq, metric)
+    want = NearestNeighbors(n_neighbors=kq, metric=metric, algorithm="brute" if metric == "canberra" else "kd_tree").fit(refs).kneighbors(qs)[0]
+    got = L.knn_dist(ctx, qs, refs, kq, metric)
+    if metric == "euclidean":
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-300)
+    else:
+        np.testing.assert_allclose(got, want, rtol=1e-14, atol=1e-300)
+    edges = np.linspace(0, float(want.max()) * 1.1 + 1e-9, int(rng.integers(3, 40)))
+    qlab = rng.integers(0, 3, nq).astype(np.int32); ex = int(rng.integers(-1, 3))
+    dp = L.DevicePoints(ctx, qs, qlab)
+    hist = dp.knn_hist(refs, kq, edges, metric, ex)
+    keep = qlab != ex
+    assert hist.sum() <= keep.sum() * kq
+    if metric != "euclidean":  # (euclidean distances are compared with sklearn's at 1e-12: a histogram could differ at an edge)
+        assert np.array_equal(hist, np.histogram(got[keep], bins=edges)[0]), ("knn hist", nr, nq, kq, metric)
+    dp.close()
+    # co-occurrence: a batch of the radius thresholds on its own gives the same (cumulative) counts; row-tile shards add up
+    if len(thr) >= 2:
+        full = L.cooccur_counts(ctx, x, y, labs, kk, thr)
+        cut = int(rng.integers(1, len(thr)))
+        assert np.array_equal(L.cooccur_counts(ctx, x, y, labs, kk, thr[cut:]), full[:, :, cut:]), ("cooc interval batch", m, cut)
+        ns = int(rng.integers(2, 5))
+        assert np.array_equal(sum(L.cooccur_counts(ctx, x, y, labs, kk, thr, shard_index=r, shard_count=ns) for r in range(ns)), full), ("cooc tiles", m, ns)
+    # spatial autocorrelation: expression formats x column lists, scores and permutation statistics
+    na = int(rng.choice([5, 64, 300, 1500])); Ga = int(rng.choice([1, 2, 63, 64, 65, 130]))
+    W = sp.random(na, na, density=min(1.0, 6.0 / na), format="csr", random_state=int(rng.integers(1 << 31))); W = sp.csr_matrix(W + W.T); W.sort_indices()
+    if W.nnz == 0: W = sp.csr_matrix(np.eye(na, k=1) + np.eye(na, k=-1))
+    W.data = rng.random(W.nnz) + 0.1
+    Xa = np.where(rng.random((na, Ga)) < rng.choice([0.1, 0.6, 1.0]), np.rint(rng.gamma(2, 3, (na, Ga))), 0.0)
+    fmt = str(rng.choice(["dense64", "dense32", "csr32", "csr64", "csc32", "csc64", "pitch"])); ity = rng.choice([np.int32, np.int64])
+    if fmt.startswith("dense"): Xd = Xa.astype(np.float64 if fmt == "dense64" else np.float32)
+    elif fmt == "pitch": Xd = np.hstack([Xa, Xa])[:, :Ga]  # a column range of a wider row-major array
+    else:
+        Xd = (sp.csr_matrix if fmt.startswith("csr") else sp.csc_matrix)(Xa.astype(np.float32 if fmt.endswith("32") else np.float64))
+        Xd = type(Xd)((Xd.data, Xd.indices.astype(ity), Xd.indptr.astype(ity)), shape=Xd.shape)
+    cols = rng.integers(0, Ga, int(rng.integers(1, 2 * Ga + 1))).astype(np.int32) if rng.random() < 0.6 else None
+    note('  autocorr n', na, 'G', Ga, fmt, 'cols', None if cols is None else len(cols))
+    ga = L.Graph(ctx, W, with_data=True); dm = L.DeviceMatrix(ctx, Xd)
+    plan = L.AutocorrPlan.from_column_list(ctx, ga, dm, cols) if cols is not None else L.AutocorrPlan.from_columns(ctx, ga, dm, 0, Ga)
+    sel = Xa[:, cols] if cols is not None else Xa
+    ref_plan = L.AutocorrPlan(ctx, ga, np.ascontiguousarray(sel.T))
+    for mode in ("moran", "geary"):
+        sc = plan.scores(mode)
+        assert np.array_equal(sc, ref_plan.scores(mode), equal_nan=True), ("autocorr formats", fmt, mode)
+        want = (O.morans_i if mode == "moran" else O.gearys_c)(W, sel.T)
+        ok = ~np.isnan(want)
+        np.testing.assert_allclose(sc[ok], want[ok], rtol=1e-9, atol=1e-12)
+        Pa = int(rng.integers(1, 40)); sd = int(rng.integers(1 << 30))
+        sims = plan.perms_pcg64(mode, pcg64_states(sd, Pa))
+        red = plan.perm_stats(mode, sc, pcg_states=pcg64_states(sd, Pa), only_feature=sims.shape[1] == 1)
+        with np.errstate(invalid="ignore"):
+            assert np.array_equal(red["n_ge"], (sims >= sc).sum(0)), ("perm_stats n_ge", mode)
+            for key, val in (("sum", sims.sum(0)), ("std", sims.std(0)), ("var", np.var(sims, 0))):
+                assert np.array_equal(red[key], val, equal_nan=True), ("perm_stats", key, mode)
+        wantp = O.score_perms(mode, W, sel.T, O.autocorr_perm_indices(na, sd, Pa))
+        np.testing.assert_allclose(sims[:, ok], wantp[:, ok], rtol=1e-8, atol=1e-11)
+    plan.close(); ref_plan.close(); dm.close(); ga.close()
 print(f"fuzz ok: {it} iterations in {time.time()-t0:.0f}s")
