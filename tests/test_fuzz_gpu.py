@@ -1,7 +1,9 @@
 """The randomised differential test of tools/fuzz_gpu.py (libsqgr against the CPU oracle over random graphs — symmetric /
 directed / with self loops / non-canonical —, cluster counts across every kernel regime incl. 16-bit labels, libraries,
 launch geometries, unaligned permutation ranges, both generators, co-occurrence, Ripley pair counts, numpy permutation
-streams, ligrec) with a FIXED seed list, so that a failure is reproducible (`FUZZ_ITERS=5 python tools/fuzz_gpu.py 0 <seed>`)."""
+streams, ligrec; round 3: batched pair counts, cell-list kNN and its histograms, co-occurrence shards, expression formats x
+column lists, the device p-value reductions) and of tools/fuzz_frontend.py (the `sq.gr.*` front ends with random options, value
+sources and matrix formats against the oracle's restatement of the reference pipelines, in numpy's streams) with a FIXED seed list, so that a failure is reproducible (`FUZZ_ITERS=5 python tools/fuzz_gpu.py 0 <seed>`)."""
 import os
 import subprocess
 import sys
@@ -17,3 +19,10 @@ def test_fuzz_fixed_seeds(seed):
     env = dict(os.environ, PYTHONPATH=ROOT, FUZZ_ITERS="5")
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_gpu.py"), "0", str(seed)], env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0 and "fuzz ok: 5 iterations" in res.stdout, res.stdout[-1500:] + res.stderr[-3000:]
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_fuzz_frontends_fixed_seeds(seed):
+    env = dict(os.environ, PYTHONPATH=ROOT, FUZZ_ITERS="150")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_frontend.py"), "0", str(seed)], env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0 and "fuzz_frontend ok: 150 iterations" in res.stdout, res.stdout[-1500:] + res.stderr[-3000:]
