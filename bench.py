@@ -445,11 +445,13 @@ def config3_full_leg(with_cpu_value: float | None) -> dict:
         warnings.simplefilter("ignore")
         sq.gr.spatial_autocorr(adata, genes=list(adata.var_names[:256]), mode="moran", n_perms=64, seed=1, copy=True)  # warm-up (module load)
         for mode in ("moran", "geary"):
-            t0 = time.perf_counter()
-            df = sq.gr.spatial_autocorr(adata, mode=mode, n_perms=P, seed=1, copy=True)
-            dt = time.perf_counter() - t0
-            assert df.shape == (G, 9) and np.isfinite(df.iloc[:, 0]).all()
-            out[mode] = {"seconds": dt, "genes_per_s": G / dt}
+            runs = []
+            for _ in range(2):  # two whole calls: the 16 GB pageable upload inside the call is at the mercy of the host (page
+                t0 = time.perf_counter()  # migration between the calls was seen to turn 0.28 s into 2.8 s once in a while)
+                df = sq.gr.spatial_autocorr(adata, mode=mode, n_perms=P, seed=1, copy=True)
+                runs.append(time.perf_counter() - t0)
+                assert df.shape == (G, 9) and np.isfinite(df.iloc[:, 0]).all()
+            out[mode] = {"seconds": min(runs), "genes_per_s": G / min(runs), "runs_s": runs}
     if with_cpu_value:
         out["cpu_baseline"] = {"value": G / with_cpu_value, "unit": "s", "cores": 1, "kind": "port",
                                "sample": "config 3 (Moran) at the per-gene rate of the secondary leg's CPU baseline (C restatement, 1 core): 20 000 genes / that rate"}
