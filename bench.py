@@ -446,8 +446,8 @@ def config3_full_leg(with_cpu_value: float | None) -> dict:
         sq.gr.spatial_autocorr(adata, genes=list(adata.var_names[:256]), mode="moran", n_perms=64, seed=1, copy=True)  # warm-up (module load)
         for mode in ("moran", "geary"):
             runs = []
-            for _ in range(2):  # two whole calls: the 16 GB pageable upload inside the call is at the mercy of the host (page
-                t0 = time.perf_counter()  # migration between the calls was seen to turn 0.28 s into 2.8 s once in a while)
+            for _ in range(2):  # two whole calls, both listed (the second call of a process used to stall ~5 s in hipMalloc once
+                t0 = time.perf_counter()  # the driver had handed out all of the HBM once; buffers are parked and reused now)
                 df = sq.gr.spatial_autocorr(adata, mode=mode, n_perms=P, seed=1, copy=True)
                 runs.append(time.perf_counter() - t0)
                 assert df.shape == (G, 9) and np.isfinite(df.iloc[:, 0]).all()

@@ -879,8 +879,8 @@ int sqgr_matrix::ensure_by_column() const {
     SQGR_HIP(hipMemsetAsync(cnt.p, 0, ((size_t)n_cols + 1) * 8, st));
     const size_t count = (size_t)std::max<int64_t>(nnz, 1);
     SQGR_TRY(c_indptr.alloc((size_t)n_cols + 1));
-    SQGR_TRY(c_rows.alloc(count));
-    SQGR_TRY(f32 ? c_data32.alloc(count) : c_data.alloc(count));
+    SQGR_TRY(c_rows.alloc_pooled(count));  // (every entry is written by the scatter)
+    SQGR_TRY(f32 ? c_data32.alloc_pooled(count) : c_data.alloc_pooled(count));
     LaunchTimer t(ctx, "autocorr_csr_to_csc");
     if (nnz > 0) k_count_columns<<<(unsigned)ceil_div(nnz, 256), 256, 0, st>>>(indices.p, nnz, cnt.p);
     std::vector<unsigned long long> h((size_t)n_cols + 1);
@@ -1212,7 +1212,7 @@ int sqgr_matrix_create_dense(sqgr_ctx* ctx, const void* x, int32_t value_bytes, 
     m->ld = n_cols;  // stored densely whatever the pitch of the source
     m->f32 = value_bytes == 4;
     const size_t count = (size_t)n_rows * n_cols;
-    int rc = m->f32 ? m->data32.alloc(count) : m->data.alloc(count);
+    int rc = m->f32 ? m->data32.alloc_pooled(count) : m->data.alloc_pooled(count);  // (overwritten whole by the upload)
     if (rc != SQGR_OK) {
         delete m;
         return rc;
@@ -1269,7 +1269,7 @@ static int matrix_create_sparse(sqgr_ctx* ctx, int kind, int64_t n_rows, int64_t
     };
     int rc = SQGR_OK;
     const size_t cnt = (size_t)std::max<int64_t>(nnz, 1);
-    if ((rc = m->indptr.alloc((size_t)nptr)) || (rc = m->indices.alloc(cnt)) || (rc = m->f32 ? m->data32.alloc(cnt) : m->data.alloc(cnt))) return fail(rc);
+    if ((rc = m->indptr.alloc((size_t)nptr)) || (rc = m->indices.alloc_pooled(cnt)) || (rc = m->f32 ? m->data32.alloc_pooled(cnt) : m->data.alloc_pooled(cnt))) return fail(rc);
     hipError_t e = hipSuccess;
     if (index_bytes == 8) {
         DevBuf<int64_t> wide;

@@ -95,31 +95,75 @@ struct LaunchTimer {
     }
 };
 
+// Parked device buffers (sqgr_ctx.hip).  One spatial_autocorr call over 20 000 genes allocates and frees ~100 GB (the 16 GB
+// expression matrix, ~9 GB of working buffers per 2048-gene block); after two or three calls the driver had handed out all of
+// the 288 GB once and the next hipMalloc stalled for ~5 s while freed memory was reclaimed (HIP API trace of bench.py: one
+// hipMalloc of 1.6 GB taking 4.85 s).  So buffers of 64 MB and more are parked per device when their owner lets go of them and
+// handed to the next request of about that size instead of going back to the driver.  A reused buffer is zeroed (a fresh
+// allocation reads as zeros too) after a device synchronise (hipFree used to provide that one); alloc_pooled skips the zeroing
+// for buffers whose every byte the owner writes.  Bounded (SQGR_POOL_GB, default 64; 0 switches it off); flushed when any
+// hipMalloc of the library fails (which is then retried) and when a context is destroyed.
+constexpr size_t POOL_MIN_BYTES = (size_t)64 << 20;
+void* pool_take(size_t bytes, size_t* capacity);  // a parked buffer of [bytes, 1.5 * bytes] on the current device, or NULL
+void pool_give(void* p, size_t capacity);         // parks p or frees it
+void pool_flush();                                // frees everything parked on the current device
+
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
+    size_t pooled_bytes = 0;  // != 0: capacity of a buffer that goes back to the pool
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p && pooled_bytes) pool_give(p, pooled_bytes);
+        else if (p) (void)hipFree(p);
         p = nullptr;
         n = 0;
+        pooled_bytes = 0;
     }
-    int alloc(size_t count) {
+    int alloc_impl(size_t count, bool zero_reused) {
         release();
         if (count == 0) count = 1;
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+        const size_t bytes = count * sizeof(T);
+        if (bytes >= POOL_MIN_BYTES) {
+            size_t cap = 0;
+            if (void* q = pool_take(bytes, &cap)) {
+                hipError_t e = hipDeviceSynchronize();  // nothing of the previous owner is in flight any more
+                if (e == hipSuccess && zero_reused) {
+                    e = hipMemsetAsync(q, 0, bytes, nullptr);
+                    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+                }
+                if (e != hipSuccess) {
+                    (void)hipFree(q);
+                    set_error("reusing a parked buffer failed: %s", hipGetErrorString(e));
+                    return SQGR_ERR_HIP;
+                }
+                p = static_cast<T*>(q);
+                n = count;
+                pooled_bytes = cap;
+                return SQGR_OK;
+            }
+        }
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), bytes);
+        if (e == hipErrorOutOfMemory) {  // give the parked buffers back to the driver and try once more
+            (void)hipGetLastError();
+            pool_flush();
+            e = hipMalloc(reinterpret_cast<void**>(&p), bytes);
+        }
         if (e != hipSuccess) {
             p = nullptr;
-            set_error("hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+            set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
             return SQGR_ERR_NOMEM;
         }
         n = count;
+        pooled_bytes = bytes >= POOL_MIN_BYTES ? bytes : 0;
         return SQGR_OK;
     }
+    int alloc(size_t count) { return alloc_impl(count, true); }
+    int alloc_pooled(size_t count) { return alloc_impl(count, false); }  // contents undefined: the owner overwrites every byte
     int ensure(size_t count) { return (count <= n && p) ? SQGR_OK : alloc(count); }
     size_t bytes() const { return n * sizeof(T); }
 };

@@ -2,6 +2,7 @@
 #include "sqgr_common.h"
 
 #include <cstdlib>
+#include <mutex>
 
 #include <hipcub/hipcub.hpp>
 
@@ -14,6 +15,63 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// ---- parked device buffers (declared in sqgr_common.h)
+struct PoolEntry {
+    int device;
+    void* p;
+    size_t cap;
+};
+static std::mutex g_pool_mutex;
+static std::vector<PoolEntry> g_pool;
+
+static size_t pool_limit() {
+    const char* e = getenv("SQGR_POOL_GB");
+    const double gb = (e && *e) ? atof(e) : 64.0;
+    return gb <= 0.0 ? 0 : (size_t)(gb * (double)((size_t)1 << 30));
+}
+
+void* pool_take(size_t bytes, size_t* capacity) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    int best = -1;
+    for (int k = 0; k < (int)g_pool.size(); ++k)
+        if (g_pool[k].device == dev && g_pool[k].cap >= bytes && g_pool[k].cap - bytes <= bytes / 2 && (best < 0 || g_pool[k].cap < g_pool[best].cap)) best = k;
+    if (best < 0) return nullptr;
+    void* p = g_pool[best].p;
+    *capacity = g_pool[best].cap;
+    g_pool.erase(g_pool.begin() + best);
+    return p;
+}
+
+void pool_give(void* p, size_t capacity) {
+    int dev = 0;
+    if (capacity >= POOL_MIN_BYTES && hipGetDevice(&dev) == hipSuccess) {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        size_t held = 0;
+        for (const PoolEntry& e : g_pool) held += e.device == dev ? e.cap : 0;
+        if (held + capacity <= pool_limit()) {
+            g_pool.push_back({dev, p, capacity});
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+
+void pool_flush() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    for (size_t k = 0; k < g_pool.size();) {
+        if (g_pool[k].device == dev) {
+            (void)hipFree(g_pool[k].p);
+            g_pool.erase(g_pool.begin() + (long)k);
+        } else {
+            ++k;
+        }
+    }
 }
 
 // one thread per edge: erow[e] = row owning edge e (binary search in indptr; built once per graph)
@@ -367,6 +425,7 @@ int sqgr_ctx_destroy(sqgr_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamSynchronize(ctx->stream2);
+    sqgr::pool_flush();
     for (auto& tl : ctx->launches) {
         (void)hipEventDestroy(tl.start);
         (void)hipEventDestroy(tl.stop);

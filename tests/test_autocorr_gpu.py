@@ -474,3 +474,34 @@ def test_gene_subsets_are_selected_on_the_device(L, ctx, fmt, dtype, monkeypatch
         L.AutocorrPlan.from_column_list(ctx, graph, dm, np.array([-1], dtype=np.int32))
     dm.close()
     graph.close()
+
+
+def test_matrix_buffers_are_parked_and_reused_without_stale_contents(L, ctx):
+    """The payload buffers of a destroyed `sqgr_matrix` are parked for the next one (a 16 GB hipMalloc was seen to stall for
+    seconds on a fragmented heap).  A reused buffer carries the last owner's bytes: every format must overwrite what it reads —
+    a smaller matrix after a larger one, dense after sparse and back, give the results of a fresh process."""
+    rng = np.random.default_rng(0)
+    n, G = 6000, 4000  # 192 MB of float64: above the pool's 64 MB threshold
+    g = knn_graph(rng.random((n, 2)), 6)
+    g.data = rng.random(g.nnz) + 0.1
+    graph = L.Graph(ctx, g)
+    big = rng.gamma(2.0, 1.0, size=(n, G))
+    small = rng.gamma(2.0, 1.0, size=(n, G - 900))  # fits the parked buffer (within 1.5x)
+    sparse_x = sp.random(n, G, density=0.5, format="csr", random_state=3, dtype=np.float64)  # 96 MB of values (parked), 48 MB of indices
+    want = {}
+    for name, x in (("big", big), ("small", small), ("sparse", sparse_x)):
+        dense = np.asarray(x.todense()) if sp.issparse(x) else x
+        ref = L.AutocorrPlan(ctx, graph, np.ascontiguousarray(dense[:, 5:70].T))
+        want[name] = ref.scores("moran")
+        ref.close()
+    for name, x in (("big", big), ("small", small), ("sparse", sparse_x), ("big", big), ("sparse", sparse_x), ("small", small)):
+        dm = L.DeviceMatrix(ctx, x)
+        plan = L.AutocorrPlan.from_columns(ctx, graph, dm, 5, 65)
+        np.testing.assert_array_equal(plan.scores("moran"), want[name])
+        plan.close()
+        cols = np.arange(69, 4, -1, dtype=np.int32)
+        plan = L.AutocorrPlan.from_column_list(ctx, graph, dm, cols)  # (CSR: the by-column twin comes out of the pool as well)
+        np.testing.assert_array_equal(plan.scores("moran"), want[name][::-1])
+        plan.close()
+        dm.close()
+    graph.close()
