@@ -53,6 +53,30 @@ class ComplexPolicy(ModeEnum):
     ALL = "all"
 
 
+class Transform(Enum):
+    """Adjacency transform of the graph builders (_constants/_constants.py:33-36).  A plain enum like the reference's — ``NONE``
+    carries ``None`` — with its ``s`` / ``v`` accessors and its error text for an invalid option."""
+
+    SPECTRAL = "spectral"
+    COSINE = "cosine"
+    NONE = None
+
+    @classmethod
+    def _missing_(cls, value: Any) -> Any:
+        raise ValueError(f"Invalid option `{value}` for `{cls.__name__}`. Valid options are: `{[m.value for m in cls]}`.")
+
+    @property
+    def s(self) -> str:
+        return str(self.value)
+
+    @property
+    def v(self) -> Any:
+        return self.value
+
+    def __str__(self) -> str:
+        return str(self.value)
+
+
 def _suffixed(value: str | None, suffix: str) -> str:
     """``None`` -> ``spatial_<suffix>``; ``"foo"`` -> ``"foo_<suffix>"``; an already suffixed key is kept."""
     stem = "spatial" if value is None else value

@@ -3,7 +3,9 @@
 ``spatial_neighbors_from_builder`` (gr/_build.py:388-452).
 
 ``GraphBuilder`` is the protocol custom builders implement — ``build_graph(coords) -> (adj, dst)`` and ``uns_params()``,
-optionally ``postprocessors()`` and ``combine(mats, ixs)`` for ``library_key`` — exactly as upstream.  The four built-in
+optionally ``postprocessors()`` and ``combine(mats, ixs)`` for ``library_key`` — exactly as upstream, with the reusable post-build
+steps (``DistanceIntervalPostprocessor``, ``PercentilePostprocessor``, ``TransformPostprocessor``) and the ``Transform`` enum on
+``builder.transform``.  The four built-in
 builders (``KNNBuilder``, ``RadiusBuilder``, ``DelaunayBuilder``, ``GridBuilder``) take the reference's constructor
 arguments and produce the reference's matrices, but their neighbour searches run in ``libsqgr.so`` (device cell list,
 ``csrc/sqgr_neighbors.hip``) through ``squidpy_amd.gr._build`` — they are what ``spatial_neighbors_knn`` etc. execute."""
@@ -18,22 +20,26 @@ from typing import Any
 import numpy as np
 from scipy import sparse
 
+from collections.abc import Callable
+from dataclasses import dataclass
+from typing import TypeVar
+
+from .._constants import Transform
 from .._utils import assert_positive
 
-__all__ = ["GraphBuilder", "GraphBuilderCSR", "KNNBuilder", "RadiusBuilder", "DelaunayBuilder", "GridBuilder"]
+__all__ = ["GraphMatrixT", "GraphBuilder", "GraphBuilderCSR", "GraphPostprocessor", "DistanceIntervalPostprocessor", "PercentilePostprocessor",
+           "TransformPostprocessor", "KNNBuilder", "RadiusBuilder", "DelaunayBuilder", "GridBuilder"]
 
-
-def _transform_name(transform: Any) -> str | None:
-    from ._build import _check_transform
-
-    return _check_transform(getattr(transform, "value", transform))
+# the matrix type a builder produces, and a post-build step on it (gr/neighbors.py:49-51)
+GraphMatrixT = TypeVar("GraphMatrixT")
+GraphPostprocessor = Callable[[GraphMatrixT, GraphMatrixT], tuple[GraphMatrixT, GraphMatrixT]]
 
 
 class GraphBuilder(ABC):
     """Base class for spatial graph construction strategies (gr/neighbors.py:54-106)."""
 
     def __init__(self, transform: Any = None, set_diag: bool = False, percentile: float | None = None, postprocessors: Sequence[Any] = ()) -> None:
-        self.transform = _transform_name(transform)
+        self.transform = Transform.NONE if transform is None else Transform(getattr(transform, "value", transform))
         self.set_diag = set_diag
         self.percentile = percentile
         self._postprocessors = list(postprocessors)
@@ -79,6 +85,59 @@ class GraphBuilderCSR(GraphBuilder, ABC):
         return sparse.csr_matrix(adj), sparse.csr_matrix(dst)
 
 
+# ---- the reusable post-build steps custom builders compose (gr/neighbors.py:427-477); each works on the pair in place like the
+# reference's and returns it
+@dataclass(frozen=True)
+class DistanceIntervalPostprocessor:
+    """Edges whose length lies outside ``interval = (min, max)`` are zeroed in both matrices; the adjacency diagonal is kept."""
+
+    interval: tuple[float, float]
+
+    def __call__(self, adj: sparse.csr_matrix, dst: sparse.csr_matrix) -> tuple[sparse.csr_matrix, sparse.csr_matrix]:
+        lo, hi = self.interval
+        outside = (dst.data < lo) | (dst.data > hi)
+        diagonal = adj.diagonal()
+        dst.data[outside] = 0.0
+        adj.data[outside] = 0.0
+        adj.setdiag(diagonal)
+        return adj, dst
+
+
+@dataclass(frozen=True)
+class PercentilePostprocessor:
+    """Edges longer than the given percentile of the stored distances are zeroed in both matrices."""
+
+    percentile: float
+
+    def __call__(self, adj: sparse.csr_matrix, dst: sparse.csr_matrix) -> tuple[sparse.csr_matrix, sparse.csr_matrix]:
+        threshold = np.percentile(dst.data, self.percentile)
+        too_long = dst > threshold
+        adj[too_long] = 0.0
+        dst[too_long] = 0.0
+        return adj, dst
+
+
+@dataclass(frozen=True)
+class TransformPostprocessor:
+    """Explicit zeros are dropped from both matrices, then the adjacency is transformed (spectral: D^-1/2 A D^-1/2; cosine)."""
+
+    transform: Transform
+
+    def __call__(self, adj: sparse.csr_matrix, dst: sparse.csr_matrix) -> tuple[sparse.csr_matrix, sparse.csr_matrix]:
+        from ._build import _spectral
+
+        adj.eliminate_zeros()
+        dst.eliminate_zeros()
+        kind = Transform.NONE if self.transform is None else Transform(getattr(self.transform, "value", self.transform))
+        if kind == Transform.SPECTRAL:
+            return _spectral(adj if sparse.isspmatrix_csr(adj) else sparse.csr_matrix(adj)), dst
+        if kind == Transform.COSINE:
+            from sklearn.metrics.pairwise import cosine_similarity
+
+            return cosine_similarity(adj, dense_output=False), dst
+        return adj, dst
+
+
 class _DeviceBuilder(GraphBuilderCSR):
     """A built-in builder: the whole recipe (search on the device, pruning, transform) is `_build._build_one(spec)`."""
 
@@ -114,7 +173,7 @@ class KNNBuilder(_DeviceBuilder):
     def _spec(self) -> Any:
         from ._build import _Spec
 
-        return _Spec("knn", n_neighs=self.n_neighs, transform=self.transform, set_diag=self.set_diag, percentile=self.percentile)
+        return _Spec("knn", n_neighs=self.n_neighs, transform=self.transform.value, set_diag=self.set_diag, percentile=self.percentile)
 
 
 class RadiusBuilder(_DeviceBuilder):
@@ -127,7 +186,7 @@ class RadiusBuilder(_DeviceBuilder):
     def _spec(self) -> Any:
         from ._build import _Spec
 
-        return _Spec("radius", radius=self.radius, transform=self.transform, set_diag=self.set_diag, percentile=self.percentile)
+        return _Spec("radius", radius=self.radius, transform=self.transform.value, set_diag=self.set_diag, percentile=self.percentile)
 
 
 class DelaunayBuilder(_DeviceBuilder):
@@ -143,7 +202,7 @@ class DelaunayBuilder(_DeviceBuilder):
     def _spec(self) -> Any:
         from ._build import _Spec
 
-        return _Spec("delaunay", radius=self.radius, transform=self.transform, set_diag=self.set_diag, percentile=self.percentile)
+        return _Spec("delaunay", radius=self.radius, transform=self.transform.value, set_diag=self.set_diag, percentile=self.percentile)
 
 
 class GridBuilder(_DeviceBuilder):
@@ -158,4 +217,4 @@ class GridBuilder(_DeviceBuilder):
     def _spec(self) -> Any:
         from ._build import _Spec
 
-        return _Spec("grid", n_neighs=self.n_neighs, n_rings=self.n_rings, transform=self.transform, set_diag=self.set_diag, delaunay=self.delaunay)
+        return _Spec("grid", n_neighs=self.n_neighs, n_rings=self.n_rings, transform=self.transform.value, set_diag=self.set_diag, delaunay=self.delaunay)

@@ -134,3 +134,83 @@ def test_spatial_neighbors_from_builder_with_a_custom_builder():
     a = sq.gr.spatial_neighbors_from_builder(adata, DelaunayBuilder(radius=3.0), copy=True)
     b = sq.gr.spatial_neighbors_delaunay(adata, radius=3.0, copy=True)
     assert (a.connectivities != b.connectivities).nnz == 0 and (a.distances != b.distances).nnz == 0
+
+
+def test_reusable_postprocessors_and_the_transform_enum():
+    """The extension API of gr/neighbors.py:33-51,442-477 (docs/extensibility.md): custom builders compose the public post-build steps
+    and read `self.transform` as the `Transform` enum.  Each step against plain numpy on a small dense matrix."""
+    import warnings
+
+    from scipy import sparse
+
+    import squidpy_amd as sq
+    from squidpy_amd._constants import Transform
+    from squidpy_amd.gr import neighbors as nb
+
+    assert set(nb.__all__) >= {"GraphMatrixT", "GraphPostprocessor", "DistanceIntervalPostprocessor", "PercentilePostprocessor", "TransformPostprocessor"}
+    assert Transform(None) is Transform.NONE and Transform("cosine") is Transform.COSINE and Transform.NONE.value is None and Transform.SPECTRAL.s == "spectral"
+    with pytest.raises(ValueError, match="Invalid option `foo` for `Transform`"):
+        Transform("foo")
+    assert nb.KNNBuilder(transform="spectral").transform is Transform.SPECTRAL and nb.KNNBuilder().transform is Transform.NONE
+    assert nb.KNNBuilder(transform=Transform.COSINE).uns_params()["transform"] == "cosine"
+
+    rng = np.random.default_rng(0)
+    xy = rng.random((30, 2)) * 10
+    d = np.sqrt(((xy[:, None] - xy[None]) ** 2).sum(-1))
+    near = (d < 4.0) & ~np.eye(30, dtype=bool)
+
+    def fresh(diag=False):  # both matrices share one sparsity structure, as the reference's builders produce them (set_diag: an
+        stored = near | (np.eye(30, dtype=bool) if diag else False)  # explicit 1 / 0 on the diagonal)
+        r, c = np.nonzero(stored)
+        adj = sparse.csr_matrix((np.ones(len(r)), (r, c)), shape=(30, 30))
+        dst = sparse.csr_matrix((d[r, c], (r, c)), shape=(30, 30))
+        return adj, dst
+
+    adj, dst = nb.DistanceIntervalPostprocessor((1.0, 3.0))(*fresh(diag=True))
+    keep = near & (d >= 1.0) & (d <= 3.0)
+    np.testing.assert_array_equal(adj.toarray(), keep.astype(float) + np.eye(30))  # the diagonal survives
+    np.testing.assert_array_equal(dst.toarray(), np.where(keep, d, 0.0))
+
+    adj, dst = fresh()
+    thr = np.percentile(dst.data, 60.0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", sparse.SparseEfficiencyWarning)
+        adj, dst = nb.PercentilePostprocessor(60.0)(adj, dst)
+    np.testing.assert_array_equal(adj.toarray(), (near & (d <= thr)).astype(float))
+    np.testing.assert_array_equal(dst.toarray(), np.where(near & (d <= thr), d, 0.0))
+
+    adj, dst = fresh()
+    adj.data[:3] = 0.0
+    a2, d2 = nb.TransformPostprocessor(Transform.SPECTRAL)(adj, dst)
+    dense = adj.toarray()
+    deg = dense.sum(0)
+    with np.errstate(divide="ignore"):
+        want = dense * np.sqrt(1.0 / deg)[:, None] * np.sqrt(1.0 / deg)[None, :]
+    np.testing.assert_allclose(a2.toarray(), np.nan_to_num(want, posinf=0.0), rtol=1e-6)
+    assert a2.dtype == np.float32 and (a2.data != 0).all()  # explicit zeros were dropped first
+    from sklearn.metrics.pairwise import cosine_similarity
+
+    a3, _ = nb.TransformPostprocessor("cosine")(*fresh())
+    np.testing.assert_allclose(a3.toarray(), cosine_similarity(near.astype(float)), rtol=1e-12)
+    a4, _ = nb.TransformPostprocessor(Transform.NONE)(*fresh())
+    np.testing.assert_array_equal(a4.toarray(), near.astype(float))
+
+    class Composed(nb.GraphBuilderCSR):  # a custom builder in the documented style
+        def __init__(self, radius, **kw):
+            super().__init__(postprocessors=[nb.DistanceIntervalPostprocessor((0.0, radius)), nb.TransformPostprocessor(Transform(kw.get("transform")))], **kw)
+
+        def build_graph(self, coords):
+            dd = np.sqrt(((coords[:, None] - coords[None]) ** 2).sum(-1))
+            m = (dd < 4.0) & ~np.eye(len(coords), dtype=bool)
+            return sparse.csr_matrix(m.astype(np.float64)), sparse.csr_matrix(np.where(m, dd, 0.0))
+
+        def uns_params(self):
+            return {"transform": self.transform.value}
+
+    adata = sq.AnnDataLite(obs=pd.DataFrame(index=[str(i) for i in range(30)]), obsm={"spatial": xy})
+    res = sq.gr.spatial_neighbors_from_builder(adata, Composed(2.5, transform="spectral"), copy=True)
+    keep = near & (d <= 2.5)
+    deg = keep.sum(0).astype(float)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        want = keep * np.sqrt(1.0 / deg)[:, None] * np.sqrt(1.0 / deg)[None, :]
+    np.testing.assert_allclose(res.connectivities.toarray(), np.nan_to_num(want, posinf=0.0), rtol=1e-6)
