@@ -119,10 +119,10 @@ while (it < ITERS) if ITERS else (time.time() - t0 < budget):
     kw = dict(n_neigh=int(rng.integers(1, 4)), n_simulations=int(rng.integers(1, 8)), n_observations=int(rng.choice([5, 40, 300])),
               max_dist=None if rng.random() < 0.5 else float(rng.random() * xy.max()), n_steps=int(rng.choice([2, 11, 50])), seed=sd)
     if min(np.bincount(cl, minlength=K)) <= kw["n_neigh"] or kw["n_observations"] <= kw["n_neigh"]: kw["n_neigh"] = 1
-    if min(np.bincount(cl, minlength=K)) < 2: continue
-    note("  ripley", rmode, metric, kw)
-    res = sq.gr.ripley(adata, "cl", mode=rmode, metric=metric, copy=True, **kw)
-    if metric == "euclidean" or rmode != "L":  # (the oracle's L is written for the euclidean KDTree)
+    do_ripley = min(np.bincount(cl, minlength=K)) >= 2
+    note("  ripley", rmode, metric, kw, do_ripley)
+    res = sq.gr.ripley(adata, "cl", mode=rmode, metric=metric, copy=True, **kw) if do_ripley else None
+    if do_ripley and (metric == "euclidean" or rmode != "L"):  # (the oracle's L is written for the euclidean KDTree)
         ref = O.ripley(xy, obs["cl"].to_numpy(), mode=rmode, metric=metric, **kw)
         assert np.array_equal(res["bins"], ref["bins"])
         ns = kw["n_steps"]
@@ -130,4 +130,63 @@ while (it < ITERS) if ITERS else (time.time() - t0 < budget):
         np.testing.assert_allclose(got_obs, ref["obs"], rtol=1e-12, atol=1e-12)
         np.testing.assert_allclose(got_sims, ref["sims"], rtol=1e-12, atol=1e-12)
         assert np.array_equal(res["pvalues"], ref["pvalues"])
+    # ---- graph builders ("next" row f-3) against the restated reference builders (sklearn's KD tree as the reference calls it)
+    kind = str(rng.choice(["knn", "radius", "grid", "delaunay"]))
+    # (grid: a lattice whose coordination number is the n_neighs asked for — with ties at the k-th distance sklearn's choice depends on
+    #  its tree traversal; libsqgr's documented policy is the smaller index)
+    grid_k = int(rng.choice([4, 6])); gr_, gc_ = int(rng.integers(3, 9)), int(rng.integers(3, 12))
+    lattice = O.hex_grid(gr_, gc_) if grid_k == 6 else np.stack(np.meshgrid(np.arange(float(gc_)), np.arange(float(gr_))), -1).reshape(-1, 2) * 10.0
+    pts = rng.random((n, 2)) * rng.choice([1.0, 300.0]) if kind != "grid" else lattice + rng.normal(0, 0.5, (1, 2))  # (continuous: no ties)
+    span = float(np.ptp(pts, axis=0).max()) + 1e-9
+    bkw = dict(set_diag=bool(rng.random() < 0.4), transform=[None, "spectral", "cosine"][int(rng.integers(0, 3))])
+    # (k < n/2: from there on sklearn answers by brute force with inexact distances, and a percentile threshold can land on either side)
+    if kind == "knn": bkw.update(n_neighs=int(rng.integers(1, max(1, min((len(pts) - 1) // 2, 9)) + 1)), percentile=None if rng.random() < 0.6 else float(rng.choice([50.0, 90.0, 99.0])))
+    elif kind == "radius":
+        r1 = span * float(rng.choice([0.05, 0.15, 0.4]))
+        bkw.update(radius=r1 if rng.random() < 0.5 else (r1 * 0.3, r1), percentile=None if rng.random() < 0.7 else 80.0)
+    elif kind == "grid": bkw.update(n_neighs=grid_k, n_rings=int(rng.integers(1, 4)), delaunay=bool(rng.random() < 0.3))
+    else: bkw.update(radius=None if rng.random() < 0.5 else (0.0, span * 0.3))
+    note("  graph", kind, bkw)
+    gdata = sq.AnnDataLite(X=np.ones((len(pts), 2)), obsm={"spatial": pts})
+    fn = {"knn": sq.gr.spatial_neighbors_knn, "radius": sq.gr.spatial_neighbors_radius, "grid": sq.gr.spatial_neighbors_grid, "delaunay": sq.gr.spatial_neighbors_delaunay}[kind]
+    got = fn(gdata, copy=True, **bkw)
+    radj, rdst = O.spatial_graph(pts, kind, **bkw)
+    assert got.connectivities.dtype == radj.dtype and got.distances.dtype == rdst.dtype, (kind, got.connectivities.dtype, radj.dtype)
+    np.testing.assert_allclose(got.connectivities.toarray(), radj.toarray(), rtol=1e-6, atol=1e-7, err_msg=f"{kind} adj {bkw}")
+    # (sklearn switches to brute force for k >= n/2 and forms those distances through the expanded |x|^2 - 2xy + |y|^2: ~1e-12 off)
+    np.testing.assert_allclose(got.distances.toarray(), rdst.toarray(), rtol=1e-9, atol=0, err_msg=f"{kind} dst {bkw}")
+
+    # ---- interaction_matrix ("next" row f-2)
+    wts = bool(rng.random() < 0.5); nrm = bool(rng.random() < 0.5)
+    wconn = conn.copy(); wconn.data = (rng.random(conn.nnz) + 0.5).astype(conn.dtype)
+    adata.obsp["spatial_connectivities"] = wconn
+    got = sq.gr.interaction_matrix(adata, "cl", weights=wts, normalized=nrm, copy=True)
+    want = O.interaction_matrix(wconn.data, wconn.indices, wconn.indptr, labels, K, wts).astype(np.float64)
+    if nrm:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            want = want / want.sum(axis=1).reshape((-1, 1))
+    np.testing.assert_allclose(np.asarray(got, dtype=np.float64), want, rtol=1e-12, atol=0, equal_nan=True)
+    adata.obsp["spatial_connectivities"] = conn
+
+    # ---- ligrec ("next" row f-4) in numpy's streams: p-values equal the reference's for the seed
+    if G >= 2:
+        ng = min(G, 6); Pl = int(rng.integers(1, 40))
+        pairs_l = list(dict.fromkeys((int(a), int(b)) for a, b in rng.integers(0, ng, (int(rng.integers(1, 12)), 2))))
+        thr_l = float(rng.choice([0.0, 0.1, 0.5]))
+        given = [(f"G{a}", f"G{b}") for a, b in pairs_l]
+        if len(pairs_l) == 2 or rng.random() < 0.3:  # (exactly two items would be read as (sources, targets), gr/_ligrec.py:184-185)
+            given = {"source": [g[0] for g in given], "target": [g[1] for g in given]}
+        Xl = X[:, :ng]  # the front end keeps the genes of the interactions; hand it exactly those columns' universe
+        ldata = sq.AnnDataLite(X=sp.csr_matrix(Xl) if rng.random() < 0.5 else Xl, obs=obs, var=pd.DataFrame(index=[f"G{i}" for i in range(ng)]))
+        note("  ligrec", len(pairs_l), "pairs P", Pl, "thr", thr_l)
+        res = sq.gr.ligrec(ldata, "cl", interactions=given, threshold=thr_l, n_perms=Pl, seed=sd, use_raw=False, copy=True,
+                           rng="numpy", show_progress_bar=False)
+        cpairs = np.array([(a, b) for a in range(K) for b in range(K)], dtype=np.int32)
+        means, pv = O.ligrec_analysis(Xl, labels, np.array(pairs_l, dtype=np.int32), cpairs, threshold=thr_l, n_perms=Pl, seed=sd)
+        got_pv = res["pvalues"].to_numpy(dtype=np.float64); got_means = res["means"].to_numpy(dtype=np.float64)
+        assert got_pv.shape == pv.shape, (got_pv.shape, pv.shape)
+        if not np.array_equal(got_pv, pv, equal_nan=True):
+            print("ligrec mismatch", n, ng, K, Pl, thr_l, pairs_l, "\ngot", got_pv, "\nwant", pv, "\nmeans got", got_means, "\nmeans want", means, "\nindex", res["pvalues"].index.to_list(), "\ncols", res["pvalues"].columns.to_list(), "\nX", Xl.tolist(), "\nlabels", labels.tolist(), flush=True)
+            raise AssertionError(("ligrec pvalues", n, ng, K, Pl))
+        np.testing.assert_allclose(got_means, means, rtol=1e-12, atol=0)
 print(f"fuzz_frontend ok: {it} iterations in {time.time()-t0:.0f}s")
