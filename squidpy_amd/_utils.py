@@ -173,9 +173,13 @@ class progress:
         if self._bar is not None:
             self._bar.update(n)
 
+    def close(self) -> None:
+        if self._bar is not None:
+            self._bar.close()
+            self._bar = None
+
     def __enter__(self) -> "progress":
         return self
 
     def __exit__(self, *exc: Any) -> None:
-        if self._bar is not None:
-            self._bar.close()
+        self.close()

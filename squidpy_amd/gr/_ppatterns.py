@@ -349,7 +349,7 @@ def spatial_autocorr(
             finally:
                 plan.close()
     finally:
-        bar.__exit__()
+        bar.close()
         if resident is not None:
             resident.close()
     if world > 1:

@@ -162,3 +162,53 @@ def test_side_channel_codec_is_data_only_and_round_trips(tmp_path, monkeypatch):
     os.chmod(d, 0o777)
     with pytest.raises(PermissionError):
         D._rendezvous_dir()
+
+
+def test_gene_subsets_become_lazy_column_selections():
+    """`spatial_autocorr`'s value extraction (gr/_ppatterns.py:154-166) hands a gene subset of a sparse / wide dense matrix to the
+    device as (whole matrix, column list) instead of `adata[:, genes].X`; everything else keeps the reference's host path."""
+    import pandas as pd
+    import scipy.sparse as sp
+
+    import squidpy_amd as sq
+    from squidpy_amd.gr import _ppatterns as pp
+
+    rng = np.random.default_rng(0)
+    n, G = 40, 12
+    X = rng.random((n, G))
+    var = pd.DataFrame({"highly_variable": np.arange(G) % 3 == 0}, index=[f"g{i}" for i in range(G)])
+    obs = pd.DataFrame({"a": rng.random(n)}, index=[f"s{i}" for i in range(n)])
+
+    def ad(x, **kw):
+        return sq.AnnDataLite(X=x, obs=obs, var=var, layers={"lay": x * 2} if not sp.issparse(x) else {"lay": x * 2}, **kw)
+
+    # sparse: always lazy (the subsetting copy is O(nnz) on the host); order and repeats preserved
+    vals, index = pp._extract_vals(ad(sp.csr_matrix(X)), "X", ["g7", "g2", "g7"], None, False)
+    assert isinstance(vals, pp._ColumnSelection) and vals.cols.tolist() == [7, 2, 7] and vals.shape == (3, n) and list(index) == ["g7", "g2", "g7"]
+    np.testing.assert_array_equal(vals.on_host().toarray(), X[:, [7, 2, 7]].T)
+    # the highly-variable default
+    vals, index = pp._extract_vals(ad(sp.csc_matrix(X)), "X", None, None, False)
+    assert isinstance(vals, pp._ColumnSelection) and vals.cols.tolist() == [0, 3, 6, 9] and list(index) == ["g0", "g3", "g6", "g9"]
+    # a layer
+    vals, _ = pp._extract_vals(ad(sp.csr_matrix(X)), "X", ["g1"], "lay", False)
+    assert isinstance(vals, pp._ColumnSelection) and abs(vals.base - sp.csr_matrix(X) * 2).max() == 0
+    # dense: lazy only when a good part of the matrix is asked for (the whole matrix is uploaded)
+    vals, _ = pp._extract_vals(ad(X), "X", ["g1", "g2"], None, False)
+    assert not isinstance(vals, pp._ColumnSelection) and vals.shape == (2, n)
+    vals, _ = pp._extract_vals(ad(X), "X", [f"g{i}" for i in range(0, G, 2)], None, False)
+    assert isinstance(vals, pp._ColumnSelection) and vals.device_bytes() == n * G * 8
+    # every gene in order: the matrix itself, no selection at all
+    vals, _ = pp._extract_vals(ad(sp.csr_matrix(X)), "X", list(var.index), None, False)
+    assert not isinstance(vals, pp._ColumnSelection) and vals.shape == (G, n)
+    # an unknown gene: the reference's own KeyError path decides
+    with pytest.raises(KeyError):
+        pp._extract_vals(ad(sp.csr_matrix(X)), "X", ["g1", "nope"], None, False)
+    # use_raw: intersected with raw.var_names, then lazy as well
+    a = ad(sp.csr_matrix(X))
+    a.raw = sq.AnnDataLite(X=sp.csr_matrix(X * 3), obs=obs, var=var)
+    vals, index = pp._extract_vals(a, "X", ["g4", "nope"], None, True)
+    assert isinstance(vals, pp._ColumnSelection) and list(index) == ["g4"] and vals.cols.tolist() == [4]
+    # CSR doubles on the device (its by-column twin), CSC does not
+    m = sp.csr_matrix(X)
+    assert pp._ColumnSelection(m, np.array([1])).device_bytes() == 2 * (m.data.nbytes + m.indices.nbytes + m.indptr.nbytes)
+    assert pp._ColumnSelection(m.tocsc(), np.array([1])).device_bytes() == m.tocsc().data.nbytes + m.tocsc().indices.nbytes + m.tocsc().indptr.nbytes
