@@ -3,6 +3,7 @@ the oracle's restatement of the reference pipelines, in the reference's own rand
 
     python tools/fuzz_frontend.py [seconds] [seed]
     FUZZ_ITERS=6 python tools/fuzz_frontend.py 0 3
+    FUZZ_BIG=1 python tools/fuzz_frontend.py 600 5       # fewer, larger cases (the CPU oracle needs ~1 min for each)
 """
 import os, sys, time, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -33,7 +34,10 @@ def knn(xy, k):
 t0 = time.time(); it = 0
 while (it < ITERS) if ITERS else (time.time() - t0 < budget):
     it += 1
-    n = int(rng.choice([12, 60, 300, 1200])); G = int(rng.choice([1, 2, 9, 40])); K = int(rng.choice([2, 3, 7]))
+    if os.environ.get("FUZZ_BIG") == "1":  # fewer, larger cases: several feature blocks, tiles, launch groups
+        n = int(rng.choice([3000, 9000, 20000])); G = int(rng.choice([3, 70, 300])); K = int(rng.choice([2, 9, 31]))
+    else:
+        n = int(rng.choice([12, 60, 300, 1200])); G = int(rng.choice([1, 2, 9, 40])); K = int(rng.choice([2, 3, 7]))
     xy = rng.random((n, 2)) * rng.choice([1.0, 100.0, 5000.0])
     if rng.random() < 0.3: xy = np.round(xy, 1)
     X = np.where(rng.random((n, G)) < rng.choice([0.2, 1.0]), np.rint(rng.gamma(2.0, 3.0, (n, G))), 0.0) + (rng.random((n, G)) < 0.02)
@@ -181,7 +185,11 @@ while (it < ITERS) if ITERS else (time.time() - t0 < budget):
         note("  ligrec", len(pairs_l), "pairs P", Pl, "thr", thr_l)
         res = sq.gr.ligrec(ldata, "cl", interactions=given, threshold=thr_l, n_perms=Pl, seed=sd, use_raw=False, copy=True,
                            rng="numpy", show_progress_bar=False)
-        cpairs = np.array([(a, b) for a in range(K) for b in range(K)], dtype=np.int32)
+        # the reference sorts the cluster PAIRS as tuples of strings (gr/_ligrec.py: `clusters = sorted(...)`) and codes the clusters
+        # in category order
+        names = [f"c{v}" for v in range(K)]
+        cpairs = np.array([(names.index(a), names.index(b)) for a, b in sorted((a, b) for a in names for b in names)], dtype=np.int32)
+        assert res["pvalues"].columns.to_list() == sorted((a, b) for a in names for b in names)
         means, pv = O.ligrec_analysis(Xl, labels, np.array(pairs_l, dtype=np.int32), cpairs, threshold=thr_l, n_perms=Pl, seed=sd)
         got_pv = res["pvalues"].to_numpy(dtype=np.float64); got_means = res["means"].to_numpy(dtype=np.float64)
         assert got_pv.shape == pv.shape, (got_pv.shape, pv.shape)
