@@ -212,3 +212,31 @@ def test_gene_subsets_become_lazy_column_selections():
     m = sp.csr_matrix(X)
     assert pp._ColumnSelection(m, np.array([1])).device_bytes() == 2 * (m.data.nbytes + m.indices.nbytes + m.indptr.nbytes)
     assert pp._ColumnSelection(m.tocsc(), np.array([1])).device_bytes() == m.tocsc().data.nbytes + m.tocsc().indices.nbytes + m.tocsc().indptr.nbytes
+
+
+def test_committed_profiles_belong_to_the_committed_kernels(monkeypatch):
+    """bench.py prices the kernels with PMC counters of a committed profile only when that profile was taken from THIS build of
+    the kernel sources (`source_sha16` == the fingerprint of csrc/* and include/sqgr.h) — the committed pair must match, and a
+    profile of another build is refused with every PMC-derived field left null."""
+    import json
+    import os
+
+    import bench
+    from squidpy_amd import _build
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", f"{bench.PROFILE_TAG}_counters.json")) as fh:
+        committed = json.load(fh)
+    assert committed["source_sha16"] == _build.source_fingerprint(), "profiles/ were taken from another build: re-run tools/profile_round.sh"
+    ok = bench.load_counters()
+    assert ok["_status"] == "ok" and ok["_source"].startswith("profiles/")
+    with open(os.path.join(root, "profiles", f"{bench.PROFILE_TAG}_bench.json")) as fh:
+        line = json.load(fh)
+    assert line["pmc_profile"] == "ok" and line["roofline"]["traffic"] is not None and 0 < line["roofline"]["frac"] <= 1
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    monkeypatch.setattr(_build, "source_fingerprint", lambda: "0" * 16)
+    stale = bench.load_counters()
+    assert "another build" in stale["_status"] and "nhood" not in stale
