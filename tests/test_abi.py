@@ -57,3 +57,12 @@ def test_product_does_not_import_oracle():
                 with open(os.path.join(dirpath, f)) as fh:
                     src = fh.read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_every_entry_point_is_named_in_the_integration_guide():
+    """INTEGRATION.md shows the reference-side binding: every function of the boundary appears there (next to the reference call
+    site it replaces, or in the list of lifecycle / introspection / parity-hook entry points)."""
+    with open(os.path.join(ROOT, "INTEGRATION.md")) as fh:
+        guide = fh.read()
+    missing = sorted(name for name in _declared() if name not in guide)
+    assert not missing, missing
