@@ -684,6 +684,114 @@ def numpy_stream_leg(ctx, plan, shift, n: int, counters: dict) -> dict:
     }
 
 
+# --------------------------------------------------------------------------------------------- the line the driver records
+def _sig(x, digits: int = 5):
+    """Numbers of the compact line carry `digits` significant figures (the full precision stays in the detail file)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (str, int)):
+        return x
+    try:
+        return float(f"{float(x):.{digits}g}")
+    except (TypeError, ValueError):
+        return None
+
+
+def _short(text, limit: int = 160):
+    text = "" if text is None else str(text)
+    return text if len(text) <= limit else text[: limit - 1] + "…"
+
+
+def _leg(rec: dict | None, *, extra: tuple = ()) -> dict | None:
+    """One leg of the compact line: its value, the roofline bound/fraction and the CPU baseline's value — one number each."""
+    if not rec:
+        return None
+    roof = rec.get("roofline") or {}
+    out = {"value": _sig(rec.get("value")), "unit": rec.get("unit"), "bound": _short(roof.get("bound"), 32), "frac": _sig(roof.get("frac"), 3),
+           "cpu": _sig((rec.get("cpu_baseline") or {}).get("value"), 4)}
+    for k in extra:
+        if rec.get(k) is not None:
+            out[k] = _sig(rec[k], 4)
+    return out
+
+
+def compact_line(detail: dict, detail_path: str | None = None) -> dict:
+    """The FINAL stdout line: the contract's keys, the headline `roofline` and `cpu_baseline`, and one number per leg —
+    under 4 KB (the driver keeps 8 KB of stdout; round 3's 20 KB line left its record unparsed).  Notes, issue limits,
+    PMC inputs and per-kernel tables go to the detail file (`detail_path`)."""
+    roof = detail.get("roofline") or {}
+    issue = roof.get("issue_limits") or {}
+    cfg = detail.get("config") or {}
+    line = {k: detail.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                        "vs_baseline", "dtype", "data")}
+    line["value"], line["ms_per_step"] = _sig(line["value"], 7), _sig(line["ms_per_step"], 6)
+    line["config"] = {"workload": _short(cfg.get("workload"), 240), "perms_per_step": cfg.get("perms_per_step"),
+                      "perms_per_step_per_gpu": cfg.get("perms_per_step_per_gpu"), "parallelism": _short(cfg.get("parallelism"), 100),
+                      "collective": _short(cfg.get("collective"), 60)}
+    line["roofline"] = {
+        "kernel": roof.get("kernel"), "bound": roof.get("bound"), "achieved": _sig(roof.get("achieved")), "peak": _sig(roof.get("peak")),
+        "unit": roof.get("unit"), "frac": _sig(roof.get("frac"), 3), "traffic": _sig(roof.get("traffic"), 6),
+        "algorithmic_frac": _sig(roof.get("algorithmic_frac"), 3), "fabric_frac": _sig(roof.get("fabric_frac"), 3),
+        "frac_basis": _short(roof.get("frac_basis"), 120), "avg_launch_ms": _sig(roof.get("avg_launch_ms")),
+        "perms_per_launch": _sig(roof.get("perms_per_launch")),
+        "issue_limits": {"l1_gather": _sig(issue.get("frac"), 3) if issue.get("bound") == "l1_gather" else None,
+                         "lds_atomic": _sig(((issue.get("lds_atomic") or issue) if issue else {}).get("frac"), 3),
+                         "valu": _sig((issue.get("valu") or {}).get("frac"), 3)},
+    }
+    kern = detail.get("kernels") or {}
+    line["kernels"] = {name: {"bound": _short(rec.get("bound"), 24), "frac": _sig(rec.get("frac"), 3), "ms": _sig(rec.get("avg_launch_ms"), 4)}
+                       for name, rec in kern.items() if isinstance(rec, dict)}
+    cpu = detail.get("cpu_baseline")
+    if cpu:
+        line["cpu_baseline"] = {"value": _sig(cpu.get("value")), "unit": cpu.get("unit"), "cores": cpu.get("cores"), "kind": cpu.get("kind"),
+                                "sample": _short(cpu.get("sample"), 200),
+                                "all_cores": {"value": _sig((cpu.get("all_cores") or {}).get("value")), "cores": (cpu.get("all_cores") or {}).get("cores")},
+                                "config1_full_perms_per_s": _sig((cpu.get("config1_full") or {}).get("value"))}
+        line["speedup_vs_cpu_1core"] = _sig(detail.get("speedup_vs_cpu_1core"))
+    sec = detail.get("secondary")
+    if sec:
+        sroof = sec.get("roofline") or {}
+        line["secondary"] = {"metric": _short(sec.get("metric"), 80), "value": _sig(sec.get("value")), "unit": sec.get("unit"),
+                             "ms_per_step": _sig(sec.get("ms_per_step")), "dtype": sec.get("dtype"),
+                             "roofline": {"kernel": sroof.get("kernel"), "bound": sroof.get("bound"), "achieved": _sig(sroof.get("achieved")),
+                                          "peak": _sig(sroof.get("peak")), "unit": sroof.get("unit"), "frac": _sig(sroof.get("frac"), 3),
+                                          "traffic": _sig(sroof.get("traffic"), 6), "frac_of_pattern_ceiling": _sig(sroof.get("frac_of_pattern_ceiling"), 3)},
+                             "cpu_baseline": {k: (_short(v, 120) if k == "sample" else _sig(v)) for k, v in (sec.get("cpu_baseline") or {}).items()
+                                              if k in ("value", "unit", "cores", "kind", "sample")}}
+    legs = dict(detail.get("legs") or {})
+    if "geary_c" not in legs and detail.get("geary_c"):
+        legs["geary_c"] = detail["geary_c"]
+    out_legs = {}
+    for name in ("geary_c", "moran_p100", "co_occurrence", "ripley_L", "ripley_G"):
+        rec = _leg(legs.get(name), extra=("kernel_ms", "speedup_vs_gather_kernel"))
+        if rec:
+            out_legs[name] = rec
+    c3 = legs.get("config3_full")
+    if c3:
+        out_legs["config3_full"] = {"moran_s": _sig((c3.get("moran") or {}).get("seconds"), 4), "geary_s": _sig((c3.get("geary") or {}).get("seconds"), 4),
+                                    "cpu_s": _sig((c3.get("cpu_baseline") or {}).get("value"), 4), "error": c3.get("error")}
+    npy = detail.get("numpy_stream_mode")
+    if npy:
+        nroof = npy.get("roofline") or {}
+        out_legs["numpy_stream"] = {"value": _sig(npy.get("value")), "unit": npy.get("unit"), "at_n_perms_1000": _sig(npy.get("at_n_perms_1000")),
+                                    "bound": nroof.get("bound"), "frac": _sig(nroof.get("frac"), 3), "traffic_frac": _sig(nroof.get("traffic_frac"), 3),
+                                    "traffic_MB_per_perm": _sig(nroof.get("traffic_MB_per_perm"), 4), "cpu": _sig((npy.get("cpu_baseline") or {}).get("value"), 4)}
+    if out_legs:
+        line["legs"] = out_legs
+    emu = detail.get("emulated_ranks")
+    if emu:
+        line["emulated_ranks"] = {"PROJECTION": "shards run one after the other on ONE GPU", "ranks": emu.get("ranks"), "total_perms": emu.get("total_perms"),
+                                  "shard_ms": _sig(max(emu.get("shard_seconds") or [0.0]) * 1e3, 4), "whole_ms": _sig((emu.get("one_gpu_seconds") or 0.0) * 1e3, 4)}
+    line["pmc_profile"] = _short(detail.get("pmc_profile"), 120)
+    line["detail"] = detail_path
+
+    def clip(obj):  # names, units and kernel labels are short by construction; nothing free-form may ever grow the line
+        if isinstance(obj, dict):
+            return {k: (v if k in ("workload", "sample") and isinstance(v, str) else clip(v)) for k, v in obj.items()}
+        return _short(obj, 72) if isinstance(obj, str) else obj
+
+    return clip(line)
+
+
+
 # --------------------------------------------------------------------------------------------- main
 def main() -> None:
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
@@ -709,6 +817,8 @@ def main() -> None:
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="projection for a node this box does not have: run the N rank shards of BASELINE config 5 (--total-perms permutations, strong "
                     "scaling) one after the other on this GPU and print per-shard times; no collective runs, labelled as a projection")
+    ap.add_argument("--detail-out", type=str, default=os.path.join("gpurun_out", "bench_detail.json"),
+                    help="where the full record goes (the final stdout line is the compact one: < 4 KB)")
     ap.add_argument("--tune", type=str, default="", help="perms_per_pass,blocks_per_batch,batches_per_launch")
     args = ap.parse_args()
 
@@ -1021,7 +1131,15 @@ def main() -> None:
                 out["numpy_stream_mode"]["cpu_baseline"] = {k: out["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind", "sample")}
                 out["numpy_stream_mode"]["speedup_vs_cpu_1core"] = out["numpy_stream_mode"]["value"] / out["cpu_baseline"]["value"]
         out["pmc_profile"] = counters.get("_status")
-        print(json.dumps(out))
+        detail_path = None
+        try:  # the full record (notes, issue limits, PMC inputs, per-kernel tables): a side file, never the driver's line
+            os.makedirs(os.path.dirname(os.path.abspath(args.detail_out)), exist_ok=True)
+            with open(args.detail_out, "w") as fh:
+                json.dump(out, fh, indent=1)
+            detail_path = args.detail_out
+        except OSError as exc:  # pragma: no cover  (read-only checkout)
+            print(f"bench.py: could not write {args.detail_out}: {exc}", file=sys.stderr)
+        print(json.dumps(compact_line(out, detail_path)), flush=True)
     if world > 1:
         _dist.barrier()
         _dist.shutdown()
