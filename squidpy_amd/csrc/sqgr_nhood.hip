@@ -1487,8 +1487,10 @@ int sqgr_nhood_run(sqgr_nhood* plan, uint64_t seed, int64_t perm_begin, int64_t 
     for (int64_t p0 = perm_begin - perm_begin % FEISTEL_GROUP; p0 < perm_end; p0 += per_launch, ++grp) {
         const int64_t todo = (perm_end - p0 < per_launch) ? perm_end - p0 : per_launch;
         const int nb = (int)ceil_div(todo, B);
-        const int buf = (int)(grp & 1);
-        if (grp >= 2) SQGR_HIP(hipStreamWaitEvent(sa, p->ev_counted[buf], 0));  // slab[buf] has been consumed
+        // one stream: the kernels of a group run in order, ONE slab serves every group (a launch group sized to the Infinity
+        // Cache then never alternates between two of them); two streams: slab and keys ping-pong
+        const int buf = (sa != st) ? (int)(grp & 1) : 0;
+        if (sa != st && grp >= 2) SQGR_HIP(hipStreamWaitEvent(sa, p->ev_counted[buf], 0));  // slab[buf] has been consumed
         {
             LaunchTimer t(ctx, "nhood_keygen", sa);
             const int64_t nk = (int64_t)nb * p->n_libs * (B / FEISTEL_GROUP + B / 2);
