@@ -1034,25 +1034,36 @@ def main() -> None:
         # ---- the line's `roofline` object: HBM (SURVEY §8d names HBM for this kernel; VERDICT r2 asks for the measured-traffic fraction).
         # What limits the kernel in practice — the issue rate of its label-row gathers / LDS atomics — stays beside it as `issue_limits`.
         issue = roof
+        # compulsory DRAM bytes of one launch: every label row of the slab is read once (n bytes per permutation), the block-partial
+        # histograms are written once, the (half) edge list comes from HBM once (8 B per entry); everything else the kernel pulls through
+        # the fabric is a re-read that the 256 MiB Infinity Cache can serve.  No gfx950 counter separates the two: TCC_EA0_RDREQ_DRAM ==
+        # TCC_EA0_RDREQ to the request, FETCH_SIZE counts Infinity-Cache hits (profiles/r04_mall_calibration.json).
+        dram_bytes = float(n) * perms_per_launch + float(info["partial_bytes_per_launch"]) + 8.0 * list_edges
+        dram_bps = dram_bytes / (avg_count_ms * 1e-3) if avg_count_ms > 0 else None
         roof = {
             "kernel": issue["kernel"], "bound": "hbm",
-            "achieved": side.get("traffic_GBps"), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": side.get("traffic_frac_of_hbm_peak"),
-            "traffic": side["traffic_bytes_per_launch"], "traffic_source": side.get("traffic_source"),
-            "traffic_formula": "2 x FETCH_SIZE + WRITE_SIZE: calibrated on this kernel's own access patterns (4 B/lane row gathers, 8 B/lane list loads, "
-            "4 B/lane stores) over 512 MiB each — FETCH_SIZE reports exactly 0.5, WRITE_SIZE 1.0 (profiles/r03_fetch_calibration.json)",
+            "achieved": dram_bps / 1e9 if dram_bps else None, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": dram_bps / HBM_PEAK if dram_bps else None,
+            "traffic": dram_bytes,
+            "frac_basis": "compulsory DRAM bytes per launch (slab once + partials once + edge list once) / HIP-event time; no counter separates Infinity-Cache hits",
+            "fabric_traffic": side["traffic_bytes_per_launch"], "fabric_GBps": side.get("traffic_GBps"), "fabric_frac": side.get("traffic_frac_of_hbm_peak"),
+            "traffic_source": side.get("traffic_source"),
+            "traffic_formula": "fabric_traffic = 2 x FETCH_SIZE + WRITE_SIZE: calibrated on this kernel's own access patterns (4 B/lane row gathers, 8 B/lane list loads, "
+            "4 B/lane stores) over 512 MiB each — FETCH_SIZE reports exactly 0.5, WRITE_SIZE 1.0 (profiles/r03_fetch_calibration.json); it counts what crosses the L2's "
+            "memory-side port INCLUDING Infinity-Cache hits (profiles/r04_mall_calibration.json: a 24 MiB buffer re-read 160 times reports 3.2 GB)",
             "launches": launches, "avg_launch_ms": avg_count_ms, "perms_per_launch": perms_per_launch, "list_edges": list_edges,
             "symmetric_half_list": info["symmetric"], "workload_key": workload,
             "algorithmic_bytes_per_launch": side["algorithmic_bytes_per_launch"], "algorithmic_GBps": side["algorithmic_GBps"],
+            "algorithmic_frac": side["algorithmic_GBps"] * 1e9 / HBM_PEAK if side.get("algorithmic_GBps") else None,
             "algorithmic_reuse": side.get("algorithmic_reuse"),
             "issue_limits": issue,
-            "note": "`achieved` = measured memory-side traffic of the CSR-gather kernel per launch (PMC, same build, same workload) / its HIP-event time on the "
-            "library's stream.  SURVEY §8d's ALGORITHMIC bytes (4*nnz + 4*(N+1) + N per permutation) are `algorithmic_reuse` times the traffic, because one "
-            "pass over the edge list serves 16 permutations — that ratio is reuse, not a roofline fraction.  The kernel is not HBM-bound: `issue_limits` "
-            "prices it against the L1 access rate of its gathers and the LDS-atomic rate (probe variants: profiles/r02_count_probes.json; "
-            "round-3 experiments: profiles/r03_nhood_experiments.json, profiles/r03_ubench_count_shape.json)",
+            "note": "`frac` = COMPULSORY DRAM bytes of the CSR-gather kernel per launch / its HIP-event time on the library's stream / 8 TB/s.  `fabric_frac` = measured memory-side "
+            "traffic (PMC, same build, same workload) — it includes re-reads of the 24 MB edge list that the Infinity Cache serves.  `algorithmic_frac` = SURVEY §8d's bytes "
+            "(4*nnz + 4*(N+1) + N per permutation) over the same time: above 1 because one pass over the edge list serves 16 permutations — REUSE, not a roofline fraction.  "
+            "The kernel is not HBM-bound: `issue_limits` prices it against the L1 access rate of its gathers and the LDS-atomic rate (probe variants: "
+            "profiles/r02_count_probes.json; experiments: profiles/r03_nhood_experiments.json, profiles/r04_mall_groups.json)",
         }
-        if roof["frac"] is None:
-            roof["note"] += ".  No PMC profile of THIS build and workload is committed (" + str(counters.get("_status")) + "): traffic / achieved / frac are null"
+        if roof["fabric_frac"] is None:
+            roof["note"] += ".  No PMC profile of THIS build and workload is committed (" + str(counters.get("_status")) + "): the fabric figures are null"
         # ---- label shuffle: VALU issue
         avg_shuf_ms = ms_shuf / max(shuf_launch, 1)
         side_s, rec_s = hbm_side("k_shuffle", n * perms_per_launch, avg_shuf_ms)
