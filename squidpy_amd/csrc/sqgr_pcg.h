@@ -1,6 +1,8 @@
 // libsqgr internal: numpy-compatible permutation streams on the device (PCG64 + Generator.shuffle / permutation).
 // Implemented in sqgr_pcg.hip.
 #pragma once
+#include <vector>
+
 #include "sqgr_common.h"
 
 namespace sqgr {
@@ -10,6 +12,12 @@ struct PcgWorkspace {
     DevBuf<uint8_t> rows;   // [permutation][n_pad] row-major shuffle workspace
     DevBuf<uint32_t> span;  // {0, n}: the single "library" of a plain permutation
     DevBuf<int32_t> cols;   // column workspace of the one-thread-per-permutation kernel (SQGR_PCG_KERNEL=lane)
+    // the bucketed replay (long arrays): time-ordered swap records per (permutation, phase, 64-record block), their directory
+    // (range | count << 8 | ordinal << 16 per block) and the blocks written per phase; library geometry cached from the device
+    DevBuf<uint32_t> recs, dir, nblk, lib_phase;
+    std::vector<uint32_t> lib_off_h;
+    const uint32_t* lib_off_key = nullptr;
+    int lib_phase_logs = -1, phases = 0;
 };
 
 // W[pos * stride + q] = element `pos` of the byte array numpy's generator q (states_dev row q: state_hi, state_lo, inc_hi,

@@ -8,6 +8,9 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
 
 namespace sqgr {
 
@@ -453,6 +456,330 @@ __global__ __launch_bounds__(64) void k_pcg_shuffle_wave(int64_t n, int64_t row_
     }
 }
 
+// ---- the bucketed replay: coalesced traffic instead of one random HBM sector per swap side --------------------------
+// At 1e6 positions the wave kernel above moves two random 64-byte sectors per swap (152 MB per permutation for a 1 MB row).
+// The swaps of numpy's Fisher-Yates can be replayed in another order without changing the result (argument and numpy-level
+// proof of the order: oracle/pcg_bucket.py, tests/test_pcg_bucket_cpu.py):
+//  * phase f = the steps whose i lies in [f*S, (f+1)*S) (S = 2^logS positions, <= 65536), range r = j / S;
+//  * position i is read only by step i itself and by earlier steps e > i with j_e == i — those lie in range r == f; no later
+//    step touches i again (j_e <= e < i).  So a phase may apply its swaps RANGE BY RANGE: first the window range r == f (both
+//    sides inside the phase's own S positions), then every range r < f in any order, time order inside a range.
+// k_pcg_draws_bucketed (G, one wave per permutation) generates the draws with the exact acceptance logic of the wave kernel and
+// appends (j mod S | (i mod S) << 16) to time-ordered lists per (phase, range), in 64-record blocks: records
+// [perm][phase][block][64], directory entry per block = range | count << 8 | ordinal-within-range << 16.
+// k_pcg_apply_bucketed (A, one 1024-lane workgroup per permutation) walks the phases from the top: window and one range at a
+// time in LDS (coalesced 64 KB loads and stores), the records of a (phase, range) list applied 1024 at a time in ROUNDS: a
+// record goes when it is the earliest pending record of the chunk on its j slot (hashed tags, atomic max of epoch | 1023 - lane)
+// and — in the window range — no earlier pending record writes to its i slot; the others wait for the next round (~3.5 rounds
+// per chunk at 1e6 positions).  Traffic per permutation: ranges 16 phases x ~0.5 MB x 2 + records 2 x 4.3 MB.
+constexpr int PCGB_MAX_RANGES = 64;   // ranges per library (lane r of the generator wave keeps range r's cursors)
+constexpr int PCGB_RING = 128;        // staging ring per range (records)
+constexpr int PCGB_SLOTS = 4096;      // conflict tags of the apply kernel
+constexpr int PCGB_THREADS = 1024;
+
+struct PcgBucketGeom {
+    int logS;              // log2 of the phase / range length
+    int n_ranges;          // max over libraries of ceil(m / S)
+    int bcap;              // blocks per phase: S / 64 + n_ranges (rounded up when S < 64)
+    int phases;            // phases of all libraries of one permutation
+};
+
+__device__ __forceinline__ uint32_t lane_get(uint32_t v, uint32_t src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src); }
+
+__global__ __launch_bounds__(64) void k_pcg_draws_bucketed(int n_libs, const uint32_t* __restrict__ lib_off, const uint32_t* __restrict__ lib_phase,
+                                                           const uint64_t* __restrict__ states, const uint64_t* __restrict__ jump, int64_t P,
+                                                           PcgBucketGeom geo, uint32_t* __restrict__ recs, uint32_t* __restrict__ dir,
+                                                           uint32_t* __restrict__ nblk, int force_slow) {
+    extern __shared__ uint32_t s_stage[];  // [n_ranges][PCGB_RING]
+    __shared__ uint64_t sA[PCGW_TAB][2], sD[PCGW_TAB][2];
+    __shared__ uint32_t sJ[64];
+    const int lane = threadIdx.x;
+    const uint32_t logS = (uint32_t)geo.logS, SM = (1u << logS) - 1u;
+    const int64_t p = blockIdx.x;
+    if (p >= P) return;
+    U128 s, inc;
+    s.hi = states[4 * p + 0];
+    s.lo = states[4 * p + 1];
+    inc.hi = states[4 * p + 2];
+    inc.lo = states[4 * p + 3];
+    if (lane < PCGW_TAB) {
+        U128 a, g;
+        a.hi = jump[4 * lane + 0];
+        a.lo = jump[4 * lane + 1];
+        g.hi = jump[4 * lane + 2];
+        g.lo = jump[4 * lane + 3];
+        const U128 d = mul128_lo(g, inc);
+        sA[lane][0] = a.hi;
+        sA[lane][1] = a.lo;
+        sD[lane][0] = d.hi;
+        sD[lane][1] = d.lo;
+    }
+    uint32_t* const rec_p = recs + (size_t)p * geo.phases * geo.bcap * 64;
+    uint32_t* const dir_p = dir + (size_t)p * geo.phases * geo.bcap;
+    uint32_t* const nblk_p = nblk + (size_t)p * geo.phases;
+    // lane r keeps the cursors of range r: records staged, ring head, blocks flushed in this phase
+    uint32_t c_cnt = 0, c_head = 0, c_ord = 0;
+    uint32_t nb = 0;   // blocks written in the current phase (uniform)
+    uint32_t ph = 0;   // global index of the current phase (uniform)
+    auto flush_block = [&](uint32_t r0, uint32_t head, uint32_t count) {  // uniform arguments
+        const uint32_t v = s_stage[r0 * PCGB_RING + ((head + (uint32_t)lane) & (PCGB_RING - 1))];
+        uint32_t* dst = rec_p + ((size_t)ph * geo.bcap + nb) * 64;
+        const uint32_t ordinal = lane_get(c_ord, r0);
+        if ((uint32_t)lane < count) dst[lane] = v;
+        if (lane == 0) dir_p[(size_t)ph * geo.bcap + nb] = r0 | (count << 8) | (ordinal << 16);
+        if ((uint32_t)lane == r0) ++c_ord;
+        ++nb;
+    };
+    auto end_phase = [&](uint32_t f) {  // the partial blocks of ranges 0..f, then the phase's block count
+        for (uint32_t r0 = 0; r0 <= f; ++r0) {
+            const uint32_t cnt = lane_get(c_cnt, r0);
+            if (cnt > 0u) flush_block(r0, lane_get(c_head, r0), cnt);
+        }
+        if (lane == 0) nblk_p[ph] = nb;
+        c_cnt = 0;
+        c_head = 0;
+        c_ord = 0;
+        nb = 0;
+    };
+    // append the records of the lanes with `in` set (lane order == time order) to their ranges' rings; full blocks go out
+    auto append = [&](bool in, uint32_t iloc, uint32_t jj) {
+        const uint32_t r = jj >> logS;
+        const uint32_t rec = (jj & SM) | (iloc << 16);
+        uint64_t todo = __ballot(in);
+        while (todo != 0ull) {
+            const uint32_t r0 = lane_get(r, (uint32_t)__builtin_ctzll(todo));
+            const bool mine = in && r == r0;
+            const uint64_t m = __ballot(mine);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            const uint32_t cnt = lane_get(c_cnt, r0), head = lane_get(c_head, r0);
+            if (mine) s_stage[r0 * PCGB_RING + ((head + cnt + rank) & (PCGB_RING - 1))] = rec;
+            uint32_t ncnt = cnt + (uint32_t)__popcll(m), nhead = head;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the ring is read back by other lanes of this wave
+            if (ncnt >= 64u) {
+                flush_block(r0, head, 64u);
+                ncnt -= 64u;
+                nhead = (head + 64u) & (PCGB_RING - 1);
+            }
+            if ((uint32_t)lane == r0) {
+                c_cnt = ncnt;
+                c_head = nhead;
+            }
+            todo &= ~m;
+        }
+    };
+    uint32_t half = 0;
+    U128 sk;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    uint32_t raw = pcgw_draw(s, half, lane, sA, sD, sk);
+    for (int l = 0; l < n_libs; ++l) {
+        const uint32_t off = lib_off[l];
+        const uint32_t m = lib_off[l + 1] - off;
+        if (m < 2) continue;
+        uint32_t mask = m - 1;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        uint32_t i = m - 1;
+        uint32_t f_cur = i >> logS;
+        ph = lib_phase[l] + f_cur;
+        while (i >= 1) {
+            uint32_t used = 64, nacc = 0, it = i;
+            bool valid = false;
+            uint32_t ipos = 0, jj = 0;
+            const bool general = force_slow || i < 192u || (mask >> 1) >= i - 64u;
+            if (!general) {  // (see k_pcg_shuffle_wave: sure / ambiguous candidates, decided from the running count)
+                const uint32_t c = raw & mask;
+                const bool sure = c <= i - 64u;
+                const uint64_t ambm = __ballot(!sure && c <= i);
+                uint64_t accm = __ballot(sure);
+                for (uint64_t rem = ambm; rem != 0ull; rem &= rem - 1ull) {
+                    const int dd = __builtin_ctzll(rem);
+                    const uint32_t cd = lane_get(c, (uint32_t)dd);
+                    const uint32_t before = (uint32_t)__popcll(accm & ((1ull << dd) - 1ull));
+                    if (cd <= i - before) accm |= 1ull << dd;
+                }
+                valid = (accm >> lane) & 1ull;
+                const uint32_t t = __builtin_amdgcn_mbcnt_hi((uint32_t)(accm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)accm, 0u));
+                nacc = (uint32_t)__popcll(accm);
+                it = i - nacc;
+                ipos = i - t;
+                jj = c;
+            } else {
+                uint32_t t = 0;
+                for (int dd = 0; dd < 64; ++dd) {
+                    const uint32_t c = lane_get(raw, (uint32_t)dd) & mask;
+                    if (c <= it) {
+                        if (lane == 0) sJ[t] = c;
+                        ++t;
+                        --it;
+                        if ((mask >> 1) >= it) mask >>= 1;
+                        if (it == 0u) {
+                            used = (uint32_t)dd + 1u;
+                            break;
+                        }
+                    }
+                }
+                nacc = t;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                valid = (uint32_t)lane < nacc;
+                ipos = i - (uint32_t)lane;
+                jj = valid ? sJ[lane] : 0u;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+            if (nacc > 0u) {
+                const uint32_t f_last = (it + 1u) >> logS;  // phase of the trip's last step
+                for (uint32_t f = f_cur;; --f) {
+                    append(valid && (ipos >> logS) == f, ipos & SM, jj);
+                    if (f == f_last) break;
+                    end_phase(f);
+                    --ph;
+                }
+                f_cur = f_last;
+            }
+            i = it;
+            if (i >= 1u && (i >> logS) != f_cur) {  // the next step opens a new phase
+                end_phase(f_cur);
+                --ph;
+                f_cur = i >> logS;
+            }
+            pcgw_advance(s, half, sk, used);
+            raw = pcgw_draw(s, half, lane, sA, sD, sk);
+        }
+        end_phase(f_cur);  // f_cur == 0 here: the library's last phase
+    }
+}
+
+__device__ __forceinline__ void pcgb_copy_in(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t len, int tid) {
+    if ((reinterpret_cast<uintptr_t>(src) & 15u) == 0u) {
+        const uint32_t n16 = len >> 4;
+        for (uint32_t k = (uint32_t)tid; k < n16; k += PCGB_THREADS) reinterpret_cast<uint4*>(dst)[k] = reinterpret_cast<const uint4*>(src)[k];
+        for (uint32_t k = (n16 << 4) + (uint32_t)tid; k < len; k += PCGB_THREADS) dst[k] = src[k];
+    } else {
+        for (uint32_t k = (uint32_t)tid; k < len; k += PCGB_THREADS) dst[k] = src[k];
+    }
+}
+__device__ __forceinline__ void pcgb_copy_out(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t len, int tid) {
+    if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0u) {
+        const uint32_t n16 = len >> 4;
+        for (uint32_t k = (uint32_t)tid; k < n16; k += PCGB_THREADS) reinterpret_cast<uint4*>(dst)[k] = reinterpret_cast<const uint4*>(src)[k];
+        for (uint32_t k = (n16 << 4) + (uint32_t)tid; k < len; k += PCGB_THREADS) dst[k] = src[k];
+    } else {
+        for (uint32_t k = (uint32_t)tid; k < len; k += PCGB_THREADS) dst[k] = src[k];
+    }
+}
+
+__global__ __launch_bounds__(PCGB_THREADS) void k_pcg_apply_bucketed(int64_t row_stride, int n_libs, const uint32_t* __restrict__ lib_off,
+                                                                     const uint32_t* __restrict__ lib_phase, const uint8_t* __restrict__ base_pos,
+                                                                     int64_t P, PcgBucketGeom geo, const uint32_t* __restrict__ recs,
+                                                                     const uint32_t* __restrict__ dir, const uint32_t* __restrict__ nblk,
+                                                                     uint8_t* __restrict__ R) {
+    extern __shared__ unsigned char s_dyn[];
+    const uint32_t logS = (uint32_t)geo.logS, S = 1u << logS;
+    uint8_t* const Xw = s_dyn;                                            // the phase's window: positions [f*S, (f+1)*S)
+    uint8_t* const Xr = s_dyn + S;                                        // one range r < f
+    uint32_t* const tags = reinterpret_cast<uint32_t*>(s_dyn + 2 * (size_t)S);  // [PCGB_SLOTS]
+    uint32_t* const blist = tags + PCGB_SLOTS;                            // [bcap] block | count << 16, sorted by (range, ordinal)
+    __shared__ uint32_t s_hist[PCGB_MAX_RANGES], s_start[PCGB_MAX_RANGES + 1];
+    __shared__ uint8_t s_dirty[PCGB_MAX_RANGES];                          // range already written to the row (else: still base_pos)
+    const int tid = threadIdx.x;
+    const uint32_t L = (uint32_t)tid;
+    for (int64_t p = blockIdx.x; p < P; p += gridDim.x) {
+        const uint32_t* const rec_p = recs + (size_t)p * geo.phases * geo.bcap * 64;
+        const uint32_t* const dir_p = dir + (size_t)p * geo.phases * geo.bcap;
+        const uint32_t* const nblk_p = nblk + (size_t)p * geo.phases;
+        uint8_t* const row = R + p * row_stride;
+        for (int k = tid; k < PCGB_SLOTS; k += PCGB_THREADS) tags[k] = 0u;
+        uint32_t epoch = 0;
+        for (int l = 0; l < n_libs; ++l) {
+            const uint32_t off = lib_off[l];
+            const uint32_t m = lib_off[l + 1] - off;
+            if (m == 0u) continue;
+            if (m == 1u) {
+                if (tid == 0) row[off] = base_pos[off];
+                continue;
+            }
+            const uint32_t F = (m + S - 1u) >> logS;
+            __syncthreads();
+            if (tid < PCGB_MAX_RANGES) s_dirty[tid] = 0;
+            for (uint32_t ff = F; ff-- > 0u;) {
+                const uint32_t f = ff;
+                const uint32_t ph = lib_phase[l] + f;
+                const uint32_t wlen = min(S, m - (f << logS));
+                __syncthreads();
+                pcgb_copy_in(Xw, (s_dirty[f] ? row : base_pos) + off + ((size_t)f << logS), wlen, tid);
+                if (tid < PCGB_MAX_RANGES) s_hist[tid] = 0u;
+                __syncthreads();
+                const uint32_t nb = nblk_p[ph];
+                for (uint32_t t = L; t < nb; t += PCGB_THREADS) atomicAdd(&s_hist[dir_p[(size_t)ph * geo.bcap + t] & 0xffu], 1u);
+                __syncthreads();
+                if (tid == 0) {
+                    uint32_t acc = 0;
+                    for (uint32_t r = 0; r <= f; ++r) {
+                        s_start[r] = acc;
+                        acc += s_hist[r];
+                    }
+                    s_start[f + 1] = acc;
+                }
+                __syncthreads();
+                for (uint32_t t = L; t < nb; t += PCGB_THREADS) {
+                    const uint32_t e = dir_p[(size_t)ph * geo.bcap + t];
+                    blist[s_start[e & 0xffu] + (e >> 16)] = t | (((e >> 8) & 0xffu) << 16);
+                }
+                __syncthreads();
+                for (uint32_t rr = 0; rr <= f; ++rr) {
+                    const uint32_t r = rr == 0u ? f : rr - 1u;  // the window range first
+                    const uint32_t nbr = s_hist[r], b0 = s_start[r];
+                    if (nbr == 0u) continue;
+                    const bool internal = r == f;
+                    uint8_t* const X2 = internal ? Xw : Xr;
+                    if (!internal) {
+                        pcgb_copy_in(Xr, (s_dirty[r] ? row : base_pos) + off + ((size_t)r << logS), S, tid);
+                        __syncthreads();
+                    }
+                    for (uint32_t c0 = 0; c0 < nbr; c0 += PCGB_THREADS / 64) {
+                        const uint32_t bi = c0 + (L >> 6);
+                        bool pending = false;
+                        uint32_t iloc = 0, jloc = 0;
+                        if (bi < nbr) {
+                            const uint32_t e = blist[b0 + bi];
+                            if ((L & 63u) < (e >> 16)) {
+                                const uint32_t rec = rec_p[((size_t)ph * geo.bcap + (e & 0xffffu)) * 64 + (L & 63u)];
+                                jloc = rec & 0xffffu;
+                                iloc = rec >> 16;
+                                pending = true;
+                            }
+                        }
+                        const uint32_t hj = (jloc * 2654435761u) >> 20, hi = (iloc * 2654435761u) >> 20;
+                        for (;;) {
+                            ++epoch;
+                            const uint32_t mine = (epoch << 10) | (1023u - L);
+                            if (pending) atomicMax(&tags[hj], mine);
+                            __syncthreads();
+                            bool go = pending && tags[hj] == mine;
+                            if (go && internal) {  // no earlier pending record of the chunk may write to this record's i position
+                                const uint32_t tg = tags[hi];
+                                go = (tg >> 10) != epoch || (1023u - (tg & 1023u)) >= L;
+                            }
+                            if (go) {
+                                const uint8_t a = Xw[iloc], b = X2[jloc];
+                                Xw[iloc] = b;
+                                X2[jloc] = a;
+                                pending = false;
+                            }
+                            if (!__syncthreads_or(pending ? 1 : 0)) break;
+                        }
+                    }
+                    if (!internal) {
+                        pcgb_copy_out(row + off + ((size_t)r << logS), Xr, S, tid);
+                        if (tid == 0) s_dirty[r] = 1;
+                        __syncthreads();
+                    }
+                }
+                pcgb_copy_out(row + off + ((size_t)f << logS), Xw, wlen, tid);  // positions of this phase are final
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // rows R[q][row_stride] (bytes) -> columns W[pos * stride + q]
 __global__ __launch_bounds__(256) void k_rows_to_columns_u8(int64_t n, int64_t row_stride, const uint8_t* __restrict__ R, int64_t P,
                                                             int64_t stride, uint8_t* __restrict__ W) {
@@ -532,10 +859,92 @@ static int pcg_force_slow() {
 
 namespace sqgr {
 
+// The bucketed replay (k_pcg_draws_bucketed + k_pcg_apply_bucketed) is chosen for long arrays, where the wave kernel's rows fall
+// out of every cache; SQGR_PCG_KERNEL=bucket|wave|lane forces a kernel, SQGR_PCG_BUCKET_LOGS the phase length (tests: many phases
+// on small arrays).
+static int pcg_bucket_logs(int64_t n_lib_max) {
+    const char* e = getenv("SQGR_PCG_BUCKET_LOGS");
+    int logs = (e && atoi(e) >= 6 && atoi(e) <= 16) ? atoi(e) : 16;
+    while (logs < 16 && ceil_div(n_lib_max, (int64_t)1 << logs) > PCGB_MAX_RANGES) ++logs;
+    return logs;
+}
+static bool pcg_use_bucket(int64_t n, int64_t n_lib_max) {
+    const char* e = getenv("SQGR_PCG_KERNEL");
+    if (e && strcmp(e, "bucket") == 0) return ceil_div(n_lib_max, (int64_t)1 << pcg_bucket_logs(n_lib_max)) <= PCGB_MAX_RANGES;
+    if (e && (strcmp(e, "wave") == 0 || strcmp(e, "lane") == 0)) return false;
+    return n >= ((int64_t)1 << 17) && ceil_div(n_lib_max, (int64_t)1 << 16) <= PCGB_MAX_RANGES;
+}
+
+static int pcg_shuffle_rows_bucketed(sqgr_ctx* ctx, PcgWorkspace& ws, int64_t n, int64_t n_pad, int n_libs, const uint32_t* lib_off_dev,
+                                     const uint8_t* base_pos_dev, const uint64_t* states_dev, int64_t pc, hipStream_t st, const char* timer_name) {
+    // geometry from the library sizes (host copy, cached per plan workspace)
+    if (ws.lib_off_key != lib_off_dev || (int)ws.lib_off_h.size() != n_libs + 1) {
+        ws.lib_off_h.resize((size_t)n_libs + 1);
+        SQGR_HIP(hipMemcpyAsync(ws.lib_off_h.data(), lib_off_dev, ((size_t)n_libs + 1) * 4, hipMemcpyDeviceToHost, st));
+        SQGR_HIP(hipStreamSynchronize(st));
+        ws.lib_off_key = lib_off_dev;
+        ws.lib_phase_logs = -1;
+    }
+    int64_t n_lib_max = 1;
+    for (int l = 0; l < n_libs; ++l) n_lib_max = std::max<int64_t>(n_lib_max, (int64_t)ws.lib_off_h[l + 1] - ws.lib_off_h[l]);
+    PcgBucketGeom geo;
+    geo.logS = pcg_bucket_logs(n_lib_max);
+    const int64_t S = (int64_t)1 << geo.logS;
+    geo.n_ranges = (int)ceil_div(n_lib_max, S);
+    geo.bcap = (int)(ceil_div(S, 64) + geo.n_ranges);
+    if (ws.lib_phase_logs != geo.logS) {
+        std::vector<uint32_t> lp((size_t)n_libs + 1);
+        uint32_t acc = 0;
+        for (int l = 0; l < n_libs; ++l) {
+            lp[l] = acc;
+            acc += (uint32_t)ceil_div((int64_t)ws.lib_off_h[l + 1] - ws.lib_off_h[l], S);
+        }
+        lp[n_libs] = acc;
+        SQGR_TRY(ws.lib_phase.ensure(lp.size()));
+        SQGR_HIP(hipMemcpyAsync(ws.lib_phase.p, lp.data(), lp.size() * 4, hipMemcpyHostToDevice, st));
+        SQGR_HIP(hipStreamSynchronize(st));
+        ws.lib_phase_logs = geo.logS;
+        ws.phases = (int)acc;
+    }
+    geo.phases = std::max(ws.phases, 1);
+    const size_t rec_words = (size_t)geo.phases * geo.bcap * 64;   // per permutation
+    // permutations per pass: <= ~12 GB of records in flight
+    const int64_t sub = std::max<int64_t>(64, std::min<int64_t>(pc, (int64_t)(((size_t)12 << 30) / (rec_words * 4))));
+    SQGR_TRY(ws.recs.ensure((size_t)sub * rec_words));
+    SQGR_TRY(ws.dir.ensure((size_t)sub * geo.phases * geo.bcap));
+    SQGR_TRY(ws.nblk.ensure((size_t)sub * geo.phases));
+    const size_t lds_g = (size_t)geo.n_ranges * PCGB_RING * 4;
+    const size_t lds_a = 2 * (size_t)S + (size_t)PCGB_SLOTS * 4 + (size_t)geo.bcap * 4;
+    SQGR_TRY(pcg_allow_lds(k_pcg_draws_bucketed, lds_g));
+    SQGR_TRY(pcg_allow_lds(k_pcg_apply_bucketed, lds_a));
+    const std::string name_g = std::string(timer_name) + "_draws", name_a = std::string(timer_name) + "_apply";
+    const int cus = std::max(ctx->cu_count, 1);
+    const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, ((size_t)160 << 10) / (lds_a + 1024)));
+    for (int64_t q0 = 0; q0 < pc; q0 += sub) {
+        const int64_t qc = std::min(sub, pc - q0);
+        SQGR_HIP(hipMemsetAsync(ws.nblk.p, 0, (size_t)qc * geo.phases * 4, st));
+        {
+            LaunchTimer t(ctx, name_g.c_str(), st);
+            k_pcg_draws_bucketed<<<(unsigned)qc, 64, lds_g, st>>>(n_libs, lib_off_dev, ws.lib_phase.p, states_dev + 4 * q0, ws.jump.p, qc, geo, ws.recs.p,
+                                                                  ws.dir.p, ws.nblk.p, pcg_force_slow());
+            SQGR_HIP(hipGetLastError());
+        }
+        {
+            LaunchTimer t(ctx, name_a.c_str(), st);
+            const unsigned grid = (unsigned)std::min<int64_t>(qc, (int64_t)cus * wg_per_cu);
+            k_pcg_apply_bucketed<<<grid, PCGB_THREADS, lds_a, st>>>(n_pad, n_libs, lib_off_dev, ws.lib_phase.p, base_pos_dev, qc, geo, ws.recs.p, ws.dir.p,
+                                                                    ws.nblk.p, ws.rows.p + (size_t)q0 * n_pad);
+            SQGR_HIP(hipGetLastError());
+        }
+    }
+    (void)n;
+    return SQGR_OK;
+}
+
 int pcg_shuffle_labels(sqgr_ctx* ctx, PcgWorkspace& ws, int64_t n, int n_libs, const uint32_t* lib_off_dev, const uint8_t* base_pos_dev,
                        const uint64_t* states_dev, int64_t pc, int64_t stride, uint8_t* W, hipStream_t st, const char* timer_name) {
-    LaunchTimer t(ctx, timer_name, st);
     if (pcg_lane_kernel()) {
+        LaunchTimer t(ctx, timer_name, st);
         const int64_t pc64 = std::min<int64_t>(stride, ceil_div(pc, 64) * 64);
         if (pc64 > pc)  // columns past pc that whole-batch consumers still read: label 0 instead of stale bytes
             SQGR_HIP(hipMemset2DAsync(W + pc, (size_t)stride, 0, (size_t)(pc64 - pc), (size_t)n, st));
@@ -546,13 +955,35 @@ int pcg_shuffle_labels(sqgr_ctx* ctx, PcgWorkspace& ws, int64_t n, int n_libs, c
     const int64_t n_pad = ceil_div(n, 64) * 64;
     SQGR_TRY(ensure_pcg_jump(ws.jump));
     SQGR_TRY(ws.rows.ensure((size_t)pc * n_pad));
-    const uint32_t wsz = pcg_window(n);
-    SQGR_TRY(pcg_allow_lds(k_pcg_shuffle_wave<uint8_t, false>, (size_t)wsz));
-    k_pcg_shuffle_wave<uint8_t, false><<<pcg_grid(pc), 64, (size_t)wsz, st>>>(n, n_pad, n_libs, lib_off_dev, base_pos_dev, states_dev,
-                                                                              ws.jump.p, pc, ws.rows.p, pcg_force_slow(), wsz);
-    SQGR_HIP(hipGetLastError());
-    k_rows_to_columns_u8<<<dim3((unsigned)ceil_div(n, 64), (unsigned)ceil_div(pc, 64)), 256, 0, st>>>(n, n_pad, ws.rows.p, pc, stride, W);
-    SQGR_HIP(hipGetLastError());
+    // library sizes decide between the wave kernel and the bucketed replay (one library: its size is n)
+    int64_t n_lib_max = n;
+    if (n_libs > 1 && (ws.lib_off_key != lib_off_dev || (int)ws.lib_off_h.size() != n_libs + 1)) {
+        ws.lib_off_h.resize((size_t)n_libs + 1);
+        SQGR_HIP(hipMemcpyAsync(ws.lib_off_h.data(), lib_off_dev, ((size_t)n_libs + 1) * 4, hipMemcpyDeviceToHost, st));
+        SQGR_HIP(hipStreamSynchronize(st));
+        ws.lib_off_key = lib_off_dev;
+        ws.lib_phase_logs = -1;
+    }
+    if (n_libs > 1) {
+        n_lib_max = 1;
+        for (int l = 0; l < n_libs; ++l) n_lib_max = std::max<int64_t>(n_lib_max, (int64_t)ws.lib_off_h[l + 1] - ws.lib_off_h[l]);
+    }
+    if (pcg_use_bucket(n, n_lib_max)) {
+        SQGR_TRY(pcg_shuffle_rows_bucketed(ctx, ws, n, n_pad, n_libs, lib_off_dev, base_pos_dev, states_dev, pc, st, timer_name));
+    } else {
+        LaunchTimer t(ctx, timer_name, st);
+        const uint32_t wsz = pcg_window(n);
+        SQGR_TRY(pcg_allow_lds(k_pcg_shuffle_wave<uint8_t, false>, (size_t)wsz));
+        k_pcg_shuffle_wave<uint8_t, false><<<pcg_grid(pc), 64, (size_t)wsz, st>>>(n, n_pad, n_libs, lib_off_dev, base_pos_dev, states_dev,
+                                                                                  ws.jump.p, pc, ws.rows.p, pcg_force_slow(), wsz);
+        SQGR_HIP(hipGetLastError());
+    }
+    {
+        const std::string name_t = std::string(timer_name) + "_rows_to_columns";
+        LaunchTimer t(ctx, name_t.c_str(), st);
+        k_rows_to_columns_u8<<<dim3((unsigned)ceil_div(n, 64), (unsigned)ceil_div(pc, 64)), 256, 0, st>>>(n, n_pad, ws.rows.p, pc, stride, W);
+        SQGR_HIP(hipGetLastError());
+    }
     return SQGR_OK;
 }
 

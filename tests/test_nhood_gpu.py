@@ -351,6 +351,51 @@ def test_numpy_shuffle_kernel_variants_agree_with_numpy(L, ctx, variant, monkeyp
     assert len({w.tobytes() for w in want}) == P  # the counts do depend on the arrangement
 
 
+@pytest.mark.parametrize("logs", ["6", "8", "12", "default"])
+def test_numpy_shuffle_bucketed_replay_agrees_with_numpy(L, ctx, logs, monkeypatch):
+    """The bucketed replay of `Generator.shuffle` (draws appended to per-(phase, range) lists, swaps applied range by range in
+    concurrent rounds: csrc/sqgr_pcg.hip, oracle/pcg_bucket.py) must leave numpy's arrays bit for bit — phase lengths of 64,
+    256 and 4096 positions put tens to thousands of phases, partial top phases and phase boundaries inside a 64-draw trip on
+    small arrays; "default" is the production geometry (65536) on a 200 001-element array.  The counts over the ring graph
+    i -> i+1 with ~250 distinct labels see every misplaced element."""
+    from squidpy_amd._utils import pcg64_states
+
+    monkeypatch.setenv("SQGR_PCG_KERNEL", "bucket")
+    if logs != "default":
+        monkeypatch.setenv("SQGR_PCG_BUCKET_LOGS", logs)
+    sizes = (2, 3, 63, 64, 65, 129, 193, 1000, 4097, 33000) if logs != "default" else (1000, 70001, 200001)
+    for n in sizes:
+        if logs == "6" and n > 4097:  # at most 64 ranges per library: S = 64 serves up to 4096 positions
+            continue
+        P, k = (40 if n < 10000 else 6), 251
+        labels = (np.arange(n) * 7919 % k).astype(np.int32)
+        ring = sp.csr_matrix((np.ones(n, np.float32), (np.arange(n), (np.arange(n) + 1) % n)), shape=(n, n))
+        g = L.Graph(ctx, ring)
+        plan = L.NhoodPlan(ctx, g, labels, k)
+        _, _, perms = plan.run_pcg64(pcg64_states(n, P), return_perms=True)
+        ref = O.nhood_perm_counts_numpy(ring.indices, ring.indptr, labels, k, n, P)
+        np.testing.assert_array_equal(perms, ref.astype(np.uint32), err_msg=f"n={n} logS={logs}")
+        plan.close()
+        g.close()
+    if logs in ("6", "default"):
+        return
+    # libraries (`_shuffle_group`): one generator walks them in category order; sizes from 1 to thousands, unaligned offsets
+    rng = np.random.default_rng(5)
+    n, k, n_libs, P = 6000, 9, 7, 40
+    labels = rng.integers(0, k, n).astype(np.int32)
+    libs = rng.integers(0, n_libs, n).astype(np.int32)
+    libs[:300] = 3
+    libs[libs == 6] = np.where(rng.random((libs == 6).sum()) < 0.01, 6, 0)
+    ring = sp.csr_matrix((np.ones(n, np.float32), (np.arange(n), (np.arange(n) + 1) % n)), shape=(n, n))
+    g = L.Graph(ctx, ring)
+    plan = L.NhoodPlan(ctx, g, labels, k, libs, n_libs)
+    _, _, perms = plan.run_pcg64(pcg64_states(21, P), return_perms=True)
+    want = np.stack([
+        O.nhood_counts(ring.indices, ring.indptr, O.shuffle_group(labels, libs, n_libs, rs), k) for rs in O.spawn_generators(21, P)
+    ])
+    np.testing.assert_array_equal(perms, want.astype(np.uint32))
+
+
 def test_skewed_cluster_sizes(L, ctx):
     """SURVEY §8d skewed variant: Dirichlet(0.5) cluster proportions (a few huge clusters, some almost empty, one
     empty) concentrate the count kernel's LDS atomics on few counters and make label boundaries fall inside single
