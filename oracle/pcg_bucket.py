@@ -75,8 +75,9 @@ def apply_bucketed(x: np.ndarray, j: np.ndarray, S: int, chunk: int = 1024, slot
             for c0 in range(0, len(rec), chunk):
                 ch = rec[c0:c0 + chunk]
                 ii, jj = i_of[ch], j[ch]
-                hj = ((jj % S) * 2654435761 % (1 << 32)) >> 20 if slots == 4096 else (jj % S) % slots
-                hi = ((ii % S) * 2654435761 % (1 << 32)) >> 20 if slots == 4096 else (ii % S) % slots
+                shift = 32 - int(np.log2(slots))  # the device's multiplicative hash of the position inside its range
+                hj = ((jj % S) * 2654435761 % (1 << 32)) >> shift
+                hi = ((ii % S) * 2654435761 % (1 << 32)) >> shift
                 pending = np.ones(len(ch), dtype=bool)
                 chunks_total += 1
                 while pending.any():

@@ -835,6 +835,39 @@ __global__ __launch_bounds__(256) void k_columns_to_slab(int64_t n, int64_t stri
     for (int v = 0; v < B / 16; ++v) dst[v] = src[v];
 }
 
+// rows of the numpy-stream shuffle -> slab rows of the batched count kernel, without the column matrix in between (no libraries:
+// position == spot): slab[(batch*n + i)*B + b] = R[(q0 + batch*B + b) * row_stride + i].  A thread takes 4 consecutive spots:
+// one dword from each of the batch's B rows (a wave reads 256 contiguous bytes per row), a 4 x B byte transposition in registers
+// (v_perm_b32), 4 slab rows = 4*B contiguous bytes out.  Rows past `pc` read as label 0 (consumers read whole batches).
+template <int B>
+__global__ __launch_bounds__(256) void k_rows_to_slab(int64_t n, int64_t row_stride, const uint8_t* __restrict__ R, int64_t q0, int64_t pc,
+                                                      uint8_t* __restrict__ slab_all) {
+    const int64_t i4 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4;
+    if (i4 >= n) return;
+    const int batch = blockIdx.y;
+    uint32_t v[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        const int64_t q = q0 + (int64_t)batch * B + b;
+        v[b] = q < pc ? *reinterpret_cast<const uint32_t*>(R + q * row_stride + i4) : 0u;  // (row_stride is a multiple of 64 >= n)
+    }
+    uint8_t* dst = slab_all + ((size_t)batch * n + i4) * B;
+#pragma unroll
+    for (int sp = 0; sp < 4; ++sp) {
+        if (i4 + sp >= n) break;
+        const uint32_t sel = (uint32_t)sp | ((4u + (uint32_t)sp) << 4);  // byte sp of x, byte sp of y
+        uint32_t w[B / 4];
+#pragma unroll
+        for (int k = 0; k < B / 4; ++k) {
+            const uint32_t lo = __byte_perm(v[4 * k], v[4 * k + 1], sel), hi = __byte_perm(v[4 * k + 2], v[4 * k + 3], sel);
+            w[k] = __byte_perm(lo, hi, 0x5410);
+        }
+#pragma unroll
+        for (int k = 0; k < B / 16; ++k)
+            reinterpret_cast<uint4*>(dst + (size_t)sp * B)[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+    }
+}
+
 // numpy's float64 `perms.mean(axis=0)` and `perms.std(axis=0)` of the (P, K, K) count array, bit for bit: a reduction over
 // the first axis of a C-contiguous array is a plain sequential accumulation per cell (one rounded add per permutation,
 // in permutation order) — `mean = sum / P`, then `sum((x - mean)**2) / P` accumulated the same way, then sqrt.  One
@@ -1658,18 +1691,32 @@ static int run_pcg64_impl(sqgr_nhood* plan, const uint64_t* pcg_states, int64_t 
         int64_t chunk = std::max<int64_t>(64, std::min<int64_t>(budget / std::max<int64_t>(n, 1), 1 << 17));
         chunk = std::min<int64_t>(chunk, ceil_div(std::max<int64_t>(n_perms, 1), 64) * 64) / 64 * 64;
         const int64_t stride = chunk;  // multiple of 64 => 16-byte aligned slab gathers
-        SQGR_TRY(p->wcol.ensure((size_t)n * stride));
+        // without libraries the shuffled ROWS go straight into the slab (k_rows_to_slab); with libraries (position != spot) through
+        // the column matrix as before
+        const bool via_rows = !p->has_libs && pcg_rows_available();
+        if (!via_rows) SQGR_TRY(p->wcol.ensure((size_t)n * stride));
         SQGR_TRY(p->pcg_states.ensure((size_t)chunk * 4));
         const int64_t per_launch = (int64_t)p->nbatch * B;
         for (int64_t c0 = 0; c0 < n_perms; c0 += chunk) {
             const int64_t pc = std::min(chunk, n_perms - c0);
             SQGR_HIP(hipMemcpyAsync(p->pcg_states.p, pcg_states + (size_t)c0 * 4, (size_t)pc * 32, hipMemcpyHostToDevice, st));
-            SQGR_TRY(pcg_shuffle_labels(ctx, p->pcg_ws, n, p->n_libs, p->lib_off.p, p->base_pos.p, p->pcg_states.p, pc, stride, p->wcol.p, st,
-                                        "nhood_pcg64_shuffle"));
+            int64_t row_stride = 0;
+            if (via_rows)
+                SQGR_TRY(pcg_shuffle_rows(ctx, p->pcg_ws, n, p->n_libs, p->lib_off.p, p->base_pos.p, p->pcg_states.p, pc, st, "nhood_pcg64_shuffle",
+                                          &row_stride));
+            else
+                SQGR_TRY(pcg_shuffle_labels(ctx, p->pcg_ws, n, p->n_libs, p->lib_off.p, p->base_pos.p, p->pcg_states.p, pc, stride, p->wcol.p, st,
+                                            "nhood_pcg64_shuffle"));
             for (int64_t q0 = 0; q0 < pc; q0 += per_launch) {
                 const int64_t todo = std::min(per_launch, pc - q0);
                 const int nb = (int)ceil_div(todo, B);
-                {
+                if (via_rows) {
+                    LaunchTimer t(ctx, "nhood_rows_to_slab");
+                    dim3 grid((unsigned)ceil_div(ceil_div(n, 4), 256), nb);
+                    if (B == 32) k_rows_to_slab<32><<<grid, 256, 0, st>>>(n, row_stride, p->pcg_ws.rows.p, q0, pc, p->slab.p);
+                    else k_rows_to_slab<16><<<grid, 256, 0, st>>>(n, row_stride, p->pcg_ws.rows.p, q0, pc, p->slab.p);
+                    SQGR_HIP(hipGetLastError());
+                } else {
                     LaunchTimer t(ctx, "nhood_columns_to_slab");
                     dim3 grid((unsigned)ceil_div(n, 256), nb);
     #define SQGR_C2S(BB, LIBS) k_columns_to_slab<BB, LIBS><<<grid, 256, 0, st>>>(n, stride, p->wcol.p, q0, p->lib_of.p, p->rank_of.p, p->lib_off.p, p->slab.p)

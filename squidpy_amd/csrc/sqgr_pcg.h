@@ -25,6 +25,11 @@ struct PcgWorkspace {
 int pcg_shuffle_labels(sqgr_ctx* ctx, PcgWorkspace& ws, int64_t n, int n_libs, const uint32_t* lib_off_dev, const uint8_t* base_pos_dev,
                        const uint64_t* states_dev, int64_t pc, int64_t stride, uint8_t* W, hipStream_t st, const char* timer_name);
 
+// The same arrays as ROWS: ws.rows[q * (*row_stride) + pos] (no transposition; not for SQGR_PCG_KERNEL=lane: pcg_rows_available()).
+bool pcg_rows_available();
+int pcg_shuffle_rows(sqgr_ctx* ctx, PcgWorkspace& ws, int64_t n, int n_libs, const uint32_t* lib_off_dev, const uint8_t* base_pos_dev,
+                     const uint64_t* states_dev, int64_t pc, hipStream_t st, const char* timer_name, int64_t* row_stride);
+
 // idx_dev[q * n + i] = element i of `Generator.permutation(n)` drawn by generator q (states_dev row q), q < pc.
 int pcg_permutations_dev(sqgr_ctx* ctx, PcgWorkspace& ws, int64_t n, const uint64_t* states_dev, int64_t pc, int32_t* idx_dev,
                          hipStream_t st);

@@ -474,7 +474,8 @@ __global__ __launch_bounds__(64) void k_pcg_shuffle_wave(int64_t n, int64_t row_
 // per chunk at 1e6 positions).  Traffic per permutation: ranges 16 phases x ~0.5 MB x 2 + records 2 x 4.3 MB.
 constexpr int PCGB_MAX_RANGES = 64;   // ranges per library (lane r of the generator wave keeps range r's cursors)
 constexpr int PCGB_RING = 128;        // staging ring per range (records)
-constexpr int PCGB_SLOTS = 4096;      // conflict tags of the apply kernel
+constexpr int PCGB_SLOTS = 3328;      // conflict tags of the apply kernel (two buffers: rounds alternate)
+constexpr int PCGB_CHUNK_BLOCKS = 32; // 64-record blocks per chunk of the apply kernel: two records per lane
 constexpr int PCGB_THREADS = 1024;
 
 struct PcgBucketGeom {
@@ -493,7 +494,9 @@ __global__ __launch_bounds__(64) void k_pcg_draws_bucketed(int n_libs, const uin
     extern __shared__ uint32_t s_stage[];  // [n_ranges][PCGB_RING]
     __shared__ uint64_t sA[PCGW_TAB][2], sD[PCGW_TAB][2];
     __shared__ uint32_t sJ[64];
+    __shared__ unsigned long long s_lanes[PCGB_MAX_RANGES];  // per range: the lanes whose record goes there (zero between appends)
     const int lane = threadIdx.x;
+    s_lanes[lane] = 0ull;
     const uint32_t logS = (uint32_t)geo.logS, SM = (1u << logS) - 1u;
     const int64_t p = blockIdx.x;
     if (p >= P) return;
@@ -541,30 +544,33 @@ __global__ __launch_bounds__(64) void k_pcg_draws_bucketed(int n_libs, const uin
         c_ord = 0;
         nb = 0;
     };
-    // append the records of the lanes with `in` set (lane order == time order) to their ranges' rings; full blocks go out
+    // append the records of the lanes with `in` set (lane order == time order) to their ranges' rings; full blocks go out.
+    // The lanes of a range find each other through a 64-bit lane mask per range in LDS (one ds_or per record, one read): the
+    // rank of a record among its range's records of this trip is a count of the mask bits below its lane, the owner lane of a
+    // range adds the population count to its cursor — no loop over the ranges (a first version walked them one by one and made
+    // this kernel issue-bound at ~2000 clk per trip).
     auto append = [&](bool in, uint32_t iloc, uint32_t jj) {
         const uint32_t r = jj >> logS;
         const uint32_t rec = (jj & SM) | (iloc << 16);
-        uint64_t todo = __ballot(in);
-        while (todo != 0ull) {
-            const uint32_t r0 = lane_get(r, (uint32_t)__builtin_ctzll(todo));
-            const bool mine = in && r == r0;
-            const uint64_t m = __ballot(mine);
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            const uint32_t cnt = lane_get(c_cnt, r0), head = lane_get(c_head, r0);
-            if (mine) s_stage[r0 * PCGB_RING + ((head + cnt + rank) & (PCGB_RING - 1))] = rec;
-            uint32_t ncnt = cnt + (uint32_t)__popcll(m), nhead = head;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the ring is read back by other lanes of this wave
-            if (ncnt >= 64u) {
-                flush_block(r0, head, 64u);
-                ncnt -= 64u;
-                nhead = (head + 64u) & (PCGB_RING - 1);
-            }
+        if (in) atomicOr(&s_lanes[r], 1ull << lane);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const unsigned long long mk = in ? s_lanes[r] : 0ull;
+        const unsigned long long own = (lane < geo.n_ranges) ? s_lanes[lane] : 0ull;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (lane < geo.n_ranges) s_lanes[lane] = 0ull;  // re-armed for the next call
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+        const uint32_t cur = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(r << 2), (int)(c_cnt | (c_head << 8)));  // the cursors of MY range
+        if (in) s_stage[r * PCGB_RING + (((cur >> 8) + (cur & 0xffu) + rank) & (PCGB_RING - 1))] = rec;
+        c_cnt += (uint32_t)__popcll(own);
+        uint64_t full = __ballot(c_cnt >= 64u);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the rings are read back by other lanes of this wave
+        for (; full != 0ull; full &= full - 1ull) {
+            const uint32_t r0 = (uint32_t)__builtin_ctzll(full);
+            flush_block(r0, lane_get(c_head, r0), 64u);
             if ((uint32_t)lane == r0) {
-                c_cnt = ncnt;
-                c_head = nhead;
+                c_cnt -= 64u;
+                c_head = (c_head + 64u) & (PCGB_RING - 1);
             }
-            todo &= ~m;
         }
     };
     uint32_t half = 0;
@@ -675,8 +681,9 @@ __global__ __launch_bounds__(PCGB_THREADS) void k_pcg_apply_bucketed(int64_t row
     const uint32_t logS = (uint32_t)geo.logS, S = 1u << logS;
     uint8_t* const Xw = s_dyn;                                            // the phase's window: positions [f*S, (f+1)*S)
     uint8_t* const Xr = s_dyn + S;                                        // one range r < f
-    uint32_t* const tags = reinterpret_cast<uint32_t*>(s_dyn + 2 * (size_t)S);  // [PCGB_SLOTS]
-    uint32_t* const blist = tags + PCGB_SLOTS;                            // [bcap] block | count << 16, sorted by (range, ordinal)
+    uint32_t* const tags = reinterpret_cast<uint32_t*>(s_dyn + 2 * (size_t)S);  // [2][PCGB_SLOTS]: rounds alternate between the buffers
+    uint32_t* const blist = tags + 2 * PCGB_SLOTS;                     // [bcap] block | count << 16, sorted by (range, ordinal)
+    __shared__ uint32_t s_wave_any[2][PCGB_THREADS / 64];                 // per round parity and wave: a record is still pending
     __shared__ uint32_t s_hist[PCGB_MAX_RANGES], s_start[PCGB_MAX_RANGES + 1];
     __shared__ uint8_t s_dirty[PCGB_MAX_RANGES];                          // range already written to the row (else: still base_pos)
     const int tid = threadIdx.x;
@@ -686,7 +693,7 @@ __global__ __launch_bounds__(PCGB_THREADS) void k_pcg_apply_bucketed(int64_t row
         const uint32_t* const dir_p = dir + (size_t)p * geo.phases * geo.bcap;
         const uint32_t* const nblk_p = nblk + (size_t)p * geo.phases;
         uint8_t* const row = R + p * row_stride;
-        for (int k = tid; k < PCGB_SLOTS; k += PCGB_THREADS) tags[k] = 0u;
+        for (int k = tid; k < 2 * PCGB_SLOTS; k += PCGB_THREADS) tags[k] = 0u;
         uint32_t epoch = 0;
         for (int l = 0; l < n_libs; ++l) {
             const uint32_t off = lib_off[l];
@@ -724,55 +731,130 @@ __global__ __launch_bounds__(PCGB_THREADS) void k_pcg_apply_bucketed(int64_t row
                     blist[s_start[e & 0xffu] + (e >> 16)] = t | (((e >> 8) & 0xffu) << 16);
                 }
                 __syncthreads();
-                for (uint32_t rr = 0; rr <= f; ++rr) {
-                    const uint32_t r = rr == 0u ? f : rr - 1u;  // the window range first
-                    const uint32_t nbr = s_hist[r], b0 = s_start[r];
-                    if (nbr == 0u) continue;
-                    const bool internal = r == f;
+                // Ranges in processing order: rr = 0 is the window range f, rr >= 1 is range rr - 1.  Two software pipelines hide
+                // the global latencies a single resident workgroup cannot overlap otherwise: the records of the NEXT chunk and
+                // the bytes of the NEXT range are loaded into registers while the current chunk runs its rounds.
+                auto range_of = [&](uint32_t rr) { return rr == 0u ? f : rr - 1u; };
+                auto next_range = [&](uint32_t rr) {  // first rr' > rr with records (f + 1: none)
+                    for (++rr; rr <= f && s_hist[range_of(rr)] == 0u; ++rr) {}
+                    return rr;
+                };
+                auto load_recs = [&](uint32_t rr, uint32_t blk0, bool& have) -> uint32_t {  // this wave's block blk0 + wave of range rr
+                    have = false;
+                    if (rr > f) return 0u;
+                    const uint32_t r = range_of(rr), bi = blk0 + (L >> 6);
+                    if (bi >= s_hist[r]) return 0u;
+                    const uint32_t e = blist[s_start[r] + bi];
+                    if ((L & 63u) >= (e >> 16)) return 0u;
+                    have = true;
+                    return rec_p[((size_t)ph * geo.bcap + (e & 0xffffu)) * 64 + (L & 63u)];
+                };
+                uint4 pre0, pre1, pre2, pre3;  // the next range's bytes (16-byte pieces tid, tid + 1024, ...): S <= 65536 = 4 x 1024 x 16
+                pre0 = pre1 = pre2 = pre3 = make_uint4(0u, 0u, 0u, 0u);
+                auto range_src = [&](uint32_t rr) { return (s_dirty[range_of(rr)] ? row : base_pos) + off + ((size_t)range_of(rr) << logS); };
+                const uint32_t n16 = S >> 4;
+                // only whole, 16-byte aligned ranges are prefetched (else: plain copy at the switch)
+#define SQGR_PCGB_PREFETCH(RR, OK)                                                                            \
+    do {                                                                                                      \
+        OK = false;                                                                                           \
+        const uint32_t rr__ = (RR);                                                                           \
+        if (rr__ <= f && rr__ != 0u && S >= 16u) {                                                            \
+            const uint4* src__ = reinterpret_cast<const uint4*>(range_src(rr__));                             \
+            if ((reinterpret_cast<uintptr_t>(src__) & 15u) == 0u) {                                           \
+                if ((uint32_t)tid < n16) pre0 = src__[tid];                                                   \
+                if ((uint32_t)tid + 1024u < n16) pre1 = src__[tid + 1024];                                    \
+                if ((uint32_t)tid + 2048u < n16) pre2 = src__[tid + 2048];                                    \
+                if ((uint32_t)tid + 3072u < n16) pre3 = src__[tid + 3072];                                    \
+                OK = true;                                                                                    \
+            }                                                                                                 \
+        }                                                                                                     \
+    } while (0)
+                uint32_t rr = s_hist[f] != 0u ? 0u : next_range(0u), c0 = 0;
+                // a chunk = 32 blocks in time order: lane L of the workgroup holds record L (blocks c0 .. c0+15) and record 1024 + L
+                // (blocks c0+16 .. c0+31)
+                bool have_a = false, have_b = false;
+                uint32_t rec_a = load_recs(rr, c0, have_a), rec_b = load_recs(rr, c0 + 16u, have_b);
+                bool pre_ok = false;
+                while (rr <= f) {
+                    const uint32_t r = range_of(rr), nbr = s_hist[r];
+                    const bool internal = rr == 0u;
                     uint8_t* const X2 = internal ? Xw : Xr;
-                    if (!internal) {
-                        pcgb_copy_in(Xr, (s_dirty[r] ? row : base_pos) + off + ((size_t)r << logS), S, tid);
-                        __syncthreads();
-                    }
-                    for (uint32_t c0 = 0; c0 < nbr; c0 += PCGB_THREADS / 64) {
-                        const uint32_t bi = c0 + (L >> 6);
-                        bool pending = false;
-                        uint32_t iloc = 0, jloc = 0;
-                        if (bi < nbr) {
-                            const uint32_t e = blist[b0 + bi];
-                            if ((L & 63u) < (e >> 16)) {
-                                const uint32_t rec = rec_p[((size_t)ph * geo.bcap + (e & 0xffffu)) * 64 + (L & 63u)];
-                                jloc = rec & 0xffffu;
-                                iloc = rec >> 16;
-                                pending = true;
+                    // the chunk after this one: next chunk of the range, or the first chunk of the next range with records
+                    const bool last_chunk = c0 + PCGB_CHUNK_BLOCKS >= nbr;
+                    const uint32_t rr_n = last_chunk ? next_range(rr) : rr, c0_n = last_chunk ? 0u : c0 + PCGB_CHUNK_BLOCKS;
+                    if (c0 == 0u) {  // entering range r
+                        if (!internal) {
+                            if (pre_ok) {
+                                uint4* dst = reinterpret_cast<uint4*>(Xr);
+                                if ((uint32_t)tid < n16) dst[tid] = pre0;
+                                if ((uint32_t)tid + 1024u < n16) dst[tid + 1024] = pre1;
+                                if ((uint32_t)tid + 2048u < n16) dst[tid + 2048] = pre2;
+                                if ((uint32_t)tid + 3072u < n16) dst[tid + 3072] = pre3;
+                            } else {
+                                pcgb_copy_in(Xr, range_src(rr), S, tid);
                             }
-                        }
-                        const uint32_t hj = (jloc * 2654435761u) >> 20, hi = (iloc * 2654435761u) >> 20;
-                        for (;;) {
-                            ++epoch;
-                            const uint32_t mine = (epoch << 10) | (1023u - L);
-                            if (pending) atomicMax(&tags[hj], mine);
                             __syncthreads();
-                            bool go = pending && tags[hj] == mine;
-                            if (go && internal) {  // no earlier pending record of the chunk may write to this record's i position
-                                const uint32_t tg = tags[hi];
-                                go = (tg >> 10) != epoch || (1023u - (tg & 1023u)) >= L;
-                            }
-                            if (go) {
-                                const uint8_t a = Xw[iloc], b = X2[jloc];
-                                Xw[iloc] = b;
-                                X2[jloc] = a;
-                                pending = false;
-                            }
-                            if (!__syncthreads_or(pending ? 1 : 0)) break;
+                        }
+                        SQGR_PCGB_PREFETCH(next_range(rr), pre_ok);  // in flight while this range is replayed
+                    }
+                    bool have_na = false, have_nb = false;
+                    const uint32_t rec_na = load_recs(rr_n, c0_n, have_na), rec_nb = load_recs(rr_n, c0_n + 16u, have_nb);
+                    bool pend_a = have_a, pend_b = have_b;
+                    const uint32_t ja = rec_a & 0xffffu, ia = rec_a >> 16, jb = rec_b & 0xffffu, ib = rec_b >> 16;
+                    const uint32_t hja = __umulhi(ja * 2654435761u, (uint32_t)PCGB_SLOTS), hia = __umulhi(ia * 2654435761u, (uint32_t)PCGB_SLOTS);
+                    const uint32_t hjb = __umulhi(jb * 2654435761u, (uint32_t)PCGB_SLOTS), hib = __umulhi(ib * 2654435761u, (uint32_t)PCGB_SLOTS);
+                    // ONE barrier per round: the tags of consecutive rounds live in different buffers (a fast wave's claims of round
+                    // k + 1 cannot disturb a slow wave still reading round k; the barrier of round k + 1 protects the buffer's
+                    // re-use in round k + 2), and so do the per-wave "still pending" words.  Tag = epoch | 2047 - index in the chunk.
+                    // (Measured alternatives, all slower on MI355X: compacting the records the first round leaves onto the first
+                    // waves — one more barrier and an LDS queue per chunk, 91 ms instead of 75 ms per 8192 permutations of 1e6
+                    // positions; a branch-free round with per-lane dummy slots instead of masked lanes — 95 instructions per round
+                    // instead of ~160, but every lane then issues every LDS operation of every round: 94 ms.)
+                    for (;;) {
+                        ++epoch;
+                        uint32_t* const T = tags + (epoch & 1u) * PCGB_SLOTS;
+                        const uint32_t mine_a = (epoch << 11) | (2047u - L), mine_b = (epoch << 11) | (1023u - L);
+                        if (pend_a) atomicMax(&T[hja], mine_a);
+                        if (pend_b) atomicMax(&T[hjb], mine_b);
+                        const bool wave_pending = __ballot(pend_a || pend_b) != 0ull;
+                        if ((L & 63u) == 0u) s_wave_any[epoch & 1u][L >> 6] = wave_pending ? 1u : 0u;
+                        __syncthreads();
+                        const uint32_t wa = s_wave_any[epoch & 1u][L & (PCGB_THREADS / 64 - 1)];
+                        const uint32_t ta = T[hja], tia = T[hia], tb = T[hjb], tib = T[hib];
+                        const uint8_t va_i = Xw[ia], va_j = X2[ja];
+                        if (__ballot(wa != 0u) == 0ull) break;  // uniform over the workgroup: every wave reads all 16 words
+                        bool go_a = pend_a && ta == mine_a, go_b = pend_b && tb == mine_b;
+                        // window range: no earlier pending record of the chunk may write to this record's i position
+                        if (internal) {
+                            go_a = go_a && ((tia >> 11) != epoch || (2047u - (tia & 2047u)) >= L);
+                            go_b = go_b && ((tib >> 11) != epoch || (2047u - (tib & 2047u)) >= 1024u + L);
+                        }
+                        if (go_a) {
+                            Xw[ia] = va_j;
+                            X2[ja] = va_i;
+                            pend_a = false;
+                        }
+                        if (go_b) {  // after this lane's own record a (had a been blocked on a shared position, so would b be)
+                            const uint8_t vb_i = Xw[ib], vb_j = X2[jb];
+                            Xw[ib] = vb_j;
+                            X2[jb] = vb_i;
+                            pend_b = false;
                         }
                     }
-                    if (!internal) {
+                    if (last_chunk && !internal) {
+                        __syncthreads();
                         pcgb_copy_out(row + off + ((size_t)r << logS), Xr, S, tid);
                         if (tid == 0) s_dirty[r] = 1;
                         __syncthreads();
                     }
+                    rr = rr_n;
+                    c0 = c0_n;
+                    rec_a = rec_na;
+                    rec_b = rec_nb;
+                    have_a = have_na;
+                    have_b = have_nb;
                 }
+#undef SQGR_PCGB_PREFETCH
                 pcgb_copy_out(row + off + ((size_t)f << logS), Xw, wlen, tid);  // positions of this phase are final
             }
         }
@@ -907,14 +989,18 @@ static int pcg_shuffle_rows_bucketed(sqgr_ctx* ctx, PcgWorkspace& ws, int64_t n,
         ws.phases = (int)acc;
     }
     geo.phases = std::max(ws.phases, 1);
+
     const size_t rec_words = (size_t)geo.phases * geo.bcap * 64;   // per permutation
-    // permutations per pass: <= ~12 GB of records in flight
-    const int64_t sub = std::max<int64_t>(64, std::min<int64_t>(pc, (int64_t)(((size_t)12 << 30) / (rec_words * 4))));
+    // permutations per pass: <= ~36 GB of records in flight (8192 permutations of 1e6 positions), a quarter of the free memory at most
+    size_t free_b = 0, total_b = 0;
+    SQGR_HIP(hipMemGetInfo(&free_b, &total_b));
+    const size_t rec_budget = std::min<size_t>((size_t)36 << 30, free_b / 4);
+    const int64_t sub = std::max<int64_t>(64, std::min<int64_t>(pc, (int64_t)(rec_budget / (rec_words * 4))));
     SQGR_TRY(ws.recs.ensure((size_t)sub * rec_words));
     SQGR_TRY(ws.dir.ensure((size_t)sub * geo.phases * geo.bcap));
     SQGR_TRY(ws.nblk.ensure((size_t)sub * geo.phases));
     const size_t lds_g = (size_t)geo.n_ranges * PCGB_RING * 4;
-    const size_t lds_a = 2 * (size_t)S + (size_t)PCGB_SLOTS * 4 + (size_t)geo.bcap * 4;
+    const size_t lds_a = 2 * (size_t)S + (size_t)2 * PCGB_SLOTS * 4 + (size_t)geo.bcap * 4;
     SQGR_TRY(pcg_allow_lds(k_pcg_draws_bucketed, lds_g));
     SQGR_TRY(pcg_allow_lds(k_pcg_apply_bucketed, lds_a));
     const std::string name_g = std::string(timer_name) + "_draws", name_a = std::string(timer_name) + "_apply";
@@ -941,18 +1027,16 @@ static int pcg_shuffle_rows_bucketed(sqgr_ctx* ctx, PcgWorkspace& ws, int64_t n,
     return SQGR_OK;
 }
 
-int pcg_shuffle_labels(sqgr_ctx* ctx, PcgWorkspace& ws, int64_t n, int n_libs, const uint32_t* lib_off_dev, const uint8_t* base_pos_dev,
-                       const uint64_t* states_dev, int64_t pc, int64_t stride, uint8_t* W, hipStream_t st, const char* timer_name) {
+bool pcg_rows_available() { return !pcg_lane_kernel(); }
+
+int pcg_shuffle_rows(sqgr_ctx* ctx, PcgWorkspace& ws, int64_t n, int n_libs, const uint32_t* lib_off_dev, const uint8_t* base_pos_dev,
+                     const uint64_t* states_dev, int64_t pc, hipStream_t st, const char* timer_name, int64_t* row_stride) {
     if (pcg_lane_kernel()) {
-        LaunchTimer t(ctx, timer_name, st);
-        const int64_t pc64 = std::min<int64_t>(stride, ceil_div(pc, 64) * 64);
-        if (pc64 > pc)  // columns past pc that whole-batch consumers still read: label 0 instead of stale bytes
-            SQGR_HIP(hipMemset2DAsync(W + pc, (size_t)stride, 0, (size_t)(pc64 - pc), (size_t)n, st));
-        k_pcg_shuffle<uint8_t, false><<<(unsigned)ceil_div(pc, 64), 64, 0, st>>>(n, n_libs, lib_off_dev, base_pos_dev, states_dev, pc, stride, W);
-        SQGR_HIP(hipGetLastError());
-        return SQGR_OK;
+        set_error("SQGR_PCG_KERNEL=lane shuffles columns, not rows");
+        return SQGR_ERR_UNSUPPORTED;
     }
     const int64_t n_pad = ceil_div(n, 64) * 64;
+    *row_stride = n_pad;
     SQGR_TRY(ensure_pcg_jump(ws.jump));
     SQGR_TRY(ws.rows.ensure((size_t)pc * n_pad));
     // library sizes decide between the wave kernel and the bucketed replay (one library: its size is n)
@@ -978,6 +1062,22 @@ int pcg_shuffle_labels(sqgr_ctx* ctx, PcgWorkspace& ws, int64_t n, int n_libs, c
                                                                                   ws.jump.p, pc, ws.rows.p, pcg_force_slow(), wsz);
         SQGR_HIP(hipGetLastError());
     }
+    return SQGR_OK;
+}
+
+int pcg_shuffle_labels(sqgr_ctx* ctx, PcgWorkspace& ws, int64_t n, int n_libs, const uint32_t* lib_off_dev, const uint8_t* base_pos_dev,
+                       const uint64_t* states_dev, int64_t pc, int64_t stride, uint8_t* W, hipStream_t st, const char* timer_name) {
+    if (pcg_lane_kernel()) {
+        LaunchTimer t(ctx, timer_name, st);
+        const int64_t pc64 = std::min<int64_t>(stride, ceil_div(pc, 64) * 64);
+        if (pc64 > pc)  // columns past pc that whole-batch consumers still read: label 0 instead of stale bytes
+            SQGR_HIP(hipMemset2DAsync(W + pc, (size_t)stride, 0, (size_t)(pc64 - pc), (size_t)n, st));
+        k_pcg_shuffle<uint8_t, false><<<(unsigned)ceil_div(pc, 64), 64, 0, st>>>(n, n_libs, lib_off_dev, base_pos_dev, states_dev, pc, stride, W);
+        SQGR_HIP(hipGetLastError());
+        return SQGR_OK;
+    }
+    int64_t n_pad = 0;
+    SQGR_TRY(pcg_shuffle_rows(ctx, ws, n, n_libs, lib_off_dev, base_pos_dev, states_dev, pc, st, timer_name, &n_pad));
     {
         const std::string name_t = std::string(timer_name) + "_rows_to_columns";
         LaunchTimer t(ctx, name_t.c_str(), st);
