@@ -8,7 +8,7 @@ from . import gr
 from ._anndata_lite import AnnDataLite
 from ._dist import init as init_distributed
 from ._dist import shutdown as shutdown_distributed
-from ._lib import clear_graph_cache
+from ._lib import clear_graph_cache, trim_device_memory
 
-__all__ = ["gr", "AnnDataLite", "init_distributed", "shutdown_distributed", "clear_graph_cache"]
+__all__ = ["gr", "AnnDataLite", "init_distributed", "shutdown_distributed", "clear_graph_cache", "trim_device_memory"]
 __version__ = "0.1.0"

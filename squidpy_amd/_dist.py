@@ -34,6 +34,7 @@ from typing import Any
 import numpy as np
 
 _TIMEOUT_S = float(os.environ.get("SQGR_DIST_TIMEOUT", "120"))
+_HELLO_TIMEOUT_S = 3.0  # the hello of a connecting rank (rank, world, secret) follows its connect at once
 
 
 # ----------------------------------------------------------------------------------------------- side channels
@@ -161,10 +162,9 @@ class SocketGroup:
     kind = "socket"
 
     def __init__(self, rank: int, world: int, addr: str = "127.0.0.1", key: str | None = None):
+        # `addr` is accepted for the launcher's MASTER_ADDR and ignored: the group is one node, the hub binds and the peers dial
+        # 127.0.0.1 only (a routable listener was never offered; a switch that pretended to offer one is gone)
         self.rank, self.world = int(rank), int(world)
-        if addr not in ("127.0.0.1", "localhost", "::1", socket.gethostname()) and os.environ.get("SQGR_DIST_ALLOW_REMOTE") != "1":
-            # a single-node group: the hub never listens on a routable address
-            addr = "127.0.0.1"
         key = key or f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
         self._path = os.path.join(_rendezvous_dir(), f"rdzv_{key}")
         self._peers: list[socket.socket] = []
@@ -187,12 +187,17 @@ class SocketGroup:
             by_rank: dict[int, socket.socket] = {}
             try:
                 while len(by_rank) < self.world - 1:
+                    if time.monotonic() > deadline:
+                        raise TimeoutError(f"rendezvous: {self.world - 1 - len(by_rank)} of {self.world - 1} peers missing after {_TIMEOUT_S:.0f} s")
                     conn, _ = srv.accept()
                     conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                    conn.settimeout(_TIMEOUT_S)
+                    # the 40-byte hello of a genuine rank is already on the wire when accept() returns: a local client that
+                    # connects and stays silent costs the accept loop this long and no more (it used to hold it for _TIMEOUT_S)
+                    conn.settimeout(_HELLO_TIMEOUT_S)
                     try:
                         r, w = struct.unpack("<ii", _recv_exact(conn, 8))
                         ok = hmac.compare_digest(_recv_exact(conn, 32), token)
+                        conn.settimeout(_TIMEOUT_S)
                     except (ConnectionError, OSError, struct.error):
                         conn.close()
                         continue

@@ -31,6 +31,7 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "sqgr_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "sqgr_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "sqgr_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "sqgr_ctx_trim": (C.c_int, [C.c_void_p, C.c_int64]),
     "sqgr_ctx_sync": (C.c_int, [C.c_void_p]),
     "sqgr_ctx_device_info": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), c_i64p]),
     "sqgr_timer_enable": (C.c_int, [C.c_void_p, C.c_int]),
@@ -94,7 +95,7 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
 }
 
 
-ABI_VERSION = 3  # SQGR_ABI_VERSION of include/sqgr.h
+ABI_VERSION = 4  # SQGR_ABI_VERSION of include/sqgr.h
 
 
 class SqgrError(RuntimeError):
@@ -187,6 +188,10 @@ class Context:
         return {"name": buf.value.decode(), "cu_count": cu.value, "hbm_bytes": mem.value}
 
     # ---- kernel timers (HIP events on this context's stream)
+    def trim(self, keep_bytes: int = 0) -> None:
+        """Hand parked device buffers (``SQGR_POOL_GB``) back to the driver until at most ``keep_bytes`` stay parked."""
+        _check(self.lib, self.lib.sqgr_ctx_trim(self.h, int(keep_bytes)))
+
     def timer_enable(self, on: bool = True) -> None:
         _check(self.lib, self.lib.sqgr_timer_enable(self.h, int(on)))
 
@@ -211,6 +216,13 @@ class Context:
 
 
 _default_ctx: dict[int, Context] = {}
+
+
+def trim_device_memory(keep_bytes: int = 0) -> None:
+    """Hand the device buffers libsqgr keeps parked between calls (``SQGR_POOL_GB``, default 32 GB per GPU) back to the driver —
+    for processes that share the GPU with other HIP users (torch, a second library).  Resident graphs and plans stay."""
+    for ctx in _default_ctx.values():
+        ctx.trim(keep_bytes)
 
 
 def default_context(device: int | None = None) -> Context:
@@ -769,8 +781,14 @@ def pair_counts(ctx: Context, xy: np.ndarray, support: np.ndarray, metric: str =
     return out
 
 
+PAIR_BATCH_MAX_SETS = 65535  # sets per launch of sqgr_pair_counts_batch (the set index is a grid dimension)
+
+
 def pair_counts_batch(ctx: Context, sets: "list[np.ndarray]", support: np.ndarray, metric: str = "euclidean") -> np.ndarray:
-    """:func:`pair_counts` of several point sets in one launch -> int64 (n_sets, S)."""
+    """:func:`pair_counts` of several point sets -> int64 (n_sets, S).  One launch serves up to 65 535 sets of similar size: the
+    launch grid is sized by its largest set, so the sets are grouped by size class (sizes within a factor of 4) — one huge
+    cluster among a hundred small ones no longer makes every small set launch the huge set's tile grid — and any number of
+    sets (``n_simulations`` has no upper limit in the reference, gr/_ripley.py:171) is cut into launches of at most 65 535."""
     support = _as(support, np.float64)
     m = METRICS[metric]
     thr = sqrt_thresholds(support) if m == 0 else support
@@ -778,10 +796,20 @@ def pair_counts_batch(ctx: Context, sets: "list[np.ndarray]", support: np.ndarra
     if not sets:
         return out
     arrs = [_as(a, np.float64).reshape(-1, 2) for a in sets]
-    offsets = np.zeros(len(arrs) + 1, dtype=np.int64)
-    np.cumsum([len(a) for a in arrs], out=offsets[1:])
-    xy = np.ascontiguousarray(np.concatenate(arrs, axis=0)) if offsets[-1] else np.zeros((1, 2))
-    _check(ctx.lib, ctx.lib.sqgr_pair_counts_batch(ctx.h, _ptr(xy, c_f64p), _ptr(offsets, c_i64p), len(arrs), _ptr(thr, c_f64p), len(thr), m, _ptr(out, c_i64p)))
+    sizes = np.array([len(a) for a in arrs], dtype=np.int64)
+    size_class = np.zeros(len(arrs), dtype=np.int64)
+    big = sizes > 256                                        # (one tile or less: all in one class)
+    size_class[big] = np.ceil(np.log2(sizes[big] / 256.0) / 2.0).astype(np.int64)
+    for cls in np.unique(size_class):
+        members = np.nonzero(size_class == cls)[0]
+        for c0 in range(0, len(members), PAIR_BATCH_MAX_SETS):
+            idx = members[c0 : c0 + PAIR_BATCH_MAX_SETS]
+            offsets = np.zeros(len(idx) + 1, dtype=np.int64)
+            np.cumsum(sizes[idx], out=offsets[1:])
+            xy = np.ascontiguousarray(np.concatenate([arrs[i] for i in idx], axis=0)) if offsets[-1] else np.zeros((1, 2))
+            part = np.zeros((len(idx), len(support)), dtype=np.int64)
+            _check(ctx.lib, ctx.lib.sqgr_pair_counts_batch(ctx.h, _ptr(xy, c_f64p), _ptr(offsets, c_i64p), len(idx), _ptr(thr, c_f64p), len(thr), m, _ptr(part, c_i64p)))
+            out[idx] = part
     return out
 
 

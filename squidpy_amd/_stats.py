@@ -86,11 +86,14 @@ def multipletests_pvals(pvals: np.ndarray, method: str = "fdr_bh") -> np.ndarray
     if m in ("bonferroni", "b"):
         corr = np.minimum(ps * float(n), 1.0)  # statsmodels clips at 1 at the end
     elif m in ("sidak", "s"):
-        corr = 1 - np.power(1.0 - ps, n)  # the plain form statsmodels evaluates (for tiny p it rounds to 0; part of its result)
+        # statsmodels >= 0.13 (`-np.expm1(ntests * np.log1p(-pvals))`): exact for tiny p, where the plain `1 - (1 - p)**n` of
+        # 0.12.2 cancels to 0.  The reference asks for statsmodels >= 0.12 only; the form current installs evaluate is kept, the
+        # 0.12.2 golden vectors are matched to the accuracy the power form has (tests/test_stats_cpu.py)
+        corr = -np.expm1(n * np.log1p(-ps))
     elif m in ("holm", "h"):
         corr = np.maximum.accumulate(ps * np.arange(n, 0, -1))
     elif m in ("holm-sidak", "hs"):
-        corr = np.maximum.accumulate(1 - np.power(1.0 - ps, np.arange(n, 0, -1)))
+        corr = np.maximum.accumulate(-np.expm1(np.arange(n, 0, -1) * np.log1p(-ps)))
     elif m in ("simes-hochberg", "sh"):
         corr = np.minimum.accumulate((ps * np.arange(n, 0, -1))[::-1])[::-1]
     elif m in ("hommel", "ho"):

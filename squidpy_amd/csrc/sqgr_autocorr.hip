@@ -203,7 +203,12 @@ __global__ __launch_bounds__(256) void k_scatter_to_columns(const int64_t* __res
 // int64 index arrays of a scipy matrix with more than 2^31 stored entries -> the library's layout
 __global__ void k_narrow_indices(const int64_t* __restrict__ src, int64_t count, int32_t* __restrict__ dst) {
     const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (t < count) dst[t] = (int32_t)src[t];
+    // an index that does not fit int32 must not wrap into the valid range: it becomes -1, which the range check that follows
+    // (k_check_sparse: 0 <= index < minor) rejects like any other out-of-range index
+    if (t < count) {
+        const int64_t v = src[t];
+        dst[t] = (v < 0 || v > (int64_t)0x7fffffff) ? -1 : (int32_t)v;
+    }
 }
 __global__ void k_widen_indptr(const int32_t* __restrict__ src, int64_t count, int64_t* __restrict__ dst) {
     const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;

@@ -101,12 +101,14 @@ struct LaunchTimer {
 // hipMalloc of 1.6 GB taking 4.85 s).  So buffers of 64 MB and more are parked per device when their owner lets go of them and
 // handed to the next request of about that size instead of going back to the driver.  A reused buffer is zeroed (a fresh
 // allocation reads as zeros too) after a device synchronise (hipFree used to provide that one); alloc_pooled skips the zeroing
-// for buffers whose every byte the owner writes.  Bounded (SQGR_POOL_GB, default 64; 0 switches it off); flushed when any
+// for buffers whose every byte the owner writes.  Bounded (SQGR_POOL_GB, default 32; 0 switches it off; sqgr_ctx_trim hands parked
+// buffers back on request — other HIP users of the process see parked memory as taken); flushed when any
 // hipMalloc of the library fails (which is then retried) and when a context is destroyed.
 constexpr size_t POOL_MIN_BYTES = (size_t)64 << 20;
 void* pool_take(size_t bytes, size_t* capacity);  // a parked buffer of [bytes, 1.5 * bytes] on the current device, or NULL
 void pool_give(void* p, size_t capacity);         // parks p or frees it
 void pool_flush();                                // frees everything parked on the current device
+void pool_trim(int device, size_t keep_bytes);    // frees parked buffers of `device` until at most keep_bytes stay parked
 
 template <typename T>
 struct DevBuf {

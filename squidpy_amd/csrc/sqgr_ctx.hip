@@ -28,7 +28,7 @@ static std::vector<PoolEntry> g_pool;
 
 static size_t pool_limit() {
     const char* e = getenv("SQGR_POOL_GB");
-    const double gb = (e && *e) ? atof(e) : 64.0;
+    const double gb = (e && *e) ? atof(e) : 32.0;  // (config 3 in full parks ~25 GB: the 16 GB matrix and one 2048-gene block)
     return gb <= 0.0 ? 0 : (size_t)(gb * (double)((size_t)1 << 30));
 }
 
@@ -46,9 +46,20 @@ void* pool_take(size_t bytes, size_t* capacity) {
     return p;
 }
 
+// the device a buffer lives on: the one that allocated it, NOT the one that happens to be current when its owner lets go
+static bool owner_device(const void* p, int* dev) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    *dev = attr.device;
+    return true;
+}
+
 void pool_give(void* p, size_t capacity) {
     int dev = 0;
-    if (capacity >= POOL_MIN_BYTES && hipGetDevice(&dev) == hipSuccess) {
+    if (capacity >= POOL_MIN_BYTES && owner_device(p, &dev)) {
         std::lock_guard<std::mutex> lock(g_pool_mutex);
         size_t held = 0;
         for (const PoolEntry& e : g_pool) held += e.device == dev ? e.cap : 0;
@@ -60,18 +71,26 @@ void pool_give(void* p, size_t capacity) {
     (void)hipFree(p);
 }
 
+void pool_trim(int dev, size_t keep_bytes) {  // frees the largest parked buffers of `dev` until at most keep_bytes stay parked
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    for (;;) {
+        size_t held = 0;
+        int big = -1;
+        for (int k = 0; k < (int)g_pool.size(); ++k) {
+            if (g_pool[k].device != dev) continue;
+            held += g_pool[k].cap;
+            if (big < 0 || g_pool[k].cap > g_pool[big].cap) big = k;
+        }
+        if (big < 0 || held <= keep_bytes) return;
+        (void)hipFree(g_pool[big].p);
+        g_pool.erase(g_pool.begin() + big);
+    }
+}
+
 void pool_flush() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return;
-    std::lock_guard<std::mutex> lock(g_pool_mutex);
-    for (size_t k = 0; k < g_pool.size();) {
-        if (g_pool[k].device == dev) {
-            (void)hipFree(g_pool[k].p);
-            g_pool.erase(g_pool.begin() + (long)k);
-        } else {
-            ++k;
-        }
-    }
+    pool_trim(dev, 0);
 }
 
 // one thread per edge: erow[e] = row owning edge e (binary search in indptr; built once per graph)
@@ -438,6 +457,14 @@ int sqgr_ctx_destroy(sqgr_ctx* ctx) {
     (void)hipStreamDestroy(ctx->stream);
     (void)hipStreamDestroy(ctx->stream2);
     delete ctx;
+    return SQGR_OK;
+}
+
+int sqgr_ctx_trim(sqgr_ctx* ctx, int64_t keep_bytes) {
+    SQGR_REQUIRE(ctx && keep_bytes >= 0, "ctx is NULL or keep_bytes < 0");
+    SQGR_HIP(hipSetDevice(ctx->device));
+    SQGR_HIP(hipDeviceSynchronize());  // nothing of a previous owner may be in flight when a parked buffer goes back to the driver
+    sqgr::pool_trim(ctx->device, (size_t)keep_bytes);
     return SQGR_OK;
 }
 

@@ -209,3 +209,15 @@ def test_pair_counts_of_many_sets_in_one_launch(L, ctx, metric):
         if len(pts) >= 2:
             np.testing.assert_array_equal(got[k], KDTree(pts, metric=metric).two_point_correlation(pts, support, dualtree=True) - len(pts))
     assert L.pair_counts_batch(ctx, [], support).shape == (0, 37)
+
+
+def test_pair_counts_batch_is_cut_into_launches(L, ctx, monkeypatch):
+    """More sets than one launch takes (65 535: `n_simulations` has no upper limit in the reference) and sets of very different
+    sizes (each size class gets its own launch grid): same counts, in the caller's order."""
+    rng = np.random.default_rng(4)
+    sizes = [40, 5000, 300, 41, 1100, 2, 4999, 700, 39, 0, 260]
+    sets = [np.round(rng.random((m, 2)) * 30, 1) for m in sizes]
+    support = np.linspace(0, 20, 11)
+    want = np.stack([L.pair_counts(ctx, pts, support) for pts in sets])
+    monkeypatch.setattr(L, "PAIR_BATCH_MAX_SETS", 2)
+    np.testing.assert_array_equal(L.pair_counts_batch(ctx, sets, support), want)
