@@ -56,13 +56,23 @@ PERMS_PER_STEP = 10_000
 HBM_PEAK = 8.0e12   # B/s, MI355X_MICROARCH.md
 L2_PEAK = 34.5e12   # B/s aggregate L2 bandwidth, MI355X_MICROARCH.md §L2
 LDS_READ_PEAK = 256 * 256 * 2.4e9  # B/s: 256 B/clk/CU (ds_read_b64/b128, MI355X_MICROARCH.md §LDS) x 256 CUs x 2.4 GHz
-PROFILE_TAG = "r03"
+PROFILE_TAG = "r04"
 
 
 # --------------------------------------------------------------------------------------------- measured ceilings
+def _profile(name: str) -> str:
+    """profiles/<tag>_<name> of this round; an earlier round's file only while this round's lease has not produced its own (the
+    `source` / `ceiling_source` fields of the record say which file was read)."""
+    for tag in (PROFILE_TAG, "r03", "r02"):
+        path = os.path.join(ROOT, "profiles", f"{tag}_{name}")
+        if os.path.exists(path):
+            return path
+    return os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_{name}")
+
+
 def load_ceilings() -> dict:
-    """Issue-rate ceilings measured by tools/ubench_ops.hip on an MI355X (committed: profiles/r02_ubench_ops.json)."""
-    path = os.path.join(ROOT, "profiles", "r02_ubench_ops.json")  # (instruction rates of the chip: not re-measured every round)
+    """Issue-rate ceilings measured by tools/ubench_ops.hip on an MI355X (committed: profiles/<tag>_ubench_ops.json)."""
+    path = _profile("ubench_ops.json")
     out = {"source": os.path.relpath(path, ROOT), "valu_simple": None, "valu_complex": None, "lds_add": None, "lds_add_pattern": None}
     try:
         with open(path) as fh:
@@ -102,7 +112,7 @@ def load_counters() -> dict:
 def load_f64_ceilings() -> dict:
     """float64 VALU issue costs measured by tools/ubench_f64.hip (committed: profiles/r03_ubench_f64.json) as multiples of
     v_fma_f32 measured in the same process — the ratio does not depend on the clock the chip sustained during the run."""
-    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_ubench_f64.json")
+    path = _profile("ubench_f64.json")
     out = {"source": os.path.relpath(path, ROOT)}
     try:
         with open(path) as fh:
@@ -115,7 +125,7 @@ def load_f64_ceilings() -> dict:
 
 def load_ds_mix(name: str) -> dict | None:
     """DS wave-instructions/s of a named LDS instruction mix at full occupancy (tools/ubench_ds_mix.hip, profiles/r03_ubench_ds_mix.json)."""
-    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_ubench_ds_mix.json")
+    path = _profile("ubench_ds_mix.json")
     try:
         with open(path) as fh:
             rows = [r for r in json.load(fh)["ds_mix"] if r["mix"] == name]
@@ -126,8 +136,8 @@ def load_ds_mix(name: str) -> dict | None:
 
 
 def load_lds_read_ceilings() -> dict:
-    """LDS read rates measured by tools/ubench_lds_read.hip on an MI355X (committed: profiles/r02_ubench_lds_read.json)."""
-    path = os.path.join(ROOT, "profiles", "r02_ubench_lds_read.json")
+    """LDS read rates measured by tools/ubench_lds_read.hip on an MI355X (committed: profiles/<tag>_ubench_lds_read.json)."""
+    path = _profile("ubench_lds_read.json")
     out = {"source": os.path.relpath(path, ROOT), "random_b128_bytes_per_s": None, "linear_b128_bytes_per_s": None}
     try:
         with open(path) as fh:
@@ -137,6 +147,20 @@ def load_lds_read_ceilings() -> dict:
                 out["random_b128_bytes_per_s"] = r["bytes_per_s"]
             if r["pattern"].startswith("ds_read_b128 conflict-free"):
                 out["linear_b128_bytes_per_s"] = r["bytes_per_s"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return out
+
+
+def load_gather_rate() -> dict:
+    """L2 random-access rate measured by tools/ubench_gather.hip: random 16-byte rows out of a 16 MB table (rows/s, chip-wide)."""
+    path = _profile("ubench_gather.json")
+    out = {"source": os.path.relpath(path, ROOT), "random_rows_per_s": None}
+    try:
+        with open(path) as fh:
+            rows = json.load(fh)["gather"]
+        rates = [r.get("rows_per_s") for r in rows if "random" in str(r.get("pattern", "")) and r.get("rows_per_s")]
+        out["random_rows_per_s"] = max(rates) if rates else None
     except (OSError, ValueError, KeyError):
         pass
     return out
@@ -586,13 +610,23 @@ def config4_legs(ctx, ceil: dict, with_cpu: bool, counters: dict) -> dict:
     pts_dev.close()
     kms_g = sum(v[1] for name, v in kg.items() if name.startswith("ripley_knn_hist"))
     brute = sum((n - len(p)) * len(p) for p in by_cluster)
+    g_roof = {"kernel": "ripley_knn_hist_cells", "bound": "l2_random_access", "achieved": None, "peak": None, "unit": "L2 read requests/s", "frac": None, "traffic": None,
+              "queries_per_s_of_kernel_time": gq / (kms_g * 1e-3) if kms_g > 0 else None, "brute_force_distance_evaluations_avoided": brute,
+              "note": "one thread per query walks the cells ring by ring around its own (divergent, dependent loads: cell bounds, then ~2 reference points per "
+              "cell): what the kernel asks of the machine is random 64-byte requests to L2.  `achieved` = L2 read requests of the 30 timed launches (PMC "
+              "TCP_TCC_READ_REQ_sum) / their HIP-event time; `peak` = the rate at which random 16-byte rows out of a 16 MB table arrive "
+              f"(tools/ubench_gather.hip).  The brute-force sweep this replaces evaluates {brute:.3g} distances (round 2: 0.60 s at this shape)"}
+    gather = load_gather_rate()
+    pmc = kernel_counters(counters.get("legs", {}), "k_knn_cells", wkey) or kernel_counters(counters.get("legs", {}), "k_knn_hist", wkey)
+    if pmc and pmc.get("TCP_TCC_READ_REQ_sum_timed_total") is not None and kms_g > 0 and gather.get("random_rows_per_s"):
+        req = pmc["TCP_TCC_READ_REQ_sum_timed_total"]
+        g_roof.update({"achieved": req / (kms_g * 1e-3), "peak": gather["random_rows_per_s"], "frac": req / (kms_g * 1e-3) / gather["random_rows_per_s"],
+                       "l2_requests_per_query": req / gq, "l1_accesses_per_query": (pmc.get("TCP_TOTAL_CACHE_ACCESSES_sum_timed_total") or 0.0) / gq,
+                       "ceiling_source": gather["source"], "traffic_source": counters.get("_source")})
     out["ripley_G"] = {
         "metric": "ripley G nearest-neighbour queries/sec (1e6 points, 30 clusters, n_neigh=2)",
         "value": gq / wall_g, "unit": "queries/s", "wall_s": wall_g, "kernel_ms": kms_g, "queries": gq,
-        "roofline": {"kernel": "ripley_knn_hist_cells", "bound": "latency (cell-list walk)", "achieved": gq / (kms_g * 1e-3) if kms_g > 0 else None, "peak": None,
-                     "unit": "queries/s", "frac": None, "traffic": None, "brute_force_distance_evaluations_avoided": brute,
-                     "note": "one thread per query walks ~9-25 cells of ~2 reference points each (divergent, dependent loads): no throughput roofline applies; "
-                     f"the brute-force sweep this replaces evaluates {brute:.3g} distances (round 2: 0.60 s at this shape)"},
+        "roofline": g_roof,
     }
     if with_cpu:
         from oracle import cport  # checker code: cpu_baseline leg only
@@ -638,11 +672,11 @@ def config4_legs(ctx, ceil: dict, with_cpu: bool, counters: dict) -> dict:
 
 def numpy_stream_leg(ctx, plan, shift, n: int, counters: dict) -> dict:
     """The test with numpy's own PCG64 streams reproduced bit for bit on the GPU (`rng="numpy"` — the mode whose z-scores ARE
-    Squidpy's for a seed).  One wave per permutation replays `Generator.shuffle`: n - 1 swaps of position i with a uniformly
-    drawn j <= i in the permutation's own 1-byte-per-spot row.  At 1e6 spots thousands of 1 MB rows are in flight, so every j
-    side of a swap is a random 1-byte read AND a random 1-byte write in HBM — a 64-byte sector each: the kernel is bound by
-    HBM's random-sector rate, priced as 2 (n - 1) x 64 B per permutation against the 8 TB/s peak, and by the measured
-    traffic when the committed profile matches."""
+    Squidpy's for a seed).  Round 4: the swaps of `Generator.shuffle` are replayed in a cache-friendly order (csrc/sqgr_pcg.hip,
+    proof of the order: oracle/pcg_bucket.py): `k_pcg_draws_bucketed` generates the draws (one wave per permutation) into
+    time-ordered lists per (64 K-step phase, 64 KB range), `k_pcg_apply_bucketed` (one workgroup per permutation) streams window
+    and ranges through LDS in coalesced 64 KB pieces.  Algorithmic traffic per permutation of n bytes: records 2 x 4.3 n, ranges
+    ~17 n, rows in and out 2 n — against 128 n + for the one-random-sector-per-swap-side kernel of rounds 1-3."""
     from squidpy_amd._utils import pcg64_states
 
     res, kern = {}, {}
@@ -659,23 +693,35 @@ def numpy_stream_leg(ctx, plan, shift, n: int, counters: dict) -> dict:
     k = kern[8192]
     ms_shuffle = sum(v[1] for name, v in k.items() if "pcg64" in name)
     ms_all = sum(v[1] for v in k.values())
-    sector_bytes = 8192 * 2.0 * (n - 1) * 64.0  # one 64-byte sector read and one written per swap (the i side streams)
-    roof = {"kernel": "nhood_pcg64_shuffle (k_pcg_shuffle_wave)", "bound": "hbm",
-            "achieved": sector_bytes / (ms_shuffle * 1e-3) / 1e9 if ms_shuffle > 0 else None, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-            "frac": sector_bytes / (ms_shuffle * 1e-3) / HBM_PEAK if ms_shuffle > 0 else None, "traffic": None,
-            "algorithmic_sector_bytes_per_launch": sector_bytes, "workload_key": {"spots": n, "perms": 8192},
+    bucketed = any(name.endswith("_apply") for name in k)
+    # algorithmic bytes per permutation of the bucketed replay: 16 phases x 1040 blocks x 256 B of records written and read once,
+    # each range r < f read and written once per phase (sum_f f * 64 KB * 2), every window read and written once, the row -> slab pass
+    phases = -(-n // 65536)
+    alg_bytes = (2.0 * phases * (1024 + phases) * 256 + 2.0 * 65536 * phases * (phases - 1) / 2 + 2.0 * n + 2.0 * n) if bucketed else 2.0 * (n - 1) * 64.0
+    roof = {"kernel": "nhood_pcg64_shuffle_draws + _apply (k_pcg_draws_bucketed, k_pcg_apply_bucketed)" if bucketed else "nhood_pcg64_shuffle (k_pcg_shuffle_wave)",
+            "bound": "hbm", "achieved": 8192 * alg_bytes / (ms_shuffle * 1e-3) / 1e9 if ms_shuffle > 0 else None, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": 8192 * alg_bytes / (ms_shuffle * 1e-3) / HBM_PEAK if ms_shuffle > 0 else None, "traffic": None,
+            "algorithmic_bytes_per_perm": alg_bytes, "workload_key": {"spots": n, "perms": 8192},
             "swap_steps_per_s": 8192 * (n - 1) / (ms_shuffle * 1e-3) if ms_shuffle > 0 else None,
-            "note": "random 1-byte read + 1-byte write per swap, each moving a 64-byte sector of HBM (rows of thousands of permutations in flight do "
-            "not fit any cache); `achieved` = 2 (n - 1) x 64 B x permutations / kernel time — an ALGORITHMIC sector count, the measured traffic "
-            "(`traffic`, `traffic_frac`) replaces it when the committed PMC profile matches"}
-    pmc = kernel_counters(counters.get("numpy", {}), "k_pcg_shuffle_wave", {"spots": n, "perms": 8192})
-    if pmc and pmc.get("FETCH_SIZE_bytes_timed_total") is not None and pmc.get("WRITE_SIZE_bytes_timed_total") is not None and ms_shuffle > 0:
-        # totals of the profiled run minus its first dispatch (the n_perms = 1000 warm-up): 1000 timed + 2 x 8192
-        share = 8192.0 / (1000 + 2 * 8192)
-        roof["traffic"] = (2.0 * pmc["FETCH_SIZE_bytes_timed_total"] + pmc["WRITE_SIZE_bytes_timed_total"]) * share
-        roof["traffic_source"] = counters.get("_source")
-        roof["traffic_GBps"] = roof["traffic"] / (ms_shuffle * 1e-3) / 1e9
-        roof["traffic_frac"] = roof["traffic"] / (ms_shuffle * 1e-3) / HBM_PEAK
+            "note": "`achieved` = algorithmic bytes of the bucketed replay (records, ranges, windows: all coalesced) / time of the two shuffle kernels; the "
+            "measured traffic (`traffic`, `traffic_MB_per_perm`, `traffic_frac`) replaces it when the committed PMC profile matches.  Neither kernel is "
+            "HBM-bound: the draw generator is bound by VALU issue (PCG64 jump-ahead: 128-bit multiplies, ~170 wave-instructions per 64 raw draws), the "
+            "replay by instruction issue and LDS latency inside its barrier rounds (PMC: ~100 % issue-active with 4 waves per SIMD; ~5 rounds per chunk of "
+            "2048 swaps) — the HBM figure says how far the traffic is from mattering, which was the defect of the kernel it replaces (0.44 of peak on 152 MB "
+            "per permutation)"}
+    names = ("k_pcg_draws_bucketed", "k_pcg_apply_bucketed", "k_rows_to_slab", "k_pcg_shuffle_wave", "k_rows_to_columns", "k_columns_to_slab")
+    cn = counters.get("numpy", {})
+    if cn and cn.get("workload") == {"spots": n, "perms": 8192} and ms_shuffle > 0:
+        fetch = sum((rec.get("FETCH_SIZE_bytes_timed_total") or 0.0) for name, rec in cn.get("kernels", {}).items() if any(x in name for x in names))
+        write = sum((rec.get("WRITE_SIZE_bytes_timed_total") or 0.0) for name, rec in cn.get("kernels", {}).items() if any(x in name for x in names))
+        if fetch > 0 or write > 0:
+            # totals of the profiled run minus every kernel's first dispatch (the n_perms = 1000 warm-up): 1000 timed + 2 x 8192
+            share = 8192.0 / (1000 + 2 * 8192)
+            roof["traffic"] = (2.0 * fetch + write) * share
+            roof["traffic_source"] = counters.get("_source")
+            roof["traffic_MB_per_perm"] = roof["traffic"] / 8192 / 1e6
+            roof["traffic_GBps"] = roof["traffic"] / (ms_all * 1e-3) / 1e9
+            roof["traffic_frac"] = roof["traffic"] / (ms_all * 1e-3) / HBM_PEAK
     return {
         "value": res[8192], "unit": "permutations/s", "at_n_perms_1000": res[1000],
         "kernel_ms": {name: round(v[1], 3) for name, v in k.items() if v[0] > 0}, "shuffle_share_of_gpu_time": ms_shuffle / ms_all if ms_all > 0 else None,
@@ -814,7 +860,7 @@ def main() -> None:
     ap.add_argument("--no-legs", action="store_true", help="skip the co_occurrence / Ripley L legs (config 4)")
     ap.add_argument("--no-numpy-leg", action="store_true", help="skip the bit-compatible numpy-stream leg")
     ap.add_argument("--no-config3-full", action="store_true", help="skip BASELINE config 3 in full through the front end (builds a 16 GB host matrix)")
-    ap.add_argument("--emulate-ranks", type=int, default=0,
+    ap.add_argument("--emulate-ranks", type=int, default=8,
                     help="projection for a node this box does not have: run the N rank shards of BASELINE config 5 (--total-perms permutations, strong "
                     "scaling) one after the other on this GPU and print per-shard times; no collective runs, labelled as a projection")
     ap.add_argument("--detail-out", type=str, default=os.path.join("gpurun_out", "bench_detail.json"),
@@ -1015,8 +1061,8 @@ def main() -> None:
                        "l1_hit_rate": 1.0 - rec["TCP_TCC_READ_REQ_sum"] / acc if rec.get("TCP_TCC_READ_REQ_sum") is not None else None,
                        "gather_wave_instr_per_launch": rec.get("TA_FLAT_READ_WAVEFRONTS_sum"),
                        "td_busy_frac": rec["TD_TD_BUSY_sum"] / (cu_count * avg_count_ms * 1e-3 * 2.4e9) if rec.get("TD_TD_BUSY_sum") is not None else None,
-                       "probes": "profiles/r02_count_probes.json"},
-                "note": "the CSR gather of the permutation test.  Developer probes of this kernel (profiles/r02_count_probes.json) show what bounds "
+                       "probes": os.path.relpath(_profile("count_probes.json"), ROOT)},
+                "note": "the CSR gather of the permutation test.  Developer probes of this kernel (" + os.path.relpath(_profile("count_probes.json"), ROOT) + ") show what bounds "
                 "it: without the ds_add_u32 atomics it is NOT faster (0.48 vs 0.51 ms per 1024 permutations), without the label-row gathers it "
                 "runs at the LDS-atomic rate of its address pattern (0.355 ms) — the gathers of 16-byte label rows (4 lanes x 4 bytes, two rows per "
                 "edge and 16 permutations) through the vector-memory/L1 path are the limiter.  `achieved` = L1 cache accesses per launch (PMC "
@@ -1030,7 +1076,7 @@ def main() -> None:
                             "achieved": vi / (avg_count_ms * 1e-3), "peak": valu_mix_peak(ceil, 0.8), "unit": "wave-instr/s",
                             "frac": vi / (avg_count_ms * 1e-3) / valu_mix_peak(ceil, 0.8) if valu_mix_peak(ceil, 0.8) else None,
                             "note": "VALU side of the same kernel (v_perm_b32 + v_dot2_u32_u16 address, DPP offset spread; ~90 % complex class): "
-                            "the VALU-only skeleton of the kernel takes 0.24 ms per 1024 permutations (profiles/r02_count_probes.json)"}
+                            "the VALU-only skeleton of the kernel takes 0.24 ms per 1024 permutations (" + os.path.relpath(_profile("count_probes.json"), ROOT) + ")"}
         # ---- the line's `roofline` object: HBM (SURVEY §8d names HBM for this kernel; VERDICT r2 asks for the measured-traffic fraction).
         # What limits the kernel in practice — the issue rate of its label-row gathers / LDS atomics — stays beside it as `issue_limits`.
         issue = roof
@@ -1060,7 +1106,7 @@ def main() -> None:
             "traffic (PMC, same build, same workload) — it includes re-reads of the 24 MB edge list that the Infinity Cache serves.  `algorithmic_frac` = SURVEY §8d's bytes "
             "(4*nnz + 4*(N+1) + N per permutation) over the same time: above 1 because one pass over the edge list serves 16 permutations — REUSE, not a roofline fraction.  "
             "The kernel is not HBM-bound: `issue_limits` prices it against the L1 access rate of its gathers and the LDS-atomic rate (probe variants: "
-            "profiles/r02_count_probes.json; experiments: profiles/r03_nhood_experiments.json, profiles/r04_mall_groups.json)",
+            + os.path.relpath(_profile("count_probes.json"), ROOT) + "; experiments: profiles/r03_nhood_experiments.json, profiles/r04_mall_groups.json)",
         }
         if roof["fabric_frac"] is None:
             roof["note"] += ".  No PMC profile of THIS build and workload is committed (" + str(counters.get("_status")) + "): the fabric figures are null"
@@ -1072,7 +1118,7 @@ def main() -> None:
                 "labels_per_s": n * perms_per_launch / (avg_shuf_ms * 1e-3) if avg_shuf_ms > 0 else None,
                 "note": "two-level generator: one 8-round bijection per spot and 16 permutations + a 2-round network and a table look-up per "
                 "label, two labels per packed-16 instruction; ~65 % of its VALU instructions are of the complex class (packed-16 / SDWA), "
-                "the ceiling is the measured mix rate (profiles/r02_ubench_ops.json); instruction count per launch from PMC SQ_INSTS_VALU"}
+                "the ceiling is the measured mix rate (" + str(ceil.get("source")) + "); instruction count per launch from PMC SQ_INSTS_VALU"}
         if rec_s and rec_s.get("SQ_INSTS_VALU") is not None and avg_shuf_ms > 0:
             shuf["achieved"] = rec_s["SQ_INSTS_VALU"] / (avg_shuf_ms * 1e-3)
             shuf["frac"] = shuf["achieved"] / shuf["peak"] if shuf["peak"] else None

@@ -872,37 +872,32 @@ __global__ __launch_bounds__(256) void k_rows_to_slab(int64_t n, int64_t row_str
 // the first axis of a C-contiguous array is a plain sequential accumulation per cell (one rounded add per permutation,
 // in permutation order) — `mean = sum / P`, then `sum((x - mean)**2) / P` accumulated the same way, then sqrt.  One
 // thread per cell walks the permutations in order; every operation is individually rounded (-ffp-contract=off).
-__global__ __launch_bounds__(64) void k_numpy_mean_std(const uint32_t* __restrict__ perms, int64_t P, int K2, int64_t base,
-                                                       int64_t rem, int64_t rank_stride, double* __restrict__ mean,
-                                                       double* __restrict__ stdev) {
-    // Layout: permutation q lives at perms[r * rank_stride + j * K2] with (r, j) = its owner under the contiguous split
-    // of [0, P) into chunks of base + 1 (the first `rem` ranks) and base permutations — the all-gathered per-rank slices
-    // of sqgr_nhood_run_pcg64_stats; a single rank passes base = P, rem = 0.
+// The accumulation is a CHAIN that can be cut anywhere: `acc` comes in with the sum over the permutations in front of this
+// slice and leaves with this slice added — several ranks (or several segments of one rank) continue each other's running sums
+// in permutation order and arrive at numpy's own sequence of additions.  mean == nullptr: acc += x; else acc += (x - mean)^2.
+__global__ __launch_bounds__(64) void k_numpy_chain(const uint32_t* __restrict__ perms, int64_t count, int K2, const double* __restrict__ mean,
+                                                    double* __restrict__ acc) {
     const int c = blockIdx.x * 64 + threadIdx.x;
     if (c >= K2) return;
     const uint32_t* col = perms + c;
-    auto at = [&](int64_t q) -> double {
-        const int64_t cut = rem * (base + 1);
-        int64_t r, j;
-        if (q < cut) {
-            r = q / (base + 1);
-            j = q - r * (base + 1);
-        } else {
-            r = rem + (base > 0 ? (q - cut) / base : 0);
-            j = q - cut - (r - rem) * base;
+    double a = acc[c];
+    if (mean == nullptr) {
+        for (int64_t q = 0; q < count; ++q) a += (double)col[(size_t)q * K2];
+    } else {
+        const double m = mean[c];
+        for (int64_t q = 0; q < count; ++q) {
+            const double d = (double)col[(size_t)q * K2] - m;
+            a += d * d;
         }
-        return (double)col[(size_t)r * rank_stride + (size_t)j * K2];
-    };
-    double acc = 0.0;
-    for (int64_t q = 0; q < P; ++q) acc += at(q);
-    const double m = acc / (double)P;
-    double acc2 = 0.0;
-    for (int64_t q = 0; q < P; ++q) {
-        const double d = at(q) - m;
-        acc2 += d * d;
     }
-    mean[c] = m;
-    stdev[c] = sqrt(acc2 / (double)P);
+    acc[c] = a;
+}
+// op 0: v <- v / P (the mean from the finished sum); op 1: v <- sqrt(v / P)
+__global__ __launch_bounds__(64) void k_numpy_chain_finish(double* __restrict__ v, int K2, double P, int op) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= K2) return;
+    const double x = v[c] / P;
+    v[c] = op ? sqrt(x) : x;
 }
 
 }  // namespace sqgr
@@ -967,7 +962,6 @@ struct sqgr_nhood {
     DevBuf<uint64_t> acc_sq;
     DevBuf<int64_t> shift, fin;  // fin: [K2] sum of d, then [K2] sum of d*d (uint64 bit patterns) — one all-reduce
     sqgr_comm* comm = nullptr;   // optional: moments are all-reduced on the device (sqgr_nhood_set_comm)
-    DevBuf<uint32_t> perms_all;  // all-gathered per-permutation counts (numpy-stream statistics over several ranks)
     DevBuf<uint32_t> perms_dev;
     DevBuf<uint8_t> stage;
 
@@ -1774,28 +1768,46 @@ int sqgr_nhood_run_pcg64_stats(sqgr_nhood* plan, const uint64_t* pcg_states, int
     plan->comm = comm;
     sqgr_ctx* ctx = plan->ctx;
     hipStream_t st = ctx->stream;
-    SQGR_TRY(comm_agree(comm, rc, st));  // a rank whose slice failed does not leave the others waiting in the all-gather
+    SQGR_TRY(comm_agree(comm, rc, st));  // a rank whose slice failed does not leave the others waiting in the collectives
+    // numpy's order over ALL permutations without gathering them (the all-gather of round 3 moved P*K*K*4 bytes — 360 MB at config
+    // 5): the two running sums are chains (k_numpy_chain).  Round r: rank r adds its slice to the running sum it holds, then
+    // every rank takes rank r's array (an all-gather of K*K doubles, 7 KB at K = 30; RCCL has no cheaper primitive bound here and
+    // the payload is latency-bound either way).  world rounds per chain, two chains.  One rank may cut its own slice into
+    // segments (SQGR_NUMPY_STATS_SEGMENTS, tests): the same chain, the same bits.
     const uint32_t* perms = plan->perms_dev.p;
-    int64_t rank_stride = 0, kbase = n_perms, krem = 0;
-    if (world > 1) {
-        const int64_t maxc = base + (rem ? 1 : 0);
-        rank_stride = maxc * K2;
-        SQGR_TRY(plan->perms_all.ensure((size_t)world * rank_stride));
-        SQGR_TRY(comm_allgather_dev(comm, plan->perms_dev.p, plan->perms_all.p, (size_t)rank_stride * 4, st));
-        perms = plan->perms_all.p;
-        kbase = base;
-        krem = rem;
-    }
-    DevBuf<double> d_mean, d_std;
+    DevBuf<double> d_acc, d_mean, d_recv;
+    SQGR_TRY(d_acc.alloc((size_t)K2));
     SQGR_TRY(d_mean.alloc((size_t)K2));
-    SQGR_TRY(d_std.alloc((size_t)K2));
-    {
-        LaunchTimer t(ctx, "nhood_numpy_mean_std");
-        k_numpy_mean_std<<<(unsigned)ceil_div(K2, 64), 64, 0, st>>>(perms, n_perms, K2, kbase, krem, rank_stride, d_mean.p, d_std.p);
-        SQGR_HIP(hipGetLastError());
-    }
+    if (world > 1) SQGR_TRY(d_recv.alloc((size_t)world * K2));
+    int segments = 1;
+    if (const char* e = getenv("SQGR_NUMPY_STATS_SEGMENTS")) segments = std::max(1, atoi(e));
+    const unsigned gridc = (unsigned)ceil_div(K2, 64);
+    auto chain = [&](const double* mean_dev) -> int {
+        SQGR_HIP(hipMemsetAsync(d_acc.p, 0, (size_t)K2 * 8, st));
+        for (int r = 0; r < world; ++r) {
+            if (r == rank) {
+                LaunchTimer t(ctx, "nhood_numpy_mean_std");
+                for (int sgm = 0; sgm < segments; ++sgm) {
+                    const int64_t q0 = mine * sgm / segments, q1 = mine * (sgm + 1) / segments;
+                    if (q1 > q0) k_numpy_chain<<<gridc, 64, 0, st>>>(perms + (size_t)q0 * K2, q1 - q0, K2, mean_dev, d_acc.p);
+                }
+                SQGR_HIP(hipGetLastError());
+            }
+            if (world > 1) {
+                SQGR_TRY(comm_allgather_dev(comm, d_acc.p, d_recv.p, (size_t)K2 * 8, st));
+                SQGR_HIP(hipMemcpyAsync(d_acc.p, d_recv.p + (size_t)r * K2, (size_t)K2 * 8, hipMemcpyDeviceToDevice, st));
+            }
+        }
+        return SQGR_OK;
+    };
+    SQGR_TRY(chain(nullptr));
+    k_numpy_chain_finish<<<gridc, 64, 0, st>>>(d_acc.p, K2, (double)n_perms, 0);
+    SQGR_HIP(hipMemcpyAsync(d_mean.p, d_acc.p, (size_t)K2 * 8, hipMemcpyDeviceToDevice, st));
+    SQGR_TRY(chain(d_mean.p));
+    k_numpy_chain_finish<<<gridc, 64, 0, st>>>(d_acc.p, K2, (double)n_perms, 1);
+    SQGR_HIP(hipGetLastError());
     SQGR_HIP(hipMemcpyAsync(out_mean, d_mean.p, (size_t)K2 * 8, hipMemcpyDeviceToHost, st));
-    SQGR_HIP(hipMemcpyAsync(out_std, d_std.p, (size_t)K2 * 8, hipMemcpyDeviceToHost, st));
+    SQGR_HIP(hipMemcpyAsync(out_std, d_acc.p, (size_t)K2 * 8, hipMemcpyDeviceToHost, st));
     SQGR_HIP(hipStreamSynchronize(st));
     return SQGR_OK;
 }

@@ -55,6 +55,16 @@ def main() -> None:
     np.testing.assert_allclose(z, O.nhood_zscore(count, full), rtol=1e-10)
     out["nhood_z00"] = float(z[0, 0])
 
+    # ---- BASELINE config 5's strong-scaling arithmetic: 100 000 permutations over the ranks — contiguous, disjoint, complete,
+    # sizes within one of each other; config 4's 49 radius intervals likewise
+    for total in (100_000, 49, 3):
+        ranges = [_dist.shard_range(total, r, world) for r in range(world)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == total and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        sizes = [hi - lo for lo, hi in ranges]
+        assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    (tot_p,) = _dist.allreduce_sum_([np.array([_dist.shard_range(100_000, rank, world)[1] - _dist.shard_range(100_000, rank, world)[0]], dtype=np.int64)])
+    assert int(tot_p[0]) == 100_000
+
     # ---- seed=None: every rank ends up with rank 0's key
     key = _broadcast_seed(1000 + rank)
     assert key == 1000

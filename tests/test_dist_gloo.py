@@ -29,9 +29,11 @@ def test_two_rank_gloo():
     assert "DIST_OK" in res.stdout
 
 
-def test_two_and_three_rank_socket_rendezvous_without_torch():
-    """The product's own side channel: plain processes, launcher-style environment, no torch anywhere."""
-    for world in (2, 3):
+def test_socket_rendezvous_without_torch_up_to_the_node_size():
+    """The product's own side channel: plain processes, launcher-style environment, no torch anywhere — 2, 3 and 8 ranks (the
+    target machine has 8 GPUs): config 5's strong-scaling shard arithmetic, both co-occurrence shard axes (with 8 ranks and 6
+    thresholds some ranks own no interval at all), ragged feature-block ownership."""
+    for world in (2, 3, 8):
         port = _free_port()
         procs = []
         for rank in range(world):

@@ -297,6 +297,27 @@ def test_numpy_streams_reproduced_on_device(L, ctx, golden):
     np.testing.assert_array_equal(zl, O.nhood_zscore(golden["nhood_count"], golden["nhood_perms_lib"]))
 
 
+@pytest.mark.parametrize("segments", ["1", "7"])
+def test_numpy_mean_std_chain_is_cut_invariant(L, ctx, golden, segments, monkeypatch):
+    """`perms.mean(0)` / `perms.std(0)` of gr/_nhood.py:231 are formed on the device as two CHAINS of running sums in permutation
+    order (k_numpy_chain); several ranks continue each other's sums instead of gathering all per-permutation counts.  A chain cut
+    into 7 segments — what 7 ranks would do, on one GPU — gives numpy's bits like the uncut one."""
+    from squidpy_amd._utils import pcg64_states
+
+    monkeypatch.setenv("SQGR_NUMPY_STATS_SEGMENTS", segments)
+    adj = _golden_graph(golden)
+    g = L.Graph(ctx, adj)
+    k = int(golden["nhood_k"])
+    labels = golden["nhood_labels"].astype(np.int32)
+    P = 103
+    plan = L.NhoodPlan(ctx, g, labels, k)
+    mean, std = plan.run_pcg64_stats(pcg64_states(5, P))
+    _, _, perms = plan.run_pcg64(pcg64_states(5, P), return_perms=True)
+    x = perms.astype(np.float64)
+    np.testing.assert_array_equal(mean.reshape(k, k), x.mean(axis=0))
+    np.testing.assert_array_equal(std.reshape(k, k), x.std(axis=0))
+
+
 @pytest.mark.parametrize("n", [2, 77, 5000, 70001])
 def test_numpy_permutation_streams_on_device(L, ctx, n):
     from squidpy_amd._utils import pcg64_states

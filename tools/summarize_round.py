@@ -27,14 +27,13 @@ def stats_table(sub: str, limit: int = 24) -> list[str]:
 
 
 def bench_line(log: str):
-    line = None
+    """The FULL record of a profiled bench.py run (`--detail-out <out>/<name>_detail.json`; the stdout line is the compact one)."""
+    name = {"stats.log": "stats", "sqa.log": "pmc", "legs_stats.log": "legs", "legs_sqa.log": "legs", "npy_fetch.log": "npy"}.get(log, log)
     try:
-        for ln in open(os.path.join(out, log), errors="replace"):
-            if ln.startswith('{"metric"'):
-                line = json.loads(ln)
-    except OSError:
-        pass
-    return line
+        with open(os.path.join(out, f"{name}_detail.json")) as fh:
+            return json.load(fh)
+    except (OSError, ValueError):
+        return None
 
 
 lines = [f"== rocprofv3 --kernel-trace --stats -- {cmd} =="] + stats_table("stats")
@@ -103,14 +102,27 @@ rep = {
     "moran": {"workload": sec.get("roofline", {}).get("workload_key"), "kernels": section(agg, lambda k: autocorr_match(k) and "<true>" not in k)},
     "geary": {"workload": gea.get("roofline", {}).get("workload_key"), "kernels": section(agg, lambda k: autocorr_match(k) and "<false>" not in k)},
 }
-lagg = collect(("legs_sqa", "legs_fetch", "legs_write"))
+lagg = collect(("legs_sqa", "legs_fetch", "legs_write", "legs_tcp"))
 lb = bench_line("legs_sqa.log") or legs_bench or {}
 rep["legs"] = {"command": legs_cmd, "workload": (((lb.get("legs") or {}).get("co_occurrence") or {}).get("roofline") or {}).get("workload_key"),
                "kernels": section(lagg, lambda k: "k_cooccur" in k or "k_pair_hist" in k or "k_knn" in k, after_first=True)}
 nagg = collect(("npy_fetch", "npy_write"))
 nb = bench_line("npy_fetch.log") or {}
 rep["numpy"] = {"workload": (((nb.get("numpy_stream_mode") or {}).get("roofline")) or {}).get("workload_key"),
-                "kernels": section(nagg, lambda k: "k_pcg_shuffle" in k or "k_rows_to_columns" in k or "k_columns_to_slab" in k, after_first=True)}
+                "kernels": section(nagg, lambda k: "k_pcg_" in k or "k_rows_to_" in k or "k_columns_to_slab" in k, after_first=True)}
+# ---- probe variants of the count kernel (tools/count_probe.py under SQGR_COUNT_DEBUG)
+probes = {}
+for dbg, label in ((0, "full_kernel"), (1, "no_atomics_real_gathers (DBG=1)"), (2, "no_row_gathers_real_labels_through_coalesced_loads (DBG=2)"), (7, "valu_skeleton (DBG=7)")):
+    try:
+        txt = open(os.path.join(out, f"count_probe_{dbg}.log")).read()
+        import ast
+        probes[label] = {k: v for k, v in ast.literal_eval(txt[txt.index("{"): txt.index("}") + 1]).items() if k.startswith("nhood_count")}
+    except (OSError, ValueError, SyntaxError):
+        pass
+if probes:
+    json.dump({"tool": "tools/count_probe.py with SQGR_COUNT_DEBUG (csrc/sqgr_nhood.hip k_count<..., DBG>), 1e6-spot hex grid, 30 clusters, 4096 permutations, MI355X",
+               "unit": "ms per launch of the count kernel (HIP events; 2560 permutations per full launch)", "variants": probes},
+              open(os.path.join(out, f"{tag}_count_probes.json"), "w"), indent=1)
 json.dump(rep, open(os.path.join(out, f"{tag}_counters.json"), "w"), indent=1)
 print(json.dumps({k: (list(v["kernels"]) if isinstance(v, dict) and "kernels" in v else v) for k, v in rep.items() if k != "note"}, indent=1)[:3000])
 
