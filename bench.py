@@ -442,6 +442,69 @@ def autocorr_leg(ctx, mode: str, world: int, fence, reduce_max, steps: int, with
     return out
 
 
+def moran_p100_leg(ctx, cpu_value: float | None) -> dict:
+    """Moran's I on the config-3 shape with the reference's EVERYDAY number of permutations (`n_perms=100`; its docs and tests use
+    50-100, tests/graph/test_ppatterns.py): the LDS-bucketed kernel on 8 virtual permutations per permutation (what the library
+    picks below 512 permutations), and — forced through `SQGR_AUTOCORR_KERNEL=gather` — the round-1 gather kernel it replaces there."""
+    from sklearn.preprocessing import normalize
+
+    from squidpy_amd import _lib
+    from squidpy_amd._synthetic import hex_grid_graph
+
+    rows, cols, G, P, steps = 250, 400, 2048, 100, 5
+    n = rows * cols
+    g = normalize(hex_grid_graph(rows, cols), norm="l1", axis=1)
+    vals = np.random.default_rng(11).gamma(2.0, 1.0, size=(G, n))
+    graph = _lib.Graph(ctx, g, with_data=True)
+    plan = _lib.AutocorrPlan(ctx, graph, vals)
+    out, saved = {}, os.environ.get("SQGR_AUTOCORR_KERNEL")
+    try:
+        for label, env in (("default", None), ("gather", "gather")):
+            if env is None:
+                os.environ.pop("SQGR_AUTOCORR_KERNEL", None)
+            else:
+                os.environ["SQGR_AUTOCORR_KERNEL"] = env
+            score = plan.scores("moran")
+            plan.perm_stats("moran", score, seed=3, perm_begin=0, perm_end=P)  # warm-up: workspaces of this kernel
+            ctx.sync()
+            ctx.timer_enable(True)
+            ctx.timer_reset()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                score = plan.scores("moran")
+                red = plan.perm_stats("moran", score, seed=7, perm_begin=(i + 1) * P, perm_end=(i + 2) * P)
+            ctx.sync()
+            dt = time.perf_counter() - t0
+            out[label] = {"genes_per_s": steps * G / dt, "ms_per_step": dt / steps * 1e3, "kernels": ctx.timer_report()}
+            ctx.timer_enable(False)
+            assert np.isfinite(red["std"]).all()
+    finally:
+        if saved is None:
+            os.environ.pop("SQGR_AUTOCORR_KERNEL", None)
+        else:
+            os.environ["SQGR_AUTOCORR_KERNEL"] = saved
+    plan.close()
+    graph.close()
+    k = out["default"]["kernels"]
+    kname = next((name for name in k if name.startswith("autocorr_perm_dot_lds")), None)
+    cnt, ms = k.get(kname, (0, 0.0)) if kname else (0, 0.0)
+    lds_bytes = 16.0 * n * P * G
+    achieved = lds_bytes * cnt / (ms * 1e-3) if ms > 0 else None
+    return {
+        "metric": "Moran's I genes/sec (1e5 spots, CSR k=6, n_perms=100)", "value": out["default"]["genes_per_s"], "unit": "genes/s",
+        "ms_per_step": out["default"]["ms_per_step"], "gather_kernel_genes_per_s": out["gather"]["genes_per_s"],
+        "speedup_vs_gather_kernel": out["default"]["genes_per_s"] / out["gather"]["genes_per_s"],
+        "kernel_ms_per_step": {name: round(v[1] / steps, 3) for name, v in k.items() if v[0] > 0},
+        "gather_kernel_ms_per_step": {name: round(v[1] / steps, 3) for name, v in out["gather"]["kernels"].items() if v[0] > 0},
+        "roofline": {"kernel": kname, "bound": "lds_read", "achieved": achieved / 1e9 if achieved else None, "peak": LDS_READ_PEAK / 1e9, "unit": "GB/s",
+                     "frac": achieved / LDS_READ_PEAK if achieved else None, "traffic": None,
+                     "note": "16 B of LDS reads per (spot, permutation, gene), padding pairs not counted; the 8 sub-lists of a permutation are ~31 pairs long per "
+                     "bucket and padded to the longest of 64 lanes (+50 %): the fraction is that much below the n_perms = 1000 kernel's"},
+        "cpu_baseline": {"value": cpu_value * 1001.0 / 101.0, "unit": "genes/s", "cores": 1, "kind": "port",
+                         "sample": "the secondary leg's CPU rate per (gene, evaluation), scaled to 101 evaluations per gene"} if cpu_value else None,
+    }
+
+
 def config3_full_leg(with_cpu_value: float | None) -> dict:
     """BASELINE config 3 IN FULL through the front end: `spatial_autocorr` on 1e5 spots x 20 000 genes (16 GB of float64
     expression handed over as a host array), 1000 permutations, both statistics — upload, graph normalisation, p-values, FDR
@@ -956,6 +1019,8 @@ def main() -> None:
         legs = config4_legs(ctx, ceil, not args.no_cpu_baseline, counters)
         if geary is not None:
             legs["geary_c"] = geary
+        if not args.no_secondary:
+            legs["moran_p100"] = moran_p100_leg(ctx, (secondary.get("cpu_baseline") or {}).get("value") if secondary else None)
         if not args.no_secondary and not args.no_config3_full:
             try:
                 legs["config3_full"] = config3_full_leg(secondary.get("cpu_baseline", {}).get("value") if secondary else None)

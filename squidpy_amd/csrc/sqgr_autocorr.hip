@@ -414,6 +414,13 @@ constexpr int LIST_ROUND = 16;    // list lengths are multiples of it (k_bucket_
 constexpr int LDS_MAX_CHUNKS = 240;  // bucket kernels: (64 + 1) * nch counters in <= 64 KiB of LDS
 constexpr int LDS_BYTES = 160 * 1024;
 constexpr int LDS_PERM_BLOCK = 1024;  // lanes (= permutations) per workgroup
+// Few permutations (the reference's everyday calls run 50-100, tests/graph/test_ppatterns.py): a workgroup of lane = permutation
+// would be mostly empty.  The LDS kernel then runs on VIRTUAL permutations: permutation p is cut into LDS_SPLIT sub-lists (the
+// spots i = s mod LDS_SPLIT), lane = (p, s); the kernel, the bucket lists and their layout do not change, only the list builder
+// strides over the spots and k_perm_final_lds adds the LDS_SPLIT partial sums of a permutation (s ascending, then the chunks) —
+// a fixed order, so a split permutation range stays bit-identical.  100 permutations fill 13 of a workgroup's 16 waves.
+constexpr int LDS_SPLIT = 8;
+constexpr int LIST_ROUND_SPLIT = 8;   // list lengths of the split variant (its lists are ~1/8 as long; no bank-aware order)
 
 // chunk length for n spots: (m+1) Z rows + m Y rows (+ m row sums for Geary) in 160 KiB
 static inline int lds_chunk(int64_t n, bool geary, int* nch_out) {
@@ -448,24 +455,26 @@ __global__ __launch_bounds__(256) void k_repack_pairs(const double* __restrict__
 
 // len[pg][a][b] = longest list (over the 64 permutations of group pg) of bucket (a, b), rounded up to LIST_ROUND.
 // grid (a, pg), one wave; lane = permutation.  Permutations >= pc have empty lists.
-__global__ __launch_bounds__(64) void k_bucket_count(const int32_t* __restrict__ idx, int64_t n, int64_t pc, int m, int nch,
-                                                     uint32_t* __restrict__ len) {
+// S > 1: lane = virtual permutation vp = p * S + s, which owns the spots i = s (mod S) of permutation p; pc counts virtual ones.
+__global__ __launch_bounds__(64) void k_bucket_count(const int32_t* __restrict__ idx, int64_t n, int64_t pc, int m, int nch, int S,
+                                                     int round, uint32_t* __restrict__ len) {
     extern __shared__ uint32_t cnt[];  // [b][lane]
     const int lane = threadIdx.x, a = blockIdx.x;
-    const int64_t pg = blockIdx.y, p = pg * 64 + lane;
+    const int64_t pg = blockIdx.y, vp = pg * 64 + lane, p = vp / S;
+    const int sub = (int)(vp - p * S);
     for (int b = 0; b < nch; ++b) cnt[b * 64 + lane] = 0;
     const float inv_m = 1.0f / (float)m;
     const int64_t i0 = (int64_t)a * m, i1 = min(n, i0 + m);
-    if (p < pc) {
+    if (vp < pc) {
         const int32_t* row = idx + (size_t)p * n;
 #pragma unroll 8
-        for (int64_t i = i0; i < i1; ++i) cnt[chunk_of((uint32_t)row[i], (uint32_t)m, inv_m) * 64 + lane] += 1;
+        for (int64_t i = i0 + (sub - i0 % S + S) % S; i < i1; i += S) cnt[chunk_of((uint32_t)row[i], (uint32_t)m, inv_m) * 64 + lane] += 1;
     }
     for (int b = 0; b < nch; ++b) {
         uint32_t v = cnt[b * 64 + lane];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
-        if (lane == 0) len[((size_t)pg * nch + a) * nch + b] = (v + LIST_ROUND - 1) / LIST_ROUND * LIST_ROUND;
+        if (lane == 0) len[((size_t)pg * nch + a) * nch + b] = (v + (uint32_t)round - 1) / (uint32_t)round * (uint32_t)round;
     }
 }
 
@@ -511,12 +520,13 @@ __global__ void k_bucket_bases(const uint32_t* __restrict__ total, int npg, uint
 
 // lists[(base[pg] + off[pg][a][b] + k) * 64 + lane] = (i - a*m) | (idx_p(i) - b*m) << 16, pairs in ascending i; the rest of
 // the bucket's len[pg][a][b] rows = the padding pair (m, 0): row m of the Z chunk is zero.
-__global__ __launch_bounds__(64) void k_bucket_fill(const int32_t* __restrict__ idx, int64_t n, int64_t pc, int m, int nch,
+__global__ __launch_bounds__(64) void k_bucket_fill(const int32_t* __restrict__ idx, int64_t n, int64_t pc, int m, int nch, int S,
                                                     const uint32_t* __restrict__ len, const uint32_t* __restrict__ off,
                                                     const uint64_t* __restrict__ base, uint32_t* __restrict__ lists) {
     extern __shared__ uint32_t cur[];  // [b][lane], then the nch row offsets of this (pg, a)
     const int lane = threadIdx.x, a = blockIdx.x;
-    const int64_t pg = blockIdx.y, p = pg * 64 + lane;
+    const int64_t pg = blockIdx.y, vp = pg * 64 + lane, p = vp / S;
+    const int sub = (int)(vp - p * S);
     for (int b = 0; b < nch; ++b) cur[b * 64 + lane] = 0;
     const float inv_m = 1.0f / (float)m;
     const size_t bk = ((size_t)pg * nch + a) * nch;
@@ -525,10 +535,10 @@ __global__ __launch_bounds__(64) void k_bucket_fill(const int32_t* __restrict__ 
     __syncthreads();
     uint32_t* out = lists + (size_t)base[pg] * 64 + lane;
     const int64_t i0 = (int64_t)a * m, i1 = min(n, i0 + m);
-    if (p < pc) {
+    if (vp < pc) {
         const int32_t* row = idx + (size_t)p * n;
 #pragma unroll 4
-        for (int64_t i = i0; i < i1; ++i) {
+        for (int64_t i = i0 + (sub - i0 % S + S) % S; i < i1; i += S) {
             const uint32_t j = (uint32_t)row[i], b = chunk_of(j, (uint32_t)m, inv_m);
             const uint32_t k = cur[b * 64 + lane];
             cur[b * 64 + lane] = k + 1;
@@ -741,17 +751,18 @@ __global__ __launch_bounds__(LDS_PERM_BLOCK) void k_perm_dot_lds(const double* _
     }
 }
 
+// S virtual permutations per permutation (LDS_SPLIT variant; 1 otherwise): their partial sums are added in the order (s, a).
 template <bool GEARY>
-__global__ __launch_bounds__(256) void k_perm_final_lds(const double* __restrict__ part1, const double* __restrict__ part2, int nch,
+__global__ __launch_bounds__(256) void k_perm_final_lds(const double* __restrict__ part1, const double* __restrict__ part2, int nch, int S,
                                                         int64_t pc, int64_t G, int64_t n, double W, const double* __restrict__ z2ss,
                                                         const double* __restrict__ qsum, const uint8_t* __restrict__ isconst,
                                                         double* __restrict__ sims) {
     const int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t p = blockIdx.y;
     if (g >= G) return;
-    const size_t o = (((size_t)(g >> 1) * pc + p) * nch) * GP + (g & 1);
+    const size_t o = (((size_t)(g >> 1) * pc * S + p * S) * nch) * GP + (g & 1);
     double s1 = 0.0, s2 = 0.0;
-    for (int a = 0; a < nch; ++a) {
+    for (int a = 0; a < nch * S; ++a) {  // (s, a) is contiguous: [vp = p * S + s][a]
         s1 += part1[o + (size_t)a * GP];
         if (GEARY) s2 += part2[o + (size_t)a * GP];
     }
@@ -936,13 +947,14 @@ struct PermLists : sqgr::CtxCache {
     // key
     int64_t n = -1, pc = 0, perm0 = 0;
     int m = 0, nch = 0, kind = -1;  // kind 0: device generator (seed), 1: numpy streams (states)
+    int split = 1;                  // virtual permutations per permutation (LDS_SPLIT variant)
     uint64_t seed = 0;
     std::vector<uint64_t> states;
     // lists
     DevBuf<uint32_t> b_len, b_off, b_total, lists;
     DevBuf<uint64_t> b_base;
-    bool matches(int64_t n_, int64_t pc_, int64_t perm0_, int m_, int nch_, int kind_, uint64_t seed_, const uint64_t* st_) const {
-        if (n != n_ || pc != pc_ || perm0 != perm0_ || m != m_ || nch != nch_ || kind != kind_) return false;
+    bool matches(int64_t n_, int64_t pc_, int64_t perm0_, int m_, int nch_, int kind_, uint64_t seed_, const uint64_t* st_, int split_) const {
+        if (n != n_ || pc != pc_ || perm0 != perm0_ || m != m_ || nch != nch_ || kind != kind_ || split != split_) return false;
         if (kind == 0) return seed == seed_;
         return kind == 1 && st_ && states.size() == (size_t)pc_ * 4 && !memcmp(states.data(), st_, (size_t)pc_ * 32);
     }
@@ -955,21 +967,26 @@ static PermLists* perm_lists(sqgr_ctx* ctx) {
 
 // 0: the gather kernel (k_perm_dot), 1: the LDS-bucketed kernel.  SQGR_AUTOCORR_KERNEL=gather|lds overrides the choice
 // (tests run both); the LDS kernel needs <= LDS_MAX_CHUNKS chunks and pays off with many permutations per gene block.
+// 2: the LDS kernel on LDS_SPLIT virtual permutations per permutation (fewer than 512 permutations; SQGR_AUTOCORR_KERNEL=lds-split).
 static int perm_kernel_choice(int64_t n, int64_t G, int64_t P, bool geary) {
     int nch = 0;
     (void)lds_chunk(n, geary, &nch);
     if (nch > LDS_MAX_CHUNKS) return 0;
     if (const char* env = getenv("SQGR_AUTOCORR_KERNEL")) {
         if (!strcmp(env, "lds")) return 1;
+        if (!strcmp(env, "lds-split")) return 2;
         if (!strcmp(env, "gather")) return 0;
     }
-    return (P >= 512 && G >= 256 && n >= 4096) ? 1 : 0;
+    if (G < 256 || n < 4096) return 0;
+    return P >= 512 ? 1 : (P >= 8 ? 2 : 0);
 }
 
 // bucket lists of the pc permutations whose indices are in idx (the first one is permutation `perm0` of its stream) -> pl
-static int build_perm_lists(sqgr_ctx* ctx, PermLists* pl, const int32_t* idx, int64_t n, int64_t pc, int64_t perm0, int m, int nch) {
+// (split > 1: pc counts VIRTUAL permutations, idx holds pc / split index rows)
+static int build_perm_lists(sqgr_ctx* ctx, PermLists* pl, const int32_t* idx, int64_t n, int64_t pc, int64_t perm0, int m, int nch, int split) {
     hipStream_t st = ctx->stream;
     const int npg = (int)ceil_div(pc, 64);
+    const int round = split > 1 ? LIST_ROUND_SPLIT : LIST_ROUND;
     const int nb = nch * nch;
     pl->n = -1;  // invalid until complete
     SQGR_TRY(pl->b_len.ensure((size_t)npg * nb));
@@ -979,18 +996,18 @@ static int build_perm_lists(sqgr_ctx* ctx, PermLists* pl, const int32_t* idx, in
     const size_t cnt_lds = (size_t)nch * 64 * sizeof(uint32_t);
     uint64_t rows = 0;
     LaunchTimer t(ctx, "autocorr_bucket_lists");
-    k_bucket_count<<<dim3((unsigned)nch, (unsigned)npg), 64, cnt_lds, st>>>(idx, n, pc, m, nch, pl->b_len.p);
+    k_bucket_count<<<dim3((unsigned)nch, (unsigned)npg), 64, cnt_lds, st>>>(idx, n, pc, m, nch, split, round, pl->b_len.p);
     k_bucket_offsets<<<(unsigned)npg, 256, 0, st>>>(pl->b_len.p, nb, pl->b_off.p, pl->b_total.p);
     k_bucket_bases<<<1, 64, 0, st>>>(pl->b_total.p, npg, pl->b_base.p);
     SQGR_HIP(hipGetLastError());
     SQGR_HIP(hipMemcpyAsync(&rows, pl->b_base.p + npg, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     SQGR_HIP(hipStreamSynchronize(st));
     SQGR_TRY(pl->lists.ensure((size_t)rows * 64));
-    k_bucket_fill<<<dim3((unsigned)nch, (unsigned)npg), 64, cnt_lds + (size_t)nch * sizeof(uint32_t), st>>>(idx, n, pc, m, nch, pl->b_len.p, pl->b_off.p,
+    k_bucket_fill<<<dim3((unsigned)nch, (unsigned)npg), 64, cnt_lds + (size_t)nch * sizeof(uint32_t), st>>>(idx, n, pc, m, nch, split, pl->b_len.p, pl->b_off.p,
                                                                                                           pl->b_base.p, pl->lists.p);
     SQGR_HIP(hipGetLastError());
     static const bool order_lists = [] { const char* e = getenv("SQGR_AUTOCORR_ORDER_LISTS"); return !(e && atoi(e) == 0); }();
-    if (order_lists) {
+    if (order_lists && split == 1) {  // (the schedule works in rounds of 16 row classes; a sub-list of the split variant holds 2)
         k_bucket_order<<<dim3((unsigned)nb, (unsigned)npg), 64, 0, st>>>(m, nb, perm0, pl->b_len.p, pl->b_off.p, pl->b_base.p, pl->lists.p);
         SQGR_HIP(hipGetLastError());
     }
@@ -998,13 +1015,14 @@ static int build_perm_lists(sqgr_ctx* ctx, PermLists* pl, const int32_t* idx, in
 }
 
 // permutation scores of the pc permutations behind the bucket lists `pl`, through the LDS-bucketed kernel -> h->sims
-static int perms_pass_lds(sqgr_autocorr* h, int32_t mode, int64_t pc, const PermLists* pl) {
+static int perms_pass_lds(sqgr_autocorr* h, int32_t mode, int64_t pc_real, const PermLists* pl, int split) {
     sqgr_ctx* ctx = h->ctx;
     hipStream_t st = ctx->stream;
     const int64_t n = h->n, G = h->G, G2 = (G + 1) / 2;
     const bool geary = mode == 1;
     int nch = 0;
     const int m = lds_chunk(n, geary, &nch);
+    const int64_t pc = pc_real * split;  // lanes of the dot kernel: virtual permutations
     const int npg = (int)ceil_div(pc, 64);
     if (!h->pairs_ready) {
         SQGR_TRY(h->Zp.ensure((size_t)G2 * n * GP));
@@ -1022,7 +1040,8 @@ static int perms_pass_lds(sqgr_autocorr* h, int32_t mode, int64_t pc, const Perm
     const int threads = 64 * std::min(npg, LDS_PERM_BLOCK / 64);
     dim3 grid((unsigned)(ceil_div(G2, 256) * 256 * nch), (unsigned)ceil_div(npg, LDS_PERM_BLOCK / 64));
     {
-        LaunchTimer t(ctx, geary ? "autocorr_perm_dot_lds_geary" : "autocorr_perm_dot_lds_moran");
+        LaunchTimer t(ctx, split > 1 ? (geary ? "autocorr_perm_dot_lds_split_geary" : "autocorr_perm_dot_lds_split_moran")
+                                     : (geary ? "autocorr_perm_dot_lds_geary" : "autocorr_perm_dot_lds_moran"));
         if (geary) {
             if (lds > 64 * 1024)
                 SQGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_perm_dot_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1038,11 +1057,11 @@ static int perms_pass_lds(sqgr_autocorr* h, int32_t mode, int64_t pc, const Perm
     }
     {
         LaunchTimer t(ctx, "autocorr_perm_final");
-        dim3 g2((unsigned)ceil_div(G, 256), (unsigned)pc);
+        dim3 g2((unsigned)ceil_div(G, 256), (unsigned)pc_real);
         if (geary)
-            k_perm_final_lds<true><<<g2, 256, 0, st>>>(h->part1.p, h->part2.p, nch, pc, G, n, h->W, h->z2ss.p, h->qsum.p, h->isconst.p, h->sims.p);
+            k_perm_final_lds<true><<<g2, 256, 0, st>>>(h->part1.p, h->part2.p, nch, split, pc_real, G, n, h->W, h->z2ss.p, h->qsum.p, h->isconst.p, h->sims.p);
         else
-            k_perm_final_lds<false><<<g2, 256, 0, st>>>(h->part1.p, nullptr, nch, pc, G, n, h->W, h->z2ss.p, h->qsum.p, h->isconst.p, h->sims.p);
+            k_perm_final_lds<false><<<g2, 256, 0, st>>>(h->part1.p, nullptr, nch, split, pc_real, G, n, h->W, h->z2ss.p, h->qsum.p, h->isconst.p, h->sims.p);
         SQGR_HIP(hipGetLastError());
     }
     return SQGR_OK;
@@ -1403,15 +1422,18 @@ static int autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_id
     if (const char* env_r = getenv("SQGR_AUTOCORR_ROW_CHUNKS")) R = std::max(1, atoi(env_r));  // tuning knob
     R = (int)std::min<int64_t>(R, std::max<int64_t>(1, n / 256));
     const int64_t by_idx = std::max<int64_t>(PERM_TILE, ((int64_t)1 << 30) / (n * 4));
-    const bool use_lds = perm_kernel_choice(n, G, P, mode == 1) == 1;
+    const int kernel = perm_kernel_choice(n, G, P, mode == 1);
+    const bool use_lds = kernel != 0;
+    const int split = kernel == 2 ? LDS_SPLIT : 1;
     int64_t by_part = std::max<int64_t>(PERM_TILE, ((int64_t)1 << 30) / ((int64_t)h->ntiles * R * GT * 8));
     if (use_lds) {
         int nch = 0;
         (void)lds_chunk(n, mode == 1, &nch);
-        by_part = std::max<int64_t>(64, ((int64_t)1 << 30) / (((G + 1) / 2) * nch * GP * 8));
+        by_part = std::max<int64_t>(64, ((int64_t)1 << 30) / (((G + 1) / 2) * nch * GP * 8 * split));
     }
     int64_t chunk = std::min<int64_t>(std::min<int64_t>(P, 32768), std::min(by_idx, by_part));  // grid.y limit
-    if (use_lds && chunk > LDS_PERM_BLOCK) chunk = chunk / LDS_PERM_BLOCK * LDS_PERM_BLOCK;  // whole workgroups of permutations
+    const int64_t wg_perms = LDS_PERM_BLOCK / split;  // permutations per workgroup of the LDS kernel
+    if (use_lds && chunk > wg_perms) chunk = chunk / wg_perms * wg_perms;  // whole workgroups of permutations
     SQGR_TRY(h->idx.ensure((size_t)chunk * n));
     if (!use_lds) {
         SQGR_TRY(h->part1.ensure((size_t)h->ntiles * chunk * R * GT));
@@ -1431,7 +1453,7 @@ static int autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_id
         if (use_lds) lm = lds_chunk(n, mode == 1, &lnch);
         const int64_t perm0 = (perm_idx || pcg_states) ? c0 : perm_begin + c0;
         const int kind = perm_idx ? 2 : (pcg_states ? 1 : 0);
-        const bool hit = use_lds && pl->matches(n, pc, perm0, lm, lnch, kind, seed, pcg_states ? pcg_states + (size_t)c0 * 4 : nullptr);
+        const bool hit = use_lds && pl->matches(n, pc, perm0, lm, lnch, kind, seed, pcg_states ? pcg_states + (size_t)c0 * 4 : nullptr, split);
         if (!hit) {
             if (perm_idx) {
                 SQGR_HIP(hipMemcpyAsync(h->idx.p, perm_idx + (size_t)c0 * n, (size_t)pc * n * 4, hipMemcpyHostToDevice, st));
@@ -1446,12 +1468,12 @@ static int autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_id
         }
         if (use_lds) {
             if (!hit) {
-                SQGR_TRY(build_perm_lists(ctx, pl, h->idx.p, n, pc, perm0, lm, lnch));
-                pl->n = n; pl->pc = pc; pl->perm0 = perm0; pl->m = lm; pl->nch = lnch; pl->kind = kind; pl->seed = seed;
+                SQGR_TRY(build_perm_lists(ctx, pl, h->idx.p, n, pc * split, perm0, lm, lnch, split));
+                pl->n = n; pl->pc = pc; pl->perm0 = perm0; pl->m = lm; pl->nch = lnch; pl->kind = kind; pl->seed = seed; pl->split = split;
                 pl->states.clear();
                 if (pcg_states) pl->states.assign(pcg_states + (size_t)c0 * 4, pcg_states + (size_t)(c0 + pc) * 4);
             }
-            SQGR_TRY(perms_pass_lds(h, mode, pc, pl));
+            SQGR_TRY(perms_pass_lds(h, mode, pc, pl, split));
             if (dev_all) SQGR_HIP(hipMemcpyAsync(dev_all + (size_t)c0 * G, h->sims.p, (size_t)pc * G * 8, hipMemcpyDeviceToDevice, st));
             if (out_sims) SQGR_HIP(hipMemcpyAsync(out_sims + (size_t)c0 * G, h->sims.p, (size_t)pc * G * 8, hipMemcpyDeviceToHost, st));
             SQGR_HIP(hipStreamSynchronize(st));

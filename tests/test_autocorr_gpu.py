@@ -17,13 +17,14 @@ pytestmark = pytest.mark.gpu
 RTOL, ATOL = 1e-6, 1e-12
 
 
-@pytest.fixture(autouse=True, params=["gather", "lds", "lds-small-chunks"])
+@pytest.fixture(autouse=True, params=["gather", "lds", "lds-small-chunks", "lds-split", "lds-split-small-chunks"])
 def perm_kernel(request, monkeypatch):
-    """Every test of this module runs through both permutation kernels of csrc/sqgr_autocorr.hip: the gather-dot
-    (k_perm_dot) and the LDS-bucketed dot (k_perm_dot_lds), the latter also with 64-spot chunks so that small inputs are
-    cut into many (a, b) buckets.  The library reads the variables at every call."""
-    monkeypatch.setenv("SQGR_AUTOCORR_KERNEL", "gather" if request.param == "gather" else "lds")
-    if request.param == "lds-small-chunks":
+    """Every test of this module runs through the permutation kernels of csrc/sqgr_autocorr.hip: the gather-dot (k_perm_dot), the
+    LDS-bucketed dot (k_perm_dot_lds) and the same kernel on 8 virtual permutations per permutation (`lds-split`: what calls with
+    fewer than 512 permutations take), the LDS variants also with 64-spot chunks so that small inputs are cut into many (a, b)
+    buckets.  The library reads the variables at every call."""
+    monkeypatch.setenv("SQGR_AUTOCORR_KERNEL", {"gather": "gather", "lds": "lds", "lds-small-chunks": "lds"}.get(request.param, "lds-split"))
+    if request.param.endswith("small-chunks"):
         monkeypatch.setenv("SQGR_AUTOCORR_LDS_CHUNK", "64")
     return request.param
 
@@ -123,6 +124,13 @@ def test_lds_kernel_full_workgroups(L, ctx, mode, perm_kernel):
     finally:
         os.environ["SQGR_AUTOCORR_KERNEL"] = "lds"
     np.testing.assert_allclose(dev, ref, rtol=1e-9, atol=1e-13)
+    # ... and the split variant (8 virtual permutations per permutation): a third order of the same sums
+    os.environ["SQGR_AUTOCORR_KERNEL"] = "lds-split"
+    try:
+        ref8 = plan.perms(mode, seed=3, perm_begin=2, perm_end=2 + P)
+    finally:
+        os.environ["SQGR_AUTOCORR_KERNEL"] = "lds"
+    np.testing.assert_allclose(dev, ref8, rtol=1e-9, atol=1e-13)
 
 
 def _adata(n=600, G=40, seed=0):
