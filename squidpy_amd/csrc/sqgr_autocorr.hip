@@ -563,9 +563,11 @@ constexpr int ORDER_MAX = 320;
 // The rotation l' = (global permutation index) mod 16 — every ds_read_b128 lane group ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...,
 // MI355X_MICROARCH.md §LDS) holds each residue once — and the schedule runs over the lane's OWN length rounded up to 16, so the
 // order of a permutation's list depends on that permutation alone: results stay bit-identical however a range is split.
+// cls_shift 0: classes of the Z row (i mod 16); 16: classes of the Y row instead (SQGR_AUTOCORR_ORDER_BY=y, an experiment of round 4:
+// the Y side then runs conflict-free and the Z side random — measured the same to within noise).
 __global__ __launch_bounds__(64) void k_bucket_order(int m, int nb, int64_t perm0, const uint32_t* __restrict__ len,
                                                      const uint32_t* __restrict__ off, const uint64_t* __restrict__ base,
-                                                     uint32_t* __restrict__ lists) {
+                                                     uint32_t* __restrict__ lists, int cls_shift) {
     __shared__ uint32_t ent[ORDER_MAX * 64];   // [k][lane] the list as built (ascending i)
     __shared__ uint16_t hole[ORDER_MAX * 64];  // [s][lane] step of the lane's s-th hole
     __shared__ uint16_t ncls[16 * 64], rank[16 * 64], sbase[16 * 64];  // per lane and class: entries, running rank, surplus offset
@@ -587,7 +589,7 @@ __global__ __launch_bounds__(64) void k_bucket_order(int m, int nb, int64_t perm
         for (int u = 0; u < 16; ++u) {
             ent[(k0 + u) * 64 + lane] = e[u];
             if (e[u] != pad) {
-                ncls[(e[u] & 15u) * 64 + lane] += 1;
+                ncls[((e[u] >> cls_shift) & 15u) * 64 + lane] += 1;
                 ++cnt;
             }
         }
@@ -612,7 +614,7 @@ __global__ __launch_bounds__(64) void k_bucket_order(int m, int nb, int64_t perm
     for (int k = 0; k < L; ++k) {
         const uint32_t e = ent[k * 64 + lane];
         if (e == pad) continue;
-        const int c = (int)(e & 15u);
+        const int c = (int)((e >> cls_shift) & 15u);
         const int j = rank[c * 64 + lane];
         rank[c * 64 + lane] = (uint16_t)(j + 1);
         const int pos = j < D ? ((c - lp) & 15) + 16 * j : (int)hole[((int)sbase[c * 64 + lane] + j - D) * 64 + lane];
@@ -632,7 +634,7 @@ __global__ __launch_bounds__(LDS_PERM_BLOCK) void k_perm_dot_lds(const double* _
                                                                  int64_t G2, int m, int nch, const uint32_t* __restrict__ len,
                                                                  const uint32_t* __restrict__ off, const uint64_t* __restrict__ base,
                                                                  const uint32_t* __restrict__ lists, double* __restrict__ part1,
-                                                                 double* __restrict__ part2) {
+                                                                 double* __restrict__ part2, int a_per_xcd) {
     constexpr int UNR = GEARY ? LIST_UNROLL / 2 : LIST_UNROLL;  // pairs per lane between two waits (register budget: 128)
     extern __shared__ double2 smem2[];
     double2* Zc = smem2;            // [m + 1] rows (z of gene 0, z of gene 1); row m = 0
@@ -642,11 +644,15 @@ __global__ __launch_bounds__(LDS_PERM_BLOCK) void k_perm_dot_lds(const double* _
     int a;
     int64_t tile2;
     {
+        // XCD x runs blocks x, x + 8, ... : 32 of them side by side.  They own 32 / A gene pairs x A chunks: a bucket's lists are
+        // fetched from the fabric once per XCD and (pair, A chunks) share the Y chunks.  A = 1 (long lists: many permutations)
+        // gives 32 pairs walking ONE chunk's lists; the split variant's short lists weigh less than the Y chunks and take A = 4.
         const uint32_t bid = blockIdx.x, x = bid & 7, k = bid >> 3, slot = k & 31, group = k >> 5;
-        a = (int)(group % (uint32_t)nch);
-        tile2 = (int64_t)(group / (uint32_t)nch) * 256 + x * 32 + slot;
+        const uint32_t A = (uint32_t)a_per_xcd, pslots = 32u / A, nag = ((uint32_t)nch + A - 1u) / A;
+        a = (int)((group % nag) * A + slot % A);
+        tile2 = (int64_t)(group / nag) * (8 * pslots) + x * pslots + slot / A;
     }
-    if (tile2 >= G2) return;  // whole workgroup
+    if (tile2 >= G2 || a >= nch) return;  // whole workgroup
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pg_raw = (int)blockIdx.y * (LDS_PERM_BLOCK / 64) + wave;
     const bool live = pg_raw < npg;  // waves past the last group only help with the chunk loads
@@ -978,12 +984,15 @@ static int perm_kernel_choice(int64_t n, int64_t G, int64_t P, bool geary) {
         if (!strcmp(env, "gather")) return 0;
     }
     if (G < 256 || n < 4096) return 0;
-    return P >= 512 ? 1 : (P >= 8 ? 2 : 0);
+    // (measured at config 3's shape, 2048 genes: the Y chunks every workgroup streams through LDS cost the same however few
+    // permutations there are — the gather kernel wins below ~40 permutations)
+    return P >= 512 ? 1 : (P >= 40 ? 2 : 0);
 }
 
 // bucket lists of the pc permutations whose indices are in idx (the first one is permutation `perm0` of its stream) -> pl
 // (split > 1: pc counts VIRTUAL permutations, idx holds pc / split index rows)
-static int build_perm_lists(sqgr_ctx* ctx, PermLists* pl, const int32_t* idx, int64_t n, int64_t pc, int64_t perm0, int m, int nch, int split) {
+static int build_perm_lists(sqgr_ctx* ctx, PermLists* pl, const int32_t* idx, int64_t n, int64_t pc, int64_t perm0, int m, int nch, int split,
+                            bool geary) {
     hipStream_t st = ctx->stream;
     const int npg = (int)ceil_div(pc, 64);
     const int round = split > 1 ? LIST_ROUND_SPLIT : LIST_ROUND;
@@ -1008,7 +1017,11 @@ static int build_perm_lists(sqgr_ctx* ctx, PermLists* pl, const int32_t* idx, in
     SQGR_HIP(hipGetLastError());
     static const bool order_lists = [] { const char* e = getenv("SQGR_AUTOCORR_ORDER_LISTS"); return !(e && atoi(e) == 0); }();
     if (order_lists && split == 1) {  // (the schedule works in rounds of 16 row classes; a sub-list of the split variant holds 2)
-        k_bucket_order<<<dim3((unsigned)nb, (unsigned)npg), 64, 0, st>>>(m, nb, perm0, pl->b_len.p, pl->b_off.p, pl->b_base.p, pl->lists.p);
+        // Geary's C reads TWO arrays through the Y index (the y row and the row sum): its lists are scheduled by the classes of the Y
+        // row (measured 99.6 -> 94.4 ms per 2048 genes x 1000 permutations); Moran's I keeps the Z classes (66.2 vs 65.6 ms: no difference)
+        const char* e_by = getenv("SQGR_AUTOCORR_ORDER_BY");
+        const int cls_shift = e_by ? ((e_by[0] == 'y') ? 16 : 0) : (geary ? 16 : 0);
+        k_bucket_order<<<dim3((unsigned)nb, (unsigned)npg), 64, 0, st>>>(m, nb, perm0, pl->b_len.p, pl->b_off.p, pl->b_base.p, pl->lists.p, cls_shift);
         SQGR_HIP(hipGetLastError());
     }
     return SQGR_OK;
@@ -1037,8 +1050,27 @@ static int perms_pass_lds(sqgr_autocorr* h, int32_t mode, int64_t pc_real, const
     SQGR_TRY(h->part1.ensure((size_t)G2 * pc * nch * GP));
     if (geary) SQGR_TRY(h->part2.ensure((size_t)G2 * pc * nch * GP));
     const size_t lds = ((size_t)(2 * m + 1) * GP + (geary ? (size_t)m : 0)) * sizeof(double);
-    const int threads = 64 * std::min(npg, LDS_PERM_BLOCK / 64);
-    dim3 grid((unsigned)(ceil_div(G2, 256) * 256 * nch), (unsigned)ceil_div(npg, LDS_PERM_BLOCK / 64));
+    // the split variant always launches whole workgroups: waves without a permutation group still move the Y chunks (with fewer
+    // than m / 5 threads a chunk does not fit the staging registers and its loads are no longer prefetched)
+    const int threads = split > 1 ? LDS_PERM_BLOCK : 64 * std::min(npg, LDS_PERM_BLOCK / 64);
+    // chunks per XCD round (see k_perm_dot_lds): the power of two nearest sqrt(32 * Y chunk bytes / list bytes of one bucket)
+    int a_per_xcd = 1;
+    if (const char* env = getenv("SQGR_AUTOCORR_XCD_CHUNKS")) {
+        a_per_xcd = std::max(1, std::min(32, atoi(env)));
+        while (a_per_xcd & (a_per_xcd - 1)) a_per_xcd &= a_per_xcd - 1;
+    } else if (split == 1) {
+        // many permutations (measured at config 3's shape, 1000 permutations): Moran's I 66.2 ms with one chunk per round, 63.3 with 2,
+        // 62.4 with 4; Geary's C (24 instead of 16 LDS bytes per pair, 4092-spot chunks) 99.6 / 100.6 / 106.9 ms
+        a_per_xcd = geary ? 1 : 4;
+    } else {
+        const double list_bytes = (double)npg * ((double)n / split / ((double)nch * nch) * 1.5) * 256.0;  // rows of 64 entries, ~+50 % padding
+        // (measured at config 3's shape, 50 / 100 / 256 permutations: 4-8 chunks per round, -14 ... -27 % against one; twice the
+        // square-root estimate, at most 8)
+        const double want = 2.0 * std::sqrt(32.0 * (double)m * GP * 8 / std::max(list_bytes, 1.0));
+        while (a_per_xcd * 2 <= 8 && (double)a_per_xcd < want) a_per_xcd *= 2;
+    }
+    const int pslots = 32 / a_per_xcd;
+    dim3 grid((unsigned)(ceil_div(G2, 8 * pslots) * ceil_div(nch, a_per_xcd) * 256), (unsigned)ceil_div(npg, LDS_PERM_BLOCK / 64));
     {
         LaunchTimer t(ctx, split > 1 ? (geary ? "autocorr_perm_dot_lds_split_geary" : "autocorr_perm_dot_lds_split_moran")
                                      : (geary ? "autocorr_perm_dot_lds_geary" : "autocorr_perm_dot_lds_moran"));
@@ -1046,12 +1078,12 @@ static int perms_pass_lds(sqgr_autocorr* h, int32_t mode, int64_t pc_real, const
             if (lds > 64 * 1024)
                 SQGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_perm_dot_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             k_perm_dot_lds<true><<<grid, threads, lds, st>>>(h->Zp.p, h->Yp.p, h->rowsum.p, n, pc, npg, G2, m, nch, pl->b_len.p, pl->b_off.p,
-                                                              pl->b_base.p, pl->lists.p, h->part1.p, h->part2.p);
+                                                              pl->b_base.p, pl->lists.p, h->part1.p, h->part2.p, a_per_xcd);
         } else {
             if (lds > 64 * 1024)
                 SQGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_perm_dot_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             k_perm_dot_lds<false><<<grid, threads, lds, st>>>(h->Zp.p, h->Yp.p, h->rowsum.p, n, pc, npg, G2, m, nch, pl->b_len.p, pl->b_off.p,
-                                                               pl->b_base.p, pl->lists.p, h->part1.p, nullptr);
+                                                               pl->b_base.p, pl->lists.p, h->part1.p, nullptr, a_per_xcd);
         }
         SQGR_HIP(hipGetLastError());
     }
@@ -1468,7 +1500,7 @@ static int autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_id
         }
         if (use_lds) {
             if (!hit) {
-                SQGR_TRY(build_perm_lists(ctx, pl, h->idx.p, n, pc * split, perm0, lm, lnch, split));
+                SQGR_TRY(build_perm_lists(ctx, pl, h->idx.p, n, pc * split, perm0, lm, lnch, split, mode == 1));
                 pl->n = n; pl->pc = pc; pl->perm0 = perm0; pl->m = lm; pl->nch = lnch; pl->kind = kind; pl->seed = seed; pl->split = split;
                 pl->states.clear();
                 if (pcg_states) pl->states.assign(pcg_states + (size_t)c0 * 4, pcg_states + (size_t)(c0 + pc) * 4);
