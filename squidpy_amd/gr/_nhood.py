@@ -96,9 +96,10 @@ def nhood_enrichment(
         ``csrc/sqgr_rng.h`` keyed by ``(seed, permutation index, library)``; results are reproducible for a
         given ``seed`` and independent of the number of GPUs, but follow a different stream than numpy.
         ``"numpy"``: the reference's own streams (``SeedSequence(seed).spawn(n_perms)`` -> PCG64 ->
-        ``Generator.shuffle``) are reproduced bit for bit *on the GPU* (one wave per permutation, LCG jump-ahead draws), and the z-score
-        is formed with the reference's float64 ``perms.mean/std``: Squidpy's z-scores for that ``seed``, exactly
-        (1e6 spots: ~25 k permutations/s against ~1 M for ``"philox"``; the CPU does ~20/s per core).
+        ``Generator.shuffle``) are reproduced bit for bit *on the GPU* (LCG jump-ahead draws; long arrays replay the swaps phase by
+        phase through LDS, ``csrc/sqgr_pcg.hip``), and the z-score is formed with the reference's float64 ``perms.mean/std``:
+        Squidpy's z-scores for that ``seed``, exactly (1e6 spots: ~60 k permutations/s — ~36 k at the default ``n_perms=1000`` —
+        against ~1 M for ``"philox"``; the CPU does ~20/s per core).
         ``"numpy-host"``: same streams drawn by numpy on the host and injected (cross-check path).
     device
         HIP device index (default: ``LOCAL_RANK`` or 0).

@@ -195,6 +195,46 @@ def test_config3_sparse_float32_expression_at_full_shape(sq, L, config3):
     np.testing.assert_array_equal(df_sparse.loc[b.index, "I"].to_numpy(), b["I"].to_numpy())
 
 
+def _occur_count_blocked(x, y, thr2, labels, k, block=10_000):
+    """The C restatement of `_occur_count` (gr/_ppatterns.py:283-310; oracle/c/sqgr_cpu.c keeps the reference's per-point int32
+    scratch of K*K*L counters: 8.8 GB for 5e4 points) evaluated block-wise by inclusion-exclusion over pairs of point blocks:
+    counts(all) = sum_p counts(B_p) + sum_{p<q} [counts(B_p u B_q) - counts(B_p) - counts(B_q)].  Integer counts: exact."""
+    from oracle import cport
+
+    n = len(x)
+    blocks = [np.arange(b0, min(n, b0 + block)) for b0 in range(0, n, block)]
+    own = [cport.occur_count(x[b], y[b], thr2, labels[b], k, parallel=True) for b in blocks]
+    total = sum(own)
+    for p in range(len(blocks)):
+        for q in range(p + 1, len(blocks)):
+            u = np.concatenate([blocks[p], blocks[q]])
+            total = total + cport.occur_count(x[u], y[u], thr2, labels[u], k, parallel=True) - own[p] - own[q]
+    return total
+
+
+def test_config4_cooccurrence_every_cell_exact_on_a_50000_point_subcloud(sq, L):
+    """All 30 x 30 x 49 cells of config 4's count array, not only the small clusters': a 50 000-point sub-cloud of the same point
+    set (hex grid + N(0, 5) jitter, 30 uniform labels, the front end's own 49 thresholds) through `sq.gr.co_occurrence` against the
+    C restatement of the reference's loop — bit-exact integers, the reference's ratio arithmetic on top."""
+    rows = cols = 1000
+    n, k, m = rows * cols, 30, 50_000
+    rng = np.random.default_rng(4)
+    xy_all = O.hex_grid(rows, cols) + rng.normal(0, 5, (n, 2))
+    pick = np.sort(rng.choice(n, m, replace=False))
+    xy = xy_all[pick]
+    labels = rng.integers(0, k, m).astype(np.int32)
+    adata = _adata(sq, 1, m, labels, k, xy=xy, graph=False)
+    occ, interval = sq.gr.co_occurrence(adata, "cluster", interval=50, copy=True)
+    sp32 = xy.astype(np.float32)
+    np.testing.assert_array_equal(interval, np.linspace(*O.find_min_max(sp32), num=50, dtype=np.float32))
+    thr2 = interval[1:] ** 2
+    want = _occur_count_blocked(sp32[:, 0], sp32[:, 1], thr2, labels, k)
+    got = L.cooccur_counts(L.default_context(), sp32[:, 0], sp32[:, 1], labels, k, thr2)
+    np.testing.assert_array_equal(got, want)
+    assert int(want[..., -1].sum()) > 0.2 * m * (m - 1)  # the last radius (half the diagonal) reaches a good part of all ordered pairs
+    np.testing.assert_allclose(occ, O.co_occurrence_probs(want), rtol=1e-12)
+
+
 def test_config4_cooccurrence_and_ripley_1e6_points_30_clusters(sq, L):
     """Config 4 through both front ends at 1e6 points (hex grid + N(0, 5) jitter), 30 clusters, interval = 50 / n_steps = 50.
     Two of the 30 clusters are small (1500 points), so every count that involves only them has an exact brute-force oracle
