@@ -26,3 +26,14 @@ def test_fuzz_frontends_fixed_seeds(seed):
     env = dict(os.environ, PYTHONPATH=ROOT, FUZZ_ITERS="150")
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_frontend.py"), "0", str(seed)], env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0 and "fuzz_frontend ok: 150 iterations" in res.stdout, res.stdout[-1500:] + res.stderr[-3000:]
+
+
+def test_fuzz_through_the_round4_kernel_variants():
+    """The same two randomised testers with the kernel variants of round 4 FORCED (their sizes would pick the older kernels): the
+    bucketed replay of numpy's shuffle with 128-position phases (libraries, tiny arrays, every cluster regime) and the LDS
+    permutation kernel on 8 virtual permutations per permutation."""
+    env = dict(os.environ, PYTHONPATH=ROOT, SQGR_PCG_KERNEL="bucket", SQGR_PCG_BUCKET_LOGS="7", SQGR_AUTOCORR_KERNEL="lds-split")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_gpu.py"), "0", "4242"], env=dict(env, FUZZ_ITERS="4"), capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0 and "fuzz ok: 4 iterations" in res.stdout, res.stdout[-1500:] + res.stderr[-3000:]
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_frontend.py"), "0", "4243"], env=dict(env, FUZZ_ITERS="120"), capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0 and "fuzz_frontend ok: 120 iterations" in res.stdout, res.stdout[-1500:] + res.stderr[-3000:]
