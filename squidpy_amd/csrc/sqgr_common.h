@@ -82,16 +82,23 @@ struct sqgr_ctx {
 
 namespace sqgr {
 
+// roctx ranges (SQGR_ROCTX=1; libroctx64 bound at run time): every bracketed launch shows up under its name in a rocprofv3
+// `--marker-trace` timeline — the tracing hook SURVEY §5 lists next to the HIP-event timers.  No-ops otherwise.
+void roctx_push(const char* name);
+void roctx_pop();
+
 // RAII bracket: records start/stop events on ctx->stream around a kernel launch when timing is on.
 struct LaunchTimer {
     sqgr_ctx* ctx;
     TimedLaunch tl;
     bool active;
     LaunchTimer(sqgr_ctx* c, const char* name, hipStream_t st = nullptr) : ctx(c), active(false) {
+        roctx_push(name);
         if (ctx->timing) active = (ctx->begin_launch(name, &tl, st ? st : c->stream) == SQGR_OK);
     }
     ~LaunchTimer() {
         if (active) ctx->end_launch(tl);
+        roctx_pop();
     }
 };
 

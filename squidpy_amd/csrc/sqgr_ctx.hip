@@ -1,4 +1,6 @@
 // libsqgr: context, error reporting, kernel timers and the device-resident CSR graph.
+#include <dlfcn.h>
+
 #include "sqgr_common.h"
 
 #include <cstdlib>
@@ -15,6 +17,35 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// ---- roctx ranges (declared in sqgr_common.h): libroctx64 is looked up once, only when SQGR_ROCTX=1
+struct RoctxApi {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+};
+static const RoctxApi& roctx_api() {
+    static const RoctxApi api = [] {
+        RoctxApi a;
+        const char* e = getenv("SQGR_ROCTX");
+        if (!(e && atoi(e) == 1)) return a;
+        for (const char* nm : {"libroctx64.so.4", "libroctx64.so", "librocprofiler-sdk-roctx.so.1"}) {
+            if (void* h = dlopen(nm, RTLD_NOW | RTLD_LOCAL)) {
+                a.push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+                a.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (a.push && a.pop) return a;
+                a = RoctxApi();
+            }
+        }
+        return a;
+    }();
+    return api;
+}
+void roctx_push(const char* name) {
+    if (roctx_api().push) (void)roctx_api().push(name);
+}
+void roctx_pop() {
+    if (roctx_api().pop) (void)roctx_api().pop();
 }
 
 // ---- parked device buffers (declared in sqgr_common.h)

