@@ -520,9 +520,11 @@ __global__ void k_bucket_bases(const uint32_t* __restrict__ total, int npg, uint
 
 // lists[(base[pg] + off[pg][a][b] + k) * 64 + lane] = (i - a*m) | (idx_p(i) - b*m) << 16, pairs in ascending i; the rest of
 // the bucket's len[pg][a][b] rows = the padding pair (m, 0): row m of the Z chunk is zero.
+// rcls != nullptr: bits 29..31 of a pair <- the row-sum class of its j (k_perm_dot_lds RMODE 2; m < 8192)
 __global__ __launch_bounds__(64) void k_bucket_fill(const int32_t* __restrict__ idx, int64_t n, int64_t pc, int m, int nch, int S,
                                                     const uint32_t* __restrict__ len, const uint32_t* __restrict__ off,
-                                                    const uint64_t* __restrict__ base, uint32_t* __restrict__ lists) {
+                                                    const uint64_t* __restrict__ base, uint32_t* __restrict__ lists,
+                                                    const uint8_t* __restrict__ rcls) {
     extern __shared__ uint32_t cur[];  // [b][lane], then the nch row offsets of this (pg, a)
     const int lane = threadIdx.x, a = blockIdx.x;
     const int64_t pg = blockIdx.y, vp = pg * 64 + lane, p = vp / S;
@@ -542,7 +544,7 @@ __global__ __launch_bounds__(64) void k_bucket_fill(const int32_t* __restrict__ 
             const uint32_t j = (uint32_t)row[i], b = chunk_of(j, (uint32_t)m, inv_m);
             const uint32_t k = cur[b * 64 + lane];
             cur[b * 64 + lane] = k + 1;
-            out[((size_t)offl[b] + k) * 64] = (uint32_t)(i - i0) | ((j - b * (uint32_t)m) << 16);
+            out[((size_t)offl[b] + k) * 64] = (uint32_t)(i - i0) | ((j - b * (uint32_t)m) << 16) | (rcls ? (uint32_t)rcls[j] << 29 : 0u);
         }
     }
     const uint32_t pad = (uint32_t)m;
@@ -628,18 +630,26 @@ __global__ __launch_bounds__(64) void k_bucket_order(int m, int nb, int64_t perm
 // (shared by all genes) are served by that XCD's L2 — only the Y chunks are private traffic.
 // part1[((tile2 * pc + p) * nch + a) * 2 + c]
 constexpr int LDS_STAGE = 5;  // rows per thread of one chunk at LDS_PERM_BLOCK threads (m <= 5 * 1024)
-template <bool GEARY>
+// RMODE 0: Moran's I.  Geary's C also needs sum_i z_i^2 r[idx_p(i)], r = the graph's row sums: RMODE 1 keeps r[chunk b] in LDS next to
+// Y (a third random read per pair, 4092-spot chunks); RMODE 2 (round 4): the row sums take at most 8 DISTINCT values — a
+// row-normalised graph has one per degree, a binary graph its degrees — so the list entry carries the class of r[j] in its top three
+// bits and the kernel reads an 8-entry table: Moran's chunks, a read that meets in at most 8 addresses.
+template <int RMODE>
 __global__ __launch_bounds__(LDS_PERM_BLOCK) void k_perm_dot_lds(const double* __restrict__ Zp, const double* __restrict__ Yp,
                                                                  const double* __restrict__ rowsum, int64_t n, int64_t pc, int npg,
                                                                  int64_t G2, int m, int nch, const uint32_t* __restrict__ len,
                                                                  const uint32_t* __restrict__ off, const uint64_t* __restrict__ base,
                                                                  const uint32_t* __restrict__ lists, double* __restrict__ part1,
                                                                  double* __restrict__ part2, int a_per_xcd) {
-    constexpr int UNR = GEARY ? LIST_UNROLL / 2 : LIST_UNROLL;  // pairs per lane between two waits (register budget: 128)
+    constexpr bool GEARY = RMODE != 0, RARR = RMODE == 1, RCLS = RMODE == 2;
+    // pairs per lane between two waits (register budget: 128; the class-table variant spills 6 registers at 8 and is still 8 % faster
+    // than at 4: 70.8 vs 77.2 ms per 2048 genes x 1000 permutations)
+    constexpr int UNR = RARR ? LIST_UNROLL / 2 : LIST_UNROLL;
+    constexpr uint32_t JMASK = RCLS ? 0x1fffu : 0xffffu;        // RCLS: bits 29..31 of an entry hold the class of r[j]
     extern __shared__ double2 smem2[];
     double2* Zc = smem2;            // [m + 1] rows (z of gene 0, z of gene 1); row m = 0
     double2* Yc = smem2 + (m + 1);  // [m]
-    double* Rc = reinterpret_cast<double*>(Yc + m);  // [m] row sums (Geary)
+    double* Rc = reinterpret_cast<double*>(Yc + m);  // RMODE 1: [m] row sums; RMODE 2: the table of the (<= 8) distinct row sums
     const int tid = threadIdx.x, nthr = blockDim.x;
     int a;
     int64_t tile2;
@@ -676,7 +686,7 @@ __global__ __launch_bounds__(LDS_PERM_BLOCK) void k_perm_dot_lds(const double* _
             const int t = tid + u * nthr;
             if (t < mb) {
                 sy[u] = Yg[j0 + t];
-                if (GEARY) sr[u] = rowsum[j0 + t];
+                if (RARR) sr[u] = rowsum[j0 + t];
             }
         }
     };
@@ -687,7 +697,7 @@ __global__ __launch_bounds__(LDS_PERM_BLOCK) void k_perm_dot_lds(const double* _
             const int t = tid + u * nthr;
             if (t < mb) {
                 Yc[t] = sy[u];
-                if (GEARY) Rc[t] = sr[u];
+                if (RARR) Rc[t] = sr[u];
             }
         }
     };
@@ -696,6 +706,7 @@ __global__ __launch_bounds__(LDS_PERM_BLOCK) void k_perm_dot_lds(const double* _
         const int ma = (int)min((int64_t)m, n - i0);
         for (int t = tid; t < ma; t += nthr) Zc[t] = Zg[i0 + t];
         if (tid == 0) Zc[m] = make_double2(0.0, 0.0);
+        if (RCLS && tid < 8) Rc[tid] = rowsum[tid];  // (`rowsum` points at the class table)
     }
     if (staged) fetch(0);
     const size_t bk = ((size_t)pg * nch + a) * nch;
@@ -710,7 +721,7 @@ __global__ __launch_bounds__(LDS_PERM_BLOCK) void k_perm_dot_lds(const double* _
             const int mb = (int)min((int64_t)m, n - j0);
             for (int t = tid; t < mb; t += nthr) {
                 Yc[t] = Yg[j0 + t];
-                if (GEARY) Rc[t] = rowsum[j0 + t];
+                if (RARR) Rc[t] = rowsum[j0 + t];
             }
         }
         __syncthreads();
@@ -736,8 +747,9 @@ __global__ __launch_bounds__(LDS_PERM_BLOCK) void k_perm_dot_lds(const double* _
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 z[u] = Zc[cur[u] & 0xffffu];
-                y[u] = Yc[cur[u] >> 16];
-                if (GEARY) r[u] = Rc[cur[u] >> 16];
+                y[u] = Yc[(cur[u] >> 16) & JMASK];
+                if (RARR) r[u] = Rc[cur[u] >> 16];
+                if (RCLS) r[u] = Rc[cur[u] >> 29];
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
@@ -758,11 +770,12 @@ __global__ __launch_bounds__(LDS_PERM_BLOCK) void k_perm_dot_lds(const double* _
 }
 
 // S virtual permutations per permutation (LDS_SPLIT variant; 1 otherwise): their partial sums are added in the order (s, a).
+// part2 == nullptr with GEARY: uniform row sums — the z^2 r term is rs_const * sum z^2 whatever the permutation.
 template <bool GEARY>
 __global__ __launch_bounds__(256) void k_perm_final_lds(const double* __restrict__ part1, const double* __restrict__ part2, int nch, int S,
                                                         int64_t pc, int64_t G, int64_t n, double W, const double* __restrict__ z2ss,
                                                         const double* __restrict__ qsum, const uint8_t* __restrict__ isconst,
-                                                        double* __restrict__ sims) {
+                                                        double* __restrict__ sims, double rs_const) {
     const int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t p = blockIdx.y;
     if (g >= G) return;
@@ -770,8 +783,9 @@ __global__ __launch_bounds__(256) void k_perm_final_lds(const double* __restrict
     double s1 = 0.0, s2 = 0.0;
     for (int a = 0; a < nch * S; ++a) {  // (s, a) is contiguous: [vp = p * S + s][a]
         s1 += part1[o + (size_t)a * GP];
-        if (GEARY) s2 += part2[o + (size_t)a * GP];
+        if (GEARY && part2) s2 += part2[o + (size_t)a * GP];
     }
+    if (GEARY && !part2) s2 = rs_const * z2ss[g];
     double v;
     if (GEARY)
         v = ((double)(n - 1) * ((s2 - 2.0 * s1) + qsum[g])) / (2.0 * W * z2ss[g]);
@@ -945,6 +959,15 @@ struct sqgr_autocorr {
     // LDS-bucketed permutation dot: gene-pair layout of Z and Y, and the bucket lists of the permutations in flight
     DevBuf<double> Zp, Yp;
     bool pairs_ready = false;
+    // Geary's C under permutation needs sum_i z_i^2 r[idx_p(i)] with r = the graph's row sums.  On a row-normalised graph
+    // (`transformation=True`, the reference's default, gr/_ppatterns.py:212-214) every row sum is 1 up to an ulp: the term is
+    // r * sum z^2 for every permutation, and Geary's permutations run through the Moran kernel (two LDS reads per pair, not three)
+    bool rs_uniform = false;
+    double rs_const = 0.0;
+    // ... and when they take a few distinct values (one per degree): class of every spot's row sum + the table (k_perm_dot_lds RMODE 2)
+    int rs_classes = 0;  // 2..8: table mode available
+    DevBuf<uint8_t> rcls;
+    DevBuf<double> rtab;
 };
 
 // The bucket lists depend on the permutations alone: every feature block of a call (and the next call with the same seed)
@@ -992,7 +1015,7 @@ static int perm_kernel_choice(int64_t n, int64_t G, int64_t P, bool geary) {
 // bucket lists of the pc permutations whose indices are in idx (the first one is permutation `perm0` of its stream) -> pl
 // (split > 1: pc counts VIRTUAL permutations, idx holds pc / split index rows)
 static int build_perm_lists(sqgr_ctx* ctx, PermLists* pl, const int32_t* idx, int64_t n, int64_t pc, int64_t perm0, int m, int nch, int split,
-                            bool geary) {
+                            bool geary, const uint8_t* rcls) {
     hipStream_t st = ctx->stream;
     const int npg = (int)ceil_div(pc, 64);
     const int round = split > 1 ? LIST_ROUND_SPLIT : LIST_ROUND;
@@ -1013,7 +1036,7 @@ static int build_perm_lists(sqgr_ctx* ctx, PermLists* pl, const int32_t* idx, in
     SQGR_HIP(hipStreamSynchronize(st));
     SQGR_TRY(pl->lists.ensure((size_t)rows * 64));
     k_bucket_fill<<<dim3((unsigned)nch, (unsigned)npg), 64, cnt_lds + (size_t)nch * sizeof(uint32_t), st>>>(idx, n, pc, m, nch, split, pl->b_len.p, pl->b_off.p,
-                                                                                                          pl->b_base.p, pl->lists.p);
+                                                                                                          pl->b_base.p, pl->lists.p, rcls);
     SQGR_HIP(hipGetLastError());
     static const bool order_lists = [] { const char* e = getenv("SQGR_AUTOCORR_ORDER_LISTS"); return !(e && atoi(e) == 0); }();
     if (order_lists && split == 1) {  // (the schedule works in rounds of 16 row classes; a sub-list of the split variant holds 2)
@@ -1027,12 +1050,22 @@ static int build_perm_lists(sqgr_ctx* ctx, PermLists* pl, const int32_t* idx, in
     return SQGR_OK;
 }
 
+// which k_perm_dot_lds instantiation serves a statistic on this plan: 0 Moran's I — and Geary's C when all row sums are equal —,
+// 2 Geary's C through the class table (<= 8 distinct row sums), 1 Geary's C with the row sums of the chunk in LDS
+static int lds_rmode(const sqgr_autocorr* h, int32_t mode) {
+    if (mode != 1 || h->rs_uniform) return 0;
+    return h->rs_classes ? 2 : 1;
+}
+
 // permutation scores of the pc permutations behind the bucket lists `pl`, through the LDS-bucketed kernel -> h->sims
 static int perms_pass_lds(sqgr_autocorr* h, int32_t mode, int64_t pc_real, const PermLists* pl, int split) {
     sqgr_ctx* ctx = h->ctx;
     hipStream_t st = ctx->stream;
     const int64_t n = h->n, G = h->G, G2 = (G + 1) / 2;
-    const bool geary = mode == 1;
+    const bool geary_stat = mode == 1;
+    const int rmode = lds_rmode(h, mode);
+    const bool geary = rmode == 1;   // the kernel with the chunk's row sums in LDS: 4092-spot chunks
+    const bool second = rmode != 0;  // a second partial sum (z^2 r) per lane
     int nch = 0;
     const int m = lds_chunk(n, geary, &nch);
     const int64_t pc = pc_real * split;  // lanes of the dot kernel: virtual permutations
@@ -1048,8 +1081,8 @@ static int perms_pass_lds(sqgr_autocorr* h, int32_t mode, int64_t pc_real, const
         h->pairs_ready = true;
     }
     SQGR_TRY(h->part1.ensure((size_t)G2 * pc * nch * GP));
-    if (geary) SQGR_TRY(h->part2.ensure((size_t)G2 * pc * nch * GP));
-    const size_t lds = ((size_t)(2 * m + 1) * GP + (geary ? (size_t)m : 0)) * sizeof(double);
+    if (second) SQGR_TRY(h->part2.ensure((size_t)G2 * pc * nch * GP));
+    const size_t lds = ((size_t)(2 * m + 1) * GP + (geary ? (size_t)m : (rmode == 2 ? (size_t)8 : 0))) * sizeof(double);
     // the split variant always launches whole workgroups: waves without a permutation group still move the Y chunks (with fewer
     // than m / 5 threads a chunk does not fit the staging registers and its loads are no longer prefetched)
     const int threads = split > 1 ? LDS_PERM_BLOCK : 64 * std::min(npg, LDS_PERM_BLOCK / 64);
@@ -1072,28 +1105,30 @@ static int perms_pass_lds(sqgr_autocorr* h, int32_t mode, int64_t pc_real, const
     const int pslots = 32 / a_per_xcd;
     dim3 grid((unsigned)(ceil_div(G2, 8 * pslots) * ceil_div(nch, a_per_xcd) * 256), (unsigned)ceil_div(npg, LDS_PERM_BLOCK / 64));
     {
-        LaunchTimer t(ctx, split > 1 ? (geary ? "autocorr_perm_dot_lds_split_geary" : "autocorr_perm_dot_lds_split_moran")
-                                     : (geary ? "autocorr_perm_dot_lds_geary" : "autocorr_perm_dot_lds_moran"));
-        if (geary) {
-            if (lds > 64 * 1024)
-                SQGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_perm_dot_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            k_perm_dot_lds<true><<<grid, threads, lds, st>>>(h->Zp.p, h->Yp.p, h->rowsum.p, n, pc, npg, G2, m, nch, pl->b_len.p, pl->b_off.p,
-                                                              pl->b_base.p, pl->lists.p, h->part1.p, h->part2.p, a_per_xcd);
-        } else {
-            if (lds > 64 * 1024)
-                SQGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_perm_dot_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            k_perm_dot_lds<false><<<grid, threads, lds, st>>>(h->Zp.p, h->Yp.p, h->rowsum.p, n, pc, npg, G2, m, nch, pl->b_len.p, pl->b_off.p,
-                                                               pl->b_base.p, pl->lists.p, h->part1.p, nullptr, a_per_xcd);
-        }
+        LaunchTimer t(ctx, split > 1 ? (geary_stat ? "autocorr_perm_dot_lds_split_geary" : "autocorr_perm_dot_lds_split_moran")
+                                     : (geary_stat ? "autocorr_perm_dot_lds_geary" : "autocorr_perm_dot_lds_moran"));
+#define SQGR_DOT_LDS(RM, RSRC, P2)                                                                                                            \
+    do {                                                                                                                                      \
+        if (lds > 64 * 1024)                                                                                                                  \
+            SQGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_perm_dot_lds<RM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        k_perm_dot_lds<RM><<<grid, threads, lds, st>>>(h->Zp.p, h->Yp.p, RSRC, n, pc, npg, G2, m, nch, pl->b_len.p, pl->b_off.p, pl->b_base.p,  \
+                                                       pl->lists.p, h->part1.p, P2, a_per_xcd);                                              \
+    } while (0)
+        if (rmode == 1) SQGR_DOT_LDS(1, h->rowsum.p, h->part2.p);
+        else if (rmode == 2) SQGR_DOT_LDS(2, h->rtab.p, h->part2.p);
+        else SQGR_DOT_LDS(0, h->rowsum.p, nullptr);
+#undef SQGR_DOT_LDS
         SQGR_HIP(hipGetLastError());
     }
     {
         LaunchTimer t(ctx, "autocorr_perm_final");
         dim3 g2((unsigned)ceil_div(G, 256), (unsigned)pc_real);
-        if (geary)
-            k_perm_final_lds<true><<<g2, 256, 0, st>>>(h->part1.p, h->part2.p, nch, split, pc_real, G, n, h->W, h->z2ss.p, h->qsum.p, h->isconst.p, h->sims.p);
+        if (geary_stat)
+            k_perm_final_lds<true><<<g2, 256, 0, st>>>(h->part1.p, second ? h->part2.p : nullptr, nch, split, pc_real, G, n, h->W, h->z2ss.p, h->qsum.p,
+                                                       h->isconst.p, h->sims.p, h->rs_const);
         else
-            k_perm_final_lds<false><<<g2, 256, 0, st>>>(h->part1.p, nullptr, nch, split, pc_real, G, n, h->W, h->z2ss.p, h->qsum.p, h->isconst.p, h->sims.p);
+            k_perm_final_lds<false><<<g2, 256, 0, st>>>(h->part1.p, nullptr, nch, split, pc_real, G, n, h->W, h->z2ss.p, h->qsum.p, h->isconst.p, h->sims.p,
+                                                        0.0);
         SQGR_HIP(hipGetLastError());
     }
     return SQGR_OK;
@@ -1240,6 +1275,40 @@ static int autocorr_create(sqgr_ctx* ctx, const sqgr_graph* g, const double* val
     double W = 0.0;
     for (int64_t i = 0; i < n; ++i) W += rs[i];
     h->W = W;
+    {   // distinct values of the row sums (exact comparison): 1 -> the z^2 r term of Geary's permutations is a constant; <= 8 -> classes
+        const char* env = getenv("SQGR_AUTOCORR_ROWSUM_CLASSES");
+        const bool allow = !(env && atoi(env) == 0);
+        double vals8[8];
+        int nv = 0;
+        std::vector<uint8_t> cls((size_t)std::max<int64_t>(n, 1), 0);
+        for (int64_t i = 0; allow && i < n && nv <= 8; ++i) {
+            int c = 0;
+            while (c < nv && vals8[c] != rs[i]) ++c;
+            if (c == nv) {
+                if (nv == 8) {
+                    nv = 9;
+                    break;
+                }
+                vals8[nv++] = rs[i];
+            }
+            cls[i] = (uint8_t)c;
+        }
+        h->rs_uniform = allow && n > 0 && nv == 1;
+        h->rs_const = nv >= 1 ? vals8[0] : 0.0;
+        h->rs_classes = (allow && nv >= 2 && nv <= 8) ? nv : 0;
+        if (h->rs_classes) {
+            double tab[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int c = 0; c < nv; ++c) tab[c] = vals8[c];
+            if ((rc = h->rcls.alloc((size_t)n)) || (rc = h->rtab.alloc(8))) return fail(rc);
+            e = hipMemcpyAsync(h->rcls.p, cls.data(), (size_t)n, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(h->rtab.p, tab, sizeof(tab), hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) {
+                set_error("autocorr prepare failed: %s", hipGetErrorString(e));
+                return fail(SQGR_ERR_HIP);
+            }
+        }
+    }
     *out = h;
     return SQGR_OK;
 }
@@ -1454,13 +1523,15 @@ static int autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_id
     if (const char* env_r = getenv("SQGR_AUTOCORR_ROW_CHUNKS")) R = std::max(1, atoi(env_r));  // tuning knob
     R = (int)std::min<int64_t>(R, std::max<int64_t>(1, n / 256));
     const int64_t by_idx = std::max<int64_t>(PERM_TILE, ((int64_t)1 << 30) / (n * 4));
-    const int kernel = perm_kernel_choice(n, G, P, mode == 1);
+    const int rmode = lds_rmode(h, mode);
+    const bool geary_lds = rmode == 1;  // layout of the LDS kernel (chunk length): only the row-sum-array variant differs from Moran's
+    const int kernel = perm_kernel_choice(n, G, P, geary_lds);
     const bool use_lds = kernel != 0;
     const int split = kernel == 2 ? LDS_SPLIT : 1;
     int64_t by_part = std::max<int64_t>(PERM_TILE, ((int64_t)1 << 30) / ((int64_t)h->ntiles * R * GT * 8));
     if (use_lds) {
         int nch = 0;
-        (void)lds_chunk(n, mode == 1, &nch);
+        (void)lds_chunk(n, geary_lds, &nch);
         by_part = std::max<int64_t>(64, ((int64_t)1 << 30) / (((G + 1) / 2) * nch * GP * 8 * split));
     }
     int64_t chunk = std::min<int64_t>(std::min<int64_t>(P, 32768), std::min(by_idx, by_part));  // grid.y limit
@@ -1482,10 +1553,11 @@ static int autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_id
         // the LDS kernel walks bucket lists that depend on the permutations alone: reuse the context's if they are these
         PermLists* pl = use_lds ? perm_lists(ctx) : nullptr;
         int lm = 0, lnch = 0;
-        if (use_lds) lm = lds_chunk(n, mode == 1, &lnch);
+        if (use_lds) lm = lds_chunk(n, geary_lds, &lnch);
         const int64_t perm0 = (perm_idx || pcg_states) ? c0 : perm_begin + c0;
         const int kind = perm_idx ? 2 : (pcg_states ? 1 : 0);
-        const bool hit = use_lds && pl->matches(n, pc, perm0, lm, lnch, kind, seed, pcg_states ? pcg_states + (size_t)c0 * 4 : nullptr, split);
+        const int list_kind = split | (rmode == 2 ? 256 : 0);  // lists with row-sum classes in their entries serve RMODE 2 only
+        const bool hit = use_lds && pl->matches(n, pc, perm0, lm, lnch, kind, seed, pcg_states ? pcg_states + (size_t)c0 * 4 : nullptr, list_kind);
         if (!hit) {
             if (perm_idx) {
                 SQGR_HIP(hipMemcpyAsync(h->idx.p, perm_idx + (size_t)c0 * n, (size_t)pc * n * 4, hipMemcpyHostToDevice, st));
@@ -1500,8 +1572,8 @@ static int autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_id
         }
         if (use_lds) {
             if (!hit) {
-                SQGR_TRY(build_perm_lists(ctx, pl, h->idx.p, n, pc * split, perm0, lm, lnch, split, mode == 1));
-                pl->n = n; pl->pc = pc; pl->perm0 = perm0; pl->m = lm; pl->nch = lnch; pl->kind = kind; pl->seed = seed; pl->split = split;
+                SQGR_TRY(build_perm_lists(ctx, pl, h->idx.p, n, pc * split, perm0, lm, lnch, split, rmode != 0, rmode == 2 ? h->rcls.p : nullptr));
+                pl->n = n; pl->pc = pc; pl->perm0 = perm0; pl->m = lm; pl->nch = lnch; pl->kind = kind; pl->seed = seed; pl->split = list_kind;
                 pl->states.clear();
                 if (pcg_states) pl->states.assign(pcg_states + (size_t)c0 * 4, pcg_states + (size_t)(c0 + pc) * 4);
             }

@@ -133,6 +133,62 @@ def test_lds_kernel_full_workgroups(L, ctx, mode, perm_kernel):
     np.testing.assert_allclose(dev, ref8, rtol=1e-9, atol=1e-13)
 
 
+@pytest.mark.parametrize("case", ["uniform", "classes", "classes-isolated-spot", "general"])
+def test_geary_row_sum_shortcuts(L, ctx, perm_kernel, case):
+    """Geary's permutations need `sum_i z_i^2 r[idx_p(i)]`, r = the graph's row sums.  `transformation=True` (the reference's default,
+    gr/_ppatterns.py:212-214) row-normalises the graph: float64 weights give ONE row sum (the term is a constant: Moran's kernel),
+    float32 weights — what `spatial_neighbors` stores — one value per degree (a class table instead of a third random LDS read), and
+    so does a binary graph.  Both shortcuts are exact: the same scores as the general kernel (forced by
+    SQGR_AUTOCORR_ROWSUM_CLASSES=0) to the rounding of a re-ordered sum, and as the oracle."""
+    import os
+
+    from sklearn.preprocessing import normalize
+
+    rng = np.random.default_rng(8)
+    if case == "uniform":
+        xy = rng.random((9000, 2))
+        g = normalize(knn_graph(xy, 6).astype(np.float64), norm="l1", axis=1)
+    else:
+        g = O.hex_grid_graph(90, 100)                      # degrees 2..6, float32 weights
+        xy = O.hex_grid(90, 100) / 9000.0
+        if case == "general":
+            g = g.astype(np.float64)
+            g.data = rng.random(g.nnz) + 0.1
+        else:
+            g = normalize(g, norm="l1", axis=1)
+            assert g.dtype == np.float32
+            if case == "classes-isolated-spot":
+                g = g.tolil()
+                g[17, :] = 0
+                g = g.tocsr()
+                g.eliminate_zeros()
+    n, G, P = g.shape[0], 300, 70
+    n_distinct = len(np.unique(np.asarray(g.astype(np.float64).sum(axis=1)).ravel()))
+    assert {"uniform": n_distinct == 1, "classes": 2 <= n_distinct <= 8, "classes-isolated-spot": 3 <= n_distinct <= 8, "general": n_distinct > 8}[case]
+    vals = rng.gamma(2.0, 1.0, size=(G, n))
+    vals[3] += 3 * np.sin(xy[:, 0] * 6)
+    graph = L.Graph(ctx, g)
+    plan = L.AutocorrPlan(ctx, graph, vals)
+    fast = plan.perms("geary", seed=5, perm_begin=0, perm_end=P)
+    os.environ["SQGR_AUTOCORR_ROWSUM_CLASSES"] = "0"
+    try:
+        plan2 = L.AutocorrPlan(ctx, graph, vals)
+        ref = plan2.perms("geary", seed=5, perm_begin=0, perm_end=P)
+    finally:
+        del os.environ["SQGR_AUTOCORR_ROWSUM_CLASSES"]
+    np.testing.assert_allclose(fast, ref, rtol=1e-11, atol=1e-13)
+    if case == "general":
+        np.testing.assert_array_equal(fast, ref)  # more than 8 distinct row sums: the same kernel both times
+    idx = np.stack([devrng.autocorr_permutation(n, 5, p) for p in (0, 1, 69)])
+    np.testing.assert_allclose(fast[[0, 1, 69]], O.score_perms("geary", g, vals, idx), rtol=RTOL, atol=ATOL)
+    # split invariance inside the shortcut: a range in two pieces, bit for bit
+    two = np.concatenate([plan.perms("geary", seed=5, perm_begin=0, perm_end=33), plan.perms("geary", seed=5, perm_begin=33, perm_end=P)])
+    np.testing.assert_array_equal(two, fast)
+    plan.close()
+    plan2.close()
+    graph.close()
+
+
 def _adata(n=600, G=40, seed=0):
     import squidpy_amd as sq
 
