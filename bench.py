@@ -358,7 +358,9 @@ def autocorr_leg(ctx, mode: str, world: int, fence, reduce_max, steps: int, with
     lds_cnt, lds_ms = kernels.get(kname, (0, 0.0))
     geary = mode == "geary"
     b_gene = (P + 1) * 8 * n
-    per = 24.0 if geary else 16.0  # LDS bytes per (spot, permutation, gene): z and y[idx] (and r[idx] for Geary's C)
+    # LDS bytes per (spot, permutation, gene): the 16-byte z and y rows of a gene PAIR (8 + 8 per gene); Geary's C adds one 8-byte read of
+    # r[idx] — or of its class table — per pair of genes (4 per gene)
+    per = 20.0 if geary else 16.0
     if lds_cnt:  # the LDS-bucketed kernel (n_perms >= 512): both operands of every z*y product are read from LDS
         avg_ms = lds_ms / lds_cnt
         lds_bytes = per * n * P * G
