@@ -180,6 +180,10 @@ def ripley(
     stat = RipleyStat(mode)
     if stat == RipleyStat.L and metric not in KDTREE_VALID_METRICS:
         raise ValueError(f"Unsupported metric '{metric}'. Ripley's L supports {KDTREE_VALID_METRICS}")
+    if metric in ("seuclidean", "mahalanobis"):
+        # the reference fails here too: `NearestNeighbors(metric=metric)` needs V / VI, which `ripley` has no argument for
+        # (gr/_ripley.py:144,148; sklearn: TypeError for seuclidean, "Must provide either V or VI" for mahalanobis)
+        raise ValueError(f"Metric `{metric}` needs parameters (V / VI) that `ripley` cannot pass on: the reference's NearestNeighbors call fails as well.")
     if metric not in METRICS:
         raise NotImplementedError(f"Metric `{metric}` is not implemented on the GPU path; use one of {sorted(METRICS)}.")
 

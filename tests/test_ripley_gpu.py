@@ -190,6 +190,12 @@ def test_ball_tree_metrics_without_parameters(L, ctx, metric):
         sq.gr.ripley(adata, "cl", mode="L", metric=metric)
     with pytest.raises(NotImplementedError, match="not implemented on the GPU path"):
         sq.gr.ripley(adata, "cl", mode="F", metric="haversine")
+    # metrics that need parameters fail in the reference's own sklearn call as well (no argument of `ripley` could carry V / VI)
+    for needs_params in ("seuclidean", "mahalanobis"):
+        with pytest.raises((TypeError, ValueError)):
+            NearestNeighbors(metric=needs_params, n_neighbors=2).fit(ref).kneighbors(qry)
+        with pytest.raises(ValueError, match="needs parameters"):
+            sq.gr.ripley(adata, "cl", mode="G", metric=needs_params)
 
 
 @pytest.mark.parametrize("metric", ["euclidean", "chebyshev"])
