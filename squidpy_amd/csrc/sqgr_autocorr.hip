@@ -18,6 +18,7 @@
 #include "sqgr_rng.h"
 #include "sqgr_pcg.h"
 
+#include <atomic>
 #include <cstdlib>
 
 namespace sqgr {
@@ -478,26 +479,33 @@ __global__ __launch_bounds__(64) void k_bucket_count(const int32_t* __restrict__
     }
 }
 
-// off[pg][a][b] = rows (of 64 entries) in front of bucket (a, b) inside group pg's lists; total[pg] = rows of the group
+// off[pg][a][b] = rows (of 64 entries) in front of bucket (a, b) inside group pg's lists; total[pg] = rows of the group,
+// total[npg + pg] = its longest list
 __global__ __launch_bounds__(256) void k_bucket_offsets(const uint32_t* __restrict__ len, int nb, uint32_t* __restrict__ off,
                                                         uint32_t* __restrict__ total) {
-    __shared__ uint32_t part[256];
+    __shared__ uint32_t part[256], longest[256];
     const int tid = threadIdx.x;
     const size_t base = (size_t)blockIdx.x * nb;
     const int per = (nb + 255) / 256;
     const int j0 = min(nb, tid * per), j1 = min(nb, j0 + per);
-    uint32_t s = 0;
-    for (int j = j0; j < j1; ++j) s += len[base + j];
+    uint32_t s = 0, mx = 0;
+    for (int j = j0; j < j1; ++j) {
+        s += len[base + j];
+        mx = max(mx, len[base + j]);
+    }
     part[tid] = s;
+    longest[tid] = mx;
     __syncthreads();
     if (tid == 0) {
-        uint32_t run = 0;
+        uint32_t run = 0, m2 = 0;
         for (int t = 0; t < 256; ++t) {
             const uint32_t v = part[t];
             part[t] = run;
             run += v;
+            m2 = max(m2, longest[t]);
         }
         total[blockIdx.x] = run;
+        total[gridDim.x + blockIdx.x] = m2;
     }
     __syncthreads();
     uint32_t run = part[tid];
@@ -507,15 +515,18 @@ __global__ __launch_bounds__(256) void k_bucket_offsets(const uint32_t* __restri
     }
 }
 
-// base[pg] = rows in front of group pg (exclusive prefix of total), base[npg] = all rows
+// base[pg] = rows in front of group pg (exclusive prefix of total), base[npg] = all rows, base[npg + 1] = the longest list
 __global__ void k_bucket_bases(const uint32_t* __restrict__ total, int npg, uint64_t* __restrict__ base) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     uint64_t run = 0;
+    uint32_t mx = 0;
     for (int g = 0; g < npg; ++g) {
         base[g] = run;
         run += total[g];
+        mx = max(mx, total[npg + g]);
     }
     base[npg] = run;
+    base[npg + 1] = mx;
 }
 
 // lists[(base[pg] + off[pg][a][b] + k) * 64 + lane] = (i - a*m) | (idx_p(i) - b*m) << 16, pairs in ascending i; the rest of
@@ -621,6 +632,208 @@ __global__ __launch_bounds__(64) void k_bucket_order(int m, int nb, int64_t perm
         rank[c * 64 + lane] = (uint16_t)(j + 1);
         const int pos = j < D ? ((c - lp) & 15) + 16 * j : (int)hole[((int)sbase[c * 64 + lane] + j - D) * 64 + lane];
         lst[(size_t)pos * 64] = e;
+    }
+}
+
+// The JOINT schedule (round 4, the default): the order above makes one side of a pair conflict-free and leaves the other random
+// (1.46 + 2.84 LDS cycles per 16-lane group and pair).  A list may be walked in ANY order, and the 16 permutations that share a
+// `ds_read_b128` lane group can agree on theirs: lane l' still reads a Z row of class (k + l') mod 16 at step k, and among its pairs
+// of that class it takes one whose Y row class no other lane of the group has taken at that step.  Simulated 1.32 + 1.67 cycles.
+//   cell (zc, yc) = (i mod 16, j mod 16) of a pair; pool (lane, zc) = the lane's pairs with Z class zc.
+//   main phase: thread (group q, offset o) owns the steps k = o + 16 j and the pools (lane, (o + l') mod 16) of its group — no
+//     other thread touches them.  Per step it visits the 16 lanes, smallest pool first (fixed order), and gives each a free Y
+//     class of its pool (rotating start) or, failing that, any.
+//   surplus phase: pools fuller than the lane has rounds keep pairs, emptier ones leave holes; every lane fills its holes with the
+//     remaining pairs that collide least with what the main phase gave the other lanes at that step (Y first, then Z).
+// The schedule of a lane depends on the 15 lanes it shares the group with: the caller builds lists for whole 64-aligned groups of
+// the GLOBAL permutation index (sqgr_autocorr_perms generates the missing neighbours), so a split range stays bit-identical.
+// Lists longer than ORDER_SEG rows are scheduled in independent segments of ORDER_SEG rows (grid.z).  Out of place: src -> dst.
+constexpr int ORDER_SEG = 256;
+
+// lane of `ds_read_b128` group q that holds residue r = lane mod 16 (groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, + 32)
+__device__ __forceinline__ int group_lane(int q, int r) {
+    const bool mid = r >= 4 && r < 12;
+    return (q >> 1) * 32 + (((q & 1) != 0) == mid ? r : 16 + r);
+}
+
+// grid (buckets * 4 lane groups, groups of 64 permutations, segments); 16 threads: the schedule is a chain of dependent LDS accesses,
+// what counts is how many groups a CU holds at once (15 KiB of LDS each)
+__global__ __launch_bounds__(16) void k_bucket_order_joint(int m, int nb, const uint32_t* __restrict__ len, const uint32_t* __restrict__ off,
+                                                           const uint64_t* __restrict__ base, const uint32_t* __restrict__ src,
+                                                           uint32_t* __restrict__ dst) {
+    __shared__ uint16_t cw[256 * 16];    // [cell][r] pairs of the cell not yet placed << 8 | cursor into stp (mod 256; cells ascending)
+    __shared__ uint8_t stp[256 * 16];    // [.][r] the steps given to the lane's pairs, grouped by cell
+    __shared__ uint16_t amask[16 * 16];  // [zc][r] Y classes pool (lane r, zc) still holds
+    __shared__ uint16_t psize[16 * 16];  // [zc][r] pairs in pool (lane r, zc)
+    __shared__ uint16_t hbits[16 * 16];  // [o][r] bit j: step o + 16 j of lane r is taken
+    __shared__ uint32_t yz[ORDER_SEG];   // [k] Y classes (bits 0..15) and Z classes (16..31) the group reads at step k
+    __shared__ uint16_t Dl[16];          // rounds of lane r (its own length / 16, rounded up)
+    __shared__ int saturated;
+    const int t = threadIdx.x, q = (int)(blockIdx.x & 3u);
+    const int lane = group_lane(q, t);
+    const int64_t pg = blockIdx.y;
+    const size_t bk = (size_t)pg * nb + (blockIdx.x >> 2);
+    const int L = (int)len[bk], s0 = (int)blockIdx.z * ORDER_SEG;
+    if (s0 >= L) return;
+    const int Ls = min(ORDER_SEG, L - s0);  // a multiple of 16
+    const size_t row0 = ((size_t)base[pg] + off[bk] + (size_t)s0) * 64;
+    const uint32_t* a = src + row0 + lane;
+    uint32_t* d = dst + row0 + lane;
+    const uint32_t pad = (uint32_t)m;
+    for (int i = t; i < 256 * 8; i += 16) reinterpret_cast<uint32_t*>(cw)[i] = 0;
+    if (t == 0) saturated = 0;
+    __syncthreads();
+    // --- thread = lane r: the cells of its list
+    int cnt = 0;
+    bool sat = false;
+    for (int k0 = 0; k0 < Ls; k0 += 16) {
+        uint32_t e[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) e[u] = a[(size_t)(k0 + u) * 64];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (e[u] != pad) {
+                const int cell = ((((e[u] & 15u) << 4) | ((e[u] >> 16) & 15u))) * 16 + t;
+                const uint32_t w = cw[cell];
+                sat |= w >= 0xff00u;
+                cw[cell] = (uint16_t)(w + 0x100u);
+                ++cnt;
+            }
+    }
+    if (sat) saturated = 1;
+    __syncthreads();
+    if (saturated) {  // 256 pairs of one lane in one cell (an 8-bit counter): such a list has one order
+        for (int k = 0; k < Ls; ++k) d[(size_t)k * 64] = a[(size_t)k * 64];
+        return;
+    }
+    Dl[t] = (uint16_t)((cnt + 15) >> 4);
+    {
+        int run = 0;
+        for (int zc = 0; zc < 16; ++zc) {
+            uint32_t mask = 0;
+            int ps = 0;
+#pragma unroll
+            for (int y = 0; y < 16; ++y) {
+                const int c = cw[(zc * 16 + y) * 16 + t] >> 8;
+                cw[(zc * 16 + y) * 16 + t] = (uint16_t)((c << 8) | (run & 255));
+                run += c;
+                ps += c;
+                mask |= c ? (1u << y) : 0u;
+            }
+            amask[zc * 16 + t] = (uint16_t)mask;
+            psize[zc * 16 + t] = (uint16_t)ps;
+        }
+    }
+    __syncthreads();
+    // --- thread = offset o: the steps k = o + 16 j and the pools (lane r, (o + r) mod 16)
+    {
+        const int o = t;
+        int Dmax = 0;
+        uint64_t visit = 0;  // residues in visiting order, 4 bits each: smallest pool first
+        {
+            uint32_t key[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                key[r] = ((uint32_t)psize[((o + r) & 15) * 16 + r] << 4) | (uint32_t)r;
+                Dmax = max(Dmax, (int)Dl[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int rank = 0;
+#pragma unroll
+                for (int r2 = 0; r2 < 16; ++r2) rank += key[r2] < key[r] ? 1 : 0;
+                visit |= (uint64_t)r << (4 * rank);
+            }
+        }
+        uint32_t taken[16];  // per lane: bit j = step o + 16 j given away
+#pragma unroll
+        for (int r = 0; r < 16; ++r) taken[r] = 0;
+        for (int j = 0; j < Dmax; ++j) {
+            const int k = o + 16 * j;
+            uint32_t used = 0, zused = 0, got = 0;
+            for (int i = 0; i < 16; ++i) {
+                const int r = (int)((visit >> (4 * i)) & 15u);
+                if (j >= (int)Dl[r]) continue;
+                const int zc = (o + r) & 15;
+                const uint32_t avail = amask[zc * 16 + r];
+                if (!avail) continue;
+                uint32_t pick = avail & ~used;
+                if (!pick) pick = avail;
+                const int s = (j * 5 + o * 3 + r * 7) & 15;
+                const uint32_t rot = ((pick >> s) | (pick << (16 - s))) & 0xffffu;
+                const int y = (__builtin_ctz(rot) + s) & 15;
+                const int cell = (zc * 16 + y) * 16 + r;
+                const uint32_t w = cw[cell];
+                cw[cell] = (uint16_t)(((w - 0x100u) & 0xff00u) | ((w + 1u) & 0xffu));
+                if ((w >> 8) == 1u) amask[zc * 16 + r] = (uint16_t)(avail & ~(1u << y));
+                stp[(w & 0xffu) * 16 + r] = (uint8_t)k;
+                used |= 1u << y;
+                zused |= 1u << zc;
+                got |= 1u << r;
+            }
+            yz[k] = used | (zused << 16);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) taken[r] |= ((got >> r) & 1u) << j;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hbits[o * 16 + r] = (uint16_t)taken[r];
+    }
+    __syncthreads();
+    // --- thread = lane r: the pairs left over go to the lane's holes, judged by the classes the OTHER lanes read at a hole's step (as
+    // the main phase left them: the lanes do this side by side).  Three sweeps over the holes: a pair that collides on neither
+    // side, then one whose Y row does not collide, then any.
+    {
+        const uint32_t dmask = (1u << Dl[t]) - 1u;
+        uint32_t zrem = 0;
+        int rem = cnt;
+        for (int c = 0; c < 16; ++c) {
+            zrem |= amask[c * 16 + t] ? (1u << c) : 0u;
+            rem -= __builtin_popcount(hbits[c * 16 + t]);
+        }
+        for (int lvl = 0; lvl < 3; ++lvl)
+            for (int o2 = 0; o2 < 16; ++o2) {
+                uint32_t hb = hbits[o2 * 16 + t];
+                for (uint32_t hh = rem ? (~hb & dmask) : 0u; hh && rem; hh &= hh - 1) {
+                    const int j = __builtin_ctz(hh), k = o2 + 16 * j;
+                    const uint32_t w = yz[k];
+                    for (uint32_t zcand = lvl == 0 ? (zrem & ~(w >> 16)) : zrem; zcand; zcand &= zcand - 1) {
+                        const int zc = __builtin_ctz(zcand);
+                        uint32_t am = amask[zc * 16 + t];
+                        const uint32_t ym = (lvl == 2 ? am : (am & ~w)) & 0xffffu;
+                        if (!ym) continue;
+                        const int y = __builtin_ctz(ym);
+                        const int cell = (zc * 16 + y) * 16 + t;
+                        const uint32_t v = cw[cell];
+                        cw[cell] = (uint16_t)(((v - 0x100u) & 0xff00u) | ((v + 1u) & 0xffu));
+                        if ((v >> 8) == 1u) {
+                            am &= ~(1u << y);
+                            amask[zc * 16 + t] = (uint16_t)am;
+                            if (!am) zrem &= ~(1u << zc);
+                        }
+                        stp[(v & 0xffu) * 16 + t] = (uint8_t)k;
+                        hb |= 1u << j;
+                        --rem;
+                        break;
+                    }
+                }
+                hbits[o2 * 16 + t] = (uint16_t)hb;
+            }
+    }
+    // --- (same thread) every pair to its step — the cursors now stand at the end of their cells —, the padding pair elsewhere
+    for (int k = 0; k < Ls; ++k)
+        if (!((hbits[(k & 15) * 16 + t] >> (k >> 4)) & 1u)) d[(size_t)k * 64] = pad;
+    for (int k0 = 0; k0 < Ls; k0 += 16) {
+        uint32_t e[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) e[u] = a[(size_t)(k0 + u) * 64];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (e[u] != pad) {
+                const int cell = ((((e[u] & 15u) << 4) | ((e[u] >> 16) & 15u))) * 16 + t;
+                const uint32_t v = (uint32_t)cw[cell] - 1u;
+                cw[cell] = (uint16_t)v;  // (only the cursor byte is read from here on)
+                d[(size_t)stp[(v & 0xffu) * 16 + t] * 64] = e[u];
+            }
     }
 }
 
@@ -966,6 +1179,7 @@ struct sqgr_autocorr {
     double rs_const = 0.0;
     // ... and when they take a few distinct values (one per degree): class of every spot's row sum + the table (k_perm_dot_lds RMODE 2)
     int rs_classes = 0;  // 2..8: table mode available
+    uint64_t cls_serial = 0;  // identifies this plan's class assignment (bucket lists carry the classes: part of their cache key)
     DevBuf<uint8_t> rcls;
     DevBuf<double> rtab;
 };
@@ -976,14 +1190,17 @@ struct PermLists : sqgr::CtxCache {
     // key
     int64_t n = -1, pc = 0, perm0 = 0;
     int m = 0, nch = 0, kind = -1;  // kind 0: device generator (seed), 1: numpy streams (states)
-    int split = 1;                  // virtual permutations per permutation (LDS_SPLIT variant)
+    int split = 1;                  // virtual permutations per permutation (LDS_SPLIT variant) | layout flags, see autocorr_perms
     uint64_t seed = 0;
+    uint64_t cls_serial = 0;        // lists with row-sum classes in their entries: whose classes (sqgr_autocorr::cls_serial)
     std::vector<uint64_t> states;
     // lists
-    DevBuf<uint32_t> b_len, b_off, b_total, lists;
+    DevBuf<uint32_t> b_len, b_off, b_total, lists, lists_raw;
     DevBuf<uint64_t> b_base;
-    bool matches(int64_t n_, int64_t pc_, int64_t perm0_, int m_, int nch_, int kind_, uint64_t seed_, const uint64_t* st_, int split_) const {
-        if (n != n_ || pc != pc_ || perm0 != perm0_ || m != m_ || nch != nch_ || kind != kind_ || split != split_) return false;
+    bool matches(int64_t n_, int64_t pc_, int64_t perm0_, int m_, int nch_, int kind_, uint64_t seed_, const uint64_t* st_, int split_,
+                 uint64_t cls_serial_) const {
+        if (n != n_ || pc != pc_ || perm0 != perm0_ || m != m_ || nch != nch_ || kind != kind_ || split != split_ || cls_serial != cls_serial_)
+            return false;
         if (kind == 0) return seed == seed_;
         return kind == 1 && st_ && states.size() == (size_t)pc_ * 4 && !memcmp(states.data(), st_, (size_t)pc_ * 32);
     }
@@ -1012,34 +1229,62 @@ static int perm_kernel_choice(int64_t n, int64_t G, int64_t P, bool geary) {
     return P >= 512 ? 1 : (P >= 40 ? 2 : 0);
 }
 
+// How the bucket lists are ordered.  0: as built (ascending i; SQGR_AUTOCORR_ORDER_LISTS=0, and the split variant: a sub-list holds
+// two pairs per class), 1: SQGR_AUTOCORR_ORDER=single, the round-3 schedule (every list on its own: one side of a pair conflict-free),
+// 2: the joint schedule of the 16 permutations of a `ds_read_b128` lane group (k_bucket_order_joint; the default)
+static int list_order_mode(int split) {
+    // (the split variant: lane = (permutation, spots i = s mod 8) reads Z rows of two classes, s and s + 8, whatever the order —
+    // the Z side is half scheduled by construction, and sub-lists of ~30 pairs leave the schedule two rounds to work with)
+    if (split != 1) return 0;
+    if (const char* e = getenv("SQGR_AUTOCORR_ORDER_LISTS"))
+        if (atoi(e) == 0) return 0;
+    const char* e_order = getenv("SQGR_AUTOCORR_ORDER");
+    return (e_order && !strcmp(e_order, "single")) ? 1 : 2;
+}
+
 // bucket lists of the pc permutations whose indices are in idx (the first one is permutation `perm0` of its stream) -> pl
 // (split > 1: pc counts VIRTUAL permutations, idx holds pc / split index rows)
 static int build_perm_lists(sqgr_ctx* ctx, PermLists* pl, const int32_t* idx, int64_t n, int64_t pc, int64_t perm0, int m, int nch, int split,
                             bool geary, const uint8_t* rcls) {
     hipStream_t st = ctx->stream;
     const int npg = (int)ceil_div(pc, 64);
-    const int round = split > 1 ? LIST_ROUND_SPLIT : LIST_ROUND;
+    const int order = list_order_mode(split);
+    const bool order_lists = order != 0;
+    const bool joint = order == 2 && (perm0 * split) % 64 == 0;  // (the lane groups must be those of the global permutation index)
+    const int round = (split > 1 && !joint) ? LIST_ROUND_SPLIT : LIST_ROUND;
     const int nb = nch * nch;
     pl->n = -1;  // invalid until complete
     SQGR_TRY(pl->b_len.ensure((size_t)npg * nb));
     SQGR_TRY(pl->b_off.ensure((size_t)npg * nb));
-    SQGR_TRY(pl->b_total.ensure((size_t)npg));
-    SQGR_TRY(pl->b_base.ensure((size_t)npg + 1));
+    SQGR_TRY(pl->b_total.ensure((size_t)npg * 2));
+    SQGR_TRY(pl->b_base.ensure((size_t)npg + 2));
     const size_t cnt_lds = (size_t)nch * 64 * sizeof(uint32_t);
-    uint64_t rows = 0;
+    uint64_t rows_max[2] = {0, 0};  // all rows, the longest list
     LaunchTimer t(ctx, "autocorr_bucket_lists");
     k_bucket_count<<<dim3((unsigned)nch, (unsigned)npg), 64, cnt_lds, st>>>(idx, n, pc, m, nch, split, round, pl->b_len.p);
     k_bucket_offsets<<<(unsigned)npg, 256, 0, st>>>(pl->b_len.p, nb, pl->b_off.p, pl->b_total.p);
     k_bucket_bases<<<1, 64, 0, st>>>(pl->b_total.p, npg, pl->b_base.p);
     SQGR_HIP(hipGetLastError());
-    SQGR_HIP(hipMemcpyAsync(&rows, pl->b_base.p + npg, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    SQGR_HIP(hipMemcpyAsync(rows_max, pl->b_base.p + npg, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     SQGR_HIP(hipStreamSynchronize(st));
-    SQGR_TRY(pl->lists.ensure((size_t)rows * 64));
+    const uint64_t rows = rows_max[0];
+    // (with headroom: the next seed's lists are a few rows longer or shorter, and a new buffer of this size costs milliseconds)
+    if (pl->lists.n < (size_t)rows * 64 || !pl->lists.p) SQGR_TRY(pl->lists.alloc_pooled((size_t)rows * 64 + (size_t)rows * 4));
+    uint32_t* fill_to = pl->lists.p;
+    if (joint) {  // out of place: the lists as built -> lists_raw, scheduled -> lists
+        if (pl->lists_raw.n < (size_t)rows * 64 || !pl->lists_raw.p) SQGR_TRY(pl->lists_raw.alloc_pooled((size_t)rows * 64 + (size_t)rows * 4));
+        fill_to = pl->lists_raw.p;
+    }
     k_bucket_fill<<<dim3((unsigned)nch, (unsigned)npg), 64, cnt_lds + (size_t)nch * sizeof(uint32_t), st>>>(idx, n, pc, m, nch, split, pl->b_len.p, pl->b_off.p,
-                                                                                                          pl->b_base.p, pl->lists.p, rcls);
+                                                                                                          pl->b_base.p, fill_to, rcls);
     SQGR_HIP(hipGetLastError());
-    static const bool order_lists = [] { const char* e = getenv("SQGR_AUTOCORR_ORDER_LISTS"); return !(e && atoi(e) == 0); }();
-    if (order_lists && split == 1) {  // (the schedule works in rounds of 16 row classes; a sub-list of the split variant holds 2)
+    if (joint) {
+        const int segs = (int)ceil_div((int64_t)rows_max[1], (int64_t)ORDER_SEG);  // (blocks past the end of their list return at once)
+        if (segs > 0)
+            k_bucket_order_joint<<<dim3((unsigned)nb * 4u, (unsigned)npg, (unsigned)segs), 16, 0, st>>>(m, nb, pl->b_len.p, pl->b_off.p, pl->b_base.p,
+                                                                                                      pl->lists_raw.p, pl->lists.p);
+        SQGR_HIP(hipGetLastError());
+    } else if (order_lists && split == 1) {  // (the schedule works in rounds of 16 row classes; a sub-list of the split variant holds 2)
         // Geary's C reads TWO arrays through the Y index (the y row and the row sum): its lists are scheduled by the classes of the Y
         // row (measured 99.6 -> 94.4 ms per 2048 genes x 1000 permutations); Moran's I keeps the Z classes (66.2 vs 65.6 ms: no difference)
         const char* e_by = getenv("SQGR_AUTOCORR_ORDER_BY");
@@ -1297,6 +1542,8 @@ static int autocorr_create(sqgr_ctx* ctx, const sqgr_graph* g, const double* val
         h->rs_const = nv >= 1 ? vals8[0] : 0.0;
         h->rs_classes = (allow && nv >= 2 && nv <= 8) ? nv : 0;
         if (h->rs_classes) {
+            static std::atomic<uint64_t> serial{0};
+            h->cls_serial = ++serial;
             double tab[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (int c = 0; c < nv; ++c) tab[c] = vals8[c];
             if ((rc = h->rcls.alloc((size_t)n)) || (rc = h->rtab.alloc(8))) return fail(rc);
@@ -1534,9 +1781,19 @@ static int autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_id
         (void)lds_chunk(n, geary_lds, &nch);
         by_part = std::max<int64_t>(64, ((int64_t)1 << 30) / (((G + 1) / 2) * nch * GP * 8 * split));
     }
-    int64_t chunk = std::min<int64_t>(std::min<int64_t>(P, 32768), std::min(by_idx, by_part));  // grid.y limit
+    // The joint list schedule (k_bucket_order_joint) makes a permutation's summation order depend on the 15 permutations it shares a
+    // `ds_read_b128` lane group with, so the LDS kernel works on whole 64-aligned groups of the GLOBAL permutation index: with the
+    // device generator the range is widened to [begin - lead, end rounded up to 64) and the extra ("ghost") permutations are
+    // generated, scheduled, scored and dropped — a permutation's score does not depend on how a range was cut.  (Injected
+    // permutations and numpy's streams always start at permutation 0.)
+    const bool ghosts = kernel == 1 && !perm_idx && !pcg_states;
+    const int64_t galign = 64;
+    const int64_t lead = ghosts ? (perm_begin & (galign - 1)) : 0;
+    const int64_t PV = ghosts ? ((lead + P + galign - 1) & ~(galign - 1)) : P;  // permutations the passes run over
+    int64_t chunk = std::min<int64_t>(std::min<int64_t>(PV, 32768), std::min(by_idx, by_part));  // grid.y limit
     const int64_t wg_perms = LDS_PERM_BLOCK / split;  // permutations per workgroup of the LDS kernel
     if (use_lds && chunk > wg_perms) chunk = chunk / wg_perms * wg_perms;  // whole workgroups of permutations
+    else if (kernel == 1 && chunk < PV) chunk = std::max<int64_t>(galign, chunk / galign * galign);  // every pass starts a lane group
     SQGR_TRY(h->idx.ensure((size_t)chunk * n));
     if (!use_lds) {
         SQGR_TRY(h->part1.ensure((size_t)h->ntiles * chunk * R * GT));
@@ -1548,16 +1805,19 @@ static int autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_id
         for (int64_t t = 0; t < P * n; ++t)
             SQGR_REQUIRE(perm_idx[t] >= 0 && perm_idx[t] < n, "perm_idx[%lld]=%d outside [0,%lld)", (long long)t, perm_idx[t], (long long)n);
     const FeistelDomain dom = make_domain((uint32_t)n);
-    for (int64_t c0 = 0; c0 < P; c0 += chunk) {
-        const int64_t pc = std::min(chunk, P - c0);
+    for (int64_t c0 = 0; c0 < PV; c0 += chunk) {
+        const int64_t pc = std::min(chunk, PV - c0);
+        const int64_t real_lo = std::max(c0, lead), real_hi = std::min(c0 + pc, lead + P);  // this pass's part of the caller's range
         // the LDS kernel walks bucket lists that depend on the permutations alone: reuse the context's if they are these
         PermLists* pl = use_lds ? perm_lists(ctx) : nullptr;
         int lm = 0, lnch = 0;
         if (use_lds) lm = lds_chunk(n, geary_lds, &lnch);
-        const int64_t perm0 = (perm_idx || pcg_states) ? c0 : perm_begin + c0;
+        const int64_t perm0 = (perm_idx || pcg_states) ? c0 : perm_begin - lead + c0;
         const int kind = perm_idx ? 2 : (pcg_states ? 1 : 0);
-        const int list_kind = split | (rmode == 2 ? 256 : 0);  // lists with row-sum classes in their entries serve RMODE 2 only
-        const bool hit = use_lds && pl->matches(n, pc, perm0, lm, lnch, kind, seed, pcg_states ? pcg_states + (size_t)c0 * 4 : nullptr, list_kind);
+        // lists with row-sum classes in their entries serve RMODE 2 only; the order of the lists is part of what they are
+        const int list_kind = split | (rmode == 2 ? 256 : 0) | (list_order_mode(split) << 9);
+        const bool hit = use_lds && pl->matches(n, pc, perm0, lm, lnch, kind, seed, pcg_states ? pcg_states + (size_t)c0 * 4 : nullptr, list_kind,
+                                             rmode == 2 ? h->cls_serial : 0);
         if (!hit) {
             if (perm_idx) {
                 SQGR_HIP(hipMemcpyAsync(h->idx.p, perm_idx + (size_t)c0 * n, (size_t)pc * n * 4, hipMemcpyHostToDevice, st));
@@ -1566,7 +1826,7 @@ static int autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_id
                 SQGR_TRY(pcg_permutations_dev(ctx, h->pcg_ws, n, h->pcg_states.p, pc, h->idx.p, st));
             } else {
                 LaunchTimer t(ctx, "autocorr_perm_indices");
-                k_perm_indices<<<dim3((unsigned)ceil_div(n, 256), (unsigned)pc), 256, 0, st>>>(seed, perm_begin + c0, n, dom, h->idx.p);
+                k_perm_indices<<<dim3((unsigned)ceil_div(n, 256), (unsigned)pc), 256, 0, st>>>(seed, perm_begin - lead + c0, n, dom, h->idx.p);
                 SQGR_HIP(hipGetLastError());
             }
         }
@@ -1574,12 +1834,17 @@ static int autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_id
             if (!hit) {
                 SQGR_TRY(build_perm_lists(ctx, pl, h->idx.p, n, pc * split, perm0, lm, lnch, split, rmode != 0, rmode == 2 ? h->rcls.p : nullptr));
                 pl->n = n; pl->pc = pc; pl->perm0 = perm0; pl->m = lm; pl->nch = lnch; pl->kind = kind; pl->seed = seed; pl->split = list_kind;
+                pl->cls_serial = rmode == 2 ? h->cls_serial : 0;
                 pl->states.clear();
                 if (pcg_states) pl->states.assign(pcg_states + (size_t)c0 * 4, pcg_states + (size_t)(c0 + pc) * 4);
             }
             SQGR_TRY(perms_pass_lds(h, mode, pc, pl, split));
-            if (dev_all) SQGR_HIP(hipMemcpyAsync(dev_all + (size_t)c0 * G, h->sims.p, (size_t)pc * G * 8, hipMemcpyDeviceToDevice, st));
-            if (out_sims) SQGR_HIP(hipMemcpyAsync(out_sims + (size_t)c0 * G, h->sims.p, (size_t)pc * G * 8, hipMemcpyDeviceToHost, st));
+            if (real_hi > real_lo) {
+                const double* from = h->sims.p + (size_t)(real_lo - c0) * G;
+                const size_t to = (size_t)(real_lo - lead) * G, bytes = (size_t)(real_hi - real_lo) * G * 8;
+                if (dev_all) SQGR_HIP(hipMemcpyAsync(dev_all + to, from, bytes, hipMemcpyDeviceToDevice, st));
+                if (out_sims) SQGR_HIP(hipMemcpyAsync(out_sims + to, from, bytes, hipMemcpyDeviceToHost, st));
+            }
             SQGR_HIP(hipStreamSynchronize(st));
             continue;
         }

@@ -133,6 +133,86 @@ def test_lds_kernel_full_workgroups(L, ctx, mode, perm_kernel):
     np.testing.assert_allclose(dev, ref8, rtol=1e-9, atol=1e-13)
 
 
+@pytest.mark.parametrize("mode", ["moran", "geary"])
+def test_list_schedule_structured_permutations_and_ranges(L, ctx, mode, perm_kernel):
+    """The bucket lists of the LDS kernel are re-ordered so that the 16 permutations of a `ds_read_b128` lane group read different LDS
+    banks (k_bucket_order_joint): any order of a list is a valid one, so scores may move by rounding only.  Inputs the schedule
+    has to survive: the identity and a stride permutation (every pair of a list in 16 cells), a permutation whose bucket (0, 0)
+    holds 320 pairs of ONE cell (i = j = 0 mod 16: the 8-bit cell counter saturates, the segment is left as built), lists of very
+    different lengths in one group, and a range of the device generator cut at odd places (a permutation's order depends on the
+    15 permutations it shares the lane group with: the library schedules whole aligned groups and drops the extra ones)."""
+    if perm_kernel != "lds":
+        pytest.skip("default chunking of the LDS kernel only")
+    import os
+
+    rng = np.random.default_rng(12)
+    n, G = 10232, 9                        # two chunks of 5116 spots
+    m = 5116
+    xy = rng.random((n, 2))
+    g = knn_graph(xy, 6)
+    g.data = rng.random(g.nnz).astype(np.float32) + 0.1
+    vals = rng.gamma(2.0, 1.0, size=(G, n))
+    vals[2] += 2 * np.sin(xy[:, 0] * 5)
+    ident = np.arange(n, dtype=np.int32)
+    stride = ((np.arange(n, dtype=np.int64) * 4099) % n).astype(np.int32)   # gcd(4099, n) = 1; n = 8 mod 16: classes shift by chunk
+    one_cell = ident.copy()
+    a0 = np.arange(0, m, 16)                                                 # 320 spots of chunk 0, i = 0 mod 16 -> themselves, reversed
+    one_cell[a0] = a0[::-1]
+    b0 = np.setdiff1d(np.arange(m), a0)
+    b1 = np.setdiff1d(np.arange(m, 2 * m), np.arange(m, 2 * m, 16))[: b0.size]
+    one_cell[b0], one_cell[b1] = b1, b0                                      # the rest of chunk 0 <-> chunk 1
+    assert np.array_equal(np.sort(one_cell), ident) and b1.size == b0.size
+    near = ident.copy()                                                      # almost everything stays inside its chunk: a long and a short list
+    near[:16], near[m:m + 16] = np.arange(m, m + 16), np.arange(16)
+    perm_idx = np.stack([ident, stride, one_cell, near] + [rng.permutation(n).astype(np.int32) for _ in range(13)])
+    graph = L.Graph(ctx, g)
+    plan = L.AutocorrPlan(ctx, graph, vals)
+    got = plan.perms(mode, perm_idx=perm_idx)
+    np.testing.assert_allclose(got, O.score_perms(mode, g, vals, perm_idx), rtol=RTOL, atol=ATOL)
+    for env, val in (("SQGR_AUTOCORR_ORDER", "single"), ("SQGR_AUTOCORR_ORDER_LISTS", "0")):   # the round-3 schedule; the lists as built
+        os.environ[env] = val
+        try:
+            np.testing.assert_allclose(plan.perms(mode, perm_idx=perm_idx), got, rtol=1e-10, atol=1e-13)
+        finally:
+            del os.environ[env]
+    # the device generator: [70, 150) alone, in pieces cut inside a lane group, and as part of [0, 200)
+    whole = plan.perms(mode, seed=21, perm_begin=0, perm_end=200)
+    part = plan.perms(mode, seed=21, perm_begin=70, perm_end=150)
+    np.testing.assert_array_equal(part, whole[70:150])
+    pieces = np.concatenate([plan.perms(mode, seed=21, perm_begin=b, perm_end=e) for b, e in ((70, 71), (71, 129), (129, 150))])
+    np.testing.assert_array_equal(pieces, part)
+    idx = np.stack([devrng.autocorr_permutation(n, 21, p) for p in (70, 149)])
+    np.testing.assert_allclose(part[[0, -1]], O.score_perms(mode, g, vals, idx), rtol=RTOL, atol=ATOL)
+    plan.close()
+    graph.close()
+
+
+def test_bucket_lists_with_row_sum_classes_belong_to_their_plan(L, ctx, perm_kernel):
+    """The lists of the class-table kernel carry the row-sum class of every pair, and the context keeps the lists of the last call:
+    two plans of the same size, seed and permutation count on graphs whose spots fall into DIFFERENT classes must not share them."""
+    if perm_kernel != "lds":
+        pytest.skip("default chunking of the LDS kernel only")
+    from sklearn.preprocessing import normalize
+
+    rng = np.random.default_rng(3)
+    g1 = normalize(O.hex_grid_graph(70, 70), norm="l1", axis=1)
+    g2 = g1.tolil()
+    g2[[5, 900, 2000], :] = 0
+    g2 = g2.tocsr()
+    g2.eliminate_zeros()
+    vals = rng.gamma(2.0, 1.0, size=(12, g1.shape[0]))
+    out = []
+    for g in (g1, g2):
+        graph = L.Graph(ctx, g)
+        plan = L.AutocorrPlan(ctx, graph, vals)
+        out.append(plan.perms("geary", seed=5, perm_begin=0, perm_end=64))
+        idx = np.stack([devrng.autocorr_permutation(g.shape[0], 5, p) for p in (0, 63)])
+        np.testing.assert_allclose(out[-1][[0, 63]], O.score_perms("geary", g, vals, idx), rtol=RTOL, atol=ATOL)
+        plan.close()
+        graph.close()
+    assert not np.allclose(out[0], out[1], rtol=1e-9, atol=0)
+
+
 @pytest.mark.parametrize("case", ["uniform", "classes", "classes-isolated-spot", "general"])
 def test_geary_row_sum_shortcuts(L, ctx, perm_kernel, case):
     """Geary's permutations need `sum_i z_i^2 r[idx_p(i)]`, r = the graph's row sums.  `transformation=True` (the reference's default,

@@ -8,7 +8,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     from squidpy_amd import _lib as L
     from squidpy_amd._synthetic import hex_grid_graph
     ctx = L.default_context()
-    rows, cols, G, P = 250, 400, 2048, 1000
+    rows, cols, G, P = int(os.environ.get("EXP_ROWS", 250)), int(os.environ.get("EXP_COLS", 400)), 2048, int(os.environ.get("EXP_PERMS", 1000))
     n = rows * cols
     g = normalize(hex_grid_graph(rows, cols), norm="l1", axis=1)
     vals = np.random.default_rng(11).gamma(2.0, 1.0, size=(G, n))
