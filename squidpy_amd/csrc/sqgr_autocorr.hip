@@ -421,6 +421,7 @@ constexpr int LDS_PERM_BLOCK = 1024;  // lanes (= permutations) per workgroup
 // strides over the spots and k_perm_final_lds adds the LDS_SPLIT partial sums of a permutation (s ascending, then the chunks) —
 // a fixed order, so a split permutation range stays bit-identical.  100 permutations fill 13 of a workgroup's 16 waves.
 constexpr int LDS_SPLIT = 8;
+constexpr int EXC_UNROLL = 4;         // rows of an exception list (k_perm_dot_lds RMODE 3) are multiples of it
 constexpr int LIST_ROUND_SPLIT = 8;   // list lengths of the split variant (its lists are ~1/8 as long; no bank-aware order)
 
 // chunk length for n spots: (m+1) Z rows + m Y rows (+ m row sums for Geary) in 160 KiB
@@ -457,8 +458,10 @@ __global__ __launch_bounds__(256) void k_repack_pairs(const double* __restrict__
 // len[pg][a][b] = longest list (over the 64 permutations of group pg) of bucket (a, b), rounded up to LIST_ROUND.
 // grid (a, pg), one wave; lane = permutation.  Permutations >= pc have empty lists.
 // S > 1: lane = virtual permutation vp = p * S + s, which owns the spots i = s (mod S) of permutation p; pc counts virtual ones.
+// exc_cls != nullptr (RMODE 3, see "exception lists" below): xlen[pg][a] = the longest list of pairs whose j is not of class exc_main
 __global__ __launch_bounds__(64) void k_bucket_count(const int32_t* __restrict__ idx, int64_t n, int64_t pc, int m, int nch, int S,
-                                                     int round, uint32_t* __restrict__ len) {
+                                                     int round, uint32_t* __restrict__ len, const uint8_t* __restrict__ exc_cls,
+                                                     int exc_main, uint32_t* __restrict__ xlen) {
     extern __shared__ uint32_t cnt[];  // [b][lane]
     const int lane = threadIdx.x, a = blockIdx.x;
     const int64_t pg = blockIdx.y, vp = pg * 64 + lane, p = vp / S;
@@ -466,10 +469,25 @@ __global__ __launch_bounds__(64) void k_bucket_count(const int32_t* __restrict__
     for (int b = 0; b < nch; ++b) cnt[b * 64 + lane] = 0;
     const float inv_m = 1.0f / (float)m;
     const int64_t i0 = (int64_t)a * m, i1 = min(n, i0 + m);
+    uint32_t xc = 0;
     if (vp < pc) {
         const int32_t* row = idx + (size_t)p * n;
+        if (exc_cls) {
 #pragma unroll 8
-        for (int64_t i = i0 + (sub - i0 % S + S) % S; i < i1; i += S) cnt[chunk_of((uint32_t)row[i], (uint32_t)m, inv_m) * 64 + lane] += 1;
+            for (int64_t i = i0 + (sub - i0 % S + S) % S; i < i1; i += S) {
+                const uint32_t j = (uint32_t)row[i];
+                cnt[chunk_of(j, (uint32_t)m, inv_m) * 64 + lane] += 1;
+                xc += exc_cls[j] != exc_main ? 1u : 0u;
+            }
+        } else {
+#pragma unroll 8
+            for (int64_t i = i0 + (sub - i0 % S + S) % S; i < i1; i += S) cnt[chunk_of((uint32_t)row[i], (uint32_t)m, inv_m) * 64 + lane] += 1;
+        }
+    }
+    if (exc_cls) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) xc = max(xc, (uint32_t)__shfl_xor((int)xc, o, 64));
+        if (lane == 0) xlen[(size_t)pg * nch + a] = (xc + EXC_UNROLL - 1) / EXC_UNROLL * EXC_UNROLL;
     }
     for (int b = 0; b < nch; ++b) {
         uint32_t v = cnt[b * 64 + lane];
@@ -535,7 +553,9 @@ __global__ void k_bucket_bases(const uint32_t* __restrict__ total, int npg, uint
 __global__ __launch_bounds__(64) void k_bucket_fill(const int32_t* __restrict__ idx, int64_t n, int64_t pc, int m, int nch, int S,
                                                     const uint32_t* __restrict__ len, const uint32_t* __restrict__ off,
                                                     const uint64_t* __restrict__ base, uint32_t* __restrict__ lists,
-                                                    const uint8_t* __restrict__ rcls) {
+                                                    const uint8_t* __restrict__ rcls, const uint8_t* __restrict__ exc_cls, int exc_main,
+                                                    const uint32_t* __restrict__ xlen, const uint32_t* __restrict__ xoff,
+                                                    uint32_t* __restrict__ xlists) {
     extern __shared__ uint32_t cur[];  // [b][lane], then the nch row offsets of this (pg, a)
     const int lane = threadIdx.x, a = blockIdx.x;
     const int64_t pg = blockIdx.y, vp = pg * 64 + lane, p = vp / S;
@@ -547,6 +567,8 @@ __global__ __launch_bounds__(64) void k_bucket_fill(const int32_t* __restrict__ 
     for (int b = lane; b < nch; b += 64) offl[b] = off[bk + b];
     __syncthreads();
     uint32_t* out = lists + (size_t)base[pg] * 64 + lane;
+    uint32_t* xout = exc_cls ? xlists + (size_t)xoff[(size_t)pg * nch + a] * 64 + lane : nullptr;
+    uint32_t xk = 0;
     const int64_t i0 = (int64_t)a * m, i1 = min(n, i0 + m);
     if (vp < pc) {
         const int32_t* row = idx + (size_t)p * n;
@@ -556,12 +578,53 @@ __global__ __launch_bounds__(64) void k_bucket_fill(const int32_t* __restrict__ 
             const uint32_t k = cur[b * 64 + lane];
             cur[b * 64 + lane] = k + 1;
             out[((size_t)offl[b] + k) * 64] = (uint32_t)(i - i0) | ((j - b * (uint32_t)m) << 16) | (rcls ? (uint32_t)rcls[j] << 29 : 0u);
+            if (exc_cls) {
+                const uint32_t c = exc_cls[j];
+                if (c != (uint32_t)exc_main) {
+                    xout[(size_t)xk * 64] = (uint32_t)(i - i0) | (c << 29);
+                    ++xk;
+                }
+            }
         }
     }
     const uint32_t pad = (uint32_t)m;
     for (int b = 0; b < nch; ++b) {
         const uint32_t l = len[bk + b];
         for (uint32_t k = cur[b * 64 + lane]; k < l; ++k) out[((size_t)offl[b] + k) * 64] = pad;
+    }
+    if (exc_cls)
+        for (const uint32_t l = xlen[(size_t)pg * nch + a]; xk < l; ++xk) xout[(size_t)xk * 64] = pad;
+}
+
+// Exception lists (k_perm_dot_lds RMODE 3, Geary's C): when most spots share ONE row sum r0, sum_i z_i^2 r[idx_p(i)] is
+// r0 * sum z^2 (the same for every permutation) + sum over the pairs whose j has another row sum of z_i^2 (r[j] - r0).  Those
+// pairs — a few per cent on a grid: its border — get a list of their own per (group, chunk a), whatever the chunk of j: an entry
+// is (i - a*m) | class of r[j] << 29, the padding pair (m, class 0) reads the zero row of Z.
+// (counted and filled by k_bucket_count / k_bucket_fill in the same pass over the permutations' indices)
+// xoff[.] = exclusive prefix of xlen (rows of 64 entries), xoff[count] = all rows; one workgroup
+__global__ __launch_bounds__(256) void k_exc_offsets(const uint32_t* __restrict__ xlen, int count, uint32_t* __restrict__ xoff) {
+    __shared__ uint32_t part[256];
+    const int tid = threadIdx.x;
+    const int per = (count + 255) / 256;
+    const int j0 = min(count, tid * per), j1 = min(count, j0 + per);
+    uint32_t sum = 0;
+    for (int j = j0; j < j1; ++j) sum += xlen[j];
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int t = 0; t < 256; ++t) {
+            const uint32_t v = part[t];
+            part[t] = run;
+            run += v;
+        }
+        xoff[count] = run;
+    }
+    __syncthreads();
+    uint32_t run = part[tid];
+    for (int j = j0; j < j1; ++j) {
+        xoff[j] = run;
+        run += xlen[j];
     }
 }
 
@@ -853,8 +916,11 @@ __global__ __launch_bounds__(LDS_PERM_BLOCK) void k_perm_dot_lds(const double* _
                                                                  int64_t G2, int m, int nch, const uint32_t* __restrict__ len,
                                                                  const uint32_t* __restrict__ off, const uint64_t* __restrict__ base,
                                                                  const uint32_t* __restrict__ lists, double* __restrict__ part1,
-                                                                 double* __restrict__ part2, int a_per_xcd) {
-    constexpr bool GEARY = RMODE != 0, RARR = RMODE == 1, RCLS = RMODE == 2;
+                                                                 double* __restrict__ part2, int a_per_xcd,
+                                                                 const uint32_t* __restrict__ xlen, const uint32_t* __restrict__ xoff,
+                                                                 const uint32_t* __restrict__ xlists) {
+    // RMODE 3: the main loop is Moran's; the z^2 r term comes from the exception lists (see k_exc_offsets) and a constant
+    constexpr bool SECOND = RMODE != 0, GEARY = RMODE == 1 || RMODE == 2, RARR = RMODE == 1, RCLS = RMODE == 2, REXC = RMODE == 3;
     // pairs per lane between two waits (register budget: 128; the class-table variant spills 6 registers at 8 and is still 8 % faster
     // than at 4: 70.8 vs 77.2 ms per 2048 genes x 1000 permutations)
     constexpr int UNR = RARR ? LIST_UNROLL / 2 : LIST_UNROLL;
@@ -919,7 +985,7 @@ __global__ __launch_bounds__(LDS_PERM_BLOCK) void k_perm_dot_lds(const double* _
         const int ma = (int)min((int64_t)m, n - i0);
         for (int t = tid; t < ma; t += nthr) Zc[t] = Zg[i0 + t];
         if (tid == 0) Zc[m] = make_double2(0.0, 0.0);
-        if (RCLS && tid < 8) Rc[tid] = rowsum[tid];  // (`rowsum` points at the class table)
+        if ((RCLS || REXC) && tid < 8) Rc[tid] = rowsum[tid];  // (`rowsum` points at the class table; RMODE 3: of r - r0)
     }
     if (staged) fetch(0);
     const size_t bk = ((size_t)pg * nch + a) * nch;
@@ -975,10 +1041,27 @@ __global__ __launch_bounds__(LDS_PERM_BLOCK) void k_perm_dot_lds(const double* _
             }
         }
     }
+    if (REXC && live) {  // the pairs whose j carries another row sum than most: z_i^2 (r[j] - r0), chunk a's Z rows are still in LDS
+        const size_t xk = (size_t)pg * nch + a;
+        const uint32_t Lx = (uint32_t)__builtin_amdgcn_readfirstlane((int)xlen[xk]);
+        const uint32_t* q = xlists + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)xoff[xk]) * 64 + (tid & 63);
+        for (uint32_t k = 0; k < Lx; k += EXC_UNROLL) {
+            uint32_t code[EXC_UNROLL];
+#pragma unroll
+            for (int u = 0; u < EXC_UNROLL; ++u) code[u] = q[(size_t)(k + u) * 64];
+#pragma unroll
+            for (int u = 0; u < EXC_UNROLL; ++u) {
+                const double2 z = Zc[code[u] & 0xffffu];
+                const double r = Rc[code[u] >> 29];
+                b0 = fma(z.x * z.x, r, b0);
+                b1 = fma(z.y * z.y, r, b1);
+            }
+        }
+    }
     if (p < pc) {
         const size_t o = (((size_t)tile2 * pc + p) * nch + a) * GP;
         *reinterpret_cast<double2*>(part1 + o) = make_double2(a0, a1);
-        if (GEARY) *reinterpret_cast<double2*>(part2 + o) = make_double2(b0, b1);
+        if (SECOND) *reinterpret_cast<double2*>(part2 + o) = make_double2(b0, b1);
     }
 }
 
@@ -999,6 +1082,7 @@ __global__ __launch_bounds__(256) void k_perm_final_lds(const double* __restrict
         if (GEARY && part2) s2 += part2[o + (size_t)a * GP];
     }
     if (GEARY && !part2) s2 = rs_const * z2ss[g];
+    else if (GEARY && rs_const != 0.0) s2 += rs_const * z2ss[g];  // (the exception lists hold the departures from r0 = rs_const)
     double v;
     if (GEARY)
         v = ((double)(n - 1) * ((s2 - 2.0 * s1) + qsum[g])) / (2.0 * W * z2ss[g]);
@@ -1182,6 +1266,11 @@ struct sqgr_autocorr {
     uint64_t cls_serial = 0;  // identifies this plan's class assignment (bucket lists carry the classes: part of their cache key)
     DevBuf<uint8_t> rcls;
     DevBuf<double> rtab;
+    // ... and when one class holds most spots (a grid: all but its border): r0 * sum z^2 + exception lists (k_perm_dot_lds RMODE 3)
+    bool rs_exc = false;
+    int rs_main = 0;         // the class of r0
+    double rs_main_val = 0.0;
+    DevBuf<double> rtab_x;   // r_c - r0
 };
 
 // The bucket lists depend on the permutations alone: every feature block of a call (and the next call with the same seed)
@@ -1196,6 +1285,7 @@ struct PermLists : sqgr::CtxCache {
     std::vector<uint64_t> states;
     // lists
     DevBuf<uint32_t> b_len, b_off, b_total, lists, lists_raw;
+    DevBuf<uint32_t> x_len, x_off, x_lists;  // exception lists (see k_exc_offsets), when the lists serve RMODE 3
     DevBuf<uint64_t> b_base;
     bool matches(int64_t n_, int64_t pc_, int64_t perm0_, int m_, int nch_, int kind_, uint64_t seed_, const uint64_t* st_, int split_,
                  uint64_t cls_serial_) const {
@@ -1245,7 +1335,7 @@ static int list_order_mode(int split) {
 // bucket lists of the pc permutations whose indices are in idx (the first one is permutation `perm0` of its stream) -> pl
 // (split > 1: pc counts VIRTUAL permutations, idx holds pc / split index rows)
 static int build_perm_lists(sqgr_ctx* ctx, PermLists* pl, const int32_t* idx, int64_t n, int64_t pc, int64_t perm0, int m, int nch, int split,
-                            bool geary, const uint8_t* rcls) {
+                            bool geary, const uint8_t* rcls, const uint8_t* exc_cls = nullptr, int exc_main = 0) {
     hipStream_t st = ctx->stream;
     const int npg = (int)ceil_div(pc, 64);
     const int order = list_order_mode(split);
@@ -1261,12 +1351,21 @@ static int build_perm_lists(sqgr_ctx* ctx, PermLists* pl, const int32_t* idx, in
     const size_t cnt_lds = (size_t)nch * 64 * sizeof(uint32_t);
     uint64_t rows_max[2] = {0, 0};  // all rows, the longest list
     LaunchTimer t(ctx, "autocorr_bucket_lists");
-    k_bucket_count<<<dim3((unsigned)nch, (unsigned)npg), 64, cnt_lds, st>>>(idx, n, pc, m, nch, split, round, pl->b_len.p);
+    const int xcnt = npg * nch;
+    uint32_t xrows = 0;
+    if (exc_cls) {  // the pairs whose j has another row sum than most (RMODE 3) get lists of their own, built in the same two passes
+        SQGR_TRY(pl->x_len.ensure((size_t)xcnt));
+        SQGR_TRY(pl->x_off.ensure((size_t)xcnt + 1));
+    }
+    k_bucket_count<<<dim3((unsigned)nch, (unsigned)npg), 64, cnt_lds, st>>>(idx, n, pc, m, nch, split, round, pl->b_len.p, exc_cls, exc_main, pl->x_len.p);
     k_bucket_offsets<<<(unsigned)npg, 256, 0, st>>>(pl->b_len.p, nb, pl->b_off.p, pl->b_total.p);
     k_bucket_bases<<<1, 64, 0, st>>>(pl->b_total.p, npg, pl->b_base.p);
+    if (exc_cls) k_exc_offsets<<<1, 256, 0, st>>>(pl->x_len.p, xcnt, pl->x_off.p);
     SQGR_HIP(hipGetLastError());
     SQGR_HIP(hipMemcpyAsync(rows_max, pl->b_base.p + npg, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    if (exc_cls) SQGR_HIP(hipMemcpyAsync(&xrows, pl->x_off.p + xcnt, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     SQGR_HIP(hipStreamSynchronize(st));
+    if (exc_cls && (pl->x_lists.n < (size_t)xrows * 64 + 64 || !pl->x_lists.p)) SQGR_TRY(pl->x_lists.alloc_pooled((size_t)xrows * 64 + (size_t)xrows * 4 + 64));
     const uint64_t rows = rows_max[0];
     // (with headroom: the next seed's lists are a few rows longer or shorter, and a new buffer of this size costs milliseconds)
     if (pl->lists.n < (size_t)rows * 64 || !pl->lists.p) SQGR_TRY(pl->lists.alloc_pooled((size_t)rows * 64 + (size_t)rows * 4));
@@ -1276,7 +1375,8 @@ static int build_perm_lists(sqgr_ctx* ctx, PermLists* pl, const int32_t* idx, in
         fill_to = pl->lists_raw.p;
     }
     k_bucket_fill<<<dim3((unsigned)nch, (unsigned)npg), 64, cnt_lds + (size_t)nch * sizeof(uint32_t), st>>>(idx, n, pc, m, nch, split, pl->b_len.p, pl->b_off.p,
-                                                                                                          pl->b_base.p, fill_to, rcls);
+                                                                                                          pl->b_base.p, fill_to, rcls, exc_cls, exc_main,
+                                                                                                          pl->x_len.p, pl->x_off.p, pl->x_lists.p);
     SQGR_HIP(hipGetLastError());
     if (joint) {
         const int segs = (int)ceil_div((int64_t)rows_max[1], (int64_t)ORDER_SEG);  // (blocks past the end of their list return at once)
@@ -1296,10 +1396,11 @@ static int build_perm_lists(sqgr_ctx* ctx, PermLists* pl, const int32_t* idx, in
 }
 
 // which k_perm_dot_lds instantiation serves a statistic on this plan: 0 Moran's I — and Geary's C when all row sums are equal —,
-// 2 Geary's C through the class table (<= 8 distinct row sums), 1 Geary's C with the row sums of the chunk in LDS
+// 3 Geary's C as Moran's loop + exception lists (<= 8 distinct row sums, one of them on at least 3 spots in 4), 2 Geary's C through
+// the class table (<= 8 distinct row sums), 1 Geary's C with the row sums of the chunk in LDS
 static int lds_rmode(const sqgr_autocorr* h, int32_t mode) {
     if (mode != 1 || h->rs_uniform) return 0;
-    return h->rs_classes ? 2 : 1;
+    return h->rs_classes ? (h->rs_exc ? 3 : 2) : 1;
 }
 
 // permutation scores of the pc permutations behind the bucket lists `pl`, through the LDS-bucketed kernel -> h->sims
@@ -1327,7 +1428,7 @@ static int perms_pass_lds(sqgr_autocorr* h, int32_t mode, int64_t pc_real, const
     }
     SQGR_TRY(h->part1.ensure((size_t)G2 * pc * nch * GP));
     if (second) SQGR_TRY(h->part2.ensure((size_t)G2 * pc * nch * GP));
-    const size_t lds = ((size_t)(2 * m + 1) * GP + (geary ? (size_t)m : (rmode == 2 ? (size_t)8 : 0))) * sizeof(double);
+    const size_t lds = ((size_t)(2 * m + 1) * GP + (geary ? (size_t)m : (rmode >= 2 ? (size_t)8 : 0))) * sizeof(double);
     // the split variant always launches whole workgroups: waves without a permutation group still move the Y chunks (with fewer
     // than m / 5 threads a chunk does not fit the staging registers and its loads are no longer prefetched)
     const int threads = split > 1 ? LDS_PERM_BLOCK : 64 * std::min(npg, LDS_PERM_BLOCK / 64);
@@ -1357,10 +1458,11 @@ static int perms_pass_lds(sqgr_autocorr* h, int32_t mode, int64_t pc_real, const
         if (lds > 64 * 1024)                                                                                                                  \
             SQGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_perm_dot_lds<RM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         k_perm_dot_lds<RM><<<grid, threads, lds, st>>>(h->Zp.p, h->Yp.p, RSRC, n, pc, npg, G2, m, nch, pl->b_len.p, pl->b_off.p, pl->b_base.p,  \
-                                                       pl->lists.p, h->part1.p, P2, a_per_xcd);                                              \
+                                                       pl->lists.p, h->part1.p, P2, a_per_xcd, pl->x_len.p, pl->x_off.p, pl->x_lists.p);     \
     } while (0)
         if (rmode == 1) SQGR_DOT_LDS(1, h->rowsum.p, h->part2.p);
         else if (rmode == 2) SQGR_DOT_LDS(2, h->rtab.p, h->part2.p);
+        else if (rmode == 3) SQGR_DOT_LDS(3, h->rtab_x.p, h->part2.p);
         else SQGR_DOT_LDS(0, h->rowsum.p, nullptr);
 #undef SQGR_DOT_LDS
         SQGR_HIP(hipGetLastError());
@@ -1370,7 +1472,7 @@ static int perms_pass_lds(sqgr_autocorr* h, int32_t mode, int64_t pc_real, const
         dim3 g2((unsigned)ceil_div(G, 256), (unsigned)pc_real);
         if (geary_stat)
             k_perm_final_lds<true><<<g2, 256, 0, st>>>(h->part1.p, second ? h->part2.p : nullptr, nch, split, pc_real, G, n, h->W, h->z2ss.p, h->qsum.p,
-                                                       h->isconst.p, h->sims.p, h->rs_const);
+                                                       h->isconst.p, h->sims.p, rmode == 3 ? h->rs_main_val : (second ? 0.0 : h->rs_const));
         else
             k_perm_final_lds<false><<<g2, 256, 0, st>>>(h->part1.p, nullptr, nch, split, pc_real, G, n, h->W, h->z2ss.p, h->qsum.p, h->isconst.p, h->sims.p,
                                                         0.0);
@@ -1544,11 +1646,25 @@ static int autocorr_create(sqgr_ctx* ctx, const sqgr_graph* g, const double* val
         if (h->rs_classes) {
             static std::atomic<uint64_t> serial{0};
             h->cls_serial = ++serial;
-            double tab[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            double tab[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tab_x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (int c = 0; c < nv; ++c) tab[c] = vals8[c];
-            if ((rc = h->rcls.alloc((size_t)n)) || (rc = h->rtab.alloc(8))) return fail(rc);
+            // one class on at least 3 spots in 4 (SQGR_AUTOCORR_ROWSUM_EXCEPTIONS=<max share of the others, default 0.25>; 0 disables):
+            // its row sum becomes a constant term, the other spots' departures from it go through exception lists
+            int64_t pop[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int64_t i = 0; i < n; ++i) pop[cls[i]] += 1;
+            int cmain = 0;
+            for (int c = 1; c < nv; ++c)
+                if (pop[c] > pop[cmain]) cmain = c;
+            double max_share = 0.25;
+            if (const char* ex = getenv("SQGR_AUTOCORR_ROWSUM_EXCEPTIONS")) max_share = atof(ex);
+            h->rs_exc = max_share > 0.0 && (double)(n - pop[cmain]) <= max_share * (double)n;
+            h->rs_main = cmain;
+            h->rs_main_val = vals8[cmain];
+            for (int c = 0; c < nv; ++c) tab_x[c] = vals8[c] - vals8[cmain];
+            if ((rc = h->rcls.alloc((size_t)n)) || (rc = h->rtab.alloc(8)) || (rc = h->rtab_x.alloc(8))) return fail(rc);
             e = hipMemcpyAsync(h->rcls.p, cls.data(), (size_t)n, hipMemcpyHostToDevice, st);
             if (e == hipSuccess) e = hipMemcpyAsync(h->rtab.p, tab, sizeof(tab), hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(h->rtab_x.p, tab_x, sizeof(tab_x), hipMemcpyHostToDevice, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             if (e != hipSuccess) {
                 set_error("autocorr prepare failed: %s", hipGetErrorString(e));
@@ -1815,9 +1931,11 @@ static int autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_id
         const int64_t perm0 = (perm_idx || pcg_states) ? c0 : perm_begin - lead + c0;
         const int kind = perm_idx ? 2 : (pcg_states ? 1 : 0);
         // lists with row-sum classes in their entries serve RMODE 2 only; the order of the lists is part of what they are
-        const int list_kind = split | (rmode == 2 ? 256 : 0) | (list_order_mode(split) << 9);
+        // (1 << 11: with exception lists, RMODE 3)
+        const int list_kind = split | (rmode == 2 ? 256 : 0) | (list_order_mode(split) << 9) | (rmode == 3 ? 2048 : 0);
+        const uint64_t lists_cls = rmode >= 2 ? h->cls_serial : 0;
         const bool hit = use_lds && pl->matches(n, pc, perm0, lm, lnch, kind, seed, pcg_states ? pcg_states + (size_t)c0 * 4 : nullptr, list_kind,
-                                             rmode == 2 ? h->cls_serial : 0);
+                                             lists_cls);
         if (!hit) {
             if (perm_idx) {
                 SQGR_HIP(hipMemcpyAsync(h->idx.p, perm_idx + (size_t)c0 * n, (size_t)pc * n * 4, hipMemcpyHostToDevice, st));
@@ -1832,9 +1950,10 @@ static int autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_id
         }
         if (use_lds) {
             if (!hit) {
-                SQGR_TRY(build_perm_lists(ctx, pl, h->idx.p, n, pc * split, perm0, lm, lnch, split, rmode != 0, rmode == 2 ? h->rcls.p : nullptr));
+                SQGR_TRY(build_perm_lists(ctx, pl, h->idx.p, n, pc * split, perm0, lm, lnch, split, rmode != 0, rmode == 2 ? h->rcls.p : nullptr,
+                                          rmode == 3 ? h->rcls.p : nullptr, h->rs_main));
                 pl->n = n; pl->pc = pc; pl->perm0 = perm0; pl->m = lm; pl->nch = lnch; pl->kind = kind; pl->seed = seed; pl->split = list_kind;
-                pl->cls_serial = rmode == 2 ? h->cls_serial : 0;
+                pl->cls_serial = lists_cls;
                 pl->states.clear();
                 if (pcg_states) pl->states.assign(pcg_states + (size_t)c0 * 4, pcg_states + (size_t)(c0 + pc) * 4);
             }

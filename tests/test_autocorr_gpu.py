@@ -213,13 +213,15 @@ def test_bucket_lists_with_row_sum_classes_belong_to_their_plan(L, ctx, perm_ker
     assert not np.allclose(out[0], out[1], rtol=1e-9, atol=0)
 
 
-@pytest.mark.parametrize("case", ["uniform", "classes", "classes-isolated-spot", "general"])
+@pytest.mark.parametrize("case", ["uniform", "classes", "classes-isolated-spot", "classes-balanced", "general"])
 def test_geary_row_sum_shortcuts(L, ctx, perm_kernel, case):
     """Geary's permutations need `sum_i z_i^2 r[idx_p(i)]`, r = the graph's row sums.  `transformation=True` (the reference's default,
     gr/_ppatterns.py:212-214) row-normalises the graph: float64 weights give ONE row sum (the term is a constant: Moran's kernel),
-    float32 weights — what `spatial_neighbors` stores — one value per degree (a class table instead of a third random LDS read), and
-    so does a binary graph.  Both shortcuts are exact: the same scores as the general kernel (forced by
-    SQGR_AUTOCORR_ROWSUM_CLASSES=0) to the rounding of a re-ordered sum, and as the oracle."""
+    float32 weights — what `spatial_neighbors` stores — one value per degree, and so does a binary graph: a class table instead of a
+    third random LDS read, and when one value holds on 3 spots in 4 (a grid: all but its border) that value times sum z^2 plus short
+    exception lists for the other spots.  All shortcuts are exact: the same scores as the general kernel
+    (SQGR_AUTOCORR_ROWSUM_CLASSES=0) and as each other (SQGR_AUTOCORR_ROWSUM_EXCEPTIONS=0: the class table) to the rounding of a
+    re-ordered sum, and as the oracle."""
     import os
 
     from sklearn.preprocessing import normalize
@@ -242,30 +244,42 @@ def test_geary_row_sum_shortcuts(L, ctx, perm_kernel, case):
                 g[17, :] = 0
                 g = g.tocsr()
                 g.eliminate_zeros()
+            if case == "classes-balanced":                 # every other row doubled: no row sum holds on 3 spots in 4
+                g = sp.diags(np.where(np.arange(g.shape[0]) % 2 == 0, 1.0, 2.0).astype(np.float32)) @ g
+                g = sp.csr_matrix(g).astype(np.float32)
     n, G, P = g.shape[0], 300, 70
-    n_distinct = len(np.unique(np.asarray(g.astype(np.float64).sum(axis=1)).ravel()))
-    assert {"uniform": n_distinct == 1, "classes": 2 <= n_distinct <= 8, "classes-isolated-spot": 3 <= n_distinct <= 8, "general": n_distinct > 8}[case]
+    rs_vals, rs_counts = np.unique(np.asarray(g.astype(np.float64).sum(axis=1)).ravel(), return_counts=True)
+    n_distinct, others = len(rs_vals), 1.0 - rs_counts.max() / n
+    assert {"uniform": n_distinct == 1, "classes": 2 <= n_distinct <= 8 and others < 0.1, "classes-isolated-spot": 3 <= n_distinct <= 8 and others < 0.1,
+            "classes-balanced": 2 <= n_distinct <= 8 and others > 0.25, "general": n_distinct > 8}[case]
     vals = rng.gamma(2.0, 1.0, size=(G, n))
     vals[3] += 3 * np.sin(xy[:, 0] * 6)
     graph = L.Graph(ctx, g)
     plan = L.AutocorrPlan(ctx, graph, vals)
     fast = plan.perms("geary", seed=5, perm_begin=0, perm_end=P)
-    os.environ["SQGR_AUTOCORR_ROWSUM_CLASSES"] = "0"
-    try:
-        plan2 = L.AutocorrPlan(ctx, graph, vals)
-        ref = plan2.perms("geary", seed=5, perm_begin=0, perm_end=P)
-    finally:
-        del os.environ["SQGR_AUTOCORR_ROWSUM_CLASSES"]
-    np.testing.assert_allclose(fast, ref, rtol=1e-11, atol=1e-13)
-    if case == "general":
-        np.testing.assert_array_equal(fast, ref)  # more than 8 distinct row sums: the same kernel both times
+    others_plans = []
+    for env in ("SQGR_AUTOCORR_ROWSUM_EXCEPTIONS", "SQGR_AUTOCORR_ROWSUM_CLASSES"):   # the class table; the general kernel
+        os.environ[env] = "0"
+        try:
+            plan2 = L.AutocorrPlan(ctx, graph, vals)
+            ref = plan2.perms("geary", seed=5, perm_begin=0, perm_end=P)
+        finally:
+            del os.environ[env]
+        others_plans.append(plan2)
+        np.testing.assert_allclose(fast, ref, rtol=1e-11, atol=1e-13)
+        if case == "general" or (case in ("uniform", "classes-balanced") and env.endswith("EXCEPTIONS")):
+            np.testing.assert_array_equal(fast, ref)  # the same kernel both times
     idx = np.stack([devrng.autocorr_permutation(n, 5, p) for p in (0, 1, 69)])
     np.testing.assert_allclose(fast[[0, 1, 69]], O.score_perms("geary", g, vals, idx), rtol=RTOL, atol=ATOL)
     # split invariance inside the shortcut: a range in two pieces, bit for bit
     two = np.concatenate([plan.perms("geary", seed=5, perm_begin=0, perm_end=33), plan.perms("geary", seed=5, perm_begin=33, perm_end=P)])
     np.testing.assert_array_equal(two, fast)
+    # ... and numpy's streams / injected permutations take the same shortcut
+    inj = plan.perms("geary", perm_idx=idx)
+    np.testing.assert_allclose(inj, O.score_perms("geary", g, vals, idx), rtol=RTOL, atol=ATOL)
     plan.close()
-    plan2.close()
+    for p2 in others_plans:
+        p2.close()
     graph.close()
 
 

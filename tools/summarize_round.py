@@ -99,9 +99,9 @@ rep = {
     "nhood": {"workload": (pmc_bench or {}).get("roofline", {}).get("workload_key"),
               "kernels": section(agg, lambda k: "k_count" in k or "k_shuffle" in k or "k_reduce" in k or "k_keygen" in k or "k_finalize" in k)},
     # Moran and Geary launches of the same kernel template differ by their template argument: k_perm_dot_lds<0> Moran (and Geary on a
-    # graph with ONE row sum), <1> / <2> Geary (row sums in LDS / in classes); the gather kernel k_perm_dot<false> Moran, <true> Geary
+    # graph with ONE row sum), <1> / <2> / <3> Geary (row sums in LDS / in classes / exception lists); the gather kernel k_perm_dot<false> Moran, <true> Geary
     "moran": {"workload": sec.get("roofline", {}).get("workload_key"),
-              "kernels": section(agg, lambda k: autocorr_match(k) and "<true>" not in k and "<1>" not in k and "<2>" not in k)},
+              "kernels": section(agg, lambda k: autocorr_match(k) and "<true>" not in k and "<1>" not in k and "<2>" not in k and "<3>" not in k)},
     "geary": {"workload": gea.get("roofline", {}).get("workload_key"),
               "kernels": section(agg, lambda k: autocorr_match(k) and "<false>" not in k and "<0>" not in k)},
 }
