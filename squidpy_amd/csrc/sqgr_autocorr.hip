@@ -424,15 +424,28 @@ constexpr int LDS_SPLIT = 8;
 constexpr int EXC_UNROLL = 4;         // rows of an exception list (k_perm_dot_lds RMODE 3) are multiples of it
 constexpr int LIST_ROUND_SPLIT = 8;   // list lengths of the split variant (its lists are ~1/8 as long; no bank-aware order)
 
-// chunk length for n spots: (m+1) Z rows + m Y rows (+ m row sums for Geary) in 160 KiB
+// The Z chunk ends in ZERO_ROWS rows of zeros, one of every bank class (row index mod 16): the padding pair of a lane that has
+// no pair left points at one of them — and at any Y row — so the schedule can give it LDS banks nobody else reads at that step.
+constexpr int ZERO_ROWS = 16;
+// chunk length for n spots: (m + ZERO_ROWS) Z rows + m Y rows (+ m row sums for Geary) in 160 KiB
 static inline int lds_chunk(int64_t n, bool geary, int* nch_out) {
     const int per_spot = 2 * GP * 8 + (geary ? 8 : 0);
-    int m_max = ((LDS_BYTES - GP * 8) / per_spot) & ~3;
+    int m_max = ((LDS_BYTES - ZERO_ROWS * GP * 8 - 64) / per_spot) & ~3;  // (64 B: the row-sum class table of RMODE 2 / 3)
     if (const char* env = getenv("SQGR_AUTOCORR_LDS_CHUNK"))  // tests: several chunks on small inputs
-        m_max = std::max(8, std::min(m_max, atoi(env) & ~3));
+        m_max = std::max(16, std::min(m_max, atoi(env) & ~3));
     const int64_t nch = ceil_div(n, m_max);
     *nch_out = (int)nch;
     return (int)((ceil_div(n, nch) + 3) & ~(int64_t)3);
+}
+
+// Lane -> slot of its (virtual) permutation inside a group of 64.  A `ds_read_b128` serves a wave in four fixed sets of 16 lanes
+// ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, + 32; MI355X_MICROARCH.md §LDS); the slots are numbered so that set q holds the slots
+// 16 q .. 16 q + 15, slot mod 16 = lane mod 16: the 16 permutations that meet in a service group — the ones whose lists are scheduled
+// against each other, k_bucket_order_* — are 16 CONSECUTIVE permutations, whatever 16-aligned index a pass starts at.
+__device__ __forceinline__ int perm_slot(int lane) {
+    const int x = lane & 31;
+    const int odd = ((x >= 4 && x < 12) || (x >= 16 && x < 20) || x >= 28) ? 1 : 0;
+    return ((lane >> 5) * 2 + odd) * 16 + (lane & 15);
 }
 
 // chunk of spot j (j < 2^24: exact in float; the estimate is off by at most one)
@@ -464,7 +477,7 @@ __global__ __launch_bounds__(64) void k_bucket_count(const int32_t* __restrict__
                                                      int exc_main, uint32_t* __restrict__ xlen) {
     extern __shared__ uint32_t cnt[];  // [b][lane]
     const int lane = threadIdx.x, a = blockIdx.x;
-    const int64_t pg = blockIdx.y, vp = pg * 64 + lane, p = vp / S;
+    const int64_t pg = blockIdx.y, vp = pg * 64 + perm_slot(lane), p = vp / S;
     const int sub = (int)(vp - p * S);
     for (int b = 0; b < nch; ++b) cnt[b * 64 + lane] = 0;
     const float inv_m = 1.0f / (float)m;
@@ -558,7 +571,7 @@ __global__ __launch_bounds__(64) void k_bucket_fill(const int32_t* __restrict__ 
                                                     uint32_t* __restrict__ xlists) {
     extern __shared__ uint32_t cur[];  // [b][lane], then the nch row offsets of this (pg, a)
     const int lane = threadIdx.x, a = blockIdx.x;
-    const int64_t pg = blockIdx.y, vp = pg * 64 + lane, p = vp / S;
+    const int64_t pg = blockIdx.y, vp = pg * 64 + perm_slot(lane), p = vp / S;
     const int sub = (int)(vp - p * S);
     for (int b = 0; b < nch; ++b) cur[b * 64 + lane] = 0;
     const float inv_m = 1.0f / (float)m;
@@ -708,8 +721,8 @@ __global__ __launch_bounds__(64) void k_bucket_order(int m, int nb, int64_t perm
 //     class of its pool (rotating start) or, failing that, any.
 //   surplus phase: pools fuller than the lane has rounds keep pairs, emptier ones leave holes; every lane fills its holes with the
 //     remaining pairs that collide least with what the main phase gave the other lanes at that step (Y first, then Z).
-// The schedule of a lane depends on the 15 lanes it shares the group with: the caller builds lists for whole 64-aligned groups of
-// the GLOBAL permutation index (sqgr_autocorr_perms generates the missing neighbours), so a split range stays bit-identical.
+// The schedule of a lane depends on the 15 lanes it shares the group with: the caller builds lists for whole 16-aligned groups of
+// the GLOBAL permutation index (perm_slot; sqgr_autocorr_perms generates the missing neighbours), so a split range stays bit-identical.
 // Lists longer than ORDER_SEG rows are scheduled in independent segments of ORDER_SEG rows (grid.z).  Out of place: src -> dst.
 constexpr int ORDER_SEG = 256;
 
@@ -744,6 +757,7 @@ __global__ __launch_bounds__(16) void k_bucket_order_joint(int m, int nb, const 
     uint32_t* d = dst + row0 + lane;
     const uint32_t pad = (uint32_t)m;
     for (int i = t; i < 256 * 8; i += 16) reinterpret_cast<uint32_t*>(cw)[i] = 0;
+    for (int i = t; i < ORDER_SEG; i += 16) yz[i] = 0;
     if (t == 0) saturated = 0;
     __syncthreads();
     // --- thread = lane r: the cells of its list
@@ -755,7 +769,7 @@ __global__ __launch_bounds__(16) void k_bucket_order_joint(int m, int nb, const 
         for (int u = 0; u < 16; ++u) e[u] = a[(size_t)(k0 + u) * 64];
 #pragma unroll
         for (int u = 0; u < 16; ++u)
-            if (e[u] != pad) {
+            if ((e[u] & 0xffffu) < pad) {
                 const int cell = ((((e[u] & 15u) << 4) | ((e[u] >> 16) & 15u))) * 16 + t;
                 const uint32_t w = cw[cell];
                 sat |= w >= 0xff00u;
@@ -883,15 +897,21 @@ __global__ __launch_bounds__(16) void k_bucket_order_joint(int m, int nb, const 
             }
     }
     // --- (same thread) every pair to its step — the cursors now stand at the end of their cells —, the padding pair elsewhere
+    // (a padding pair: the zero row of the lane's own Z class at that step, a Y row of a class the main phase left free there)
     for (int k = 0; k < Ls; ++k)
-        if (!((hbits[(k & 15) * 16 + t] >> (k >> 4)) & 1u)) d[(size_t)k * 64] = pad;
+        if (!((hbits[(k & 15) * 16 + t] >> (k >> 4)) & 1u)) {
+            const uint32_t yfree = ~yz[k] & 0xffffu;
+            const uint32_t rot = ((yfree >> t) | (yfree << (16 - t))) & 0xffffu;
+            const uint32_t yc = yfree ? (uint32_t)((__builtin_ctz(rot) + t) & 15) : 0u;
+            d[(size_t)k * 64] = (pad + (((uint32_t)(k + t) - pad) & 15u)) | (yc << 16);
+        }
     for (int k0 = 0; k0 < Ls; k0 += 16) {
         uint32_t e[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) e[u] = a[(size_t)(k0 + u) * 64];
 #pragma unroll
         for (int u = 0; u < 16; ++u)
-            if (e[u] != pad) {
+            if ((e[u] & 0xffffu) < pad) {
                 const int cell = ((((e[u] & 15u) << 4) | ((e[u] >> 16) & 15u))) * 16 + t;
                 const uint32_t v = (uint32_t)cw[cell] - 1u;
                 cw[cell] = (uint16_t)v;  // (only the cursor byte is read from here on)
@@ -899,6 +919,254 @@ __global__ __launch_bounds__(16) void k_bucket_order_joint(int m, int nb, const 
             }
     }
 }
+
+// The STEP schedule (the default): the rotation above gives every Z class the same number of slots in a lane's list, so the ~9 % of
+// a lane's pairs that exceed their class's share land in other classes' holes and collide there.  A list of row classes can be cut
+// into steps in which all 16 lanes read DIFFERENT Z classes whatever the counts (an edge colouring of the lanes x classes
+// multigraph: as many steps as the longest lane or the fullest class needs, and the group's longest list leaves that slack).
+// Step by step, for one lane group:
+//   Z side, every four steps: the classes, fullest first (most pairs left over all lanes), each take the lane with the most pairs
+//     left among the lanes that hold the class and have no class yet; a lane keeps its class for the four steps (idle if the pool
+//     runs dry: simulated no worse, the Y side gains from drawing on one pool); a lane that can no longer afford to idle takes any
+//     class it holds.
+//   Y side, every step: the 16 Y classes in turn (rotating start) each take, among the lanes whose pool (lane, its Z class) holds
+//     the class, the one with the fewest alternatives; a lane no class took reads a colliding one.
+//   An idle lane reads a padding pair: the zero row (ZERO_ROWS) of a Z class and a Y row of a class nobody reads at that step.
+// Simulated 1.02 + 1.34 cycles per step and group (the rotation: 1.39 + 1.67; random rows: 2.85 + 2.85).  "Class c takes the best
+// lane that holds it" is integer arithmetic on a DPP row (one lane group = 16 threads): the lanes' holdings move to their places in
+// order of preference (ds_permute), 16 wave ballots give every class's holders in that order, the turns are scalar arithmetic
+// (lowest set bit = best holder still free), the lanes read their class back (ds_bpermute).  A workgroup is two lane groups,
+// 32 KiB of LDS, 5 per CU; the kernel is bound by instruction issue (PMC: 35 % VALU, 24 % SALU of its wave cycles).
+constexpr int STEP_SEG = 384;  // rows scheduled at a time (longer lists: independent segments, the full ones without slack)
+
+template <int N>
+__device__ __forceinline__ uint32_t row_ror(uint32_t v) {  // the value of the lane N places along the 16-lane row (rotating)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 | N, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t row_or(uint32_t v) {
+    v |= row_ror<1>(v);
+    v |= row_ror<2>(v);
+    v |= row_ror<4>(v);
+    return v | row_ror<8>(v);
+}
+// position of the n-th (0-based) set bit of a 16-bit mask (n < popcount)
+__device__ __forceinline__ uint32_t nth_set_bit(uint32_t mask, uint32_t n) {
+    uint32_t pos = 0, c = (uint32_t)__builtin_popcount(mask & 0xffu);
+    if (n >= c) { n -= c; pos = 8; }
+    c = (uint32_t)__builtin_popcount((mask >> pos) & 0xfu);
+    if (n >= c) { n -= c; pos += 4; }
+    c = (uint32_t)__builtin_popcount((mask >> pos) & 0x3u);
+    if (n >= c) { n -= c; pos += 2; }
+    return pos + (n >= ((mask >> pos) & 1u) ? 1u : 0u);
+}
+// the lanes of the own row whose (distinct) key is larger, as a mask over the wave's lanes; src[N] = 1 << (lane row_ror<N> reads)
+#define SQGR_ROW_OTHERS(M) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+struct RowSources {
+    uint32_t bit[16];
+};
+__device__ __forceinline__ uint32_t row_higher(uint32_t key, const RowSources& src) {
+    uint32_t hp = 0;
+#define SQGR_HP(N) hp |= row_ror<N>(key) > key ? src.bit[N] : 0u;
+    SQGR_ROW_OTHERS(SQGR_HP)
+#undef SQGR_HP
+    return hp;
+}
+
+// grid (buckets * 2 halves of the 64 lanes, groups of 64 permutations, segments); 32 threads = the two lane groups of a half.
+// "Class c takes the best lane that holds it" = one wave ballot of the holders + each lane's mask of the better lanes of its row.
+__global__ __launch_bounds__(32) void k_bucket_order_steps(int m, int nb, const uint32_t* __restrict__ len, const uint32_t* __restrict__ off,
+                                                           const uint64_t* __restrict__ base, const uint32_t* __restrict__ src,
+                                                           uint32_t* __restrict__ dst) {
+    __shared__ uint8_t cnt[256 * 32];            // [cell][t] pairs of the cell not yet placed
+    __shared__ uint8_t cur[256 * 32];            // [cell][t] slot of the cell's next pair, counted from the start of its pool
+    __shared__ uint16_t pstart[17 * 32];         // [zc][t] pairs in the pools below zc; [16]: all
+    __shared__ uint16_t amask[16 * 32];          // [zc][t] Y classes pool (lane, zc) still holds
+    __shared__ uint8_t stp[STEP_SEG * 32];       // [slot][t] the step given to the lane's pair of that slot, bits 0..7
+    __shared__ uint32_t stp8[STEP_SEG / 32 * 32];  // [slot / 32][t] bit slot % 32: bit 8 of that step
+    __shared__ int saturated;
+    const int t = threadIdx.x, r = t & 15;
+    const int lane = group_lane((int)(blockIdx.x & 1u) * 2 + (t >> 4), r);
+    const int64_t pg = blockIdx.y;
+    const size_t bk = (size_t)pg * nb + (blockIdx.x >> 1);
+    const int L = (int)len[bk], s0 = (int)blockIdx.z * STEP_SEG;
+    if (s0 >= L) return;
+    const int Ls = min(STEP_SEG, L - s0);  // a multiple of 16
+    const size_t row0 = ((size_t)base[pg] + off[bk] + (size_t)s0) * 64;
+    const uint32_t* a = src + row0 + lane;
+    uint32_t* d = dst + row0 + lane;
+    const uint32_t pad = (uint32_t)m;
+    for (int i = t; i < 256 * 8; i += 32) reinterpret_cast<uint32_t*>(cnt)[i] = 0;
+    for (int i = t; i < STEP_SEG; i += 32) stp8[i] = 0;
+    if (t == 0) saturated = 0;
+    __syncthreads();
+    // --- thread = lane: the cells of its list
+    uint32_t rem = 0;
+    bool sat = false;
+    for (int k0 = 0; k0 < Ls; k0 += 16) {
+        uint32_t e[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) e[u] = a[(size_t)(k0 + u) * 64];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if ((e[u] & 0xffffu) < pad) {
+                const int cell = ((((e[u] & 15u) << 4) | ((e[u] >> 16) & 15u))) * 32 + t;
+                const uint32_t c = cnt[cell];
+                sat |= c == 255u;
+                cnt[cell] = (uint8_t)(c + 1u);
+                ++rem;
+            }
+    }
+    uint32_t cand = 0;  // Z classes the lane still holds pairs of
+    {
+        uint32_t run = 0;
+        for (int zc = 0; zc < 16; ++zc) {
+            uint32_t mask = 0, ps = 0;
+#pragma unroll
+            for (int y = 0; y < 16; ++y) {
+                const uint32_t c = cnt[(zc * 16 + y) * 32 + t];
+                cur[(zc * 16 + y) * 32 + t] = (uint8_t)ps;
+                ps += c;
+                mask |= c ? (1u << y) : 0u;
+            }
+            sat |= ps > 255u;
+            amask[zc * 32 + t] = (uint16_t)mask;
+            pstart[zc * 32 + t] = (uint16_t)run;
+            run += ps;
+            cand |= mask ? (1u << zc) : 0u;
+        }
+        pstart[16 * 32 + t] = (uint16_t)run;
+    }
+    if (sat) saturated = 1;
+    __syncthreads();
+    if (saturated) {  // 256 pairs of one lane in one Z class (8-bit counters): the segment stays as built
+        for (int k = 0; k < Ls; ++k) d[(size_t)k * 64] = a[(size_t)k * 64];
+        return;
+    }
+    uint32_t cdeg = 0;  // thread r of a row also keeps class r: the pairs of that class all 16 lanes still hold
+#pragma unroll
+    for (int l2 = 0; l2 < 16; ++l2) cdeg += (uint32_t)pstart[(r + 1) * 32 + (t & 16) + l2] - (uint32_t)pstart[r * 32 + (t & 16) + l2];
+    RowSources rs;
+    rs.bit[0] = 0;
+#define SQGR_SRC(N) rs.bit[N] = 1u << row_ror<N>((uint32_t)t);
+    SQGR_ROW_OTHERS(SQGR_SRC)
+#undef SQGR_SRC
+    uint32_t sig_lo = 0, sig_hi = 0;  // the classes, fullest first, 4 bits each
+    uint32_t zpos = 0;                // (byte address of) the lane's place in its row by pairs left, most first
+    const uint32_t rowbase = (uint32_t)(t & 16);
+    // "The classes in turn each take the best lane that holds them": the lanes' holdings are moved to their places in order of
+    // preference (ds_permute), 16 wave ballots give every class's holders in that order, the turns are scalar arithmetic on the
+    // masks (lowest set bit = best holder still free, one 16-bit half per lane group), and the lanes read their class back.
+    auto take_turns = [&](const uint32_t (&holders)[16], uint32_t (&won)[16]) {
+        uint32_t free_places = 0xffffffffu;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t h = holders[i] & free_places, h0 = h & 0xffffu, h1 = h & 0xffff0000u;
+            won[i] = (h0 & (0u - h0)) | (h1 & (0u - h1));
+            free_places &= ~won[i];
+        }
+    };
+    uint32_t zkeep = 16;  // the lane's Z class of the current four steps
+    // The horizon of a lane group: its own longest list, rounded up to 16 — NOT the bucket's rows (the longest of all 64 lanes): the
+    // schedule of a group must not depend on the other groups (split invariance); the rows past the horizon hold padding pairs.
+    uint32_t horizon;
+    {
+        uint32_t h = rem;
+        h = max(h, row_ror<1>(h));
+        h = max(h, row_ror<2>(h));
+        h = max(h, row_ror<4>(h));
+        horizon = (max(h, row_ror<8>(h)) + 15u) & ~15u;
+    }
+    const int steps = (int)max((uint32_t)__builtin_amdgcn_readlane((int)horizon, 0), (uint32_t)__builtin_amdgcn_readlane((int)horizon, 16));
+    for (int k = steps; k < Ls; ++k) d[(size_t)k * 64] = (pad + (((uint32_t)r - pad) & 15u)) | ((uint32_t)r << 16);
+    for (int k = 0; k < steps; ++k) {
+        if ((k & 3) == 0) {
+            // Z side, every FOUR steps (a lane whose pool runs dry in between idles until the next turn: simulated no worse — the Y side
+            // even gains from drawing on one pool — and the lane groups read distinct classes all the same): the classes, fullest
+            // first, each take the lane with the most pairs left among their holders without a class
+            const uint32_t ck = (cdeg << 4) | (uint32_t)(15 - r);
+            const uint32_t rank = (uint32_t)__builtin_popcount(row_higher(ck, rs));
+            sig_lo = row_or(rank < 8 ? (uint32_t)r << (4 * rank) : 0u);
+            sig_hi = row_or(rank >= 8 ? (uint32_t)r << (4 * (rank - 8)) : 0u);
+            zpos = (rowbase + (uint32_t)__builtin_popcount(row_higher((rem << 4) | (uint32_t)(15 - r), rs))) << 2;
+            const uint32_t held = (uint32_t)__builtin_amdgcn_ds_permute((int)zpos, (int)(rem ? cand : 0u));  // (by place)
+            uint32_t zi[16], holders[16], won[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                zi[i] = ((i < 8 ? sig_lo : sig_hi) >> (4 * (i & 7))) & 15u;
+                holders[i] = (uint32_t)__builtin_amdgcn_ballot_w64(((held >> zi[i]) & 1u) != 0);
+            }
+            take_turns(holders, won);
+            uint32_t zp = 16;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) zp = __builtin_amdgcn_inverse_ballot_w64((uint64_t)won[i]) ? zi[i] : zp;
+            zkeep = (uint32_t)__builtin_amdgcn_ds_bpermute((int)zpos, (int)zp);
+        }
+        uint32_t myz = (rem && zkeep < 16 && ((cand >> zkeep) & 1u)) ? zkeep : 16u;
+        if (rem && myz == 16 && rem + (uint32_t)k >= horizon) myz = (uint32_t)__builtin_ctz(cand);  // no step to spare: a class some lane may read
+        const bool active = myz < 16;
+        const uint32_t zused = row_or(active ? (1u << myz) : 0u);
+        cdeg -= ((zused >> r) & 1u) && cdeg ? 1u : 0u;
+        // Y side: the classes in turn (rotating start) each take the lane with the fewest alternatives among the lanes whose pool holds them
+        const uint32_t av = active ? (uint32_t)amask[myz * 32 + t] : 0u;
+        uint32_t myy = 16;
+        {
+            const uint32_t ykey = active ? (((17u - (uint32_t)__builtin_popcount(av)) << 4) | (uint32_t)(15 - r)) : (uint32_t)(15 - r);
+            const uint32_t ypos = (rowbase + (uint32_t)__builtin_popcount(row_higher(ykey, rs))) << 2;
+            const uint32_t held = (uint32_t)__builtin_amdgcn_ds_permute((int)ypos, (int)av);
+            const uint32_t y0 = (uint32_t)(k * 5);
+            uint32_t holders[16], won[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) holders[i] = (uint32_t)__builtin_amdgcn_ballot_w64(((held >> ((y0 + (uint32_t)i) & 15u)) & 1u) != 0);
+            take_turns(holders, won);
+            uint32_t yp = 16;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) yp = __builtin_amdgcn_inverse_ballot_w64((uint64_t)won[i]) ? ((y0 + (uint32_t)i) & 15u) : yp;
+            myy = (uint32_t)__builtin_amdgcn_ds_bpermute((int)ypos, (int)yp);
+        }
+        const bool unas = active && myy == 16;
+        if (active && unas) myy = (uint32_t)__builtin_ctz(av);  // every class of the pool is taken: collide
+        // the idle lanes read padding pairs: the zero row of a Z class and a Y row of a class no lane reads at this step
+        const uint32_t idle = row_or(active ? 0u : (1u << r));
+        const uint32_t yused = row_or(active ? (1u << myy) : 0u);
+        if (active) {
+            const int cell = (int)(myz * 16 + myy) * 32 + t;
+            const uint32_t c = cnt[cell], slot = (uint32_t)pstart[myz * 32 + t] + cur[cell];
+            cnt[cell] = (uint8_t)(c - 1u);
+            cur[cell] = (uint8_t)(cur[cell] + 1u);
+            if (c == 1u) {
+                const uint32_t nav = av & ~(1u << myy);
+                amask[myz * 32 + t] = (uint16_t)nav;
+                if (!nav) cand &= ~(1u << myz);
+            }
+            stp[slot * 32 + t] = (uint8_t)k;
+            if (k & 256) stp8[(slot >> 5) * 32 + t] |= 1u << (slot & 31u);
+            --rem;
+        } else {
+            const uint32_t nth = (uint32_t)__builtin_popcount(idle & ((1u << r) - 1u));  // (at least as many free classes as idle lanes)
+            const uint32_t zc = nth_set_bit(~zused & 0xffffu, nth), yc = nth_set_bit(~yused & 0xffffu, nth);
+            d[(size_t)k * 64] = (pad + ((zc - pad) & 15u)) | (yc << 16);
+        }
+    }
+    __syncthreads();
+    // --- every pair to its step: the cursors now stand at the end of their cells
+    for (int k0 = 0; k0 < Ls; k0 += 16) {
+        uint32_t e[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) e[u] = a[(size_t)(k0 + u) * 64];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if ((e[u] & 0xffffu) < pad) {
+                const uint32_t zc = e[u] & 15u;
+                const int cell = (int)((zc << 4) | ((e[u] >> 16) & 15u)) * 32 + t;
+                const uint32_t within = (uint32_t)cur[cell] - 1u;
+                cur[cell] = (uint8_t)within;
+                const uint32_t slot = (uint32_t)pstart[zc * 32 + t] + (within & 0xffu);
+                const uint32_t k = (uint32_t)stp[slot * 32 + t] | (((stp8[(slot >> 5) * 32 + t] >> (slot & 31u)) & 1u) << 8);
+                d[(size_t)k * 64] = e[u];
+            }
+    }
+}
+#undef SQGR_ROW_OTHERS
 
 // grid (ceil(G2 / 256) * 256 * nch, perm blocks); block = 64 * (groups in a perm block) lanes, lane = permutation.
 // Block -> (gene pair, chunk a) with XCD affinity: hardware places block b on XCD (b % 8); the 32 workgroups an XCD runs
@@ -926,8 +1194,8 @@ __global__ __launch_bounds__(LDS_PERM_BLOCK) void k_perm_dot_lds(const double* _
     constexpr int UNR = RARR ? LIST_UNROLL / 2 : LIST_UNROLL;
     constexpr uint32_t JMASK = RCLS ? 0x1fffu : 0xffffu;        // RCLS: bits 29..31 of an entry hold the class of r[j]
     extern __shared__ double2 smem2[];
-    double2* Zc = smem2;            // [m + 1] rows (z of gene 0, z of gene 1); row m = 0
-    double2* Yc = smem2 + (m + 1);  // [m]
+    double2* Zc = smem2;            // [m + ZERO_ROWS] rows (z of gene 0, z of gene 1); rows m .. = 0
+    double2* Yc = smem2 + (m + ZERO_ROWS);  // [m]
     double* Rc = reinterpret_cast<double*>(Yc + m);  // RMODE 1: [m] row sums; RMODE 2: the table of the (<= 8) distinct row sums
     const int tid = threadIdx.x, nthr = blockDim.x;
     int a;
@@ -946,7 +1214,7 @@ __global__ __launch_bounds__(LDS_PERM_BLOCK) void k_perm_dot_lds(const double* _
     const int pg_raw = (int)blockIdx.y * (LDS_PERM_BLOCK / 64) + wave;
     const bool live = pg_raw < npg;  // waves past the last group only help with the chunk loads
     const int pg = live ? pg_raw : 0;
-    const int64_t p = live ? (int64_t)pg * 64 + (tid & 63) : pc;
+    const int64_t p = live ? (int64_t)pg * 64 + perm_slot(tid & 63) : pc;
     const double2* Zg = reinterpret_cast<const double2*>(Zp) + (size_t)tile2 * n;
     const double2* Yg = reinterpret_cast<const double2*>(Yp) + (size_t)tile2 * n;
     const bool staged = nthr * LDS_STAGE >= m;  // block-uniform: a whole chunk fits the threads' staging registers
@@ -984,7 +1252,7 @@ __global__ __launch_bounds__(LDS_PERM_BLOCK) void k_perm_dot_lds(const double* _
         const int64_t i0 = (int64_t)a * m;
         const int ma = (int)min((int64_t)m, n - i0);
         for (int t = tid; t < ma; t += nthr) Zc[t] = Zg[i0 + t];
-        if (tid == 0) Zc[m] = make_double2(0.0, 0.0);
+        if (tid < ZERO_ROWS) Zc[m + tid] = make_double2(0.0, 0.0);
         if ((RCLS || REXC) && tid < 8) Rc[tid] = rowsum[tid];  // (`rowsum` points at the class table; RMODE 3: of r - r0)
     }
     if (staged) fetch(0);
@@ -1321,7 +1589,8 @@ static int perm_kernel_choice(int64_t n, int64_t G, int64_t P, bool geary) {
 
 // How the bucket lists are ordered.  0: as built (ascending i; SQGR_AUTOCORR_ORDER_LISTS=0, and the split variant: a sub-list holds
 // two pairs per class), 1: SQGR_AUTOCORR_ORDER=single, the round-3 schedule (every list on its own: one side of a pair conflict-free),
-// 2: the joint schedule of the 16 permutations of a `ds_read_b128` lane group (k_bucket_order_joint; the default)
+// 2: SQGR_AUTOCORR_ORDER=rotation, the joint schedule of the 16 permutations of a `ds_read_b128` lane group on the fixed rotation of
+// Z classes (k_bucket_order_joint), 3: the step schedule (k_bucket_order_steps; the default)
 static int list_order_mode(int split) {
     // (the split variant: lane = (permutation, spots i = s mod 8) reads Z rows of two classes, s and s + 8, whatever the order —
     // the Z side is half scheduled by construction, and sub-lists of ~30 pairs leave the schedule two rounds to work with)
@@ -1329,7 +1598,9 @@ static int list_order_mode(int split) {
     if (const char* e = getenv("SQGR_AUTOCORR_ORDER_LISTS"))
         if (atoi(e) == 0) return 0;
     const char* e_order = getenv("SQGR_AUTOCORR_ORDER");
-    return (e_order && !strcmp(e_order, "single")) ? 1 : 2;
+    if (e_order && !strcmp(e_order, "single")) return 1;
+    if (e_order && !strcmp(e_order, "rotation")) return 2;
+    return 3;
 }
 
 // bucket lists of the pc permutations whose indices are in idx (the first one is permutation `perm0` of its stream) -> pl
@@ -1340,7 +1611,7 @@ static int build_perm_lists(sqgr_ctx* ctx, PermLists* pl, const int32_t* idx, in
     const int npg = (int)ceil_div(pc, 64);
     const int order = list_order_mode(split);
     const bool order_lists = order != 0;
-    const bool joint = order == 2 && (perm0 * split) % 64 == 0;  // (the lane groups must be those of the global permutation index)
+    const bool joint = order >= 2 && (perm0 * split) % 16 == 0;  // (the lane groups must be those of the global permutation index)
     const int round = (split > 1 && !joint) ? LIST_ROUND_SPLIT : LIST_ROUND;
     const int nb = nch * nch;
     pl->n = -1;  // invalid until complete
@@ -1379,7 +1650,10 @@ static int build_perm_lists(sqgr_ctx* ctx, PermLists* pl, const int32_t* idx, in
                                                                                                           pl->x_len.p, pl->x_off.p, pl->x_lists.p);
     SQGR_HIP(hipGetLastError());
     if (joint) {
-        const int segs = (int)ceil_div((int64_t)rows_max[1], (int64_t)ORDER_SEG);  // (blocks past the end of their list return at once)
+        if (order == 3 && rows_max[1] > 0)
+            k_bucket_order_steps<<<dim3((unsigned)nb * 2u, (unsigned)npg, (unsigned)ceil_div((int64_t)rows_max[1], (int64_t)STEP_SEG)), 32, 0, st>>>(
+                m, nb, pl->b_len.p, pl->b_off.p, pl->b_base.p, pl->lists_raw.p, pl->lists.p);
+        const int segs = order == 3 ? 0 : (int)ceil_div((int64_t)rows_max[1], (int64_t)ORDER_SEG);  // (blocks past the end of their list return at once)
         if (segs > 0)
             k_bucket_order_joint<<<dim3((unsigned)nb * 4u, (unsigned)npg, (unsigned)segs), 16, 0, st>>>(m, nb, pl->b_len.p, pl->b_off.p, pl->b_base.p,
                                                                                                       pl->lists_raw.p, pl->lists.p);
@@ -1428,7 +1702,7 @@ static int perms_pass_lds(sqgr_autocorr* h, int32_t mode, int64_t pc_real, const
     }
     SQGR_TRY(h->part1.ensure((size_t)G2 * pc * nch * GP));
     if (second) SQGR_TRY(h->part2.ensure((size_t)G2 * pc * nch * GP));
-    const size_t lds = ((size_t)(2 * m + 1) * GP + (geary ? (size_t)m : (rmode >= 2 ? (size_t)8 : 0))) * sizeof(double);
+    const size_t lds = ((size_t)(2 * m + ZERO_ROWS) * GP + (geary ? (size_t)m : (rmode >= 2 ? (size_t)8 : 0))) * sizeof(double);
     // the split variant always launches whole workgroups: waves without a permutation group still move the Y chunks (with fewer
     // than m / 5 threads a chunk does not fit the staging registers and its loads are no longer prefetched)
     const int threads = split > 1 ? LDS_PERM_BLOCK : 64 * std::min(npg, LDS_PERM_BLOCK / 64);
@@ -1898,12 +2172,12 @@ static int autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_id
         by_part = std::max<int64_t>(64, ((int64_t)1 << 30) / (((G + 1) / 2) * nch * GP * 8 * split));
     }
     // The joint list schedule (k_bucket_order_joint) makes a permutation's summation order depend on the 15 permutations it shares a
-    // `ds_read_b128` lane group with, so the LDS kernel works on whole 64-aligned groups of the GLOBAL permutation index: with the
-    // device generator the range is widened to [begin - lead, end rounded up to 64) and the extra ("ghost") permutations are
+    // `ds_read_b128` lane group with, so the LDS kernel works on whole 16-aligned groups of the GLOBAL permutation index: with the
+    // device generator the range is widened to [begin - lead, end rounded up to 16) and the extra ("ghost") permutations are
     // generated, scheduled, scored and dropped — a permutation's score does not depend on how a range was cut.  (Injected
     // permutations and numpy's streams always start at permutation 0.)
     const bool ghosts = kernel == 1 && !perm_idx && !pcg_states;
-    const int64_t galign = 64;
+    const int64_t galign = 16;  // (perm_slot: a service group holds 16 consecutive permutations)
     const int64_t lead = ghosts ? (perm_begin & (galign - 1)) : 0;
     const int64_t PV = ghosts ? ((lead + P + galign - 1) & ~(galign - 1)) : P;  // permutations the passes run over
     int64_t chunk = std::min<int64_t>(std::min<int64_t>(PV, 32768), std::min(by_idx, by_part));  // grid.y limit

@@ -136,9 +136,9 @@ def test_lds_kernel_full_workgroups(L, ctx, mode, perm_kernel):
 @pytest.mark.parametrize("mode", ["moran", "geary"])
 def test_list_schedule_structured_permutations_and_ranges(L, ctx, mode, perm_kernel):
     """The bucket lists of the LDS kernel are re-ordered so that the 16 permutations of a `ds_read_b128` lane group read different LDS
-    banks (k_bucket_order_joint): any order of a list is a valid one, so scores may move by rounding only.  Inputs the schedule
-    has to survive: the identity and a stride permutation (every pair of a list in 16 cells), a permutation whose bucket (0, 0)
-    holds 320 pairs of ONE cell (i = j = 0 mod 16: the 8-bit cell counter saturates, the segment is left as built), lists of very
+    banks (k_bucket_order_steps / _joint): any order of a list is a valid one, so scores may move by rounding only.  Inputs the
+    schedule has to survive: the identity and a stride permutation (every pair of a list in 16 cells), a permutation whose bucket
+    (0, 0) holds 320 pairs of ONE cell (i = j = 0 mod 16: the 8-bit cell counters saturate, the segment is left as built), lists of very
     different lengths in one group, and a range of the device generator cut at odd places (a permutation's order depends on the
     15 permutations it shares the lane group with: the library schedules whole aligned groups and drops the extra ones)."""
     if perm_kernel != "lds":
@@ -146,15 +146,15 @@ def test_list_schedule_structured_permutations_and_ranges(L, ctx, mode, perm_ker
     import os
 
     rng = np.random.default_rng(12)
-    n, G = 10232, 9                        # two chunks of 5116 spots
-    m = 5116
+    n, G = 10216, 9                        # two chunks of 5108 spots
+    m = 5108
     xy = rng.random((n, 2))
     g = knn_graph(xy, 6)
     g.data = rng.random(g.nnz).astype(np.float32) + 0.1
     vals = rng.gamma(2.0, 1.0, size=(G, n))
     vals[2] += 2 * np.sin(xy[:, 0] * 5)
     ident = np.arange(n, dtype=np.int32)
-    stride = ((np.arange(n, dtype=np.int64) * 4099) % n).astype(np.int32)   # gcd(4099, n) = 1; n = 8 mod 16: classes shift by chunk
+    stride = ((np.arange(n, dtype=np.int64) * 4099) % n).astype(np.int32)   # gcd(4099, n) = 1; m = 4 mod 16: classes shift by chunk
     one_cell = ident.copy()
     a0 = np.arange(0, m, 16)                                                 # 320 spots of chunk 0, i = 0 mod 16 -> themselves, reversed
     one_cell[a0] = a0[::-1]
@@ -169,7 +169,8 @@ def test_list_schedule_structured_permutations_and_ranges(L, ctx, mode, perm_ker
     plan = L.AutocorrPlan(ctx, graph, vals)
     got = plan.perms(mode, perm_idx=perm_idx)
     np.testing.assert_allclose(got, O.score_perms(mode, g, vals, perm_idx), rtol=RTOL, atol=ATOL)
-    for env, val in (("SQGR_AUTOCORR_ORDER", "single"), ("SQGR_AUTOCORR_ORDER_LISTS", "0")):   # the round-3 schedule; the lists as built
+    # the other schedules (the rotation of Z classes; every list on its own, round 3) and the lists as built
+    for env, val in (("SQGR_AUTOCORR_ORDER", "rotation"), ("SQGR_AUTOCORR_ORDER", "single"), ("SQGR_AUTOCORR_ORDER_LISTS", "0")):
         os.environ[env] = val
         try:
             np.testing.assert_allclose(plan.perms(mode, perm_idx=perm_idx), got, rtol=1e-10, atol=1e-13)
