@@ -568,7 +568,7 @@ __global__ __launch_bounds__(64) void k_bucket_fill(const int32_t* __restrict__ 
                                                     const uint64_t* __restrict__ base, uint32_t* __restrict__ lists,
                                                     const uint8_t* __restrict__ rcls, const uint8_t* __restrict__ exc_cls, int exc_main,
                                                     const uint32_t* __restrict__ xlen, const uint32_t* __restrict__ xoff,
-                                                    uint32_t* __restrict__ xlists) {
+                                                    uint32_t* __restrict__ xlists, uint16_t* __restrict__ nlen) {
     extern __shared__ uint32_t cur[];  // [b][lane], then the nch row offsets of this (pg, a)
     const int lane = threadIdx.x, a = blockIdx.x;
     const int64_t pg = blockIdx.y, vp = pg * 64 + perm_slot(lane), p = vp / S;
@@ -603,6 +603,7 @@ __global__ __launch_bounds__(64) void k_bucket_fill(const int32_t* __restrict__ 
     const uint32_t pad = (uint32_t)m;
     for (int b = 0; b < nch; ++b) {
         const uint32_t l = len[bk + b];
+        if (nlen) nlen[(bk + b) * 64 + lane] = (uint16_t)cur[b * 64 + lane];  // (the schedule kernels choose by the lists' lengths)
         for (uint32_t k = cur[b * 64 + lane]; k < l; ++k) out[((size_t)offl[b] + k) * 64] = pad;
     }
     if (exc_cls)
@@ -726,6 +727,10 @@ __global__ __launch_bounds__(64) void k_bucket_order(int m, int nb, int64_t perm
 // Lists longer than ORDER_SEG rows are scheduled in independent segments of ORDER_SEG rows (grid.z).  Out of place: src -> dst.
 constexpr int ORDER_SEG = 256;
 
+template <int N>
+__device__ __forceinline__ uint32_t row_ror(uint32_t v) {  // the value of the lane N places along the 16-lane row (rotating)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 | N, 0xf, 0xf, false);
+}
 // lane of `ds_read_b128` group q that holds residue r = lane mod 16 (groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, + 32)
 __device__ __forceinline__ int group_lane(int q, int r) {
     const bool mid = r >= 4 && r < 12;
@@ -736,7 +741,7 @@ __device__ __forceinline__ int group_lane(int q, int r) {
 // what counts is how many groups a CU holds at once (15 KiB of LDS each)
 __global__ __launch_bounds__(16) void k_bucket_order_joint(int m, int nb, const uint32_t* __restrict__ len, const uint32_t* __restrict__ off,
                                                            const uint64_t* __restrict__ base, const uint32_t* __restrict__ src,
-                                                           uint32_t* __restrict__ dst) {
+                                                           uint32_t* __restrict__ dst, const uint16_t* __restrict__ nlen, int longer_than) {
     __shared__ uint16_t cw[256 * 16];    // [cell][r] pairs of the cell not yet placed << 8 | cursor into stp (mod 256; cells ascending)
     __shared__ uint8_t stp[256 * 16];    // [.][r] the steps given to the lane's pairs, grouped by cell
     __shared__ uint16_t amask[16 * 16];  // [zc][r] Y classes pool (lane r, zc) still holds
@@ -751,6 +756,13 @@ __global__ __launch_bounds__(16) void k_bucket_order_joint(int m, int nb, const 
     const size_t bk = (size_t)pg * nb + (blockIdx.x >> 2);
     const int L = (int)len[bk], s0 = (int)blockIdx.z * ORDER_SEG;
     if (s0 >= L) return;
+    if (longer_than > 0) {  // only the lane groups whose longest list exceeds `longer_than` rows (the others: k_bucket_order_steps)
+        uint32_t h = nlen[bk * 64 + lane];
+        h = max(h, row_ror<1>(h));
+        h = max(h, row_ror<2>(h));
+        h = max(h, row_ror<4>(h));
+        if ((int)max(h, row_ror<8>(h)) <= longer_than) return;
+    }
     const int Ls = min(ORDER_SEG, L - s0);  // a multiple of 16
     const size_t row0 = ((size_t)base[pg] + off[bk] + (size_t)s0) * 64;
     const uint32_t* a = src + row0 + lane;
@@ -939,10 +951,6 @@ __global__ __launch_bounds__(16) void k_bucket_order_joint(int m, int nb, const 
 // 32 KiB of LDS, 5 per CU; the kernel is bound by instruction issue (PMC: 35 % VALU, 24 % SALU of its wave cycles).
 constexpr int STEP_SEG = 384;  // rows scheduled at a time (longer lists: independent segments, the full ones without slack)
 
-template <int N>
-__device__ __forceinline__ uint32_t row_ror(uint32_t v) {  // the value of the lane N places along the 16-lane row (rotating)
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 | N, 0xf, 0xf, false);
-}
 __device__ __forceinline__ uint32_t row_or(uint32_t v) {
     v |= row_ror<1>(v);
     v |= row_ror<2>(v);
@@ -976,28 +984,38 @@ __device__ __forceinline__ uint32_t row_higher(uint32_t key, const RowSources& s
 // "Class c takes the best lane that holds it" = one wave ballot of the holders + each lane's mask of the better lanes of its row.
 __global__ __launch_bounds__(32) void k_bucket_order_steps(int m, int nb, const uint32_t* __restrict__ len, const uint32_t* __restrict__ off,
                                                            const uint64_t* __restrict__ base, const uint32_t* __restrict__ src,
-                                                           uint32_t* __restrict__ dst) {
+                                                           uint32_t* __restrict__ dst, const uint16_t* __restrict__ nlen) {
     __shared__ uint8_t cnt[256 * 32];            // [cell][t] pairs of the cell not yet placed
     __shared__ uint8_t cur[256 * 32];            // [cell][t] slot of the cell's next pair, counted from the start of its pool
     __shared__ uint16_t pstart[17 * 32];         // [zc][t] pairs in the pools below zc; [16]: all
     __shared__ uint16_t amask[16 * 32];          // [zc][t] Y classes pool (lane, zc) still holds
     __shared__ uint8_t stp[STEP_SEG * 32];       // [slot][t] the step given to the lane's pair of that slot, bits 0..7
     __shared__ uint32_t stp8[STEP_SEG / 32 * 32];  // [slot / 32][t] bit slot % 32: bit 8 of that step
-    __shared__ int saturated;
+    __shared__ int saturated[2];                 // per lane group
     const int t = threadIdx.x, r = t & 15;
     const int lane = group_lane((int)(blockIdx.x & 1u) * 2 + (t >> 4), r);
     const int64_t pg = blockIdx.y;
     const size_t bk = (size_t)pg * nb + (blockIdx.x >> 1);
-    const int L = (int)len[bk], s0 = (int)blockIdx.z * STEP_SEG;
-    if (s0 >= L) return;
-    const int Ls = min(STEP_SEG, L - s0);  // a multiple of 16
-    const size_t row0 = ((size_t)base[pg] + off[bk] + (size_t)s0) * 64;
+    const int L = (int)len[bk];
+    if (L == 0) return;
+    // A lane group whose longest list fits STEP_SEG rows is scheduled here, in one piece; the others keep the rotation schedule in
+    // segments (k_bucket_order_joint): cut into full segments the step schedule has no slack to work with (measured at 30 000 spots,
+    // lists of ~830 pairs: 18.5 vs 17.2 ms).  The choice looks at the group's own lists only (split invariance).
+    uint32_t horizon = nlen[bk * 64 + lane];
+    horizon = max(horizon, row_ror<1>(horizon));
+    horizon = max(horizon, row_ror<2>(horizon));
+    horizon = max(horizon, row_ror<4>(horizon));
+    horizon = (max(horizon, row_ror<8>(horizon)) + 15u) & ~15u;  // the group's longest list, rounded up to 16: its steps
+    const bool mine = horizon <= (uint32_t)STEP_SEG;
+    if (!__builtin_amdgcn_ballot_w64(mine)) return;
+    const int Ls = min(STEP_SEG, L);  // a multiple of 16
+    const size_t row0 = ((size_t)base[pg] + off[bk]) * 64;
     const uint32_t* a = src + row0 + lane;
     uint32_t* d = dst + row0 + lane;
     const uint32_t pad = (uint32_t)m;
     for (int i = t; i < 256 * 8; i += 32) reinterpret_cast<uint32_t*>(cnt)[i] = 0;
     for (int i = t; i < STEP_SEG; i += 32) stp8[i] = 0;
-    if (t == 0) saturated = 0;
+    if (t < 2) saturated[t] = 0;
     __syncthreads();
     // --- thread = lane: the cells of its list
     uint32_t rem = 0;
@@ -1008,7 +1026,7 @@ __global__ __launch_bounds__(32) void k_bucket_order_steps(int m, int nb, const 
         for (int u = 0; u < 16; ++u) e[u] = a[(size_t)(k0 + u) * 64];
 #pragma unroll
         for (int u = 0; u < 16; ++u)
-            if ((e[u] & 0xffffu) < pad) {
+            if (mine && (e[u] & 0xffffu) < pad) {
                 const int cell = ((((e[u] & 15u) << 4) | ((e[u] >> 16) & 15u))) * 32 + t;
                 const uint32_t c = cnt[cell];
                 sat |= c == 255u;
@@ -1036,12 +1054,16 @@ __global__ __launch_bounds__(32) void k_bucket_order_steps(int m, int nb, const 
         }
         pstart[16 * 32 + t] = (uint16_t)run;
     }
-    if (sat) saturated = 1;
+    if (sat) saturated[t >> 4] = 1;
     __syncthreads();
-    if (saturated) {  // 256 pairs of one lane in one Z class (8-bit counters): the segment stays as built
-        for (int k = 0; k < Ls; ++k) d[(size_t)k * 64] = a[(size_t)k * 64];
-        return;
+    bool mine_sched = mine;
+    if (mine && saturated[t >> 4]) {  // 256 pairs of one lane in one Z class (8-bit counters): the group's lists stay as built
+        for (int k = 0; k < L; ++k) d[(size_t)k * 64] = a[(size_t)k * 64];
+        mine_sched = false;
+        rem = 0;
+        cand = 0;
     }
+    if (!__builtin_amdgcn_ballot_w64(mine_sched)) return;
     uint32_t cdeg = 0;  // thread r of a row also keeps class r: the pairs of that class all 16 lanes still hold
 #pragma unroll
     for (int l2 = 0; l2 < 16; ++l2) cdeg += (uint32_t)pstart[(r + 1) * 32 + (t & 16) + l2] - (uint32_t)pstart[r * 32 + (t & 16) + l2];
@@ -1066,18 +1088,13 @@ __global__ __launch_bounds__(32) void k_bucket_order_steps(int m, int nb, const 
         }
     };
     uint32_t zkeep = 16;  // the lane's Z class of the current four steps
-    // The horizon of a lane group: its own longest list, rounded up to 16 — NOT the bucket's rows (the longest of all 64 lanes): the
-    // schedule of a group must not depend on the other groups (split invariance); the rows past the horizon hold padding pairs.
-    uint32_t horizon;
-    {
-        uint32_t h = rem;
-        h = max(h, row_ror<1>(h));
-        h = max(h, row_ror<2>(h));
-        h = max(h, row_ror<4>(h));
-        horizon = (max(h, row_ror<8>(h)) + 15u) & ~15u;
-    }
-    const int steps = (int)max((uint32_t)__builtin_amdgcn_readlane((int)horizon, 0), (uint32_t)__builtin_amdgcn_readlane((int)horizon, 16));
-    for (int k = steps; k < Ls; ++k) d[(size_t)k * 64] = (pad + (((uint32_t)r - pad) & 15u)) | ((uint32_t)r << 16);
+    // The steps of a lane group: its own longest list — NOT the bucket's rows (the longest of all 64 lanes): the schedule of a group
+    // must not depend on the other groups (split invariance); the rows past it hold padding pairs.
+    const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane((int)(mine_sched ? horizon : 0u), 0);
+    const uint32_t h1 = (uint32_t)__builtin_amdgcn_readlane((int)(mine_sched ? horizon : 0u), 16);
+    const int steps = (int)max(h0, h1);
+    if (mine_sched)
+        for (int k = (int)horizon; k < L; ++k) d[(size_t)k * 64] = (pad + (((uint32_t)r - pad) & 15u)) | ((uint32_t)r << 16);
     for (int k = 0; k < steps; ++k) {
         if ((k & 3) == 0) {
             // Z side, every FOUR steps (a lane whose pool runs dry in between idles until the next turn: simulated no worse — the Y side
@@ -1141,7 +1158,7 @@ __global__ __launch_bounds__(32) void k_bucket_order_steps(int m, int nb, const 
             stp[slot * 32 + t] = (uint8_t)k;
             if (k & 256) stp8[(slot >> 5) * 32 + t] |= 1u << (slot & 31u);
             --rem;
-        } else {
+        } else if (mine_sched && (uint32_t)k < horizon) {
             const uint32_t nth = (uint32_t)__builtin_popcount(idle & ((1u << r) - 1u));  // (at least as many free classes as idle lanes)
             const uint32_t zc = nth_set_bit(~zused & 0xffffu, nth), yc = nth_set_bit(~yused & 0xffffu, nth);
             d[(size_t)k * 64] = (pad + ((zc - pad) & 15u)) | (yc << 16);
@@ -1155,7 +1172,7 @@ __global__ __launch_bounds__(32) void k_bucket_order_steps(int m, int nb, const 
         for (int u = 0; u < 16; ++u) e[u] = a[(size_t)(k0 + u) * 64];
 #pragma unroll
         for (int u = 0; u < 16; ++u)
-            if ((e[u] & 0xffffu) < pad) {
+            if (mine_sched && (e[u] & 0xffffu) < pad) {
                 const uint32_t zc = e[u] & 15u;
                 const int cell = (int)((zc << 4) | ((e[u] >> 16) & 15u)) * 32 + t;
                 const uint32_t within = (uint32_t)cur[cell] - 1u;
@@ -1553,6 +1570,7 @@ struct PermLists : sqgr::CtxCache {
     std::vector<uint64_t> states;
     // lists
     DevBuf<uint32_t> b_len, b_off, b_total, lists, lists_raw;
+    DevBuf<uint16_t> n_len;                  // [group][a][b][lane] pairs in the lane's list (the schedule kernels choose by them)
     DevBuf<uint32_t> x_len, x_off, x_lists;  // exception lists (see k_exc_offsets), when the lists serve RMODE 3
     DevBuf<uint64_t> b_base;
     bool matches(int64_t n_, int64_t pc_, int64_t perm0_, int m_, int nch_, int kind_, uint64_t seed_, const uint64_t* st_, int split_,
@@ -1642,21 +1660,25 @@ static int build_perm_lists(sqgr_ctx* ctx, PermLists* pl, const int32_t* idx, in
     if (pl->lists.n < (size_t)rows * 64 || !pl->lists.p) SQGR_TRY(pl->lists.alloc_pooled((size_t)rows * 64 + (size_t)rows * 4));
     uint32_t* fill_to = pl->lists.p;
     if (joint) {  // out of place: the lists as built -> lists_raw, scheduled -> lists
+        SQGR_TRY(pl->n_len.ensure((size_t)npg * nb * 64));
         if (pl->lists_raw.n < (size_t)rows * 64 || !pl->lists_raw.p) SQGR_TRY(pl->lists_raw.alloc_pooled((size_t)rows * 64 + (size_t)rows * 4));
         fill_to = pl->lists_raw.p;
     }
     k_bucket_fill<<<dim3((unsigned)nch, (unsigned)npg), 64, cnt_lds + (size_t)nch * sizeof(uint32_t), st>>>(idx, n, pc, m, nch, split, pl->b_len.p, pl->b_off.p,
                                                                                                           pl->b_base.p, fill_to, rcls, exc_cls, exc_main,
-                                                                                                          pl->x_len.p, pl->x_off.p, pl->x_lists.p);
+                                                                                                          pl->x_len.p, pl->x_off.p, pl->x_lists.p,
+                                                                                                          joint ? pl->n_len.p : nullptr);
     SQGR_HIP(hipGetLastError());
     if (joint) {
+        // the step schedule takes the lane groups whose longest list fits STEP_SEG rows, the rotation schedule the others (in segments)
         if (order == 3 && rows_max[1] > 0)
-            k_bucket_order_steps<<<dim3((unsigned)nb * 2u, (unsigned)npg, (unsigned)ceil_div((int64_t)rows_max[1], (int64_t)STEP_SEG)), 32, 0, st>>>(
-                m, nb, pl->b_len.p, pl->b_off.p, pl->b_base.p, pl->lists_raw.p, pl->lists.p);
-        const int segs = order == 3 ? 0 : (int)ceil_div((int64_t)rows_max[1], (int64_t)ORDER_SEG);  // (blocks past the end of their list return at once)
+            k_bucket_order_steps<<<dim3((unsigned)nb * 2u, (unsigned)npg), 32, 0, st>>>(m, nb, pl->b_len.p, pl->b_off.p, pl->b_base.p, pl->lists_raw.p,
+                                                                                      pl->lists.p, pl->n_len.p);
+        const int longer_than = order == 3 ? STEP_SEG : 0;
+        const int segs = (int64_t)rows_max[1] > longer_than ? (int)ceil_div((int64_t)rows_max[1], (int64_t)ORDER_SEG) : 0;
         if (segs > 0)
             k_bucket_order_joint<<<dim3((unsigned)nb * 4u, (unsigned)npg, (unsigned)segs), 16, 0, st>>>(m, nb, pl->b_len.p, pl->b_off.p, pl->b_base.p,
-                                                                                                      pl->lists_raw.p, pl->lists.p);
+                                                                                                      pl->lists_raw.p, pl->lists.p, pl->n_len.p, longer_than);
         SQGR_HIP(hipGetLastError());
     } else if (order_lists && split == 1) {  // (the schedule works in rounds of 16 row classes; a sub-list of the split variant holds 2)
         // Geary's C reads TWO arrays through the Y index (the y row and the row sum): its lists are scheduled by the classes of the Y
