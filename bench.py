@@ -398,7 +398,7 @@ def autocorr_leg(ctx, mode: str, world: int, fence, reduce_max, steps: int, with
             "when one row sum holds on 3 spots in 4, a constant + short exception lists).  `achieved` = "
             f"{per:.2f} B x spots x permutations x genes / time (padding pairs not counted) against the LDS read peak of the guide (256 B/clk/CU).  "
             "Random 16-byte rows conflict ~3-way inside a 16-lane service group; the lists are scheduled so that the 16 lanes of a group read "
-            "different row classes on both sides where the pairs allow it (k_bucket_order_joint): `frac_of_pattern_ceiling` prices the kernel "
+            "different row classes on both sides where the pairs allow it (k_bucket_order_steps): `frac_of_pattern_ceiling` prices the kernel "
             "against the measured rate of random rows with 16 classes per group — what a perfect schedule would reach —, `random_pattern_GBps` "
             "is the unscheduled rate (tools/ubench_lds_read.hip).  HBM side: lists + chunks, `traffic` from PMC when the committed profile matches",
         }

@@ -1,5 +1,6 @@
-"""Developer tool (GPU box): round-4 experiments on the LDS-bucketed dot at config 3's shape, 1000 permutations:
-list order by Z class (default) / by Y class / none; chunks per XCD round 1 / 2."""
+"""Developer tool (GPU box): round-4 experiments on the LDS-bucketed dot at config 3's shape, 1000 permutations.
+`--one`: one timing of both statistics under the environment given (tools/joint_order.sh drives it for the list schedules).
+Without arguments: round 3's per-list order (SQGR_AUTOCORR_ORDER=single) by Z class / by Y class / none; chunks per XCD round."""
 import os, sys, time, subprocess, json
 if len(sys.argv) > 1 and sys.argv[1] == "--one":
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -34,5 +35,5 @@ for label, env in (("defaults (Moran: Z classes, 4 chunks per XCD round; Geary: 
                    ("Z classes, 8 chunks", {"SQGR_AUTOCORR_ORDER_BY": "z", "SQGR_AUTOCORR_XCD_CHUNKS": "8"}),
                    ("Y classes, 2 chunks", {"SQGR_AUTOCORR_ORDER_BY": "y", "SQGR_AUTOCORR_XCD_CHUNKS": "2"}),
                    ("no order, 1 chunk", {"SQGR_AUTOCORR_ORDER_LISTS": "0", "SQGR_AUTOCORR_XCD_CHUNKS": "1"})):
-    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one"], env=dict(os.environ, SQGR_AUTOCORR_KERNEL="lds", **env), capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one"], env=dict(os.environ, SQGR_AUTOCORR_KERNEL="lds", SQGR_AUTOCORR_ORDER="single", **env), capture_output=True, text=True, timeout=300)
     print(json.dumps({"variant": label, "ms_per_2048_genes_x_1000_perms": json.loads(r.stdout.strip().splitlines()[-1]) if r.stdout.strip() else r.stderr[-300:]}), flush=True)
