@@ -1610,13 +1610,12 @@ static int perm_kernel_choice(int64_t n, int64_t G, int64_t P, bool geary) {
 // 2: SQGR_AUTOCORR_ORDER=rotation, the joint schedule of the 16 permutations of a `ds_read_b128` lane group on the fixed rotation of
 // Z classes (k_bucket_order_joint), 3: the step schedule (k_bucket_order_steps; the default)
 static int list_order_mode(int split) {
-    // (the split variant: lane = (permutation, spots i = s mod 8) reads Z rows of two classes, s and s + 8, whatever the order —
-    // the Z side is half scheduled by construction, and sub-lists of ~30 pairs leave the schedule two rounds to work with)
-    if (split != 1) return 0;
     if (const char* e = getenv("SQGR_AUTOCORR_ORDER_LISTS"))
         if (atoi(e) == 0) return 0;
     const char* e_order = getenv("SQGR_AUTOCORR_ORDER");
-    if (e_order && !strcmp(e_order, "single")) return 1;
+    // (the split variant — lane = (permutation, spots i = s mod 8), sub-lists of ~30 pairs on two Z classes each — takes the joint
+    // schedules like any other list: a lane group is two permutations x 8 sub-lists; round 3's per-list order has no use for it)
+    if (e_order && !strcmp(e_order, "single")) return split == 1 ? 1 : 0;
     if (e_order && !strcmp(e_order, "rotation")) return 2;
     return 3;
 }
@@ -2198,14 +2197,14 @@ static int autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_id
     // device generator the range is widened to [begin - lead, end rounded up to 16) and the extra ("ghost") permutations are
     // generated, scheduled, scored and dropped — a permutation's score does not depend on how a range was cut.  (Injected
     // permutations and numpy's streams always start at permutation 0.)
-    const bool ghosts = kernel == 1 && !perm_idx && !pcg_states;
-    const int64_t galign = 16;  // (perm_slot: a service group holds 16 consecutive permutations)
+    const bool ghosts = use_lds && !perm_idx && !pcg_states;
+    const int64_t galign = 16 / split;  // (perm_slot: a service group holds 16 consecutive lanes = permutations, or 2 x 8 sub-lists)
     const int64_t lead = ghosts ? (perm_begin & (galign - 1)) : 0;
     const int64_t PV = ghosts ? ((lead + P + galign - 1) & ~(galign - 1)) : P;  // permutations the passes run over
     int64_t chunk = std::min<int64_t>(std::min<int64_t>(PV, 32768), std::min(by_idx, by_part));  // grid.y limit
     const int64_t wg_perms = LDS_PERM_BLOCK / split;  // permutations per workgroup of the LDS kernel
     if (use_lds && chunk > wg_perms) chunk = chunk / wg_perms * wg_perms;  // whole workgroups of permutations
-    else if (kernel == 1 && chunk < PV) chunk = std::max<int64_t>(galign, chunk / galign * galign);  // every pass starts a lane group
+    else if (use_lds && chunk < PV) chunk = std::max<int64_t>(galign, chunk / galign * galign);  // every pass starts a lane group
     SQGR_TRY(h->idx.ensure((size_t)chunk * n));
     if (!use_lds) {
         SQGR_TRY(h->part1.ensure((size_t)h->ntiles * chunk * R * GT));
