@@ -850,9 +850,12 @@ def compact_line(detail: dict, detail_path: str | None = None) -> dict:
     line = {k: detail.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                         "vs_baseline", "dtype", "data")}
     line["value"], line["ms_per_step"] = _sig(line["value"], 7), _sig(line["ms_per_step"], 6)
+    if detail.get("check"):
+        line["check"] = detail["check"]
     line["config"] = {"workload": _short(cfg.get("workload"), 240), "perms_per_step": cfg.get("perms_per_step"),
                       "perms_per_step_per_gpu": cfg.get("perms_per_step_per_gpu"), "parallelism": _short(cfg.get("parallelism"), 100),
-                      "collective": _short(cfg.get("collective"), 60)}
+                      "collective": _short(cfg.get("collective"), 60), "rccl_world": cfg.get("rccl_world"),
+                      "ranks_on_devices": cfg.get("ranks_on_devices")}
     line["roofline"] = {
         "kernel": roof.get("kernel"), "bound": roof.get("bound"), "achieved": _sig(roof.get("achieved")), "peak": _sig(roof.get("peak")),
         "unit": roof.get("unit"), "frac": _sig(roof.get("frac"), 3), "traffic": _sig(roof.get("traffic"), 6),
@@ -919,6 +922,65 @@ def compact_line(detail: dict, detail_path: str | None = None) -> dict:
 
 
 
+# --------------------------------------------------------------------------------------------- launcher
+def launch_ranks(cmd: list[str], n: int, extra_env: dict | None = None, timeout_s: float | None = None) -> int:
+    """Start `n` ranks of `cmd` on this node (one process per GPU: RANK = LOCAL_RANK = r, WORLD_SIZE = n, MASTER_ADDR = 127.0.0.1,
+    MASTER_PORT = a free port — the same environment ``python -m torch.distributed.run`` exports), wait for all of them and relay
+    rank 0's stdout as our own, line by line, so that its LAST line — the compact record — is ours too.  The other ranks' stdout is
+    discarded, every rank's stderr is inherited.  Replaces the reference's joblib fan-out (/root/reference/src/squidpy/_utils.py:188-237).
+    A rank that fails takes the others down; the return value is the first non-zero exit code (0 when all ranks succeeded)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), **(extra_env or {}))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL between processes needs dmabuf IPC on this driver
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0) or None))
+    deadline = None if timeout_s is None else time.monotonic() + timeout_s
+    import threading
+
+    def relay():
+        for line in procs[0].stdout:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+
+    t = threading.Thread(target=relay, daemon=True)
+    t.start()
+    rc = 0
+    live = set(range(n))
+    try:
+        while live:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                live.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    print(f"bench.py: rank {r} exited with status {code}; stopping the other ranks", file=sys.stderr)
+                    for q in live:
+                        procs[q].terminate()
+            if deadline is not None and time.monotonic() > deadline and live:
+                rc = rc or 124
+                print(f"bench.py: ranks {sorted(live)} still running after {timeout_s:.0f} s; stopping them", file=sys.stderr)
+                for q in live:
+                    procs[q].kill()
+                deadline = None
+            if live:
+                time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        t.join(timeout=10.0)
+    return rc
+
+
 # --------------------------------------------------------------------------------------------- main
 def main() -> None:
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
@@ -947,13 +1009,31 @@ def main() -> None:
     ap.add_argument("--detail-out", type=str, default=os.path.join("gpurun_out", "bench_detail.json"),
                     help="where the full record goes (the final stdout line is the compact one: < 4 KB)")
     ap.add_argument("--tune", type=str, default="", help="perms_per_pass,blocks_per_batch,batches_per_launch")
+    ap.add_argument("--share-devices", action="store_true",
+                    help="allow more ranks than GPUs (rank r on device r mod #GPUs, integer all-reduce through the host side channel): tests on a 1-GPU box")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` with no launcher (what the driver runs): this process becomes the launcher of N ranks of itself
+        from squidpy_amd import _lib as _probe
+
+        n_dev = _probe.device_count()
+        if args.gpus > n_dev and not args.share_devices:
+            print(f"bench.py: --gpus {args.gpus} but this node has {n_dev} GPU(s); refusing to report a {args.gpus}-GPU figure from fewer devices "
+                  "(--share-devices puts several ranks on one GPU for tests: host collective, not a scaling measurement)", file=sys.stderr)
+            sys.exit(2)
+        sys.exit(launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus,
+                              extra_env={"SQGR_DIST_COLLECTIVE": "host"} if args.gpus > n_dev else None))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if args.gpus != world:
+        # the record's n_gpus is the number of ranks that RAN; a launcher that started another number than --gpus is an error, never a relabelled figure
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s)", file=sys.stderr)
+        sys.exit(2)
 
     from squidpy_amd import _dist, _lib
     from squidpy_amd._synthetic import hex_grid_graph
@@ -1022,6 +1102,7 @@ def main() -> None:
     elapsed = reduce_max(time.perf_counter() - t0)
     kernels = ctx.timer_report()
     ctx.timer_enable(False)
+    rank_devices = [local_rank % max(_lib.device_count(), 1)] if world == 1 else [int(d) for d in _dist.allgather_object(local_rank % max(_lib.device_count(), 1))]
     collective = "none" if world == 1 else ("rccl-in-library (device all-reduce of the moments)" if comm is not None else _dist.collective_kind() + " (host fall-back)")
 
     ceil = load_ceilings()
@@ -1237,6 +1318,8 @@ def main() -> None:
                 "perms_per_step_per_gpu": per_rank_step,
                 "parallelism": f"permutation ranges over {world} rank(s), one all-reduce of int64[2*K*K] moments per step",
                 "collective": collective,
+                "rccl_world": comm.info()[1] if comm is not None else None,   # what RCCL itself reports (null: no device communicator)
+                "ranks_on_devices": rank_devices,
             },
             "roofline": roof,
             "kernels": {"nhood_shuffle": shuf, "nhood_count": {k: issue.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "lds_atomic")}, "nhood_reduce": red},
@@ -1252,6 +1335,11 @@ def main() -> None:
                 "16 permutations — an algorithmic-reuse figure, NOT a roofline fraction (those are in `roofline` / `kernels`)",
             },
         }
+        import hashlib
+
+        first = args.warmup * (P if strong else P * world)
+        out["check"] = {"perm_range": [first, first + total_perms],   # the GLOBAL permutation indices of the timed steps, whatever the number of ranks
+                        "moments_sha16": hashlib.sha256(np.ascontiguousarray(tot1).tobytes() + np.ascontiguousarray(tot2).tobytes()).hexdigest()[:16]}
         if secondary is not None:
             out["secondary"] = secondary
         if legs is not None:

@@ -272,6 +272,12 @@ class Comm:
     def barrier(self) -> None:
         _check(self.ctx.lib, self.ctx.lib.sqgr_comm_barrier(self.h))
 
+    def info(self) -> tuple[int, int]:
+        """(rank, world) as RCCL reports them for this communicator (``ncclCommUserRank`` / ``ncclCommCount``)."""
+        r, w = np.zeros(1, dtype=np.int32), np.zeros(1, dtype=np.int32)
+        _check(self.ctx.lib, self.ctx.lib.sqgr_comm_info(self.h, _ptr(r, c_i32p), _ptr(w, c_i32p)))
+        return int(r[0]), int(w[0])
+
     def close(self) -> None:
         if getattr(self, "h", None):
             self.ctx.lib.sqgr_comm_destroy(self.h)

@@ -22,6 +22,8 @@ struct RcclApi {
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -56,6 +58,8 @@ static int rccl_load() {
     SQGR_SYM(AllReduce, "ncclAllReduce")
     SQGR_SYM(AllGather, "ncclAllGather")
     SQGR_SYM(Broadcast, "ncclBroadcast")
+    SQGR_SYM(CommCount, "ncclCommCount")
+    SQGR_SYM(CommUserRank, "ncclCommUserRank")
     SQGR_SYM(GetErrorString, "ncclGetErrorString")
 #undef SQGR_SYM
     g_rccl = api;
@@ -182,8 +186,14 @@ int sqgr_comm_destroy(sqgr_comm* comm) {
 
 int sqgr_comm_info(const sqgr_comm* comm, int32_t* rank, int32_t* world) {
     SQGR_REQUIRE(comm, "comm is NULL");
-    if (rank) *rank = comm->rank;
-    if (world) *world = comm->world;
+    // what RCCL itself says about the communicator, not what the caller passed to sqgr_comm_create (bench.py reports it as `rccl_world`)
+    int r = comm->rank, w = comm->world;
+    if (comm->comm) {
+        SQGR_NCCL(g_rccl.CommUserRank(comm->comm, &r));
+        SQGR_NCCL(g_rccl.CommCount(comm->comm, &w));
+    }
+    if (rank) *rank = r;
+    if (world) *world = w;
     return SQGR_OK;
 }
 
