@@ -168,7 +168,8 @@ int sqgr_pcg64_permutations(sqgr_ctx* ctx, int64_t n, const uint64_t* pcg_states
 /* Debug/parity hook: the shuffled label vector of one global permutation index, uint8[n]. */
 int sqgr_nhood_shuffled_labels(sqgr_nhood* plan, uint64_t seed, int64_t perm, uint8_t* out_labels);
 
-/* tuning knobs (0 = library default): perms per CSR pass (16|32), count blocks per batch, batches per launch */
+/* tuning knobs (0 = library default): perms per CSR pass (16|32 = width of the label slab; 8|4|2|1 = cap of the LDS pass width
+ * of a 16-wide slab — what 51 <= K <= 202 clusters select by themselves), count blocks (edge chunks) per batch, batches per launch */
 int sqgr_nhood_tune(sqgr_nhood* plan, int32_t perms_per_pass, int32_t blocks_per_batch, int32_t batches_per_launch);
 
 /* weighted K x K edge sums: `_interaction_matrix` (gr/_nhood.py:412-429); out: float64[K*K].

@@ -179,8 +179,9 @@ struct DevBuf {
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// zero entries behind the nhood edge lists (sqgr_graph::coo / half): the count kernel's look-ahead loads stay in bounds
-constexpr int LIST_PAD = 6400;
+// zero entries behind the nhood edge lists (sqgr_graph::coo / half): the count kernels' look-ahead loads stay in bounds
+// (six iterations of the widest one — one lane per edge, 4096 edges per iteration of a block — and a lane's own four edges)
+constexpr int LIST_PAD = 6 * 4096 + 64;
 
 // device-side collectives of an sqgr_comm (sqgr_comm.hip); no-ops for a NULL communicator or a single rank
 int comm_allreduce_i64_dev(sqgr_comm* c, int64_t* dev_buf, size_t count, bool op_max, hipStream_t st);

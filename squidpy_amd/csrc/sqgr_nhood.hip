@@ -634,48 +634,200 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
     }
 }
 
-// Large-K variants: BE (< 16) permutations [b0, b0+BE) of a 16-wide slab per pass; BE == 0: K*K does not
-// fit LDS at all -> device-scope atomics straight into the (single) partial.
-template <int BE>
-__global__ __launch_bounds__(COUNT_THREADS) void k_count_wide(int64_t nnz, const int32_t* __restrict__ erow,
-                                                              const int32_t* __restrict__ indices,
-                                                              const uint8_t* __restrict__ slab_all, int64_t n, int K, int b0,
-                                                              int64_t edges_per_block, int partial_blocks,
-                                                              uint32_t* __restrict__ partial_all) {
+// 51 <= K <= 202 (round 5): K*K*16 counters no longer fit the 160 KB of LDS, so a block counts only B = 8 | 4 | 2 | 1 of the slab's 16
+// permutations — one PASS — with k_count's machinery: the (half) edge list, 4-byte gathers out of the 16-byte label rows, the
+// three-stage pipeline without prologue code, the counter address in two instructions (v_perm_b32 + v_dot2_u32_u16), h + h^T
+// out of LDS.  What changes with B is how many lanes share an edge: LPE = B / 4 lanes, each owning ONE dword of the row = 4
+// permutations (NS = 4 atomics per edge and lane); below B = 4 one lane per edge uses NS = 2 | 1 bytes of its dword.  Every lane
+// handles U = 4 edges per iteration whatever LPE is, so an iteration of the block covers 1024 * 4 / LPE edges and the list
+// arrives in 16- and 32-byte pieces per lane.  The 16 / B passes of one edge chunk are separate blocks, CONSECUTIVE in the dispatch
+// order of ONE XCD (block id -> XCD id % 8): they walk the same chunk at the same time, so it crosses the fabric once per
+// chunk and batch and the other passes find it in that XCD's L2.  (The round-1 fallback this replaces, k_count_wide<8/4/2/1>,
+// walked the FULL CSR edge by edge with byte loads, one 16 / B-launch sequence per batch and no pipeline.)
+template <int LPE, int NS, bool SELF>
+__global__ __launch_bounds__(COUNT_THREADS, 4) void k_count_pass(uint32_t nnz, const int2* __restrict__ coo,
+                                                                 const uint8_t* __restrict__ slab_all, int64_t n, int K,
+                                                                 uint32_t edges_per_chunk, uint32_t self_begin, int add_transposed,
+                                                                 int nchunks, uint32_t* __restrict__ partial_all) {
     extern __shared__ uint32_t hist[];
+    static_assert((LPE == 4 || LPE == 2 || LPE == 1) && (NS == 4 || NS == 2 || NS == 1) && (NS == 4 || LPE == 1), "shape");
+    constexpr int B = NS == 4 ? LPE * 4 : NS;  // permutations per pass
+    constexpr int P = 16 / B;                  // passes per batch of 16
+    constexpr int U = 4;
+    constexpr uint32_t STEP = (COUNT_THREADS / LPE) * U;
+    static_assert(6 * STEP + 2 * U <= LIST_PAD, "look-ahead exceeds the padding of the edge lists");
+    const int tid = threadIdx.x;
+    const int hist_words = K * K * B;
+    for (int i = tid; i < hist_words; i += COUNT_THREADS) hist[i] = 0;
+    __syncthreads();
+
+    // block -> (chunk, pass): XCD x takes the x-th eighth of the chunks and runs the P passes of a chunk back to back
+    int chunk, pass;
+    if ((nchunks & 7) == 0) {
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        pass = j % P;
+        chunk = x * (nchunks >> 3) + j / P;
+    } else {
+        pass = blockIdx.x % P;
+        chunk = blockIdx.x / P;
+    }
+    const int b0 = pass * B;                             // first permutation (byte of the 16-byte row) of this pass
+    const uint8_t* slab = slab_all + (size_t)blockIdx.y * n * 16 + (b0 & ~3);
+    const uint32_t base_byte = (uint32_t)b0 & 3u;        // NS < 4: where the pass's bytes start inside the lane's dword
+    const uint32_t e0 = (uint32_t)chunk * edges_per_chunk;
+    const uint32_t e1 = min(nnz, e0 + edges_per_chunk);
+    const bool uniform_block = (e0 + edges_per_chunk <= nnz) && (!SELF || e0 + edges_per_chunk <= self_begin);
+    const uint32_t q = tid & 3;
+    const uint32_t d = LPE == 4 ? q : (LPE == 2 ? (q & 1u) : 0u);   // the lane's dword inside the pass
+    const uint32_t qoff = d * 4;
+    const uint32_t el = LPE == 4 ? (uint32_t)tid >> 2 : (LPE == 2 ? (uint32_t)tid >> 1 : (uint32_t)tid);  // stagger of the byte order
+    // first edge of this lane inside an iteration's STEP edges
+    const uint32_t lane_edge = LPE == 4 ? ((uint32_t)tid >> 2) * 4 : (LPE == 2 ? ((uint32_t)tid >> 2) * 8 + (q >> 1) * 4 : (uint32_t)tid * 4);
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)hist;
+    uint32_t bank_ofs[NS], sel[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const uint32_t byte = (s + el) & (NS - 1);
+        bank_ofs[s] = (d * NS + byte) * 4 + lds_base;
+        sel[s] = 0x0c000c00u | ((4u + base_byte + byte) << 16) | (base_byte + byte);  // b row byte -> bits 0..7, a row byte -> bits 16..23
+    }
+    const uint32_t dot_k = ((uint32_t)(K * B * 4) << 16) | (uint32_t)(B * 4);  // {hi: bytes per la row, lo: bytes per pair}
+
+    struct Pairs { uint32_t r[U], c[U]; };
+    struct Loaded { int4 v[LPE == 1 ? 2 : 1]; };  // LPE 4: one pair (x, y); LPE 2: two pairs; LPE 1: four pairs
+    auto load_pair = [&](uint32_t e) {            // e: first edge of the block's iteration
+        Loaded L;
+        if constexpr (LPE == 4) {
+            const int2 v = coo[e + ((uint32_t)tid >> 2) * 4 + q];
+            L.v[0] = make_int4(v.x, v.y, 0, 0);
+        } else if constexpr (LPE == 2) {
+            L.v[0] = *reinterpret_cast<const int4*>(coo + e + ((uint32_t)tid >> 2) * 8 + q * 2);
+        } else {
+            L.v[0] = *reinterpret_cast<const int4*>(coo + e + (uint32_t)tid * 4);
+            L.v[1] = *reinterpret_cast<const int4*>(coo + e + (uint32_t)tid * 4 + 2);
+        }
+        return L;
+    };
+#define SQGR_ADD_DPP(dst, src, sel)                                                                      \
+    asm("v_add_u32_dpp %0, %1, %2 quad_perm:[" sel "] row_mask:0xf bank_mask:0xf" : "=v"(dst) : "v"(src), "v"(qoff))
+    auto spread = [&](const Loaded& L) {
+        Pairs pr;
+        if constexpr (LPE == 4) {
+            SQGR_ADD_DPP(pr.r[0], L.v[0].x, "0,0,0,0"); SQGR_ADD_DPP(pr.c[0], L.v[0].y, "0,0,0,0");
+            SQGR_ADD_DPP(pr.r[1], L.v[0].x, "1,1,1,1"); SQGR_ADD_DPP(pr.c[1], L.v[0].y, "1,1,1,1");
+            SQGR_ADD_DPP(pr.r[2], L.v[0].x, "2,2,2,2"); SQGR_ADD_DPP(pr.c[2], L.v[0].y, "2,2,2,2");
+            SQGR_ADD_DPP(pr.r[3], L.v[0].x, "3,3,3,3"); SQGR_ADD_DPP(pr.c[3], L.v[0].y, "3,3,3,3");
+        } else if constexpr (LPE == 2) {
+            // the quad's 8 edges: lane q loaded edges 2q, 2q+1; lanes {0, 1} handle edges 0..3, lanes {2, 3} edges 4..7
+            SQGR_ADD_DPP(pr.r[0], L.v[0].x, "0,0,2,2"); SQGR_ADD_DPP(pr.c[0], L.v[0].y, "0,0,2,2");
+            SQGR_ADD_DPP(pr.r[1], L.v[0].z, "0,0,2,2"); SQGR_ADD_DPP(pr.c[1], L.v[0].w, "0,0,2,2");
+            SQGR_ADD_DPP(pr.r[2], L.v[0].x, "1,1,3,3"); SQGR_ADD_DPP(pr.c[2], L.v[0].y, "1,1,3,3");
+            SQGR_ADD_DPP(pr.r[3], L.v[0].z, "1,1,3,3"); SQGR_ADD_DPP(pr.c[3], L.v[0].w, "1,1,3,3");
+        } else {
+            pr.r[0] = L.v[0].x; pr.c[0] = L.v[0].y; pr.r[1] = L.v[0].z; pr.c[1] = L.v[0].w;
+            pr.r[2] = L.v[1].x; pr.c[2] = L.v[1].y; pr.r[3] = L.v[1].z; pr.c[3] = L.v[1].w;
+        }
+        return pr;
+    };
+#undef SQGR_ADD_DPP
+    auto gather_rows = [&](const Pairs& pr, uint32_t (&ra)[U], uint32_t (&rb)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            ra[u] = *reinterpret_cast<const uint32_t*>(slab + pr.r[u]);
+            rb[u] = *reinterpret_cast<const uint32_t*>(slab + pr.c[u]);
+        }
+    };
+    auto histogram = [&](const uint32_t (&row_a)[U], const uint32_t (&row_b)[U], uint32_t eb, auto general_tag) {
+        constexpr bool GENERAL = decltype(general_tag)::value;
+        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            uint32_t inc = SELF ? 2u : 1u;
+            if constexpr (GENERAL) {  // branch-free tail: out-of-range edges add 0, self loops 1
+                inc = (eb + u < e1) ? 1u : 0u;
+                if constexpr (SELF) inc += (eb + u < min(e1, self_begin)) ? 1u : 0u;
+            }
+            uint32_t addr[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                addr[s] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(row_a[u], row_b[u], sel[s])),
+                                                 __builtin_bit_cast(u16x2, dot_k), bank_ofs[s], false);
+            if constexpr (NS == 4)
+                asm volatile("ds_add_u32 %0, %4\n\tds_add_u32 %1, %4\n\tds_add_u32 %2, %4\n\tds_add_u32 %3, %4"
+                             :
+                             : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(inc)
+                             : "memory");
+            else if constexpr (NS == 2)
+                asm volatile("ds_add_u32 %0, %2\n\tds_add_u32 %1, %2" : : "v"(addr[0]), "v"(addr[1]), "v"(inc) : "memory");
+            else
+                asm volatile("ds_add_u32 %0, %1" : : "v"(addr[0]), "v"(inc) : "memory");
+        }
+    };
+    auto sweep = [&](auto general_tag) {
+        // the uniform three-stage loop of k_count (T + 2 stages, two dummy gathers in front: one wait pattern for every stage)
+        uint32_t e = e0;
+        uint32_t ra[3][U], rb[3][U];
+        Loaded pr[3];
+        const uint32_t T = (e1 - e0 + STEP - 1) / STEP;
+        Pairs dummy;
+#pragma unroll
+        for (int u = 0; u < U; ++u) dummy.r[u] = dummy.c[u] = qoff;
+        pr[0] = load_pair(e);
+        gather_rows(dummy, ra[1], rb[1]);
+        pr[1] = load_pair(e + STEP);
+        gather_rows(dummy, ra[2], rb[2]);
+        for (uint32_t j = 0; j < T + 2; j += 3) {
+#pragma unroll
+            for (int st = 0; st < 3; ++st) {
+                pr[(st + 2) % 3] = load_pair(e + (st + 2) * STEP);
+                gather_rows(spread(pr[st]), ra[st], rb[st]);
+                if (j + st >= 2 && j + st - 2 < T)
+                    histogram(ra[(st + 1) % 3], rb[(st + 1) % 3], e + st * STEP - 2 * STEP + lane_edge, general_tag);
+            }
+            e += 3 * STEP;
+        }
+    };
+    __builtin_amdgcn_s_setprio(3);
+    if (e0 < nnz) {
+        if (uniform_block)
+            sweep(std::false_type{});
+        else
+            sweep(std::true_type{});
+    }
+    __syncthreads();
+    // the pass's B columns of the chunk's partial histogram [pair][16]
+    uint32_t* dst = partial_all + ((size_t)blockIdx.y * nchunks + chunk) * ((size_t)K * K * 16) + b0;
+    for (int i = tid; i < hist_words; i += COUNT_THREADS) {
+        const int pair = i / B, b = i - pair * B;
+        uint32_t v = hist[i];
+        if (add_transposed) {
+            const int la = pair / K, lb = pair - la * K;
+            v += hist[(lb * K + la) * B + b];
+        }
+        dst[(size_t)pair * 16 + b] = v;
+    }
+}
+
+// K*K does not fit LDS even for one permutation (K > 202) -> device-scope atomics straight into the (single) partial (BE == 0).
+__global__ __launch_bounds__(COUNT_THREADS) void k_count_global(int64_t nnz, const int32_t* __restrict__ erow,
+                                                                const int32_t* __restrict__ indices,
+                                                                const uint8_t* __restrict__ slab_all, int64_t n, int K,
+                                                                int64_t edges_per_block, uint32_t* __restrict__ partial_all) {
     constexpr int B = 16;
     const int K2 = K * K;
     const int tid = threadIdx.x;
-    const int hw = K2 * (BE > 0 ? BE : 1);
-    if (BE > 0) {
-        for (int i = tid; i < hw; i += COUNT_THREADS) hist[i] = 0;
-        __syncthreads();
-    }
     const uint8_t* slab = slab_all + (size_t)blockIdx.y * n * B;
-    uint32_t* dst = partial_all + ((size_t)blockIdx.y * partial_blocks + (BE > 0 ? blockIdx.x : 0)) * ((size_t)K2 * B);
+    uint32_t* dst = partial_all + (size_t)blockIdx.y * ((size_t)K2 * B);
     const int64_t e0 = (int64_t)blockIdx.x * edges_per_block;
     const int64_t e1 = min(nnz, e0 + edges_per_block);
     for (int64_t e = e0 + tid; e < e1; e += COUNT_THREADS) {
-        const uint8_t* ra = slab + (size_t)erow[e] * B;
-        const uint8_t* rb = slab + (size_t)indices[e] * B;
-        if (BE > 0) {
+        const uint4 ra = *reinterpret_cast<const uint4*>(slab + (size_t)erow[e] * B);
+        const uint4 rb = *reinterpret_cast<const uint4*>(slab + (size_t)indices[e] * B);
+        const uint32_t wa[4] = {ra.x, ra.y, ra.z, ra.w}, wb[4] = {rb.x, rb.y, rb.z, rb.w};
 #pragma unroll
-            for (int bb = 0; bb < BE; ++bb) {
-                uint32_t pair = (uint32_t)ra[b0 + bb] * K + rb[b0 + bb];
-                atomicAdd(&hist[pair * BE + bb], 1u);
-            }
-        } else {
-            for (int b = 0; b < B; ++b) {
-                uint32_t pair = (uint32_t)ra[b] * K + rb[b];
-                atomicAdd(&dst[(size_t)pair * B + b], 1u);
-            }
-        }
-    }
-    if constexpr (BE > 0) {
-        __syncthreads();
-        for (int i = tid; i < hw; i += COUNT_THREADS) {
-            int pair = i / BE, bb = i % BE;
-            dst[(size_t)pair * B + b0 + bb] = hist[i];
+        for (int b = 0; b < B; ++b) {
+            const uint32_t pair = ((wa[b >> 2] >> (8 * (b & 3))) & 255u) * K + ((wb[b >> 2] >> (8 * (b & 3))) & 255u);
+            atomicAdd(&dst[(size_t)pair * B + b], 1u);
         }
     }
 }
@@ -912,13 +1064,6 @@ static int allow_lds(KernelT kernel, size_t bytes) {
     return SQGR_OK;
 }
 
-template <int BE>
-static void launch_wide(dim3 grid, size_t lds, hipStream_t st, int64_t nnz, const int32_t* erow, const int32_t* indices,
-                        const uint8_t* slab, int64_t n, int K, int b0, int64_t epb, int pblocks, uint32_t* partial) {
-    (void)allow_lds(k_count_wide<BE>, lds);
-    k_count_wide<BE><<<grid, COUNT_THREADS, lds, st>>>(nnz, erow, indices, slab, n, K, b0, epb, pblocks, partial);
-}
-
 struct sqgr_nhood {
     sqgr_ctx* ctx = nullptr;
     const sqgr_graph* g = nullptr;
@@ -966,25 +1111,37 @@ struct sqgr_nhood {
     DevBuf<uint8_t> stage;
 
     int hist_words() const { return K2 * B; }
-    int be() const {  // permutations whose histograms fit LDS together (for the B=16 slab)
+    // permutations of the 16-wide slab whose K*K histograms fit LDS together: 16 -> k_count; 8, 4, 2, 1 -> that many per PASS of
+    // k_count_pass (16 / be passes per batch); 0: not even one (K > 202) -> device-scope counters (k_count_global).
+    // sqgr_nhood_tune(perms_per_pass = 8|4|2|1) / SQGR_COUNT_PASS_B cap it (tests: every pass width on one input; experiments:
+    // fewer permutations per pass, more blocks per CU).
+    int pass_cap = 16;
+    int be() const {
+        static const int env_cap = [] { const char* e = getenv("SQGR_COUNT_PASS_B"); return e ? std::max(atoi(e), 1) : 16; }();
+        const int cap = std::min(pass_cap, env_cap);
         for (int b : {16, 8, 4, 2, 1})
-            if ((size_t)K2 * b * 4 <= LDS_BUDGET) return b;
+            if ((size_t)K2 * b * 4 <= LDS_BUDGET && b <= cap) return b;
         return 0;
     }
-    // 1024-thread blocks per batch of a launch with `nb` batches.  nblk > 0: fixed by sqgr_nhood_tune.  Auto: ~8 blocks
-    // per CU over the whole launch, at least 32 per batch — measured on MI355X (tools/tune_sweep.sh): with 64 batches in
-    // flight 32-48 blocks per batch beat one block per CU by 15 % (fewer partial histograms to write and re-read:
-    // blocks * K*K*B*4 bytes per batch; longer edge runs per block).
+    bool lds_path() const { return !wide() && (B == 32 || be() > 0); }  // block-local LDS histograms, (half) edge list
+    int passes() const { return (B == 16 && !wide() && be() > 0) ? 16 / be() : 1; }
+    // 1024-thread blocks per batch of a launch with `nb` batches = edge chunks per batch (k_count_pass: times `passes()` blocks).
+    // nblk > 0: fixed by sqgr_nhood_tune.  Auto: ~8 blocks per CU over the whole launch, at least 32 per batch — measured on MI355X
+    // (tools/tune_sweep.sh): with 64 batches in flight 32-48 blocks per batch beat one block per CU by 15 % (fewer partial
+    // histograms to write and re-read: blocks * K*K*B*4 bytes per batch; longer edge runs per block).  With passes a chunk is walked
+    // by 16 / be blocks and its partial histogram is K*K*64 bytes whatever be is (2.5 MB at K = 200): at least 8 chunks, 32 / passes
+    // when that is more.
     int blocks_for(int nb) const {
         if (nblk > 0) return nblk;
         const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
         // rounded DOWN to a multiple of 8 (whole XCD shares): nb * blocks must not spill a few blocks into one more round of
         // 2 blocks per CU — 49 batches x 42 blocks = 2058 blocks ran 5 rounds for 4.02 rounds of work
-        return (int)std::max<int64_t>(32, std::min<int64_t>(cus, (((int64_t)8 * cus) / std::max(nb, 1)) & ~(int64_t)7));
+        const int64_t fill = (((int64_t)8 * cus) / std::max(nb * passes(), 1)) & ~(int64_t)7;
+        return (int)std::max<int64_t>(std::max(8, 32 / passes()), std::min<int64_t>(cus, fill));
     }
     int nblk_launch = 0;  // blocks per batch of the launch in flight (count -> reduce)
     int sym_launch = 0;   // k_reduce mode of the launch in flight (0 full edge list, 1 half list, 2 half list with self loops)
-    int partial_blocks(int nb) const { return (wide() || (B == 16 && be() == 0)) ? 1 : blocks_for(nb); }
+    int partial_blocks(int nb) const { return lds_path() ? blocks_for(nb) : 1; }
     size_t partial_words() const {  // largest nb * blocks_for(nb) * hist_words over the launches this plan can issue
         size_t m = 0;
         for (int nb = 1; nb <= nbatch; ++nb) m = std::max(m, (size_t)nb * partial_blocks(nb));
@@ -1057,6 +1214,38 @@ int sqgr_nhood::count_batches(int nb, int buf) {
         SQGR_HIP(hipMemsetAsync(partial.p, 0, (size_t)nb * hw * 4, st));
         k_count_wide16<<<dim3((unsigned)ceil_div(nnz, 256), nb), 256, 0, st>>>(nnz, g->erow.p, g->indices.p,
                                                                               reinterpret_cast<const uint16_t*>(slab_p), n, K, partial.p);
+    } else if (lds_path() && B == 16 && be() < 16) {
+        // 51 <= K <= 202: passes of be permutations over the (half) edge list, the passes of a chunk side by side on one XCD
+        SQGR_TRY(g->ensure_half());
+        const bool half = g->sym_state == 1;
+        const int2* list = half ? g->half.p : g->coo.p;
+        const uint32_t m = (uint32_t)(half ? g->n_half + g->n_self : nnz);
+        const uint32_t self_begin = (uint32_t)(half ? g->n_half : nnz);
+        const bool self = half && g->n_self > 0;
+        sym_launch = self ? 2 : 0;
+        const int e = be();
+        const uint32_t step = (uint32_t)(COUNT_THREADS * 4 / (e >= 8 ? 2 : 1));             // edges per iteration of a block
+        const uint32_t epc = (uint32_t)(ceil_div(ceil_div((int64_t)m, nblk), step) * step);  // whole iterations per chunk
+        const size_t lds = (size_t)K2 * e * 4;
+        const dim3 grid(nblk * (16 / e), nb);
+        LaunchTimer t(ctx, half ? "nhood_count_pass_half" : "nhood_count_pass");
+#define SQGR_PASS(LPE, NS)                                                                                                        \
+    do {                                                                                                                          \
+        if (self) {                                                                                                               \
+            SQGR_TRY(allow_lds(k_count_pass<LPE, NS, true>, lds));                                                                \
+            k_count_pass<LPE, NS, true><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, epc, self_begin, half ? 1 : 0, nblk, partial.p); \
+        } else {                                                                                                                  \
+            SQGR_TRY(allow_lds(k_count_pass<LPE, NS, false>, lds));                                                               \
+            k_count_pass<LPE, NS, false><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, epc, self_begin, half ? 1 : 0, nblk, partial.p); \
+        }                                                                                                                         \
+    } while (0)
+        switch (e) {
+            case 8: SQGR_PASS(2, 4); break;
+            case 4: SQGR_PASS(1, 4); break;
+            case 2: SQGR_PASS(1, 2); break;
+            default: SQGR_PASS(1, 1); break;
+        }
+#undef SQGR_PASS
     } else if (B == 32 || be() == 16) {
         // LDS-histogram kernels: on a structurally symmetric graph they walk the half list (see sqgr_graph::ensure_half)
         SQGR_TRY(g->ensure_half());
@@ -1116,25 +1305,12 @@ int sqgr_nhood::count_batches(int nb, int buf) {
         }
 #undef SQGR_COUNT
 #undef SQGR_COUNT_D
-    } else {
-        const int e = be();
-        const int64_t epb = ceil_div(nnz, nblk);
-        LaunchTimer t(ctx, "nhood_count_wide");
-        if (e == 0) {
-            SQGR_HIP(hipMemsetAsync(partial.p, 0, (size_t)nb * hw * 4, st));
-            k_count_wide<0><<<dim3(nblk, nb), COUNT_THREADS, 0, st>>>(nnz, g->erow.p, g->indices.p, slab_p, n, K, 0, epb, 1,
-                                                                     partial.p);
-        } else {
-            for (int b0 = 0; b0 < 16; b0 += e) {
-                const size_t lds = (size_t)K2 * e * 4;
-                switch (e) {
-                    case 8: launch_wide<8>(dim3(nblk, nb), lds, st, nnz, g->erow.p, g->indices.p, slab_p, n, K, b0, epb, nblk, partial.p); break;
-                    case 4: launch_wide<4>(dim3(nblk, nb), lds, st, nnz, g->erow.p, g->indices.p, slab_p, n, K, b0, epb, nblk, partial.p); break;
-                    case 2: launch_wide<2>(dim3(nblk, nb), lds, st, nnz, g->erow.p, g->indices.p, slab_p, n, K, b0, epb, nblk, partial.p); break;
-                    default: launch_wide<1>(dim3(nblk, nb), lds, st, nnz, g->erow.p, g->indices.p, slab_p, n, K, b0, epb, nblk, partial.p); break;
-                }
-            }
-        }
+    } else {  // K*K counters do not fit LDS: device-scope atomics into ONE histogram per batch
+        const int gblk = std::max(nblk, 64);
+        const int64_t epb = ceil_div(nnz, gblk);
+        LaunchTimer t(ctx, "nhood_count_global");
+        SQGR_HIP(hipMemsetAsync(partial.p, 0, (size_t)nb * hw * 4, st));
+        k_count_global<<<dim3(gblk, nb), COUNT_THREADS, 0, st>>>(nnz, g->erow.p, g->indices.p, slab_p, n, K, epb, partial.p);
     }
     SQGR_HIP(hipGetLastError());
     return SQGR_OK;
@@ -1418,10 +1594,13 @@ int sqgr_nhood_destroy(sqgr_nhood* plan) {
 
 int sqgr_nhood_tune(sqgr_nhood* plan, int32_t perms_per_pass, int32_t blocks_per_batch, int32_t batches_per_launch) {
     SQGR_REQUIRE(plan, "plan is NULL");
-    SQGR_REQUIRE(perms_per_pass == 0 || perms_per_pass == 16 || perms_per_pass == 32, "perms_per_pass must be 0, 16 or 32");
+    SQGR_REQUIRE(perms_per_pass == 0 || perms_per_pass == 16 || perms_per_pass == 32 || perms_per_pass == 8 || perms_per_pass == 4 ||
+                     perms_per_pass == 2 || perms_per_pass == 1,
+                 "perms_per_pass must be 0, 32, 16 (slab width) or 8, 4, 2, 1 (cap of the LDS pass width of a 16-wide slab)");
     SQGR_REQUIRE(blocks_per_batch >= 0 && blocks_per_batch <= 65535 && batches_per_launch >= 0 && batches_per_launch <= 1024,
                  "tuning value out of range");
-    plan->B = perms_per_pass ? perms_per_pass : 16;
+    plan->B = perms_per_pass == 32 ? 32 : 16;
+    plan->pass_cap = (perms_per_pass > 0 && perms_per_pass < 16) ? perms_per_pass : 16;
     plan->nblk = blocks_per_batch;
     plan->nbatch = batches_per_launch;  // 0: automatic (resolve_tuning)
     // force re-allocation with the new geometry
@@ -1817,7 +1996,7 @@ int sqgr_nhood_info(sqgr_nhood* plan, int64_t* out_info) {
     sqgr_nhood* p = plan;
     SQGR_HIP(hipSetDevice(p->ctx->device));
     SQGR_TRY(p->resolve_tuning());
-    const bool lds_path = p->g && (p->B == 32 || p->be() == 16);
+    const bool lds_path = p->g && p->lds_path();
     if (lds_path) SQGR_TRY(p->g->ensure_half());
     const bool half = lds_path && p->g->sym_state == 1;
     out_info[0] = p->B;

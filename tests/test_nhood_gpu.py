@@ -177,6 +177,39 @@ def test_all_cluster_count_regimes(L, ctx, k):
     np.testing.assert_array_equal(perms, ref.astype(np.uint32))
 
 
+@pytest.mark.parametrize("graph", ["hex", "hex+self", "knn"])
+@pytest.mark.parametrize("k,width,blocks", [(60, 0, 0), (60, 4, 0), (71, 8, 5), (72, 0, 0), (100, 0, 0), (101, 2, 0), (102, 0, 0), (130, 1, 0), (30, 8, 0), (30, 4, 16),
+                                             (30, 2, 0), (7, 1, 3)])
+def test_lds_pass_kernel_every_width_on_half_and_full_lists(L, ctx, graph, k, width, blocks):
+    """51 <= K <= 202 clusters count in PASSES of 8 | 4 | 2 | 1 of the slab's 16 permutations (k_count_pass: the machinery of the
+    K <= 50 kernel at 2 | 1 lanes per edge).  Every width — the one K selects (width 0) and narrower ones forced through
+    `tune` — on the symmetric half list without and with self loops (weights 2 and 1, halved sums) and on a directed kNN
+    graph (full list); chunks cut so that whole-iteration blocks, a ragged last chunk and empty chunks all occur; chunk counts
+    that are and are not a multiple of 8 (the XCD-aware block map and the plain one).  Per-permutation counts `==` the oracle."""
+    rng = np.random.default_rng(k * 7 + width)
+    if graph == "knn":
+        n = 21000
+        adj = knn_graph(rng.random((n, 2)), 6)
+    else:
+        adj = O.hex_grid_graph(150, 160)
+        n = adj.shape[0]
+        if graph == "hex+self":
+            adj = sp.csr_matrix(adj + sp.identity(n, format="csr", dtype=np.float32))
+            adj.sort_indices()
+    labels = rng.integers(0, k, n).astype(np.int32)
+    g = L.Graph(ctx, adj)
+    plan = L.NhoodPlan(ctx, g, labels, k)
+    if width or blocks:
+        plan.tune(width, blocks, 3)
+    info = plan.info()
+    assert info["symmetric"] == (graph != "knn")
+    n_perms = 50  # 3 batches of 16 per launch group -> two launch groups, the last batch partly filled
+    _, _, perms = plan.run(11, 5, 5 + n_perms, None, return_perms=True)
+    ref = O.nhood_perm_counts_philox(adj.indices, adj.indptr, labels, k, 11, 5, 5 + n_perms)
+    np.testing.assert_array_equal(perms, ref.astype(np.uint32))
+    assert int(perms[0].sum()) == adj.nnz
+
+
 def test_ragged_and_empty_rows(L, ctx):
     """Rows without neighbours, self loops, duplicate and explicit-zero entries all count like the reference."""
     rng = np.random.default_rng(0)
