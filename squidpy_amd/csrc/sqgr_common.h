@@ -211,4 +211,25 @@ struct sqgr_graph {
     mutable int64_t n_half = 0;  // edges with r < c
     mutable int64_t n_self = 0;  // self loops, stored behind them
     int ensure_half() const;
+    // The pass kernel of the permutation test (51 <= K <= 202 clusters, sqgr_nhood.hip: k_count_pass) reads the SAME list in
+    // another order and with other offsets: inside every aligned group of 4*J entries (J = 32 | 64 edge slots of a wavefront)
+    // slot j of gather instruction u = 0..3 — physical position 4*j + u — holds the list's entry (u/R)*(J*R) + j*R + u%R, so
+    // that with R = 1 one gather instruction touches the label rows of J consecutive edges instead of every fourth edge of the
+    // group (R = 4: the list's own order); and the entries are byte offsets (w*row, w*col) into a PLANE of w = 8 | 4 | 2 | 1
+    // label bytes per spot instead of (16*row, 16*col).  pass_list builds the copy on first use (half list on symmetric
+    // graphs, the full list otherwise; length rounded up to whole groups + LIST_PAD zero entries).
+    struct PassList {
+        int J = 0, R = 0, w = 0;
+        sqgr::DevBuf<int2> list;
+    };
+    mutable PassList pass_lists[4];
+    int pass_list(int J, int R, int w, const int2** out) const;
 };
+
+namespace sqgr {
+// logical position (in the list's own order) of physical position p of a pass list
+__host__ __device__ inline uint32_t pass_list_logical(uint32_t p, uint32_t J, uint32_t R) {
+    const uint32_t G = 4 * J, base = p / G * G, w = p - base, j = w >> 2, u = w & 3;
+    return base + (u / R) * (J * R) + j * R + (u % R);
+}
+}  // namespace sqgr

@@ -353,6 +353,42 @@ int sqgr_graph::ensure_half() const {
     return SQGR_OK;
 }
 
+__global__ __launch_bounds__(256) void k_pass_list(const int2* __restrict__ src, uint32_t m, uint32_t total, uint32_t J, uint32_t R, int shift,
+                                                   int2* __restrict__ dst) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= total) return;
+    const uint32_t l = pass_list_logical(p, J, R);
+    int2 v = l < m ? src[l] : make_int2(0, 0);
+    v.x = (int)((uint32_t)v.x >> shift);  // 16 * spot -> w * spot
+    v.y = (int)((uint32_t)v.y >> shift);
+    dst[p] = v;
+}
+
+int sqgr_graph::pass_list(int J, int R, int w, const int2** out) const {
+    SQGR_TRY(ensure_half());
+    const bool is_half = sym_state == 1;
+    const int2* src = is_half ? half.p : coo.p;
+    const int64_t m = is_half ? n_half + n_self : nnz;
+    SQGR_REQUIRE((J == 32 || J == 64) && (R == 1 || R == 2 || R == 4) && (w == 8 || w == 4 || w == 2 || w == 1), "pass list (%d, %d, %d)", J, R, w);
+    const int shift = w == 8 ? 1 : w == 4 ? 2 : w == 2 ? 3 : 4;
+    PassList& pl = pass_lists[shift - 1];
+    if (pl.J != J || pl.R != R || pl.w != w || !pl.list.p) {
+        SQGR_HIP(hipSetDevice(ctx->device));
+        const int64_t G = 4 * (int64_t)J;
+        const int64_t total = ceil_div(m, G) * G + LIST_PAD;
+        pl.list.release();
+        SQGR_TRY(pl.list.alloc((size_t)total));
+        LaunchTimer t(ctx, "graph_pass_list");
+        k_pass_list<<<(unsigned)ceil_div(total, 256), 256, 0, ctx->stream>>>(src, (uint32_t)m, (uint32_t)total, (uint32_t)J, (uint32_t)R, shift, pl.list.p);
+        SQGR_HIP(hipGetLastError());
+        pl.J = J;
+        pl.R = R;
+        pl.w = w;
+    }
+    *out = pl.list.p;
+    return SQGR_OK;
+}
+
 int sqgr_ctx::timer_id(const char* name) {
     auto it = timer_ids.find(name);
     if (it != timer_ids.end()) return it->second;

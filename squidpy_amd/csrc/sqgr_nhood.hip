@@ -106,11 +106,38 @@ __device__ __forceinline__ void put_label(uint32_t& word, uint32_t e, uint32_t b
 #undef SQGR_PUT
 }
 
+// The 16 shuffled labels of spot i (4 words, label b in byte b & 3 of word b >> 2) into a batch's 16 * n bytes of the slab.
+// pw = 16: row i of [n][16] — what k_count gathers.  pw = 8 | 4 | 2 | 1 (51 <= K <= 202 clusters, k_count_pass): 16 / pw PLANES
+// [n][pw], plane q = permutations [q * pw, (q + 1) * pw) — a pass of pw permutations then gathers from dense rows of exactly
+// the bytes it uses (round 5: out of 16-byte rows a pass of 4 pulled four times the cache lines through L1 and L2).
+__device__ __forceinline__ void slab_store16(uint8_t* __restrict__ batch_base, int64_t n, int64_t i, int pw, uint32_t w0, uint32_t w1,
+                                             uint32_t w2, uint32_t w3) {
+    if (pw == 16) {
+        *reinterpret_cast<uint4*>(batch_base + (size_t)i * 16) = make_uint4(w0, w1, w2, w3);
+    } else if (pw == 8) {
+        *reinterpret_cast<uint2*>(batch_base + (size_t)i * 8) = make_uint2(w0, w1);
+        *reinterpret_cast<uint2*>(batch_base + (size_t)n * 8 + (size_t)i * 8) = make_uint2(w2, w3);
+    } else if (pw == 4) {
+        uint32_t* d = reinterpret_cast<uint32_t*>(batch_base) + i;
+        d[0] = w0; d[(size_t)n] = w1; d[(size_t)2 * n] = w2; d[(size_t)3 * n] = w3;
+    } else if (pw == 2) {
+        uint16_t* d = reinterpret_cast<uint16_t*>(batch_base) + i;
+        const uint32_t w[4] = {w0, w1, w2, w3};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) d[(size_t)q * n] = (uint16_t)(w[q >> 1] >> (16 * (q & 1)));
+    } else {
+        uint8_t* d = batch_base + i;
+        const uint32_t w[4] = {w0, w1, w2, w3};
+#pragma unroll
+        for (int q = 0; q < 16; ++q) d[(size_t)q * n] = (uint8_t)(w[q >> 2] >> (8 * (q & 3)));
+    }
+}
+
 template <int B, bool HAS_LIBS, bool SMALLK>
 __global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __restrict__ cum, int kpad, int blk_words, int K,
                                                  const uint32_t* __restrict__ keys, LibDom dom0, int n_libs, int nrows,
                                                  const int32_t* __restrict__ lib_of, const int32_t* __restrict__ rank_of,
-                                                 const LibDom* __restrict__ libdoms, uint8_t* __restrict__ slab_all) {
+                                                 const LibDom* __restrict__ libdoms, uint8_t* __restrict__ slab_all, int pw) {
     extern __shared__ uint32_t s_lds[];               // [blk_words] block table (byte offset 0), then [n_libs][kpad] boundaries
     uint32_t* s_cum = s_lds + blk_words;
     for (int t = threadIdx.x; t < n_libs * kpad; t += 256) s_cum[t] = cum[t];
@@ -234,8 +261,8 @@ __global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __re
         dst[0] = make_uint4(outA[0], outA[1], outA[2], outA[3]);
         dst[1] = make_uint4(outB[0], outB[1], outB[2], outB[3]);
     } else {
-        *reinterpret_cast<uint4*>(slab_all + ((size_t)row0 * n + i) * B) = make_uint4(outA[0], outA[1], outA[2], outA[3]);
-        if (store1) *reinterpret_cast<uint4*>(slab_all + ((size_t)row1 * n + i) * B) = make_uint4(outB[0], outB[1], outB[2], outB[3]);
+        slab_store16(slab_all + (size_t)row0 * n * 16, n, i, pw, outA[0], outA[1], outA[2], outA[3]);
+        if (store1) slab_store16(slab_all + (size_t)row1 * n * 16, n, i, pw, outB[0], outB[1], outB[2], outB[3]);
     }
     }
 }
@@ -352,15 +379,24 @@ __global__ __launch_bounds__(256) void k_count_wide16(int64_t nnz, const int32_t
 // injected permutations: lab[(p)*n + i] (perm-major, host order) -> slab rows
 template <int B>
 __global__ __launch_bounds__(256) void k_transpose_labels(int64_t n, const uint8_t* __restrict__ lab, int64_t nperm_valid,
-                                                          uint8_t* __restrict__ slab_all) {
+                                                          uint8_t* __restrict__ slab_all, int pw) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int batch = blockIdx.y;
-    uint8_t* dst = slab_all + ((size_t)batch * n + i) * B;
+    uint32_t w[B / 4];
+#pragma unroll
+    for (int k = 0; k < B / 4; ++k) w[k] = 0;
 #pragma unroll
     for (int b = 0; b < B; ++b) {
         int64_t p = (int64_t)batch * B + b;
-        dst[b] = p < nperm_valid ? lab[(size_t)p * n + i] : (uint8_t)0;
+        w[b >> 2] |= (p < nperm_valid ? (uint32_t)lab[(size_t)p * n + i] : 0u) << (8 * (b & 3));
+    }
+    if constexpr (B == 16) {
+        slab_store16(slab_all + (size_t)batch * n * 16, n, i, pw, w[0], w[1], w[2], w[3]);
+    } else {
+        uint4* dst = reinterpret_cast<uint4*>(slab_all + ((size_t)batch * n + i) * B);
+#pragma unroll
+        for (int v = 0; v < B / 16; ++v) dst[v] = make_uint4(w[4 * v], w[4 * v + 1], w[4 * v + 2], w[4 * v + 3]);
     }
 }
 
@@ -621,6 +657,11 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
             sweep(std::true_type{});
     }
     if constexpr ((DBG & 1) != 0) hist[tid] = dbg_acc;
+    // The ds_add_u32 of the DOT2 path are inline asm: the compiler's wait-count pass does not know them, and the release fence of
+    // __syncthreads() is a "soft" wait it drops when it sees no pending LDS operation — the barrier was reached with atomics still
+    // in flight (found in round 5 on the pass kernel below: one increment in ~5e5 cells lost now and then; this kernel had the
+    // same barrier without a wait in its ISA, never caught by a test).  The wait is explicit.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
     uint32_t* dst = partial_all + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * hist_words;
     if (add_transposed) {  // half list: the block's contribution to count = h + h^T is formed here, out of LDS
@@ -637,23 +678,31 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
 // 51 <= K <= 202 (round 5): K*K*16 counters no longer fit the 160 KB of LDS, so a block counts only B = 8 | 4 | 2 | 1 of the slab's 16
 // permutations — one PASS — with k_count's machinery: the (half) edge list, 4-byte gathers out of the 16-byte label rows, the
 // three-stage pipeline without prologue code, the counter address in two instructions (v_perm_b32 + v_dot2_u32_u16), h + h^T
-// out of LDS.  What changes with B is how many lanes share an edge: LPE = B / 4 lanes, each owning ONE dword of the row = 4
-// permutations (NS = 4 atomics per edge and lane); below B = 4 one lane per edge uses NS = 2 | 1 bytes of its dword.  Every lane
-// handles U = 4 edges per iteration whatever LPE is, so an iteration of the block covers 1024 * 4 / LPE edges and the list
-// arrives in 16- and 32-byte pieces per lane.  The 16 / B passes of one edge chunk are separate blocks, CONSECUTIVE in the dispatch
-// order of ONE XCD (block id -> XCD id % 8): they walk the same chunk at the same time, so it crosses the fabric once per
-// chunk and batch and the other passes find it in that XCD's L2.  (The round-1 fallback this replaces, k_count_wide<8/4/2/1>,
-// walked the FULL CSR edge by edge with byte loads, one 16 / B-launch sequence per batch and no pipeline.)
+// out of LDS.  What changes with B is how many lanes share an edge: LPE = 2 lanes at B = 8, each owning ONE dword of the row = 4
+// permutations (NS = 4 atomics per edge and lane); one lane per edge from B = 4 down, using NS = 4 | 2 | 1 bytes of its dword.
+// Every lane handles U = 4 edges per iteration whatever LPE is, so a wavefront covers J = 64 / LPE edges per gather instruction,
+// 4 * J per iteration, and loads its list entries in 16- and 32-byte pieces per lane (entries 4j .. 4j + 3 of slot j).
+// WHICH edges a gather instruction covers decides what the kernel costs (PMC, round 5: with entry 4j + u in instruction u — every
+// fourth edge of a 128- or 256-edge run — the 32 or 64 label rows of one instruction spread over 4x and 8x the cache lines of
+// k_count's 16 rows and the L1 access rate, k_count's own limiter, capped the kernel at 3.2x k_count's time per permutation).
+// The list is therefore read in a permuted order (sqgr_graph::pass_list): instruction u of slot j gets entry
+// (u/R)*(J*R) + j*R + u%R of its group, R = 1: J consecutive edges per instruction.
+// The 16 / B passes of one edge chunk are separate blocks, CONSECUTIVE in the dispatch order of ONE XCD (block id -> XCD id % 8):
+// they walk the same chunk at the same time, so it crosses the fabric once per chunk and batch and the other passes find it in
+// that XCD's L2 (PMC: L2 hit rate 0.70 / 0.86 / 0.97 at 2 / 4 / 16 passes, fabric reads 1.4x k_count's whatever the number of
+// passes).  (The round-1 fallback this replaces, k_count_wide<8/4/2/1>, walked the FULL CSR edge by edge with byte loads, one
+// 16 / B-launch sequence per batch and no pipeline.)
 template <int LPE, int NS, bool SELF>
 __global__ __launch_bounds__(COUNT_THREADS, 4) void k_count_pass(uint32_t nnz, const int2* __restrict__ coo,
                                                                  const uint8_t* __restrict__ slab_all, int64_t n, int K,
                                                                  uint32_t edges_per_chunk, uint32_t self_begin, int add_transposed,
-                                                                 int nchunks, uint32_t* __restrict__ partial_all) {
+                                                                 int nchunks, uint32_t R, uint32_t* __restrict__ partial_all) {
     extern __shared__ uint32_t hist[];
-    static_assert((LPE == 4 || LPE == 2 || LPE == 1) && (NS == 4 || NS == 2 || NS == 1) && (NS == 4 || LPE == 1), "shape");
+    static_assert((LPE == 2 || LPE == 1) && (NS == 4 || NS == 2 || NS == 1) && (NS == 4 || LPE == 1), "shape");
     constexpr int B = NS == 4 ? LPE * 4 : NS;  // permutations per pass
     constexpr int P = 16 / B;                  // passes per batch of 16
     constexpr int U = 4;
+    constexpr uint32_t J = 64 / LPE;           // edge slots of a wavefront
     constexpr uint32_t STEP = (COUNT_THREADS / LPE) * U;
     static_assert(6 * STEP + 2 * U <= LIST_PAD, "look-ahead exceeds the padding of the edge lists");
     const int tid = threadIdx.x;
@@ -671,18 +720,21 @@ __global__ __launch_bounds__(COUNT_THREADS, 4) void k_count_pass(uint32_t nnz, c
         pass = blockIdx.x % P;
         chunk = blockIdx.x / P;
     }
-    const int b0 = pass * B;                             // first permutation (byte of the 16-byte row) of this pass
-    const uint8_t* slab = slab_all + (size_t)blockIdx.y * n * 16 + (b0 & ~3);
-    const uint32_t base_byte = (uint32_t)b0 & 3u;        // NS < 4: where the pass's bytes start inside the lane's dword
+    const int b0 = pass * B;                             // first permutation of this pass
+    const uint8_t* slab = slab_all + (size_t)blockIdx.y * n * 16 + (size_t)pass * n * B;  // the pass's plane [n][B] (slab_store16)
+    constexpr uint32_t base_byte = 0;
     const uint32_t e0 = (uint32_t)chunk * edges_per_chunk;
     const uint32_t e1 = min(nnz, e0 + edges_per_chunk);
     const bool uniform_block = (e0 + edges_per_chunk <= nnz) && (!SELF || e0 + edges_per_chunk <= self_begin);
     const uint32_t q = tid & 3;
-    const uint32_t d = LPE == 4 ? q : (LPE == 2 ? (q & 1u) : 0u);   // the lane's dword inside the pass
+    const uint32_t d = LPE == 2 ? (q & 1u) : 0u;   // the lane's dword inside the pass
     const uint32_t qoff = d * 4;
-    const uint32_t el = LPE == 4 ? (uint32_t)tid >> 2 : (LPE == 2 ? (uint32_t)tid >> 1 : (uint32_t)tid);  // stagger of the byte order
-    // first edge of this lane inside an iteration's STEP edges
-    const uint32_t lane_edge = LPE == 4 ? ((uint32_t)tid >> 2) * 4 : (LPE == 2 ? ((uint32_t)tid >> 2) * 8 + (q >> 1) * 4 : (uint32_t)tid * 4);
+    const uint32_t lane = (uint32_t)tid & 63u, wave = (uint32_t)tid >> 6;
+    const uint32_t slot = LPE == 2 ? 2 * (lane >> 2) + (q >> 1) : lane;  // edge slot j of this lane inside its wavefront
+    const uint32_t el = LPE == 2 ? (uint32_t)tid >> 1 : (uint32_t)tid;   // stagger of the byte order
+    uint32_t lane_log[U];  // where the lane's U edges lie in the list's own order (tails only), relative to the iteration's first edge
+#pragma unroll
+    for (int u = 0; u < U; ++u) lane_log[u] = wave * (4 * J) + ((uint32_t)u / R) * (J * R) + slot * R + ((uint32_t)u % R);
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)hist;
     uint32_t bank_ofs[NS], sel[NS];
 #pragma unroll
@@ -694,17 +746,15 @@ __global__ __launch_bounds__(COUNT_THREADS, 4) void k_count_pass(uint32_t nnz, c
     const uint32_t dot_k = ((uint32_t)(K * B * 4) << 16) | (uint32_t)(B * 4);  // {hi: bytes per la row, lo: bytes per pair}
 
     struct Pairs { uint32_t r[U], c[U]; };
-    struct Loaded { int4 v[LPE == 1 ? 2 : 1]; };  // LPE 4: one pair (x, y); LPE 2: two pairs; LPE 1: four pairs
-    auto load_pair = [&](uint32_t e) {            // e: first edge of the block's iteration
+    struct Loaded { int4 v[LPE == 1 ? 2 : 1]; };  // LPE 2: two entries; LPE 1: four entries
+    auto load_pair = [&](uint32_t e) {            // e: first edge of the block's iteration; physical entries 4 * slot .. + 3 of the wavefront's group
         Loaded L;
-        if constexpr (LPE == 4) {
-            const int2 v = coo[e + ((uint32_t)tid >> 2) * 4 + q];
-            L.v[0] = make_int4(v.x, v.y, 0, 0);
-        } else if constexpr (LPE == 2) {
-            L.v[0] = *reinterpret_cast<const int4*>(coo + e + ((uint32_t)tid >> 2) * 8 + q * 2);
+        const int2* grp = coo + e + wave * (4 * J);
+        if constexpr (LPE == 2) {
+            L.v[0] = *reinterpret_cast<const int4*>(grp + lane * 2);  // the quad's 8 entries: lane q holds entries 2q, 2q + 1
         } else {
-            L.v[0] = *reinterpret_cast<const int4*>(coo + e + (uint32_t)tid * 4);
-            L.v[1] = *reinterpret_cast<const int4*>(coo + e + (uint32_t)tid * 4 + 2);
+            L.v[0] = *reinterpret_cast<const int4*>(grp + lane * 4);
+            L.v[1] = *reinterpret_cast<const int4*>(grp + lane * 4 + 2);
         }
         return L;
     };
@@ -712,13 +762,8 @@ __global__ __launch_bounds__(COUNT_THREADS, 4) void k_count_pass(uint32_t nnz, c
     asm("v_add_u32_dpp %0, %1, %2 quad_perm:[" sel "] row_mask:0xf bank_mask:0xf" : "=v"(dst) : "v"(src), "v"(qoff))
     auto spread = [&](const Loaded& L) {
         Pairs pr;
-        if constexpr (LPE == 4) {
-            SQGR_ADD_DPP(pr.r[0], L.v[0].x, "0,0,0,0"); SQGR_ADD_DPP(pr.c[0], L.v[0].y, "0,0,0,0");
-            SQGR_ADD_DPP(pr.r[1], L.v[0].x, "1,1,1,1"); SQGR_ADD_DPP(pr.c[1], L.v[0].y, "1,1,1,1");
-            SQGR_ADD_DPP(pr.r[2], L.v[0].x, "2,2,2,2"); SQGR_ADD_DPP(pr.c[2], L.v[0].y, "2,2,2,2");
-            SQGR_ADD_DPP(pr.r[3], L.v[0].x, "3,3,3,3"); SQGR_ADD_DPP(pr.c[3], L.v[0].y, "3,3,3,3");
-        } else if constexpr (LPE == 2) {
-            // the quad's 8 edges: lane q loaded edges 2q, 2q+1; lanes {0, 1} handle edges 0..3, lanes {2, 3} edges 4..7
+        if constexpr (LPE == 2) {
+            // lanes {0, 1} of the quad handle its entries 0..3 (slot 2t), lanes {2, 3} its entries 4..7 (slot 2t + 1)
             SQGR_ADD_DPP(pr.r[0], L.v[0].x, "0,0,2,2"); SQGR_ADD_DPP(pr.c[0], L.v[0].y, "0,0,2,2");
             SQGR_ADD_DPP(pr.r[1], L.v[0].z, "0,0,2,2"); SQGR_ADD_DPP(pr.c[1], L.v[0].w, "0,0,2,2");
             SQGR_ADD_DPP(pr.r[2], L.v[0].x, "1,1,3,3"); SQGR_ADD_DPP(pr.c[2], L.v[0].y, "1,1,3,3");
@@ -732,9 +777,17 @@ __global__ __launch_bounds__(COUNT_THREADS, 4) void k_count_pass(uint32_t nnz, c
 #undef SQGR_ADD_DPP
     auto gather_rows = [&](const Pairs& pr, uint32_t (&ra)[U], uint32_t (&rb)[U]) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            ra[u] = *reinterpret_cast<const uint32_t*>(slab + pr.r[u]);
-            rb[u] = *reinterpret_cast<const uint32_t*>(slab + pr.c[u]);
+        for (int u = 0; u < U; ++u) {  // list entries of a pass list are byte offsets into a plane: B * spot
+            if constexpr (NS == 4) {
+                ra[u] = *reinterpret_cast<const uint32_t*>(slab + pr.r[u]);
+                rb[u] = *reinterpret_cast<const uint32_t*>(slab + pr.c[u]);
+            } else if constexpr (NS == 2) {
+                ra[u] = *reinterpret_cast<const uint16_t*>(slab + pr.r[u]);
+                rb[u] = *reinterpret_cast<const uint16_t*>(slab + pr.c[u]);
+            } else {
+                ra[u] = slab[pr.r[u]];
+                rb[u] = slab[pr.c[u]];
+            }
         }
     };
     auto histogram = [&](const uint32_t (&row_a)[U], const uint32_t (&row_b)[U], uint32_t eb, auto general_tag) {
@@ -744,8 +797,9 @@ __global__ __launch_bounds__(COUNT_THREADS, 4) void k_count_pass(uint32_t nnz, c
         for (int u = 0; u < U; ++u) {
             uint32_t inc = SELF ? 2u : 1u;
             if constexpr (GENERAL) {  // branch-free tail: out-of-range edges add 0, self loops 1
-                inc = (eb + u < e1) ? 1u : 0u;
-                if constexpr (SELF) inc += (eb + u < min(e1, self_begin)) ? 1u : 0u;
+                const uint32_t idx = eb + lane_log[u];
+                inc = (idx < e1) ? 1u : 0u;
+                if constexpr (SELF) inc += (idx < min(e1, self_begin)) ? 1u : 0u;
             }
             uint32_t addr[NS];
 #pragma unroll
@@ -782,7 +836,7 @@ __global__ __launch_bounds__(COUNT_THREADS, 4) void k_count_pass(uint32_t nnz, c
                 pr[(st + 2) % 3] = load_pair(e + (st + 2) * STEP);
                 gather_rows(spread(pr[st]), ra[st], rb[st]);
                 if (j + st >= 2 && j + st - 2 < T)
-                    histogram(ra[(st + 1) % 3], rb[(st + 1) % 3], e + st * STEP - 2 * STEP + lane_edge, general_tag);
+                    histogram(ra[(st + 1) % 3], rb[(st + 1) % 3], e + st * STEP - 2 * STEP, general_tag);
             }
             e += 3 * STEP;
         }
@@ -794,14 +848,17 @@ __global__ __launch_bounds__(COUNT_THREADS, 4) void k_count_pass(uint32_t nnz, c
         else
             sweep(std::true_type{});
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the inline-asm atomics are invisible to the compiler's wait counts (see k_count)
     __syncthreads();
     // the pass's B columns of the chunk's partial histogram [pair][16]
     uint32_t* dst = partial_all + ((size_t)blockIdx.y * nchunks + chunk) * ((size_t)K * K * 16) + b0;
+    const float inv_k = 1.0f / (float)K;  // pair / K without an integer division: (pair + 0.5) / K is at least 0.5 / K away from an
+                                          // integer, the float product is off by < 2^-22 * K (pair < 2^16, K <= 202)
     for (int i = tid; i < hist_words; i += COUNT_THREADS) {
         const int pair = i / B, b = i - pair * B;
         uint32_t v = hist[i];
         if (add_transposed) {
-            const int la = pair / K, lb = pair - la * K;
+            const int la = (int)(((float)pair + 0.5f) * inv_k), lb = pair - la * K;
             v += hist[(lb * K + la) * B + b];
         }
         dst[(size_t)pair * 16 + b] = v;
@@ -976,15 +1033,20 @@ __global__ __launch_bounds__(64) void k_sum_partials(const double* __restrict__ 
 template <int B, bool HAS_LIBS>
 __global__ __launch_bounds__(256) void k_columns_to_slab(int64_t n, int64_t stride, const uint8_t* __restrict__ W, int64_t p0,
                                                          const int32_t* __restrict__ lib_of, const int32_t* __restrict__ rank_of,
-                                                         const uint32_t* __restrict__ lib_off, uint8_t* __restrict__ slab_all) {
+                                                         const uint32_t* __restrict__ lib_off, uint8_t* __restrict__ slab_all, int pw) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int batch = blockIdx.y;
     const int64_t pos = HAS_LIBS ? (int64_t)lib_off[lib_of[i]] + rank_of[i] : i;
     const uint4* src = reinterpret_cast<const uint4*>(W + pos * stride + p0 + (int64_t)batch * B);  // 16-byte aligned
-    uint4* dst = reinterpret_cast<uint4*>(slab_all + ((size_t)batch * n + i) * B);
+    if constexpr (B == 16) {
+        const uint4 v = src[0];
+        slab_store16(slab_all + (size_t)batch * n * 16, n, i, pw, v.x, v.y, v.z, v.w);
+    } else {
+        uint4* dst = reinterpret_cast<uint4*>(slab_all + ((size_t)batch * n + i) * B);
 #pragma unroll
-    for (int v = 0; v < B / 16; ++v) dst[v] = src[v];
+        for (int v = 0; v < B / 16; ++v) dst[v] = src[v];
+    }
 }
 
 // rows of the numpy-stream shuffle -> slab rows of the batched count kernel, without the column matrix in between (no libraries:
@@ -993,7 +1055,7 @@ __global__ __launch_bounds__(256) void k_columns_to_slab(int64_t n, int64_t stri
 // (v_perm_b32), 4 slab rows = 4*B contiguous bytes out.  Rows past `pc` read as label 0 (consumers read whole batches).
 template <int B>
 __global__ __launch_bounds__(256) void k_rows_to_slab(int64_t n, int64_t row_stride, const uint8_t* __restrict__ R, int64_t q0, int64_t pc,
-                                                      uint8_t* __restrict__ slab_all) {
+                                                      uint8_t* __restrict__ slab_all, int pw) {
     const int64_t i4 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4;
     if (i4 >= n) return;
     const int batch = blockIdx.y;
@@ -1013,6 +1075,10 @@ __global__ __launch_bounds__(256) void k_rows_to_slab(int64_t n, int64_t row_str
         for (int k = 0; k < B / 4; ++k) {
             const uint32_t lo = __byte_perm(v[4 * k], v[4 * k + 1], sel), hi = __byte_perm(v[4 * k + 2], v[4 * k + 3], sel);
             w[k] = __byte_perm(lo, hi, 0x5410);
+        }
+        if (B == 16 && pw != 16) {  // planes of the pass kernel
+            slab_store16(slab_all + (size_t)batch * n * 16, n, i4 + sp, pw, w[0], w[1], w[2], w[3]);
+            continue;
         }
 #pragma unroll
         for (int k = 0; k < B / 16; ++k)
@@ -1125,6 +1191,8 @@ struct sqgr_nhood {
     }
     bool lds_path() const { return !wide() && (B == 32 || be() > 0); }  // block-local LDS histograms, (half) edge list
     int passes() const { return (B == 16 && !wide() && be() > 0) ? 16 / be() : 1; }
+    // layout of a batch's 16 * n slab bytes: 16 = rows [n][16]; 8 | 4 | 2 | 1 = 16 / w planes [n][w], one per pass (slab_store16)
+    int plane_w() const { return (B == 16 && !wide() && be() > 0) ? be() : 16; }
     // 1024-thread blocks per batch of a launch with `nb` batches = edge chunks per batch (k_count_pass: times `passes()` blocks).
     // nblk > 0: fixed by sqgr_nhood_tune.  Auto: ~8 blocks per CU over the whole launch, at least 32 per batch — measured on MI355X
     // (tools/tune_sweep.sh): with 64 batches in flight 32-48 blocks per batch beat one block per CU by 15 % (fewer partial
@@ -1218,12 +1286,16 @@ int sqgr_nhood::count_batches(int nb, int buf) {
         // 51 <= K <= 202: passes of be permutations over the (half) edge list, the passes of a chunk side by side on one XCD
         SQGR_TRY(g->ensure_half());
         const bool half = g->sym_state == 1;
-        const int2* list = half ? g->half.p : g->coo.p;
         const uint32_t m = (uint32_t)(half ? g->n_half + g->n_self : nnz);
         const uint32_t self_begin = (uint32_t)(half ? g->n_half : nnz);
         const bool self = half && g->n_self > 0;
         sym_launch = self ? 2 : 0;
         const int e = be();
+        // order of the list inside a wavefront's group of entries (sqgr_graph::pass_list): R = 1 — a gather instruction covers
+        // consecutive edges — unless SQGR_COUNT_PASS_R says 2 or 4 (experiments; 4 = the list as it is)
+        static const int order_r = [] { const char* v = getenv("SQGR_COUNT_PASS_R"); const int r = v ? atoi(v) : 1; return (r == 2 || r == 4) ? r : 1; }();
+        const int2* list = nullptr;
+        SQGR_TRY(g->pass_list(e >= 8 ? 32 : 64, order_r, e, &list));
         const uint32_t step = (uint32_t)(COUNT_THREADS * 4 / (e >= 8 ? 2 : 1));             // edges per iteration of a block
         const uint32_t epc = (uint32_t)(ceil_div(ceil_div((int64_t)m, nblk), step) * step);  // whole iterations per chunk
         const size_t lds = (size_t)K2 * e * 4;
@@ -1233,10 +1305,10 @@ int sqgr_nhood::count_batches(int nb, int buf) {
     do {                                                                                                                          \
         if (self) {                                                                                                               \
             SQGR_TRY(allow_lds(k_count_pass<LPE, NS, true>, lds));                                                                \
-            k_count_pass<LPE, NS, true><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, epc, self_begin, half ? 1 : 0, nblk, partial.p); \
+            k_count_pass<LPE, NS, true><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, epc, self_begin, half ? 1 : 0, nblk, (uint32_t)order_r, partial.p); \
         } else {                                                                                                                  \
             SQGR_TRY(allow_lds(k_count_pass<LPE, NS, false>, lds));                                                               \
-            k_count_pass<LPE, NS, false><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, epc, self_begin, half ? 1 : 0, nblk, partial.p); \
+            k_count_pass<LPE, NS, false><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, epc, self_begin, half ? 1 : 0, nblk, (uint32_t)order_r, partial.p); \
         }                                                                                                                         \
     } while (0)
         switch (e) {
@@ -1608,7 +1680,7 @@ int sqgr_nhood_tune(sqgr_nhood* plan, int32_t perms_per_pass, int32_t blocks_per
     return SQGR_OK;
 }
 
-static int launch_shuffle_raw(sqgr_nhood* p, int B, int nb, const uint32_t* keys, uint8_t* slab, hipStream_t st) {
+static int launch_shuffle_raw(sqgr_nhood* p, int B, int nb, const uint32_t* keys, uint8_t* slab, hipStream_t st, int pw = 16) {
     unsigned gx = (unsigned)ceil_div(p->n, 256);
     // ~96 blocks per CU over all batches of the launch, each walking several spots (grid stride): amortises the LDS table
     // set-up and the key loads — measured 7 % faster on MI355X than one block per 256 spots (tools/shuf_sweep.sh)
@@ -1639,7 +1711,7 @@ static int launch_shuffle_raw(sqgr_nhood* p, int B, int nb, const uint32_t* keys
     const unsigned gy = (unsigned)(B == 32 ? nb : (nb + 1) / 2);  // 16-permutation rows are shuffled in pairs
 #define SQGR_SHUFFLE(BB, LIBS, SK)                                                                                               \
     k_shuffle<BB, LIBS, SK><<<dim3(gx, gy), 256, lds, st>>>(p->n, p->cum.p, p->kpad, p->blk_bytes, p->K, keys, p->dom0, p->n_libs, nb, \
-                                                            p->lib_of.p, p->rank_of.p, p->libs.p, slab)
+                                                            p->lib_of.p, p->rank_of.p, p->libs.p, slab, pw)
 #define SQGR_SHUFFLE_K(BB, LIBS) \
     if (p->K <= 126) SQGR_SHUFFLE(BB, LIBS, true); else SQGR_SHUFFLE(BB, LIBS, false)
     if (B == 32) {
@@ -1654,7 +1726,7 @@ static int launch_shuffle_raw(sqgr_nhood* p, int B, int nb, const uint32_t* keys
 }
 
 static int launch_shuffle(sqgr_nhood* p, int nb, int buf, hipStream_t st) {
-    return launch_shuffle_raw(p, p->B, nb, p->keys.p + (size_t)buf * p->keys_stride(), p->slab.p + (size_t)buf * p->slab_stride(), st);
+    return launch_shuffle_raw(p, p->B, nb, p->keys.p + (size_t)buf * p->keys_stride(), p->slab.p + (size_t)buf * p->slab_stride(), st, p->plane_w());
 }
 
 int sqgr_nhood_run(sqgr_nhood* plan, uint64_t seed, int64_t perm_begin, int64_t perm_end, const int64_t* shift,
@@ -1747,7 +1819,10 @@ int sqgr_nhood_shuffled_labels(sqgr_nhood* plan, uint64_t seed, int64_t perm, ui
     std::vector<uint8_t> rows((size_t)p->n * B);
     SQGR_HIP(hipMemcpyAsync(rows.data(), p->slab.p, rows.size(), hipMemcpyDeviceToHost, st));
     SQGR_HIP(hipStreamSynchronize(st));
-    for (int64_t i = 0; i < p->n; ++i) out_labels[i] = rows[(size_t)i * B + (size_t)(perm - perm_row)];
+    const int pw = p->plane_w(), slot = (int)(perm - perm_row);
+    for (int64_t i = 0; i < p->n; ++i)
+        out_labels[i] = pw == 16 || B != 16 ? rows[(size_t)i * B + (size_t)slot]
+                                            : rows[(size_t)(slot / pw) * p->n * pw + (size_t)i * pw + (size_t)(slot % pw)];
     return SQGR_OK;
 }
 
@@ -1780,9 +1855,9 @@ int sqgr_nhood_counts_batch(sqgr_ctx* ctx, const sqgr_graph* g, const uint8_t* l
             {
                 LaunchTimer t(ctx, "nhood_transpose_labels");
                 if (B == 32)
-                    k_transpose_labels<32><<<dim3((unsigned)ceil_div(n, 256), nb), 256, 0, st>>>(n, p->stage.p, todo, p->slab.p);
+                    k_transpose_labels<32><<<dim3((unsigned)ceil_div(n, 256), nb), 256, 0, st>>>(n, p->stage.p, todo, p->slab.p, 16);
                 else
-                    k_transpose_labels<16><<<dim3((unsigned)ceil_div(n, 256), nb), 256, 0, st>>>(n, p->stage.p, todo, p->slab.p);
+                    k_transpose_labels<16><<<dim3((unsigned)ceil_div(n, 256), nb), 256, 0, st>>>(n, p->stage.p, todo, p->slab.p, p->plane_w());
             }
             if ((rc = p->count_batches(nb, 0)) != SQGR_OK) break;
             if ((rc = p->reduce_batches(nb, p0, 0, n_perms, p->perms_dev.p)) != SQGR_OK) break;
@@ -1886,13 +1961,13 @@ static int run_pcg64_impl(sqgr_nhood* plan, const uint64_t* pcg_states, int64_t 
                 if (via_rows) {
                     LaunchTimer t(ctx, "nhood_rows_to_slab");
                     dim3 grid((unsigned)ceil_div(ceil_div(n, 4), 256), nb);
-                    if (B == 32) k_rows_to_slab<32><<<grid, 256, 0, st>>>(n, row_stride, p->pcg_ws.rows.p, q0, pc, p->slab.p);
-                    else k_rows_to_slab<16><<<grid, 256, 0, st>>>(n, row_stride, p->pcg_ws.rows.p, q0, pc, p->slab.p);
+                    if (B == 32) k_rows_to_slab<32><<<grid, 256, 0, st>>>(n, row_stride, p->pcg_ws.rows.p, q0, pc, p->slab.p, 16);
+                    else k_rows_to_slab<16><<<grid, 256, 0, st>>>(n, row_stride, p->pcg_ws.rows.p, q0, pc, p->slab.p, p->plane_w());
                     SQGR_HIP(hipGetLastError());
                 } else {
                     LaunchTimer t(ctx, "nhood_columns_to_slab");
                     dim3 grid((unsigned)ceil_div(n, 256), nb);
-    #define SQGR_C2S(BB, LIBS) k_columns_to_slab<BB, LIBS><<<grid, 256, 0, st>>>(n, stride, p->wcol.p, q0, p->lib_of.p, p->rank_of.p, p->lib_off.p, p->slab.p)
+    #define SQGR_C2S(BB, LIBS) k_columns_to_slab<BB, LIBS><<<grid, 256, 0, st>>>(n, stride, p->wcol.p, q0, p->lib_of.p, p->rank_of.p, p->lib_off.p, p->slab.p, p->plane_w())
                     if (B == 32) { if (p->has_libs) SQGR_C2S(32, true); else SQGR_C2S(32, false); }
                     else { if (p->has_libs) SQGR_C2S(16, true); else SQGR_C2S(16, false); }
     #undef SQGR_C2S

@@ -73,5 +73,7 @@ if "--sweep" in sys.argv:
                 for nbatch in (0, 64):
                     measure(K, (w, blocks, nbatch) if (w or blocks or nbatch) else None, reps=1)
 else:
-    for K in (30, 50, 51, 64, 71, 72, 100, 101, 102, 150, 200, 202, 203, 256):
-        measure(K)
+    ks = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--K=")] or [30, 50, 51, 64, 71, 72, 100, 101, 102, 150, 200, 202, 203, 256]
+    tune = [tuple(int(v) for v in a.split("=")[1].split(",")) for a in sys.argv if a.startswith("--tune=")]
+    for K in ks:
+        measure(K, tune[0] if tune else None)
