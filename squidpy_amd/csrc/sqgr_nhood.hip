@@ -692,25 +692,24 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
 // that XCD's L2 (PMC: L2 hit rate 0.70 / 0.86 / 0.97 at 2 / 4 / 16 passes, fabric reads 1.4x k_count's whatever the number of
 // passes).  (The round-1 fallback this replaces, k_count_wide<8/4/2/1>, walked the FULL CSR edge by edge with byte loads, one
 // 16 / B-launch sequence per batch and no pipeline.)
-template <int LPE, int NS, bool SELF>
+// SPLIT = 2 (203 <= K <= 256: not even one permutation's K*K counters fit): a block keeps the rows la of one HALF of the labels
+// only and skips the other edges' atomics — twice the blocks, every one of them walking the whole chunk; h + h^T is then formed
+// by k_reduce (sym bit 2), a block does not hold the transposed rows.
+template <int LPE, int NS, bool SELF, int SPLIT = 1>
 __global__ __launch_bounds__(COUNT_THREADS, 4) void k_count_pass(uint32_t nnz, const int2* __restrict__ coo,
                                                                  const uint8_t* __restrict__ slab_all, int64_t n, int K,
                                                                  uint32_t edges_per_chunk, uint32_t self_begin, int add_transposed,
                                                                  int nchunks, uint32_t R, uint32_t* __restrict__ partial_all) {
     extern __shared__ uint32_t hist[];
-    static_assert((LPE == 2 || LPE == 1) && (NS == 4 || NS == 2 || NS == 1) && (NS == 4 || LPE == 1), "shape");
+    static_assert((LPE == 2 || LPE == 1) && (NS == 4 || NS == 2 || NS == 1) && (NS == 4 || LPE == 1) && (SPLIT == 1 || NS == 1), "shape");
     constexpr int B = NS == 4 ? LPE * 4 : NS;  // permutations per pass
-    constexpr int P = 16 / B;                  // passes per batch of 16
+    constexpr int P = (16 / B) * SPLIT;        // blocks per chunk and batch of 16: passes x row halves
     constexpr int U = 4;
     constexpr uint32_t J = 64 / LPE;           // edge slots of a wavefront
     constexpr uint32_t STEP = (COUNT_THREADS / LPE) * U;
     static_assert(6 * STEP + 2 * U <= LIST_PAD, "look-ahead exceeds the padding of the edge lists");
     const int tid = threadIdx.x;
-    const int hist_words = K * K * B;
-    for (int i = tid; i < hist_words; i += COUNT_THREADS) hist[i] = 0;
-    __syncthreads();
-
-    // block -> (chunk, pass): XCD x takes the x-th eighth of the chunks and runs the P passes of a chunk back to back
+    // block -> (chunk, pass[, half]): XCD x takes the x-th eighth of the chunks and runs the P blocks of a chunk back to back
     int chunk, pass;
     if ((nchunks & 7) == 0) {
         const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -720,7 +719,13 @@ __global__ __launch_bounds__(COUNT_THREADS, 4) void k_count_pass(uint32_t nnz, c
         pass = blockIdx.x % P;
         chunk = blockIdx.x / P;
     }
-    const int b0 = pass * B;                             // first permutation of this pass
+    const int half = pass % SPLIT;
+    pass /= SPLIT;
+    const int Kh = (K + SPLIT - 1) / SPLIT, a0 = half * Kh;          // this block's rows of the histogram: la in [a0, a0 + rows)
+    const int rows = min(Kh, K - a0);
+    const int hist_words = rows * K * B;
+    for (int i = tid; i < hist_words; i += COUNT_THREADS) hist[i] = 0;
+    __syncthreads();
     const uint8_t* slab = slab_all + (size_t)blockIdx.y * n * 16 + (size_t)pass * n * B;  // the pass's plane [n][B] (slab_store16)
     constexpr uint32_t base_byte = 0;
     const uint32_t e0 = (uint32_t)chunk * edges_per_chunk;
@@ -740,7 +745,7 @@ __global__ __launch_bounds__(COUNT_THREADS, 4) void k_count_pass(uint32_t nnz, c
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const uint32_t byte = (s + el) & (NS - 1);
-        bank_ofs[s] = (d * NS + byte) * 4 + lds_base;
+        bank_ofs[s] = (d * NS + byte) * 4 + lds_base - (uint32_t)(a0 * K * B * 4);  // (wraps; row a0 lands on the first counter)
         sel[s] = 0x0c000c00u | ((4u + base_byte + byte) << 16) | (base_byte + byte);  // b row byte -> bits 0..7, a row byte -> bits 16..23
     }
     const uint32_t dot_k = ((uint32_t)(K * B * 4) << 16) | (uint32_t)(B * 4);  // {hi: bytes per la row, lo: bytes per pair}
@@ -813,7 +818,9 @@ __global__ __launch_bounds__(COUNT_THREADS, 4) void k_count_pass(uint32_t nnz, c
                              : "memory");
             else if constexpr (NS == 2)
                 asm volatile("ds_add_u32 %0, %2\n\tds_add_u32 %1, %2" : : "v"(addr[0]), "v"(addr[1]), "v"(inc) : "memory");
-            else
+            else if constexpr (SPLIT == 1)
+                asm volatile("ds_add_u32 %0, %1" : : "v"(addr[0]), "v"(inc) : "memory");
+            else if (addr[0] - lds_base < (uint32_t)hist_words * 4u)  // la in this block's half of the rows (unsigned: rows below a0 wrap)
                 asm volatile("ds_add_u32 %0, %1" : : "v"(addr[0]), "v"(inc) : "memory");
         }
     };
@@ -850,18 +857,20 @@ __global__ __launch_bounds__(COUNT_THREADS, 4) void k_count_pass(uint32_t nnz, c
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the inline-asm atomics are invisible to the compiler's wait counts (see k_count)
     __syncthreads();
-    // the pass's B columns of the chunk's partial histogram [pair][16]
-    uint32_t* dst = partial_all + ((size_t)blockIdx.y * nchunks + chunk) * ((size_t)K * K * 16) + b0;
+    // the chunk's partial histogram is [16 / B planes][pair][B] (k_reduce's slot order): a block writes ONE contiguous run — its
+    // plane, or its half of the plane's rows (first version: [pair][16] with the pass's B columns scattered into it — 4 bytes
+    // per 64-byte line at B = 1, 7.4 GB of write traffic per 2560 permutations at K = 200 instead of 3.3)
+    uint32_t* dst = partial_all + ((size_t)blockIdx.y * nchunks + chunk) * ((size_t)K * K * 16) + (size_t)pass * K * K * B + (size_t)a0 * K * B;
     const float inv_k = 1.0f / (float)K;  // pair / K without an integer division: (pair + 0.5) / K is at least 0.5 / K away from an
-                                          // integer, the float product is off by < 2^-22 * K (pair < 2^16, K <= 202)
+                                          // integer, the float product is off by < 2^-22 * K (pair < 2^16, K <= 256)
     for (int i = tid; i < hist_words; i += COUNT_THREADS) {
-        const int pair = i / B, b = i - pair * B;
         uint32_t v = hist[i];
-        if (add_transposed) {
+        if (SPLIT == 1 && add_transposed) {
+            const int pair = i / B, b = i - pair * B;
             const int la = (int)(((float)pair + 0.5f) * inv_k), lb = pair - la * K;
             v += hist[(lb * K + la) * B + b];
         }
-        dst[(size_t)pair * 16 + b] = v;
+        dst[i] = v;
     }
 }
 
@@ -890,68 +899,83 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_global(int64_t nnz, con
 }
 
 // ---------------------------------------------------------------------------------------------- reduction
-// word w = pair*B + b.  acc slots are private to (batch, w): no atomics, bit-reproducible.
-// 256 threads = 64 words x 4 slices of the block loop (combined through LDS).
-// sym: 0 the partials hold the counts (for half lists k_count has already formed h + h^T per block);
-//      2 they hold them in doubled units (half lists with self loops): count = sum / 2.
-__global__ __launch_bounds__(256) void k_reduce(const uint32_t* __restrict__ partial_all, int nblk, int hist_words, int B,
+// Partial histograms and accumulator slots of a batch are laid out [16 / pw planes][pair][pw]: slot j <-> permutation
+// b = (j / (K2 * pw)) * pw + j % pw of pair (j / pw) % K2 — pw = B (one plane, word = pair * B + b) for k_count and the
+// device-scope kernels, pw = the pass width for k_count_pass, whose blocks each write ONE contiguous plane (or, for K > 202,
+// one half of its rows).  acc slots are private to (batch, j): no atomics, bit-reproducible.
+// 256 threads = 64 slots x 4 slices of the block loop (combined through LDS).
+// sym: bit 1 (value 2): the partials are in doubled units (half lists with self loops): count = sum / 2;
+//      bit 2 (value 4): the partials hold h of the half list, not h + h^T: the transposed pair's slot is added here (the
+//      pass kernel with split rows cannot form it in LDS).
+__global__ __launch_bounds__(256) void k_reduce(const uint32_t* __restrict__ partial_all, int nblk, int nsum, int hist_words, int B, int pw,
                                                 int K, int sym, const int64_t* __restrict__ shift, int64_t perm_batch0,
                                                 int64_t perm_begin, int64_t perm_end, int64_t* __restrict__ acc_sum,
                                                 uint64_t* __restrict__ acc_sq, uint32_t* __restrict__ perms_out) {
     __shared__ unsigned long long part[4][64];
     const int wl = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const int w = blockIdx.x * 64 + wl;
+    const int j = blockIdx.x * 64 + wl;
     const int batch = blockIdx.y;
     const int K2 = K * K;
+    int pair = 0, b = 0, jt = 0;
+    if (j < hist_words) {
+        const int plane = j / (K2 * pw), rem = j - plane * (K2 * pw);
+        pair = rem / pw;
+        b = plane * pw + (rem - pair * pw);
+        if (sym & 4) {
+            const int la = pair / K, lb = pair - la * K;
+            jt = plane * (K2 * pw) + (lb * K + la) * pw + (rem - pair * pw);
+        }
+    }
     unsigned long long c = 0;
-    if (w < hist_words) {
-        const uint32_t* src = partial_all + (size_t)batch * nblk * hist_words + w;
-        for (int k = slice; k < nblk; k += 4) c += src[(size_t)k * hist_words];
+    if (j < hist_words) {
+        const uint32_t* src = partial_all + (size_t)batch * nblk * hist_words;
+        for (int k = slice; k < nsum; k += 4) {  // nblk: partials per batch (stride); nsum: how many of them hold something to add
+            c += src[(size_t)k * hist_words + j];
+            if (sym & 4) c += src[(size_t)k * hist_words + jt];
+        }
     }
     part[slice][wl] = c;
     __syncthreads();
-    if (slice != 0 || w >= hist_words) return;
+    if (slice != 0 || j >= hist_words) return;
     c = part[0][wl] + part[1][wl] + part[2][wl] + part[3][wl];
-    if (sym == 2) c >>= 1;
-    const int pair = w / B, b = w % B;
+    if (sym & 2) c >>= 1;
     const int64_t p = perm_batch0 + (int64_t)batch * B + b;
     if (p >= perm_end || p < perm_begin) return;
     const int64_t d = (int64_t)c - shift[pair];
-    const size_t slot = (size_t)batch * hist_words + w;
+    const size_t slot = (size_t)batch * hist_words + j;
     acc_sum[slot] += d;
     acc_sq[slot] += (uint64_t)(d * d);
     if (perms_out) perms_out[(size_t)(p - perm_begin) * K2 + pair] = (uint32_t)c;
 }
 
-// one block per pair: sums the nbatch*B private slots (fixed order inside a thread, fixed tree across threads:
-// bit-reproducible, and integer addition is exact anyway)
+// thread per slot j of a batch: sums the slot over the batches (coalesced whatever the plane width), then adds into its pair's
+// total — 16 integer atomics per pair and moment; integer addition is exact and order-independent, so the result is
+// bit-reproducible.  out_sum / out_sq are zeroed by the caller.
 __global__ __launch_bounds__(256) void k_finalize(const int64_t* __restrict__ acc_sum, const uint64_t* __restrict__ acc_sq, int nbatch,
-                                                  int hist_words, int B, int K2, int64_t* __restrict__ out_sum,
+                                                  int hist_words, int pw, int K2, int64_t* __restrict__ out_sum,
                                                   uint64_t* __restrict__ out_sq) {
-    __shared__ int64_t s_s[256];
-    __shared__ uint64_t s_q[256];
-    const int pair = blockIdx.x;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= hist_words) return;
     int64_t s = 0;
     uint64_t q = 0;
-    for (int t = threadIdx.x; t < nbatch * B; t += 256) {
-        const size_t slot = (size_t)(t / B) * hist_words + (size_t)pair * B + (t % B);
-        s += acc_sum[slot];
-        q += acc_sq[slot];
+    for (int t = 0; t < nbatch; ++t) {
+        s += acc_sum[(size_t)t * hist_words + j];
+        q += acc_sq[(size_t)t * hist_words + j];
     }
-    s_s[threadIdx.x] = s;
-    s_q[threadIdx.x] = q;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) {
-            s_s[threadIdx.x] += s_s[threadIdx.x + off];
-            s_q[threadIdx.x] += s_q[threadIdx.x + off];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        out_sum[pair] = s_s[0];
-        out_sq[pair] = s_q[0];
-    }
+    const int pair = (j % (K2 * pw)) / pw;
+    atomicAdd(reinterpret_cast<unsigned long long*>(out_sum) + pair, (unsigned long long)s);
+    atomicAdd(reinterpret_cast<unsigned long long*>(out_sq) + pair, (unsigned long long)q);
+}
+
+// in place: chunk 0's partial of every batch becomes the sum over the batch's chunks (k_reduce with nsum = 1 then reads every
+// slot — and, for sym bit 2, its transposed twin — once instead of once per chunk)
+__global__ __launch_bounds__(256) void k_sum_chunks(uint32_t* __restrict__ partial_all, int nblk, int hist_words) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= hist_words) return;
+    uint32_t* src = partial_all + (size_t)blockIdx.y * nblk * hist_words + j;
+    uint32_t c = 0;
+    for (int k = 0; k < nblk; ++k) c += src[(size_t)k * hist_words];
+    src[0] = c;
 }
 
 // observed counts / interaction matrix: one pass, thread per edge
@@ -1187,10 +1211,13 @@ struct sqgr_nhood {
         const int cap = std::min(pass_cap, env_cap);
         for (int b : {16, 8, 4, 2, 1})
             if ((size_t)K2 * b * 4 <= LDS_BUDGET && b <= cap) return b;
+        if (!wide() && (size_t)((K + 1) / 2) * K * 4 <= LDS_BUDGET) return 1;  // half of the rows per block (split() == 2)
         return 0;
     }
+    int split() const { return (B == 16 && !wide() && be() == 1 && (size_t)K2 * 4 > LDS_BUDGET) ? 2 : 1; }
+    int partial_w() const { return (B == 16 && !wide() && be() > 0 && be() < 16) ? be() : B; }  // plane width of partials and accumulator slots
     bool lds_path() const { return !wide() && (B == 32 || be() > 0); }  // block-local LDS histograms, (half) edge list
-    int passes() const { return (B == 16 && !wide() && be() > 0) ? 16 / be() : 1; }
+    int passes() const { return (B == 16 && !wide() && be() > 0) ? (16 / be()) * split() : 1; }
     // layout of a batch's 16 * n slab bytes: 16 = rows [n][16]; 8 | 4 | 2 | 1 = 16 / w planes [n][w], one per pass (slab_store16)
     int plane_w() const { return (B == 16 && !wide() && be() > 0) ? be() : 16; }
     // 1024-thread blocks per batch of a launch with `nb` batches = edge chunks per batch (k_count_pass: times `passes()` blocks).
@@ -1298,8 +1325,10 @@ int sqgr_nhood::count_batches(int nb, int buf) {
         SQGR_TRY(g->pass_list(e >= 8 ? 32 : 64, order_r, e, &list));
         const uint32_t step = (uint32_t)(COUNT_THREADS * 4 / (e >= 8 ? 2 : 1));             // edges per iteration of a block
         const uint32_t epc = (uint32_t)(ceil_div(ceil_div((int64_t)m, nblk), step) * step);  // whole iterations per chunk
-        const size_t lds = (size_t)K2 * e * 4;
-        const dim3 grid(nblk * (16 / e), nb);
+        const int sp = split();
+        const size_t lds = (size_t)((K + sp - 1) / sp) * K * e * 4;
+        if (sp > 1 && half) sym_launch |= 4;  // h + h^T in k_reduce
+        const dim3 grid(nblk * (16 / e) * sp, nb);
         LaunchTimer t(ctx, half ? "nhood_count_pass_half" : "nhood_count_pass");
 #define SQGR_PASS(LPE, NS)                                                                                                        \
     do {                                                                                                                          \
@@ -1315,7 +1344,17 @@ int sqgr_nhood::count_batches(int nb, int buf) {
             case 8: SQGR_PASS(2, 4); break;
             case 4: SQGR_PASS(1, 4); break;
             case 2: SQGR_PASS(1, 2); break;
-            default: SQGR_PASS(1, 1); break;
+            default:
+                if (sp == 1) {
+                    SQGR_PASS(1, 1);
+                } else if (self) {
+                    SQGR_TRY(allow_lds((k_count_pass<1, 1, true, 2>), lds));
+                    k_count_pass<1, 1, true, 2><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, epc, self_begin, 0, nblk, (uint32_t)order_r, partial.p);
+                } else {
+                    SQGR_TRY(allow_lds((k_count_pass<1, 1, false, 2>), lds));
+                    k_count_pass<1, 1, false, 2><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, epc, self_begin, 0, nblk, (uint32_t)order_r, partial.p);
+                }
+                break;
         }
 #undef SQGR_PASS
     } else if (B == 32 || be() == 16) {
@@ -1391,7 +1430,12 @@ int sqgr_nhood::count_batches(int nb, int buf) {
 int sqgr_nhood::reduce_batches(int nb, int64_t perm_batch0, int64_t perm_begin, int64_t perm_end, uint32_t* perms_out_dev) {
     const int hw = hist_words();
     LaunchTimer t(ctx, "nhood_reduce");
-    k_reduce<<<dim3((unsigned)ceil_div(hw, 64), nb), 256, 0, ctx->stream>>>(partial.p, nblk_launch, hw, B, K, sym_launch, shift.p,
+    int nsum = nblk_launch;
+    if ((sym_launch & 4) && nblk_launch > 1) {  // the transposed reads are scattered: do them once per slot, not once per chunk
+        k_sum_chunks<<<dim3((unsigned)ceil_div(hw, 256), nb), 256, 0, ctx->stream>>>(partial.p, nblk_launch, hw);
+        nsum = 1;
+    }
+    k_reduce<<<dim3((unsigned)ceil_div(hw, 64), nb), 256, 0, ctx->stream>>>(partial.p, nblk_launch, nsum, hw, B, partial_w(), K, sym_launch, shift.p,
                                                                             perm_batch0, perm_begin, perm_end, acc_sum.p,
                                                                             acc_sq.p, perms_out_dev);
     SQGR_HIP(hipGetLastError());
@@ -1784,8 +1828,9 @@ int sqgr_nhood_run(sqgr_nhood* plan, uint64_t seed, int64_t perm_begin, int64_t 
     }
     {
         LaunchTimer t(ctx, "nhood_finalize");
-        k_finalize<<<(unsigned)K2, 256, 0, st>>>(p->acc_sum.p, p->acc_sq.p, p->nbatch, hw, B, K2, p->fin.p,
-                                                reinterpret_cast<uint64_t*>(p->fin.p + K2));
+        SQGR_HIP(hipMemsetAsync(p->fin.p, 0, (size_t)2 * K2 * 8, st));
+        k_finalize<<<(unsigned)ceil_div(hw, 256), 256, 0, st>>>(p->acc_sum.p, p->acc_sq.p, p->nbatch, hw, p->partial_w(), K2, p->fin.p,
+                                                               reinterpret_cast<uint64_t*>(p->fin.p + K2));
         SQGR_HIP(hipGetLastError());
     }
     return SQGR_OK;
@@ -1981,8 +2026,9 @@ static int run_pcg64_impl(sqgr_nhood* plan, const uint64_t* pcg_states, int64_t 
     }
     {
         LaunchTimer t(ctx, "nhood_finalize");
-        k_finalize<<<(unsigned)K2, 256, 0, st>>>(p->acc_sum.p, p->acc_sq.p, p->nbatch, hw, B, K2, p->fin.p,
-                                                reinterpret_cast<uint64_t*>(p->fin.p + K2));
+        SQGR_HIP(hipMemsetAsync(p->fin.p, 0, (size_t)2 * K2 * 8, st));
+        k_finalize<<<(unsigned)ceil_div(hw, 256), 256, 0, st>>>(p->acc_sum.p, p->acc_sq.p, p->nbatch, hw, p->partial_w(), K2, p->fin.p,
+                                                               reinterpret_cast<uint64_t*>(p->fin.p + K2));
         SQGR_HIP(hipGetLastError());
     }
     return SQGR_OK;

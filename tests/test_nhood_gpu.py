@@ -179,7 +179,7 @@ def test_all_cluster_count_regimes(L, ctx, k):
 
 @pytest.mark.parametrize("graph", ["hex", "hex+self", "knn"])
 @pytest.mark.parametrize("k,width,blocks", [(60, 0, 0), (60, 4, 0), (71, 8, 5), (72, 0, 0), (100, 0, 0), (101, 2, 0), (102, 0, 0), (130, 1, 0), (30, 8, 0), (30, 4, 16),
-                                             (30, 2, 0), (7, 1, 3)])
+                                             (30, 2, 0), (7, 1, 3), (202, 0, 0), (203, 0, 0), (231, 0, 5), (256, 0, 0)])
 def test_lds_pass_kernel_every_width_on_half_and_full_lists(L, ctx, graph, k, width, blocks):
     """51 <= K <= 202 clusters count in PASSES of 8 | 4 | 2 | 1 of the slab's 16 permutations (k_count_pass: the machinery of the
     K <= 50 kernel at 2 | 1 lanes per edge).  Every width — the one K selects (width 0) and narrower ones forced through
