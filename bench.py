@@ -19,21 +19,25 @@ Rank 0 prints ONE JSON line:
 
 * ``roofline``            the CSR-gather kernel (``nhood_count*``) against HBM: measured memory-side traffic per launch (PMC
                           of this build and workload, 2 x FETCH_SIZE + WRITE_SIZE as calibrated in
-                          profiles/r03_fetch_calibration.json) / its HIP-event time / 8 TB/s.  SURVEY §8d's algorithmic
-                          bytes exceed the traffic by ``algorithmic_reuse`` (16 permutations per pass over the edge list).
+                          profiles/<round>_fetch_calibration.json) / its HIP-event time / 8 TB/s; ``frac`` is the compulsory-DRAM
+                          model (no counter separates Infinity-Cache hits).  SURVEY §8d's algorithmic bytes exceed the traffic by
+                          ``algorithmic_reuse`` (16 permutations per pass over the edge list).
                           ``issue_limits``: what actually limits the kernel — the L1 access rate of its label-row gathers,
                           the ``ds_add_u32`` rate of its LDS atomics, VALU issue — each against a rate measured on this chip.
 * ``kernels``             the same for the other kernels of the step (label shuffle: VALU issue; reduce: HBM).
-* ``secondary``           Moran's I genes/s on the config-3 shape (LDS-read bound; p-value reductions on the device).
-* ``legs``                co_occurrence / Ripley L / Ripley G on the config-4 shape, Geary's C on the config-3 shape, and
-                          config 3 IN FULL through the front end (20 000 genes, upload included); every leg with its own
-                          ``roofline`` and ``cpu_baseline`` (Ripley: the reference's own sklearn calls).
+* ``secondary``           Moran's I genes/s on the config-3 shape — SURVEY §8d's directed kNN-6 graph, 2048 genes resident per
+                          step (LDS-read bound; p-value reductions on the device).
+* ``legs``                co_occurrence / Ripley L / Ripley G on the config-4 shape; Geary's C (hex grid: row-sum classes) and
+                          Geary's general kernel (arbitrary float64 weights) on the config-3 shape; config 3 IN FULL through the
+                          front end (20 000 genes, upload included); the headline's other regimes — 64 / 100 / 200 clusters, the
+                          directed kNN-6 graph, Dirichlet cluster sizes (``nhood_*``); every leg with its own ``roofline``, the
+                          statistics' legs with a ``cpu_baseline`` (Ripley: the reference's own sklearn calls).
 * ``numpy_stream_mode``   the test with numpy's own PCG64 streams reproduced bit for bit on the GPU.
 * ``cpu_baseline``        the oracle's C restatement of Squidpy's numba kernel driven by numpy's PCG64 shuffles, timed
                           on this box's host cores on a bounded sample (N=1, rank 0 only).
 * ``emulated_ranks``      (``--emulate-ranks N``) the N shards of config 5 run one after the other on this GPU: a projection.
 PMC-derived inputs (HBM traffic, instruction counts per launch) cannot be collected inside this process; they come from
-``profiles/r03_counters.json``, written by ``tools/profile_round.sh`` from rocprofv3 ``--pmc`` passes of THIS command, and
+``profiles/<PROFILE_TAG>_counters.json``, written by ``tools/profile_round.sh`` from rocprofv3 ``--pmc`` passes of THIS command, and
 are used only when that file was taken from this build of the kernels (``source_sha16``) on this workload."""
 
 from __future__ import annotations
@@ -56,14 +60,14 @@ PERMS_PER_STEP = 10_000
 HBM_PEAK = 8.0e12   # B/s, MI355X_MICROARCH.md
 L2_PEAK = 34.5e12   # B/s aggregate L2 bandwidth, MI355X_MICROARCH.md §L2
 LDS_READ_PEAK = 256 * 256 * 2.4e9  # B/s: 256 B/clk/CU (ds_read_b64/b128, MI355X_MICROARCH.md §LDS) x 256 CUs x 2.4 GHz
-PROFILE_TAG = "r04"
+PROFILE_TAG = "r05"
 
 
 # --------------------------------------------------------------------------------------------- measured ceilings
 def _profile(name: str) -> str:
     """profiles/<tag>_<name> of this round; an earlier round's file only while this round's lease has not produced its own (the
     `source` / `ceiling_source` fields of the record say which file was read)."""
-    for tag in (PROFILE_TAG, "r03", "r02"):
+    for tag in (PROFILE_TAG, "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{tag}_{name}")
         if os.path.exists(path):
             return path
@@ -327,19 +331,41 @@ def gather_roofline(kernels: dict, counters: dict, n: int, G: int, P: int, steps
     return roof
 
 
-def autocorr_leg(ctx, mode: str, world: int, fence, reduce_max, steps: int, with_cpu: bool, counters: dict) -> dict:
-    """Second half of BASELINE.json's metric: Moran's I (``mode="moran"``; ``"geary"``: Geary's C) genes/sec on the C3 shape
-    (1e5 spots, k=6 CSR graph, n_perms=1000); one step = observed score + 1000 permuted scores for a resident block of 2048
-    genes per GPU, the p-value reductions formed on the device (``sqgr_autocorr_perm_stats``)."""
+GRAPH_KINDS = {
+    "knn6": "directed 6-nearest-neighbour graph of the jittered lattice (KNNBuilder logic, SURVEY §8d), row-normalised: one row sum",
+    "hex": "hex-grid graph (degrees 2-6), row-normalised float32 weights: one row sum per degree",
+    "general": "hex-grid graph with float64 weights uniform(0.5, 1.5), transformation=False: every row sum different",
+}
+
+
+def autocorr_graph(ctx, kind: str, rows: int, cols: int):
+    """The scipy CSR graph of an autocorr leg (GRAPH_KINDS)."""
     from sklearn.preprocessing import normalize
 
+    from squidpy_amd._synthetic import hex_grid, hex_grid_graph, knn_directed_graph
+
+    if kind == "knn6":
+        xy = hex_grid(rows, cols) + np.random.default_rng(5).normal(0.0, 1.0, (rows * cols, 2))
+        return normalize(knn_directed_graph(xy, 6, ctx), norm="l1", axis=1)
+    g = hex_grid_graph(rows, cols)
+    if kind == "hex":
+        return normalize(g, norm="l1", axis=1)
+    g = g.astype(np.float64)
+    g.data = np.random.default_rng(9).uniform(0.5, 1.5, g.nnz)
+    return g
+
+
+def autocorr_leg(ctx, mode: str, world: int, fence, reduce_max, steps: int, with_cpu: bool, counters: dict, graph_kind: str = "knn6") -> dict:
+    """Second half of BASELINE.json's metric: Moran's I (``mode="moran"``; ``"geary"``: Geary's C) genes/sec on the C3 shape
+    (1e5 spots, n_perms=1000) on the graph `graph_kind` names (GRAPH_KINDS; the headline of the leg runs SURVEY §8d's directed
+    kNN-6 graph); one step = observed score + 1000 permuted scores for a resident block of 2048 genes per GPU, the p-value
+    reductions formed on the device (``sqgr_autocorr_perm_stats``)."""
     from squidpy_amd import _lib
-    from squidpy_amd._synthetic import hex_grid_graph
 
     rows, cols, G, P = 250, 400, 2048, 1000
     n = rows * cols
     rank = int(os.environ.get("RANK", "0"))
-    g = normalize(hex_grid_graph(rows, cols), norm="l1", axis=1)
+    g = autocorr_graph(ctx, graph_kind, rows, cols)
     vals = np.random.default_rng(1 + rank).gamma(2.0, 1.0, size=(G, n))
     graph = _lib.Graph(ctx, g, with_data=True)
     plan = _lib.AutocorrPlan(ctx, graph, vals)  # resident from here on
@@ -422,13 +448,14 @@ def autocorr_leg(ctx, mode: str, world: int, fence, reduce_max, steps: int, with
         roof = gather_roofline(kernels, counters, n, G, P, steps, b_gene)
     stat = "Geary's C" if geary else "Moran's I"
     out = {
-        "metric": f"{stat} genes/sec (1e5 spots, CSR k=6, n_perms=1000)",
+        "metric": f"{stat} genes/sec (1e5 spots, {graph_kind} graph, {G} genes/step, n_perms=1000)",
+        "graph": GRAPH_KINDS[graph_kind], "genes_per_step": G,
         "value": steps * G * world / elapsed,
         "unit": "genes/s",
         "ms_per_step": elapsed / steps * 1e3,
         "dtype": "f64",
-        "config": {"workload": f"spatial_autocorr {mode}: {n} spots, {G} genes per GPU per step, {P} permutations, device permutations, "
-                               "p-value reductions on the device (G x 4 numbers leave the GPU per step)"},
+        "config": {"workload": f"spatial_autocorr {mode}: {n} spots, {GRAPH_KINDS[graph_kind]}; {G} genes resident per GPU and step, {P} permutations, "
+                               "device permutations, p-value reductions on the device (G x 4 numbers leave the GPU per step)"},
         "kernel_time_share": {k: round(v[1] / max(sum(x[1] for x in kernels.values()), 1e-9), 3) for k, v in kernels.items() if v[0] > 0},
         "roofline": roof,
     }
@@ -464,14 +491,11 @@ def moran_p100_leg(ctx, cpu_value: float | None) -> dict:
     """Moran's I on the config-3 shape with the reference's EVERYDAY number of permutations (`n_perms=100`; its docs and tests use
     50-100, tests/graph/test_ppatterns.py): the LDS-bucketed kernel on 8 virtual permutations per permutation (what the library
     picks below 512 permutations), and — forced through `SQGR_AUTOCORR_KERNEL=gather` — the round-1 gather kernel it replaces there."""
-    from sklearn.preprocessing import normalize
-
     from squidpy_amd import _lib
-    from squidpy_amd._synthetic import hex_grid_graph
 
     rows, cols, G, P, steps = 250, 400, 2048, 100, 5
     n = rows * cols
-    g = normalize(hex_grid_graph(rows, cols), norm="l1", axis=1)
+    g = autocorr_graph(ctx, "knn6", rows, cols)
     vals = np.random.default_rng(11).gamma(2.0, 1.0, size=(G, n))
     graph = _lib.Graph(ctx, g, with_data=True)
     plan = _lib.AutocorrPlan(ctx, graph, vals)
@@ -504,12 +528,12 @@ def moran_p100_leg(ctx, cpu_value: float | None) -> dict:
     plan.close()
     graph.close()
     k = out["default"]["kernels"]
-    kname = next((name for name in k if name.startswith("autocorr_perm_dot_lds")), None)
+    kname = next((name for name, v in k.items() if name.startswith("autocorr_perm_dot_lds") and v[0] > 0), None)  # (timers of earlier legs report 0 launches)
     cnt, ms = k.get(kname, (0, 0.0)) if kname else (0, 0.0)
     lds_bytes = 16.0 * n * P * G
     achieved = lds_bytes * cnt / (ms * 1e-3) if ms > 0 else None
     return {
-        "metric": "Moran's I genes/sec (1e5 spots, CSR k=6, n_perms=100)", "value": out["default"]["genes_per_s"], "unit": "genes/s",
+        "metric": "Moran's I genes/sec (1e5 spots, knn6 graph, 2048 genes/step, n_perms=100)", "value": out["default"]["genes_per_s"], "unit": "genes/s",
         "ms_per_step": out["default"]["ms_per_step"], "gather_kernel_genes_per_s": out["gather"]["genes_per_s"],
         "speedup_vs_gather_kernel": out["default"]["genes_per_s"] / out["gather"]["genes_per_s"],
         "kernel_ms_per_step": {name: round(v[1] / steps, 3) for name, v in k.items() if v[0] > 0},
@@ -811,6 +835,66 @@ def numpy_stream_leg(ctx, plan, shift, n: int, counters: dict) -> dict:
     }
 
 
+# --------------------------------------------------------------------------------------------- the headline's other regimes
+def nhood_variant_legs(ctx, adj, graph, n: int, headline_value: float | None, perms: int = 10_000) -> dict:
+    """The regimes the headline number does not describe: more than 50 clusters (the LDS pass kernel: 8 | 4 | 1
+    permutations per pass at K = 64 | 100 | 200), the directed kNN-6 graph (full edge list: no symmetry to halve) and SURVEY
+    §8d's Dirichlet(0.5) cluster sizes (the LDS atomics pile onto few counters) — all at the headline's size (1e6 spots), one step of
+    `perms` permutations each.  `roofline` = the count kernel's compulsory DRAM bytes per launch (label slab once, partial
+    histograms once, edge list once) / its HIP-event time / 8 TB/s, as for the headline; `vs_k30` = value / headline value."""
+    from squidpy_amd import _lib
+    from squidpy_amd._synthetic import hex_grid, knn_directed_graph
+    from squidpy_amd.gr._nhood import expected_counts
+
+    rng = np.random.default_rng(0)
+    legs = {}
+
+    def run(name: str, g, nnz: int, labels: np.ndarray, K: int, what: str) -> None:
+        plan = _lib.NhoodPlan(ctx, g, labels, K)
+        shift = expected_counts(labels, K, nnz)
+        plan.run(3, 0, 64, shift)            # edge lists, workspaces
+        ctx.sync()
+        ctx.timer_enable(True)
+        ctx.timer_reset()
+        t0 = time.perf_counter()
+        s1, s2, _ = plan.run(3, 0, perms, shift)
+        ctx.sync()
+        dt = time.perf_counter() - t0
+        kern = ctx.timer_report()
+        ctx.timer_enable(False)
+        info = plan.info()
+        cnt = [(k, v) for k, v in kern.items() if k.startswith("nhood_count") and v[0] > 0]
+        launches = sum(v[0] for _, v in cnt)
+        ms = sum(v[1] for _, v in cnt)
+        per_launch = perms / max(launches, 1)
+        avg_ms = ms / max(launches, 1)
+        dram = float(n) * per_launch + float(info["blocks_per_batch"]) * info["hist_words"] * 4.0 * (per_launch / 16.0) + 8.0 * info["list_edges"]
+        legs[name] = {"value": perms / dt, "unit": "permutations/s", "clusters": K, "what": what,
+                      "vs_k30": perms / dt / headline_value if headline_value else None,
+                      "count_kernel": "+".join(k for k, _ in cnt), "count_us_per_perm": ms * 1e3 / perms, "perms_per_pass": info["perms_per_pass"],
+                      "list_edges": info["list_edges"], "symmetric_half_list": info["symmetric"], "kernel_ms": {k: round(v[1], 3) for k, v in kern.items() if v[0] > 0},
+                      "roofline": {"kernel": "+".join(k for k, _ in cnt), "bound": "hbm", "achieved": dram / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else None,
+                                   "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": dram / (avg_ms * 1e-3) / HBM_PEAK if avg_ms > 0 else None, "traffic": dram,
+                                   "frac_basis": "compulsory DRAM bytes per launch (slab once + partials once + edge list once) / HIP-event time"}}
+        plan.close()
+
+    nnz = int(adj.nnz)
+    for K in (64, 100, 200):
+        run(f"nhood_K{K}", graph, nnz, rng.integers(0, K, n).astype(np.int32), K, f"hex grid, {K} uniform clusters")
+    lab30 = np.random.default_rng(0).integers(0, N_CLS, n).astype(np.int32)
+    rows = int(round(np.sqrt(n)))
+    if rows * rows == n:
+        xy = hex_grid(rows, rows) + np.random.default_rng(1).normal(0.0, 5.0, (n, 2))
+        knn = knn_directed_graph(xy, 6, ctx)
+        gk = _lib.Graph(ctx, knn, with_data=False)
+        run("nhood_knn6_directed", gk, int(knn.nnz), lab30, N_CLS, "directed 6-nearest-neighbour graph of the jittered lattice (full edge list), 30 uniform clusters")
+        gk.close()
+    lab_rng = np.random.default_rng(0)
+    skew = lab_rng.choice(N_CLS, size=n, p=lab_rng.dirichlet(np.full(N_CLS, 0.5))).astype(np.int32)
+    run("nhood_dirichlet", graph, nnz, skew, N_CLS, "hex grid, 30 clusters with Dirichlet(0.5) proportions")
+    return legs
+
+
 # --------------------------------------------------------------------------------------------- the line the driver records
 def _sig(x, digits: int = 5):
     """Numbers of the compact line carry `digits` significant figures (the full precision stays in the detail file)."""
@@ -879,7 +963,7 @@ def compact_line(detail: dict, detail_path: str | None = None) -> dict:
     sec = detail.get("secondary")
     if sec:
         sroof = sec.get("roofline") or {}
-        line["secondary"] = {"metric": _short(sec.get("metric"), 80), "value": _sig(sec.get("value")), "unit": sec.get("unit"),
+        line["secondary"] = {"metric": _short(sec.get("metric"), 90), "value": _sig(sec.get("value")), "unit": sec.get("unit"),
                              "ms_per_step": _sig(sec.get("ms_per_step")), "dtype": sec.get("dtype"),
                              "roofline": {"kernel": sroof.get("kernel"), "bound": sroof.get("bound"), "achieved": _sig(sroof.get("achieved")),
                                           "peak": _sig(sroof.get("peak")), "unit": sroof.get("unit"), "frac": _sig(sroof.get("frac"), 3),
@@ -890,10 +974,14 @@ def compact_line(detail: dict, detail_path: str | None = None) -> dict:
     if "geary_c" not in legs and detail.get("geary_c"):
         legs["geary_c"] = detail["geary_c"]
     out_legs = {}
-    for name in ("geary_c", "moran_p100", "co_occurrence", "ripley_L", "ripley_G"):
+    for name in ("geary_c", "geary_general", "moran_p100", "co_occurrence", "ripley_L", "ripley_G"):
         rec = _leg(legs.get(name), extra=("kernel_ms", "speedup_vs_gather_kernel"))
         if rec:
             out_legs[name] = rec
+    for name in ("nhood_K64", "nhood_K100", "nhood_K200", "nhood_knn6_directed", "nhood_dirichlet"):  # permutations/s, HBM fraction, ratio to the headline
+        rec = legs.get(name)
+        if rec:
+            out_legs[name] = {"value": _sig(rec.get("value"), 4), "frac": _sig((rec.get("roofline") or {}).get("frac"), 3), "vs_k30": _sig(rec.get("vs_k30"), 3)}
     c3 = legs.get("config3_full")
     if c3:
         out_legs["config3_full"] = {"moran_s": _sig((c3.get("moran") or {}).get("seconds"), 4), "geary_s": _sig((c3.get("geary") or {}).get("seconds"), 4),
@@ -1111,8 +1199,8 @@ def main() -> None:
     with_cpu = world == 1 and rank == 0 and not args.no_cpu_baseline
     if not args.no_secondary:
         secondary = autocorr_leg(ctx, "moran", world, fence, reduce_max, max(1, min(args.steps, 3)), with_cpu, counters)
-        if world == 1:
-            geary = autocorr_leg(ctx, "geary", world, fence, reduce_max, max(1, min(args.steps, 3)), with_cpu, counters)
+        if world == 1:  # Geary's C on the hex grid: the float32 row sums of its degrees exercise the constant + exception lists
+            geary = autocorr_leg(ctx, "geary", world, fence, reduce_max, max(1, min(args.steps, 3)), with_cpu, counters, graph_kind="hex")
     legs = None
     if world == 1 and not args.no_legs:
         legs = config4_legs(ctx, ceil, not args.no_cpu_baseline, counters)
@@ -1120,6 +1208,12 @@ def main() -> None:
             legs["geary_c"] = geary
         if not args.no_secondary:
             legs["moran_p100"] = moran_p100_leg(ctx, (secondary.get("cpu_baseline") or {}).get("value") if secondary else None)
+            # Geary's general kernel (a third random LDS read per pair: row sums that take more than 8 values) — arbitrary weights, transformation=False
+            legs["geary_general"] = autocorr_leg(ctx, "geary", world, fence, reduce_max, 2, False, counters, graph_kind="general")
+        try:
+            legs.update(nhood_variant_legs(ctx, adj, graph, n, None))
+        except Exception as exc:  # pragma: no cover  (a leg must never cost the headline line)
+            legs["nhood_variants_error"] = {"error": repr(exc)}
         if not args.no_secondary and not args.no_config3_full:
             try:
                 legs["config3_full"] = config3_full_leg(secondary.get("cpu_baseline", {}).get("value") if secondary else None)
@@ -1171,7 +1265,8 @@ def main() -> None:
                     "algorithmic_GBps": algorithmic_bytes_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else None,
                     "traffic_bytes_per_launch": None, "traffic_source": None}
             if rec and rec.get("FETCH_SIZE_bytes") is not None and rec.get("WRITE_SIZE_bytes") is not None:
-                # MI355X_MICROARCH.md §HBM: FETCH_SIZE counts half the bytes of wide coalesced reads on gfx950 -> doubled
+                # FETCH_SIZE reports exactly half the bytes of this kernel's access patterns, WRITE_SIZE all of them: calibrated in this
+                # repository (tools/ubench_fetch_calib.hip -> profiles/<round>_fetch_calibration.json); the guide's §HBM says the same
                 traffic = 2.0 * rec["FETCH_SIZE_bytes"] + rec["WRITE_SIZE_bytes"]
                 side["traffic_bytes_per_launch"] = traffic
                 side["traffic_source"] = counters.get("_source")
@@ -1343,6 +1438,9 @@ def main() -> None:
         if secondary is not None:
             out["secondary"] = secondary
         if legs is not None:
+            for name, rec in legs.items():
+                if name.startswith("nhood_") and isinstance(rec, dict) and rec.get("value"):
+                    rec["vs_k30"] = rec["value"] / out["value"] if world == 1 else None
             out["legs"] = legs
         elif geary is not None:
             out["geary_c"] = geary

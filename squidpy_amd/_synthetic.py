@@ -39,6 +39,20 @@ def hex_grid_graph(rows: int, cols: int) -> sparse.csr_matrix:
     return g
 
 
+def knn_directed_graph(xy: np.ndarray, k: int = 6, ctx=None) -> sparse.csr_matrix:
+    """The directed k-nearest-neighbour connectivity graph of a point cloud (what ``KNNBuilder`` yields for
+    ``coord_type="generic"``, /root/reference/src/squidpy/gr/neighbors.py:157-209, before any symmetrisation): row i holds
+    ones at its k nearest other points.  Searched on the device (``sqgr_knn_self``); SURVEY.md §8d's graph for config 3 and
+    the full-edge-list case of the nhood bench."""
+    from . import _lib
+
+    n = xy.shape[0]
+    _, idx = _lib.knn_self(ctx if ctx is not None else _lib.default_context(), np.asarray(xy, dtype=np.float64), k)
+    g = sparse.csr_matrix((np.ones(n * k, dtype=np.float32), idx.ravel(), np.arange(0, n * k + 1, k)), shape=(n, n))
+    g.sort_indices()
+    return g
+
+
 def hex_adata(rows: int, cols: int, n_cls: int, seed: int = 0, n_genes: int = 0) -> AnnDataLite:
     rng = np.random.default_rng(seed)
     n = rows * cols
