@@ -250,14 +250,15 @@ class PermutationTest:
         n_jobs: int | None = None,
         show_progress_bar: bool = True,
         *,
-        rng: str = "philox",
+        rng: str = "numpy",
         device: int | None = None,
     ) -> Mapping[str, pd.DataFrame] | None:
         """Perform the permutation test (gr/_ligrec.py:234-373).  Returns / stores ``{'means', 'pvalues', 'metadata'}``.
 
         ``n_jobs`` and ``show_progress_bar`` are accepted (``n_jobs`` validated) and do not influence the GPU path.
-        ``rng='philox'`` shuffles with the device generator keyed by ``(seed, permutation)``; ``rng='numpy'``
-        reproduces the reference's PCG64 streams bit for bit, i.e. Squidpy's p-values for that ``seed``.
+        ``rng='numpy'`` (default since round 5) reproduces the reference's PCG64 streams (gr/_ligrec.py:616-673) bit for bit on
+        the device, i.e. Squidpy's p-values for that ``seed``; ``rng='philox'`` shuffles with the device generator keyed by
+        ``(seed, permutation)`` (throughput mode, another stream).
 
         Limits of the GPU path: at most ``2048`` clusters among the requested cluster pairs (``NotImplementedError`` beyond;
         the reference has no limit; more than 256 run in cluster tiles of 255 on 16-bit labels); a subset that resolves to a single cluster is computed on the host like the reference does."""
@@ -436,7 +437,7 @@ def ligrec(
     transmitter_params: Mapping[str, Any] = MappingProxyType({"categories": "ligand"}),
     receiver_params: Mapping[str, Any] = MappingProxyType({"categories": "receptor"}),
     table_key: str | None = None,
-    rng: str = "philox",
+    rng: str = "numpy",
     device: int | None = None,
 ) -> Mapping[str, pd.DataFrame] | None:
     """Perform the permutation test as described in CellPhoneDB (drop-in for ``squidpy.gr.ligrec``, gr/_ligrec.py:548-612).

@@ -80,7 +80,7 @@ def nhood_enrichment(
     show_progress_bar: bool = True,
     *,
     table_key: str | None = None,
-    rng: str = "philox",
+    rng: str = "numpy",
     device: int | None = None,
 ) -> NhoodEnrichmentResult | None:
     """Compute neighborhood enrichment by permutation test (drop-in for ``squidpy.gr.nhood_enrichment``).
@@ -92,15 +92,17 @@ def nhood_enrichment(
     Extra keyword-only parameters
     -----------------------------
     rng
-        ``"philox"`` (default): label shuffles are generated on the GPU by the counter-based generator of
-        ``csrc/sqgr_rng.h`` keyed by ``(seed, permutation index, library)``; results are reproducible for a
-        given ``seed`` and independent of the number of GPUs, but follow a different stream than numpy.
-        ``"numpy"``: the reference's own streams (``SeedSequence(seed).spawn(n_perms)`` -> PCG64 ->
-        ``Generator.shuffle``) are reproduced bit for bit *on the GPU* (LCG jump-ahead draws; long arrays replay the swaps phase by
-        phase through LDS, ``csrc/sqgr_pcg.hip``), and the z-score is formed with the reference's float64 ``perms.mean/std``:
-        Squidpy's z-scores for that ``seed``, exactly (1e6 spots: ~60 k permutations/s — ~36 k at the default ``n_perms=1000`` —
-        against ~1 M for ``"philox"``; the CPU does ~20/s per core).
-        ``"numpy-host"``: same streams drawn by numpy on the host and injected (cross-check path).
+        ``"numpy"`` (default since round 5): the reference's own streams (``SeedSequence(seed).spawn(n_perms)`` -> PCG64 ->
+        ``Generator.shuffle``, gr/_nhood.py:213, 530-539) are reproduced bit for bit *on the GPU* (LCG jump-ahead draws; long
+        arrays replay the swaps phase by phase through LDS, ``csrc/sqgr_pcg.hip``), and the z-score is formed with the
+        reference's float64 ``perms.mean/std``: a default call returns **Squidpy's z-scores for that ``seed``, exactly**
+        (1e6 spots: tens of thousands of permutations/s — a default call of 1000 permutations takes ~30 ms; the CPU does ~20/s
+        per core).
+        ``"philox"``: the throughput mode (~1 M permutations/s at 1e6 spots x 30 clusters): label shuffles by the counter-based
+        generator of ``csrc/sqgr_rng.h`` keyed by ``(seed, permutation index, library)``; reproducible for a given ``seed``
+        and independent of the number of GPUs, but another stream than numpy's — the z-scores agree with Squidpy's
+        statistically (same null distribution, ``tests/test_null_moments_gpu.py``), not digit for digit.
+        ``"numpy-host"``: numpy's streams drawn by numpy on the host and injected (cross-check path).
     device
         HIP device index (default: ``LOCAL_RANK`` or 0).
 

@@ -245,7 +245,7 @@ def spatial_autocorr(
     show_progress_bar: bool = True,
     *,
     table_key: str | None = None,
-    rng: str = "philox",
+    rng: str = "numpy",
     device: int | None = None,
     gene_block: int = 2048,
 ) -> pd.DataFrame | None:
@@ -256,9 +256,10 @@ def spatial_autocorr(
     (``I``/``C``, ``pval_norm``, ``var_norm``, and with ``n_perms``: ``pval_z_sim``, ``pval_sim``, ``var_sim``),
     ``{pval}_{corr_method}`` columns, sort order and ``adata.uns['moranI'|'gearyC']`` slot as the reference.
 
-    Extra keyword-only parameters: ``rng`` — ``"philox"`` (default) draws the row permutations on the GPU, keyed by
-    ``(seed, permutation index)``; ``"numpy"`` reproduces the reference's ``rng.permutation(N)`` streams bit for bit on the GPU
-    (Squidpy's permutation columns for that ``seed``; ``"numpy-host"`` draws them with numpy on the host); ``device``; ``gene_block`` — features
+    Extra keyword-only parameters: ``rng`` — ``"numpy"`` (default since round 5) reproduces the reference's ``rng.permutation(N)``
+    streams (gr/_ppatterns.py:269-272) bit for bit on the GPU: Squidpy's permutation columns for that ``seed``; ``"philox"`` draws
+    the row permutations with the device's counter-based generator, keyed by ``(seed, permutation index)`` — the throughput mode,
+    statistically equivalent, another stream; ``"numpy-host"`` draws numpy's streams on the host; ``device``; ``gene_block`` — features
     resident on the GPU at a time.  With a ``torch.distributed`` process group, feature blocks are split across ranks
     and the score columns gathered.
     """

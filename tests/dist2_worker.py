@@ -24,10 +24,10 @@ def main():
     adj = adata.obsp["spatial_connectivities"]
     lab = codes(adata, "cluster")
     # nhood: permutation ranges + all-reduce of the integer moments; the device generator is keyed by the global index
-    res = sq.gr.nhood_enrichment(adata, "cluster", n_perms=75, seed=3, copy=True)
+    res = sq.gr.nhood_enrichment(adata, "cluster", n_perms=75, seed=3, copy=True, rng="philox")
     ref = O.nhood_perm_counts_philox(adj.indices, adj.indptr, lab, 5, 3, 0, 75)
     np.testing.assert_allclose(res.zscore, O.nhood_zscore(res.counts, ref), rtol=1e-9)
-    res_np = sq.gr.nhood_enrichment(adata, "cluster", n_perms=31, seed=4, copy=True, rng="numpy")
+    res_np = sq.gr.nhood_enrichment(adata, "cluster", n_perms=31, seed=4, copy=True)
     ref_np = O.nhood_perm_counts_numpy(adj.indices, adj.indptr, lab, 5, 4, 31)
     np.testing.assert_array_equal(res_np.zscore, O.nhood_zscore(res_np.counts, ref_np))
     # co-occurrence: row tiles t % world == rank, all-reduce of the pair counts
@@ -38,7 +38,7 @@ def main():
     occ_iv, _ = sq.gr.co_occurrence(adata, "cluster", interval=8, copy=True, shard="intervals")
     np.testing.assert_array_equal(occ_iv, occ)
     # autocorr: contiguous runs of feature blocks per rank (3 blocks over 2 ranks), each rank uploads its columns only; gathered
-    df = sq.gr.spatial_autocorr(adata, mode="geary", n_perms=12, seed=5, copy=True, rng="numpy", gene_block=64)
+    df = sq.gr.spatial_autocorr(adata, mode="geary", n_perms=12, seed=5, copy=True, gene_block=64)
     want = O.spatial_autocorr(adj, adata.X.T, adata.var_names, mode="geary", n_perms=12, seed=5)
     for c in df.columns:
         np.testing.assert_allclose(df[c].to_numpy(), want[c].to_numpy(), rtol=1e-6, atol=1e-12, err_msg=c)
@@ -51,7 +51,7 @@ def main():
     # ligrec: permutation ranges, all-reduce of the indicator counts
     genes = list(adata.var_names[:6])
     inter = [(a, b) for a in genes for b in genes if a != b]
-    lr = sq.gr.ligrec(adata, "cluster", interactions=inter, n_perms=33, seed=6, use_raw=False, copy=True, rng="numpy", threshold=0.1)
+    lr = sq.gr.ligrec(adata, "cluster", interactions=inter, n_perms=33, seed=6, use_raw=False, copy=True, threshold=0.1)
     gi = {g: i for i, g in enumerate(genes)}
     _, pv = O.ligrec_analysis(np.asarray(adata.X)[:, :6], lab, np.array([(gi[a], gi[b]) for a, b in inter]),
                               np.array([(a, b) for a in range(5) for b in range(5)]), threshold=0.1, n_perms=33, seed=6)

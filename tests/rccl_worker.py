@@ -36,7 +36,7 @@ def main():
     adata = hex_adata(30, 40, 5, seed=2)
     adj = adata.obsp["spatial_connectivities"]
     lab = codes(adata, "cluster")
-    res = sq.gr.nhood_enrichment(adata, "cluster", n_perms=70, seed=3, copy=True)
+    res = sq.gr.nhood_enrichment(adata, "cluster", n_perms=70, seed=3, copy=True, rng="philox")
     ref = O.nhood_perm_counts_philox(adj.indices, adj.indptr, lab, 5, 3, 0, 70)
     np.testing.assert_allclose(res.zscore, O.nhood_zscore(res.counts, ref), rtol=1e-9)
     occ, _ = sq.gr.co_occurrence(adata, "cluster", interval=8, copy=True)
@@ -45,7 +45,7 @@ def main():
     res_np = sq.gr.nhood_enrichment(adata, "cluster", n_perms=20, seed=None, copy=True, rng="numpy")  # seed broadcast path
     assert np.isfinite(res_np.zscore).all()
     # numpy streams with the communicator attached: counts all-gathered on the device, Squidpy's z-scores exactly
-    res_np = sq.gr.nhood_enrichment(adata, "cluster", n_perms=33, seed=4, copy=True, rng="numpy")
+    res_np = sq.gr.nhood_enrichment(adata, "cluster", n_perms=33, seed=4, copy=True)
     ref_np = O.nhood_perm_counts_numpy(adj.indices, adj.indptr, lab, 5, 4, 33)
     np.testing.assert_array_equal(res_np.zscore, O.nhood_zscore(res_np.counts, ref_np))
     # the plan-level device all-reduce returns what the plain run returns (one rank: identity)

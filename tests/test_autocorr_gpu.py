@@ -301,12 +301,12 @@ def _adata(n=600, G=40, seed=0):
 
 @pytest.mark.parametrize("mode", ["moran", "geary"])
 def test_frontend_dataframe_equals_reference_pipeline(L, mode):
-    """Whole-function parity (rng="numpy" = the reference's permutation streams): every column of the result
+    """Whole-function parity of a DEFAULT call (the reference's permutation streams, reproduced on the device): every column of the result
     equals the oracle's restatement of gr/_ppatterns.py:196-255."""
     import squidpy_amd as sq
 
     adata = _adata()
-    df = sq.gr.spatial_autocorr(adata, mode=mode, n_perms=50, seed=11, copy=True, rng="numpy")
+    df = sq.gr.spatial_autocorr(adata, mode=mode, n_perms=50, seed=11, copy=True)  # the default: numpy's streams on the device
     hv = adata.var["highly_variable"].to_numpy()
     ref = O.spatial_autocorr(adata.obsp["spatial_connectivities"], adata.X[:, hv].T, adata.var_names[hv], mode=mode, n_perms=50, seed=11)
     stat = "I" if mode == "moran" else "C"
@@ -338,7 +338,7 @@ def test_frontend_structure_ported_from_reference_tests(L):
     v_geary = ((2 * s1 + s2) * (n - 1) - 4 * s0 * s0) / (2 * (n + 1) * s0 * s0)
     np.testing.assert_allclose(df["var_norm"].to_numpy(), v_moran, rtol=1e-10)
     np.testing.assert_allclose(adata.uns["gearyC"]["var_norm"].to_numpy(), v_geary, rtol=1e-10)
-    # reproducibility / seed (philox default): same seed same frame, different seed different sims
+    # reproducibility / seed: same seed same frame, different seed different sims
     a = sq.gr.spatial_autocorr(adata, n_perms=30, seed=1, copy=True, n_jobs=2, backend="threading")
     b = sq.gr.spatial_autocorr(adata, n_perms=30, seed=1, copy=True)
     c = sq.gr.spatial_autocorr(adata, n_perms=30, seed=2, copy=True)

@@ -37,21 +37,21 @@ def _adata(sq, rows, cols, labels, k, X=None, xy=None, graph=True):
 
 def test_config1_nhood_5000_spots_10_clusters_1000_perms(sq):
     """Config 1 (the reference's own CPU-runnable case) in full, both generators: every one of the 1000 permutations
-    against the oracle — rng="numpy": Squidpy's z-scores for the seed, bit for bit; rng="philox": the oracle's restatement of
-    the device generator."""
+    against the oracle — the DEFAULT call (numpy's streams on the device): Squidpy's z-scores for the seed, bit for bit;
+    rng="philox": the oracle's restatement of the device generator."""
     rows, cols, k, P = 50, 100, 10, 1000
     labels = np.random.default_rng(0).integers(0, k, rows * cols).astype(np.int32)
     adata = _adata(sq, rows, cols, labels, k)
     adj = adata.obsp["spatial_connectivities"]
     count = O.nhood_counts(adj.indices, adj.indptr, labels, k)
-    res = sq.gr.nhood_enrichment(adata, "cluster", n_perms=P, seed=42, copy=True, rng="numpy")
+    res = sq.gr.nhood_enrichment(adata, "cluster", n_perms=P, seed=42, copy=True)
     np.testing.assert_array_equal(res.counts, count)
     np.testing.assert_array_equal(res.zscore, O.nhood_zscore(count, O.nhood_perm_counts_numpy(adj.indices, adj.indptr, labels, k, 42, P)))
-    res = sq.gr.nhood_enrichment(adata, "cluster", n_perms=P, seed=42, copy=True)
+    res = sq.gr.nhood_enrichment(adata, "cluster", n_perms=P, seed=42, copy=True, rng="philox")
     np.testing.assert_array_equal(res.counts, count)
     np.testing.assert_allclose(res.zscore, O.nhood_zscore(count, O.nhood_perm_counts_philox(adj.indices, adj.indptr, labels, k, 42, 0, P)), rtol=1e-9)
     # and through the AnnData slot (gr/_nhood.py:236-242)
-    sq.gr.nhood_enrichment(adata, "cluster", n_perms=P, seed=42)
+    sq.gr.nhood_enrichment(adata, "cluster", n_perms=P, seed=42, rng="philox")
     np.testing.assert_array_equal(adata.uns["cluster_nhood_enrichment"]["zscore"], res.zscore)
     np.testing.assert_array_equal(adata.uns["cluster_nhood_enrichment"]["count"], count)
 
@@ -63,7 +63,7 @@ def test_config2_nhood_1e5_spots_20_clusters_10000_perms(sq, L):
     labels = np.random.default_rng(2).integers(0, k, rows * cols).astype(np.int32)
     adata = _adata(sq, rows, cols, labels, k)
     adj = adata.obsp["spatial_connectivities"]
-    res = sq.gr.nhood_enrichment(adata, "cluster", n_perms=P, seed=seed, copy=True)
+    res = sq.gr.nhood_enrichment(adata, "cluster", n_perms=P, seed=seed, copy=True, rng="philox")
     np.testing.assert_array_equal(res.counts, O.nhood_counts(adj.indices, adj.indptr, labels, k))
     ctx = L.default_context()
     g = L.Graph(ctx, adj, with_data=False)
@@ -283,7 +283,7 @@ def test_config5_nhood_1e6_spots_30_clusters_100000_perms(sq, L):
     labels = np.random.default_rng(0).integers(0, k, rows * cols).astype(np.int32)
     adata = _adata(sq, rows, cols, labels, k)
     adj = adata.obsp["spatial_connectivities"]
-    res = sq.gr.nhood_enrichment(adata, "cluster", n_perms=P, seed=seed, copy=True)
+    res = sq.gr.nhood_enrichment(adata, "cluster", n_perms=P, seed=seed, copy=True, rng="philox")
     np.testing.assert_array_equal(res.counts, O.nhood_counts(adj.indices, adj.indptr, labels, k))
     ctx = L.default_context()
     g = L.Graph(ctx, adj, with_data=False)

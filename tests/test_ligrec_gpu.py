@@ -161,7 +161,7 @@ def _adata_from(data, cl, names=None):
 
 @pytest.mark.parametrize("tag", ["A", "B", "C"])
 def test_front_end_reproduces_reference_golden(gold, tag):
-    """rng='numpy': p-values of the reference's own `_analysis` source for the same seed, exactly."""
+    """A default call (numpy's streams, reproduced on the device): p-values of the reference's own `_analysis` source for the same seed, exactly."""
     import squidpy_amd as sq
 
     data, cl = gold[f"{tag}_data"], gold[f"{tag}_clusters"]
@@ -170,7 +170,7 @@ def test_front_end_reproduces_reference_golden(gold, tag):
     res = sq.gr.ligrec(
         adata, "cluster", interactions=[(f"G{s}", f"G{t}") for s, t in inter], clusters=[(f"c{a}", f"c{b}") for a, b in cp],
         threshold=float(gold[f"{tag}_threshold"]), n_perms=int(gold[f"{tag}_n_perms"]), seed=int(gold[f"{tag}_seed"]),
-        use_raw=False, copy=True, rng="numpy",
+        use_raw=False, copy=True,
     )
     assert list(res["pvalues"].index) == [(f"G{s}", f"G{t}") for s, t in inter]
     assert list(res["pvalues"].columns) == [(f"c{a}", f"c{b}") for a, b in cp]
@@ -267,7 +267,7 @@ def test_pvalues_reference_held_by_the_reference_repo():
     """The reference's own pinned result (tests/graph/test_ligrec.py:346-360 `test_pvalues_reference` against
     tests/_data/ligrec_pvalues_reference.h5ad): ligrec(adata, "leiden", interactions=product(raw.var_names[:5] x 2), n_perms=25,
     seed=42) on the tests/_data/test_data.h5ad fixture (raw = the AnnData itself, tests/conftest.py:40-41).  Both files are
-    exported to tests/golden/*.npz by `make_golden.py --export-h5ad`; with rng="numpy" the device must reproduce Squidpy's
+    exported to tests/golden/*.npz by `make_golden.py --export-h5ad`; the DEFAULT call (numpy's streams on the device) must reproduce Squidpy's
     p-values for that seed: assert_allclose like the reference test, and the same NaN pattern."""
     import os
     from itertools import product
@@ -286,7 +286,7 @@ def test_pvalues_reference_held_by_the_reference_repo():
     raw = sq.AnnDataLite(X=X, obs=obs.copy(), var=pd.DataFrame(index=names))
     adata = sq.AnnDataLite(X=X, obs=obs, var=pd.DataFrame(index=names), raw=raw)
     interactions = tuple(product(names[:5], names[:5]))
-    r = sq.gr.ligrec(adata, "leiden", interactions=interactions, n_perms=25, copy=True, show_progress_bar=False, seed=42, n_jobs=1, rng="numpy")
+    r = sq.gr.ligrec(adata, "leiden", interactions=interactions, n_perms=25, copy=True, show_progress_bar=False, seed=42, n_jobs=1)  # the reference test's call, verbatim
     index = pd.MultiIndex.from_arrays([ref["source"], ref["target"]], names=["source", "target"])
     columns = pd.MultiIndex.from_arrays([ref["cluster_1"], ref["cluster_2"]], names=["cluster_1", "cluster_2"])
     for key in ("means", "pvalues"):

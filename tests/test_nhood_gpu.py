@@ -237,7 +237,7 @@ def test_frontend_config1_hex_grid(L):
     adata = hex_adata(50, 100, 10, seed=0)
     adj = adata.obsp["spatial_connectivities"]
     lab = codes(adata, "cluster")
-    res = sq.gr.nhood_enrichment(adata, "cluster", n_perms=1000, seed=0, copy=True)
+    res = sq.gr.nhood_enrichment(adata, "cluster", n_perms=1000, seed=0, copy=True, rng="philox")
     count_ref = O.nhood_counts(adj.indices, adj.indptr, lab, 10)
     np.testing.assert_array_equal(res.counts, count_ref)
     assert res.counts.dtype == np.uint32 and res.zscore.dtype == np.float64 and res.zscore.shape == (10, 10)
@@ -245,7 +245,7 @@ def test_frontend_config1_hex_grid(L):
     z_ref = O.nhood_zscore(count_ref, ref)
     np.testing.assert_allclose(res.zscore, z_ref, rtol=1e-9, atol=1e-12)  # exact-integer moments vs numpy mean/std
     # rng="numpy" reproduces Squidpy's own streams: equal (==) to the reference restatement
-    res_np = sq.gr.nhood_enrichment(adata, "cluster", n_perms=200, seed=7, copy=True, rng="numpy")
+    res_np = sq.gr.nhood_enrichment(adata, "cluster", n_perms=200, seed=7, copy=True)
     perms_np = O.nhood_perm_counts_numpy(adj.indices, adj.indptr, lab, 10, 7, 200)
     np.testing.assert_array_equal(res_np.zscore, O.nhood_zscore(count_ref, perms_np))
     # statistical agreement between the two generators: same null distribution
@@ -272,7 +272,7 @@ def test_frontend_slots_reproducibility_and_libraries(L):
     np.testing.assert_array_equal(r1.zscore, slot["zscore"])
     np.testing.assert_array_equal(r1.counts, r2.counts)
     assert not np.allclose(r1.zscore, r2.zscore)
-    rl = sq.gr.nhood_enrichment(adata, "cluster", library_key="library", n_perms=50, seed=42, copy=True)
+    rl = sq.gr.nhood_enrichment(adata, "cluster", library_key="library", n_perms=50, seed=42, copy=True, rng="philox")
     np.testing.assert_array_equal(rl.counts, r1.counts)
     assert not np.allclose(rl.zscore, r1.zscore)
     adj = adata.obsp["spatial_connectivities"]
@@ -469,7 +469,7 @@ def test_skewed_cluster_sizes(L, ctx):
     plan = L.NhoodPlan(ctx, g, lab, k)
     _, _, perms = plan.run(17, 0, 48, None, return_perms=True)
     np.testing.assert_array_equal(perms, O.nhood_perm_counts_philox(adj.indices, adj.indptr, lab, k, 17, 0, 48).astype(np.uint32))
-    res = sq.gr.nhood_enrichment(adata, "cluster", n_perms=48, seed=17, copy=True)
+    res = sq.gr.nhood_enrichment(adata, "cluster", n_perms=48, seed=17, copy=True, rng="philox")
     ref = O.nhood_zscore(res.counts, perms.astype(np.float64))
     ok = np.isfinite(ref)
     np.testing.assert_allclose(res.zscore[ok], ref[ok], rtol=1e-9)
@@ -489,7 +489,7 @@ def test_more_than_256_clusters_run_batched_on_the_device(L, ctx):
     adata.obs["cluster"] = pd.Categorical.from_codes(lab, [f"c{i:03d}" for i in range(k)])
     adj = adata.obsp["spatial_connectivities"]
     count = O.nhood_counts(adj.indices, adj.indptr, lab, k)
-    res = sq.gr.nhood_enrichment(adata, "cluster", n_perms=40, seed=3, copy=True)
+    res = sq.gr.nhood_enrichment(adata, "cluster", n_perms=40, seed=3, copy=True, rng="philox")
     np.testing.assert_array_equal(res.counts, count)
     want = O.nhood_zscore(count, O.nhood_perm_counts_philox(adj.indices, adj.indptr, lab, k, 3, 0, 40))
     np.testing.assert_array_equal(np.isnan(res.zscore), np.isnan(want))
@@ -538,9 +538,9 @@ def test_300_clusters_at_1e5_spots_is_a_device_path(L, ctx):
     lab = np.random.default_rng(8).integers(0, k, n).astype(np.int32)
     adata.obs["cluster"] = pd.Categorical.from_codes(lab, [f"c{i:03d}" for i in range(k)])
     adj = adata.obsp["spatial_connectivities"]
-    sq.gr.nhood_enrichment(adata, "cluster", n_perms=32, seed=1, copy=True)  # warm-up (allocations)
+    sq.gr.nhood_enrichment(adata, "cluster", n_perms=32, seed=1, copy=True, rng="philox")  # warm-up (allocations)
     t0 = time.perf_counter()
-    res = sq.gr.nhood_enrichment(adata, "cluster", n_perms=P, seed=1, copy=True)
+    res = sq.gr.nhood_enrichment(adata, "cluster", n_perms=P, seed=1, copy=True, rng="philox")
     dt = time.perf_counter() - t0
     assert np.isfinite(res.zscore).all()
     g = L.Graph(ctx, adj, with_data=False)
