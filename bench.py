@@ -921,6 +921,8 @@ def _leg(rec: dict | None, *, extra: tuple = ()) -> dict | None:
     for k in extra:
         if rec.get(k) is not None:
             out[k] = _sig(rec[k], 4)
+    if out.get("cpu") is None:
+        out.pop("cpu", None)
     return out
 
 
@@ -936,15 +938,15 @@ def compact_line(detail: dict, detail_path: str | None = None) -> dict:
     line["value"], line["ms_per_step"] = _sig(line["value"], 7), _sig(line["ms_per_step"], 6)
     if detail.get("check"):
         line["check"] = detail["check"]
-    line["config"] = {"workload": _short(cfg.get("workload"), 240), "perms_per_step": cfg.get("perms_per_step"),
-                      "perms_per_step_per_gpu": cfg.get("perms_per_step_per_gpu"), "parallelism": _short(cfg.get("parallelism"), 100),
+    line["config"] = {"workload": _short(cfg.get("workload"), 200), "perms_per_step": cfg.get("perms_per_step"),
+                      "perms_per_step_per_gpu": cfg.get("perms_per_step_per_gpu"),
                       "collective": _short(cfg.get("collective"), 60), "rccl_world": cfg.get("rccl_world"),
                       "ranks_on_devices": cfg.get("ranks_on_devices")}
     line["roofline"] = {
         "kernel": roof.get("kernel"), "bound": roof.get("bound"), "achieved": _sig(roof.get("achieved")), "peak": _sig(roof.get("peak")),
         "unit": roof.get("unit"), "frac": _sig(roof.get("frac"), 3), "traffic": _sig(roof.get("traffic"), 6),
         "algorithmic_frac": _sig(roof.get("algorithmic_frac"), 3), "fabric_frac": _sig(roof.get("fabric_frac"), 3),
-        "frac_basis": _short(roof.get("frac_basis"), 120), "avg_launch_ms": _sig(roof.get("avg_launch_ms")),
+        "frac_basis": "compulsory DRAM bytes / HIP-event time" if roof.get("frac_basis") else None, "avg_launch_ms": _sig(roof.get("avg_launch_ms")),
         "perms_per_launch": _sig(roof.get("perms_per_launch")),
         "issue_limits": {"l1_gather": _sig(issue.get("frac"), 3) if issue.get("bound") == "l1_gather" else None,
                          "lds_atomic": _sig(((issue.get("lds_atomic") or issue) if issue else {}).get("frac"), 3),
@@ -956,19 +958,19 @@ def compact_line(detail: dict, detail_path: str | None = None) -> dict:
     cpu = detail.get("cpu_baseline")
     if cpu:
         line["cpu_baseline"] = {"value": _sig(cpu.get("value")), "unit": cpu.get("unit"), "cores": cpu.get("cores"), "kind": cpu.get("kind"),
-                                "sample": _short(cpu.get("sample"), 200),
+                                "sample": _short(cpu.get("sample"), 130),
                                 "all_cores": {"value": _sig((cpu.get("all_cores") or {}).get("value")), "cores": (cpu.get("all_cores") or {}).get("cores")},
                                 "config1_full_perms_per_s": _sig((cpu.get("config1_full") or {}).get("value"))}
         line["speedup_vs_cpu_1core"] = _sig(detail.get("speedup_vs_cpu_1core"))
     sec = detail.get("secondary")
     if sec:
         sroof = sec.get("roofline") or {}
-        line["secondary"] = {"metric": _short(sec.get("metric"), 90), "value": _sig(sec.get("value")), "unit": sec.get("unit"),
+        line["secondary"] = {"metric": _short(sec.get("metric"), 84), "value": _sig(sec.get("value")), "unit": sec.get("unit"),
                              "ms_per_step": _sig(sec.get("ms_per_step")), "dtype": sec.get("dtype"),
                              "roofline": {"kernel": sroof.get("kernel"), "bound": sroof.get("bound"), "achieved": _sig(sroof.get("achieved")),
                                           "peak": _sig(sroof.get("peak")), "unit": sroof.get("unit"), "frac": _sig(sroof.get("frac"), 3),
                                           "traffic": _sig(sroof.get("traffic"), 6), "frac_of_pattern_ceiling": _sig(sroof.get("frac_of_pattern_ceiling"), 3)},
-                             "cpu_baseline": {k: (_short(v, 120) if k == "sample" else _sig(v)) for k, v in (sec.get("cpu_baseline") or {}).items()
+                             "cpu_baseline": {k: (_short(v, 72) if k == "sample" else _sig(v)) for k, v in (sec.get("cpu_baseline") or {}).items()
                                               if k in ("value", "unit", "cores", "kind", "sample")}}
     legs = dict(detail.get("legs") or {})
     if "geary_c" not in legs and detail.get("geary_c"):
@@ -996,7 +998,7 @@ def compact_line(detail: dict, detail_path: str | None = None) -> dict:
         line["legs"] = out_legs
     emu = detail.get("emulated_ranks")
     if emu:
-        line["emulated_ranks"] = {"PROJECTION": "shards run one after the other on ONE GPU", "ranks": emu.get("ranks"), "total_perms": emu.get("total_perms"),
+        line["emulated_ranks"] = {"PROJECTION": "shards run one by one on ONE GPU", "ranks": emu.get("ranks"), "total_perms": emu.get("total_perms"),
                                   "shard_ms": _sig(max(emu.get("shard_seconds") or [0.0]) * 1e3, 4), "whole_ms": _sig((emu.get("one_gpu_seconds") or 0.0) * 1e3, 4)}
     line["pmc_profile"] = _short(detail.get("pmc_profile"), 120)
     line["detail"] = detail_path
@@ -1112,8 +1114,10 @@ def main() -> None:
             print(f"bench.py: --gpus {args.gpus} but this node has {n_dev} GPU(s); refusing to report a {args.gpus}-GPU figure from fewer devices "
                   "(--share-devices puts several ranks on one GPU for tests: host collective, not a scaling measurement)", file=sys.stderr)
             sys.exit(2)
+        # (a bound on the whole launch: an RCCL rendezvous that never completes must not hold the driver's node forever)
         sys.exit(launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus,
-                              extra_env={"SQGR_DIST_COLLECTIVE": "host"} if args.gpus > n_dev else None))
+                              extra_env={"SQGR_DIST_COLLECTIVE": "host"} if args.gpus > n_dev else None,
+                              timeout_s=float(os.environ.get("SQGR_BENCH_LAUNCH_TIMEOUT", "2400"))))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
