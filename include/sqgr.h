@@ -234,7 +234,12 @@ int sqgr_autocorr_scores(sqgr_autocorr* h, int32_t mode, double* out_scores);
  *   out_sims[p][g] = func(g[idx_p, :], vals)[g]        (rows of the graph permuted, values fixed)
  * perm_idx: int32[P][n] caller-supplied permutations (e.g. numpy's `rng.permutation(n)` streams) or NULL to
  * generate permutations [perm_begin, perm_end) on the device (csrc/sqgr_rng.h, keyed by seed and the global
- * permutation index => independent of how the range is split).  out_sims: float64[P][G], P = perm_end-perm_begin. */
+ * permutation index => the PERMUTATIONS are independent of how the range is split).  out_sims: float64[P][G],
+ * P = perm_end-perm_begin.  The scores' last bits also depend on which of the three summation kernels runs, and that is
+ * chosen from the length of THIS call's range (fewer than 40 permutations, 40-511, 512 and more — for >= 256 features and
+ * >= 4096 spots; the gather kernel otherwise): a caller that cuts one test into several calls and wants bit-identical scores
+ * keeps every piece on one side of these thresholds (or sets SQGR_AUTOCORR_KERNEL).  The front end never cuts permutation
+ * ranges — ranks own feature blocks — so its frames do not depend on the number of ranks. */
 int sqgr_autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_idx, uint64_t seed, int64_t perm_begin,
                         int64_t perm_end, double* out_sims);
 /* sqgr_autocorr_perms with the reference's own numpy streams generated ON THE DEVICE: pcg_states holds n_perms rows

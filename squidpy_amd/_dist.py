@@ -165,6 +165,11 @@ class SocketGroup:
         # `addr` is accepted for the launcher's MASTER_ADDR and ignored: the group is one node, the hub binds and the peers dial
         # 127.0.0.1 only (a routable listener was never offered; a switch that pretended to offer one is gone)
         self.rank, self.world = int(rank), int(world)
+        if addr not in ("127.0.0.1", "localhost", "::1", "") and addr != socket.gethostname():
+            import warnings
+
+            warnings.warn(f"squidpy_amd: MASTER_ADDR={addr!r} is ignored — the socket rendezvous connects the ranks of ONE node over 127.0.0.1 "
+                          "(ranks on other hosts cannot join; use a torch.distributed group for that)", RuntimeWarning, stacklevel=2)
         key = key or f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
         self._path = os.path.join(_rendezvous_dir(), f"rdzv_{key}")
         self._peers: list[socket.socket] = []
@@ -207,6 +212,11 @@ class SocketGroup:
                     if w != self.world or not 0 < r < self.world or r in by_rank:
                         conn.close()
                         raise RuntimeError(f"rendezvous: unexpected peer (rank {r} of {w}) for a {self.world}-rank group")
+                    try:
+                        conn.sendall(b"\x01")  # the rank keeps dialling until it has read this: a hello that came too late is re-sent
+                    except OSError:
+                        conn.close()
+                        continue
                     by_rank[r] = conn
             finally:
                 srv.close()
@@ -225,10 +235,20 @@ class SocketGroup:
                     s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                     s.settimeout(_TIMEOUT_S)
                     s.sendall(struct.pack("<ii", self.rank, self.world) + bytes.fromhex(token_hex))
+                    # the hub acknowledges a hello it has accepted; one it gave up on (it waits _HELLO_TIMEOUT_S per connection) closes
+                    # the socket instead, and this rank dials again — it used to keep the dead socket and fail later in barrier()
+                    s.settimeout(2.0 * _HELLO_TIMEOUT_S + 5.0)
+                    if _recv_exact(s, 1) != b"\x01":
+                        raise ConnectionError("rendezvous: the hub did not acknowledge the hello")
+                    s.settimeout(_TIMEOUT_S)
                     self._hub = s
                     break
-                except (OSError, ValueError) as exc:  # file not there yet / stale port of an earlier run
+                except (OSError, ValueError) as exc:  # file not there yet / stale port of an earlier run / hello not acknowledged
                     last = exc
+                    try:
+                        s.close()
+                    except (NameError, OSError):
+                        pass
                     time.sleep(0.05)
             if self._hub is None:
                 raise TimeoutError(f"rank {self.rank}: no rendezvous with rank 0 within {_TIMEOUT_S:.0f} s ({last!r})")

@@ -2195,7 +2195,9 @@ static int autocorr_perms(sqgr_autocorr* h, int32_t mode, const int32_t* perm_id
     // The joint list schedule (k_bucket_order_joint) makes a permutation's summation order depend on the 15 permutations it shares a
     // `ds_read_b128` lane group with, so the LDS kernel works on whole 16-aligned groups of the GLOBAL permutation index: with the
     // device generator the range is widened to [begin - lead, end rounded up to 16) and the extra ("ghost") permutations are
-    // generated, scheduled, scored and dropped — a permutation's score does not depend on how a range was cut.  (Injected
+    // generated, scheduled, scored and dropped — INSIDE ONE KERNEL a permutation's score does not depend on how a range was cut.
+    // (The kernel itself is chosen from the length of the call's range, perm_kernel_choice: pieces on different sides of its
+    // thresholds sum in different orders — include/sqgr.h says so; the front end always passes the whole range.  Injected
     // permutations and numpy's streams always start at permutation 0.)
     const bool ghosts = use_lds && !perm_idx && !pcg_states;
     const int64_t galign = 16 / split;  // (perm_slot: a service group holds 16 consecutive lanes = permutations, or 2 x 8 sub-lists)

@@ -1835,7 +1835,13 @@ int sqgr_nhood_run(sqgr_nhood* plan, uint64_t seed, int64_t perm_begin, int64_t 
     }
     return SQGR_OK;
     };
-    SQGR_TRY(comm_agree(p->comm, local(), st));
+    const int local_rc = local();
+    // the swap records of the bucketed replay (up to 36 GB at 1e6 spots x 8192 permutations per pass) belong to this run, not to
+    // the plan: back to the context's pool (parked up to SQGR_POOL_GB, the rest to the driver) — ADVICE r4
+    p->pcg_ws.recs.release();
+    p->pcg_ws.dir.release();
+    p->pcg_ws.nblk.release();
+    SQGR_TRY(comm_agree(p->comm, local_rc, st));
     // multi-GPU: the ranks ran disjoint permutation ranges; one RCCL all-reduce of the 2*K*K exact integer moments on the
     // device, then every rank copies out the global sums
     SQGR_TRY(comm_allreduce_i64_dev(p->comm, p->fin.p, (size_t)2 * K2, false, st));
@@ -2033,7 +2039,13 @@ static int run_pcg64_impl(sqgr_nhood* plan, const uint64_t* pcg_states, int64_t 
     }
     return SQGR_OK;
     };
-    SQGR_TRY(comm_agree(p->comm, local(), st));
+    const int local_rc = local();
+    // the swap records of the bucketed replay (up to 36 GB at 1e6 spots x 8192 permutations per pass) belong to this run, not to
+    // the plan: back to the context's pool (parked up to SQGR_POOL_GB, the rest to the driver) — ADVICE r4
+    p->pcg_ws.recs.release();
+    p->pcg_ws.dir.release();
+    p->pcg_ws.nblk.release();
+    SQGR_TRY(comm_agree(p->comm, local_rc, st));
     // multi-GPU: the ranks ran disjoint permutation ranges; one RCCL all-reduce of the 2*K*K exact integer moments on the
     // device, then every rank copies out the global sums
     SQGR_TRY(comm_allreduce_i64_dev(p->comm, p->fin.p, (size_t)2 * K2, false, st));

@@ -711,6 +711,10 @@ __global__ __launch_bounds__(PCGB_THREADS) void k_pcg_apply_bucketed(int64_t row
                 const uint32_t ph = lib_phase[l] + f;
                 const uint32_t wlen = min(S, m - (f << logS));
                 __syncthreads();
+                // the conflict tags hold (epoch << 11 | index): epoch restarts with every phase — a phase has at most S / 2048 chunks of
+                // <= 2048 rounds each, far below 2^21, so the epoch field cannot wrap whatever the array length
+                for (int k = tid; k < 2 * PCGB_SLOTS; k += PCGB_THREADS) tags[k] = 0u;
+                epoch = 0;
                 pcgb_copy_in(Xw, (s_dirty[f] ? row : base_pos) + off + ((size_t)f << logS), wlen, tid);
                 if (tid < PCGB_MAX_RANGES) s_hist[tid] = 0u;
                 __syncthreads();
@@ -1063,9 +1067,14 @@ int pcg_shuffle_rows(sqgr_ctx* ctx, PcgWorkspace& ws, int64_t n, int n_libs, con
         n_lib_max = 1;
         for (int l = 0; l < n_libs; ++l) n_lib_max = std::max<int64_t>(n_lib_max, (int64_t)ws.lib_off_h[l + 1] - ws.lib_off_h[l]);
     }
+    int rc_bucket = SQGR_ERR_UNSUPPORTED;
     if (pcg_use_bucket(n, n_lib_max)) {
-        SQGR_TRY(pcg_shuffle_rows_bucketed(ctx, ws, n, n_pad, n_libs, lib_off_dev, base_pos_dev, states_dev, pc, st, timer_name));
-    } else {
+        rc_bucket = pcg_shuffle_rows_bucketed(ctx, ws, n, n_pad, n_libs, lib_off_dev, base_pos_dev, states_dev, pc, st, timer_name);
+        if (rc_bucket != SQGR_OK && rc_bucket != SQGR_ERR_NOMEM) return rc_bucket;
+        // no room for the records (even the floor of 64 permutations per pass: 270 MB at 1e6 positions): the wave kernel below
+        // needs none (the call must not fail where it ran before the replay existed)
+    }
+    if (rc_bucket != SQGR_OK) {
         LaunchTimer t(ctx, timer_name, st);
         const uint32_t wsz = pcg_window(n);
         SQGR_TRY(pcg_allow_lds(k_pcg_shuffle_wave<uint8_t, false>, (size_t)wsz));

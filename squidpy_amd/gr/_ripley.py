@@ -183,7 +183,9 @@ def ripley(
     if metric in ("seuclidean", "mahalanobis"):
         # the reference fails here too: `NearestNeighbors(metric=metric)` needs V / VI, which `ripley` has no argument for
         # (gr/_ripley.py:144,148; sklearn: TypeError for seuclidean, "Must provide either V or VI" for mahalanobis)
-        raise ValueError(f"Metric `{metric}` needs parameters (V / VI) that `ripley` cannot pass on: the reference's NearestNeighbors call fails as well.")
+        # same exception TYPES as the reference's sklearn call raises for them: TypeError / ValueError
+        exc = TypeError if metric == "seuclidean" else ValueError
+        raise exc(f"Metric `{metric}` needs parameters (V / VI) that `ripley` cannot pass on: the reference's NearestNeighbors call fails as well.")
     if metric not in METRICS:
         raise NotImplementedError(f"Metric `{metric}` is not implemented on the GPU path; use one of {sorted(METRICS)}.")
 

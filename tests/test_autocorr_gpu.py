@@ -188,6 +188,31 @@ def test_list_schedule_structured_permutations_and_ranges(L, ctx, mode, perm_ker
     graph.close()
 
 
+def test_range_cuts_with_the_default_kernel_choice(L, ctx, monkeypatch, perm_kernel):
+    """the summation kernel is chosen from the length of the CALL's range (gather < 40 <= lds-split < 512 <= lds), so
+    bit-identity across range cuts holds for pieces on one side of the thresholds — with the library's own choice, not a forced
+    kernel: [0, 1100) == [0, 560) + [560, 1100) (both `lds`), [0, 300) == [0, 130) + [130, 300) (both `lds-split`); a piece
+    on the other side agrees to rounding only (documented in include/sqgr.h)."""
+    if perm_kernel != "gather":
+        pytest.skip("runs once, with no kernel forced")
+    monkeypatch.delenv("SQGR_AUTOCORR_KERNEL", raising=False)
+    rng = np.random.default_rng(12)
+    n, G = 6000, 256
+    g = knn_graph(rng.random((n, 2)), 6)
+    vals = rng.gamma(2.0, 1.0, size=(G, n))
+    graph = L.Graph(ctx, g)
+    plan = L.AutocorrPlan(ctx, graph, vals)
+    whole = plan.perms("moran", seed=5, perm_begin=0, perm_end=1100)
+    cut = np.concatenate([plan.perms("moran", seed=5, perm_begin=b, perm_end=e) for b, e in ((0, 560), (560, 1100))])
+    np.testing.assert_array_equal(cut, whole)
+    small = plan.perms("moran", seed=5, perm_begin=0, perm_end=300)
+    cut = np.concatenate([plan.perms("moran", seed=5, perm_begin=b, perm_end=e) for b, e in ((0, 130), (130, 300))])
+    np.testing.assert_array_equal(cut, small)
+    np.testing.assert_allclose(small, whole[:300], rtol=1e-11, atol=1e-14)   # another kernel: another summation order, the same scores
+    plan.close()
+    graph.close()
+
+
 def test_bucket_lists_with_row_sum_classes_belong_to_their_plan(L, ctx, perm_kernel):
     """The lists of the class-table kernel carry the row-sum class of every pair, and the context keeps the lists of the last call:
     two plans of the same size, seed and permutation count on graphs whose spots fall into DIFFERENT classes must not share them."""
