@@ -138,16 +138,124 @@ def resolve_seed(seed: int | None) -> int:
     return int(seed) & 0xFFFFFFFFFFFFFFFF
 
 
-def pcg64_states(seed: int | None, n: int, begin: int = 0, end: int | None = None) -> np.ndarray:
-    """Initial PCG64 states of ``spawn_generators(seed, n)[begin:end]`` as (k, 4) uint64 rows
-    ``[state_hi, state_lo, inc_hi, inc_lo]`` — what the device needs to continue numpy's streams bit for bit."""
-    end = n if end is None else end
+def _pcg64_states_numpy(seed: Any, n: int, begin: int, end: int) -> np.ndarray:
+    """The states as numpy itself produces them: one SeedSequence child and one PCG64 object per stream (13 us each)."""
     mask = (1 << 64) - 1
     seqs = np.random.SeedSequence(seed).spawn(n)[begin:end]
     out = np.empty((len(seqs), 4), dtype=np.uint64)
     for k, s in enumerate(seqs):
         st = np.random.PCG64(s).state["state"]
         out[k] = (st["state"] >> 64, st["state"] & mask, st["inc"] >> 64, st["inc"] & mask)
+    return out
+
+
+_SS_INIT_A, _SS_MULT_A, _SS_INIT_B, _SS_MULT_B = 0x43B0D7E5, 0x931E8875, 0x8B51F9DD, 0x58F38DED
+_SS_MIX_L, _SS_MIX_R, _M32 = 0xCA01F9DD, 0x4973F715, 0xFFFFFFFF
+_PCG_MULT = 0x2360ED051FC65DA44385DF649FCCF645
+
+
+def _u32_words(v: int) -> list[int]:
+    """numpy's `_coerce_to_uint32_array` of a non-negative int: little-endian 32-bit words, [0] for 0."""
+    out = []
+    while True:
+        out.append(v & _M32)
+        v >>= 32
+        if v == 0:
+            return out
+
+
+def pcg64_states(seed: int | None, n: int, begin: int = 0, end: int | None = None) -> np.ndarray:
+    """Initial PCG64 states of ``spawn_generators(seed, n)[begin:end]`` (/root/reference/src/squidpy/_utils.py:240-241) as (k, 4)
+    uint64 rows ``[state_hi, state_lo, inc_hi, inc_lo]`` — what the device needs to continue numpy's streams bit for bit.
+
+    ``SeedSequence(seed).spawn(n)`` + ``PCG64(child)`` restated in vectorised numpy (round 5): the children of one SeedSequence
+    differ only in the LAST word of their entropy (the spawn key), so the entropy pool is mixed once up to that word, the last
+    mixing step, ``generate_state(4, uint64)`` and the two LCG steps of PCG64's seeding run over all children at once in 32-bit
+    limbs.  100 000 streams: 1.2 s through numpy's objects, ~20 ms here; `==` numpy's own states (tests/test_host_logic_cpu.py),
+    and anything this restatement does not cover (non-integer entropy, a pool size other than 4) goes through numpy itself."""
+    end = n if end is None else end
+    ss = np.random.SeedSequence(seed)
+    if not isinstance(ss.entropy, int) or ss.entropy < 0 or ss.pool_size != 4 or ss.spawn_key != () or end - begin < 16 or n >= 2**32:
+        return _pcg64_states_numpy(seed if seed is not None else ss.entropy, n, begin, end)
+    # ---- the part of `mix_entropy` every child shares: run entropy (padded to the pool size when a spawn key follows)
+    words = _u32_words(ss.entropy)
+    words += [0] * (4 - len(words))
+    hc = _SS_INIT_A
+
+    def hashmix(v: int) -> int:
+        nonlocal hc
+        v ^= hc
+        hc = (hc * _SS_MULT_A) & _M32
+        v = (v * hc) & _M32
+        return v ^ (v >> 16)
+
+    def mix(x: int, y: int) -> int:
+        r = (_SS_MIX_L * x - _SS_MIX_R * y) & _M32
+        return r ^ (r >> 16)
+
+    pool = [hashmix(words[i]) for i in range(4)]
+    for i_src in range(4):
+        for i_dst in range(4):
+            if i_src != i_dst:
+                pool[i_dst] = mix(pool[i_dst], hashmix(pool[i_src]))
+    for w in words[4:]:
+        for i_dst in range(4):
+            pool[i_dst] = mix(pool[i_dst], hashmix(w))
+    # ---- the child's own word (spawn key (i,), i < 2^32: one word) over all children at once
+    key = np.arange(begin, end, dtype=np.uint64)  # uint64 arithmetic masked to 32 bits
+    m32 = np.uint64(_M32)
+    P = []
+    for i_dst in range(4):
+        v = key ^ np.uint64(hc)
+        hc = (hc * _SS_MULT_A) & _M32
+        v = (v * np.uint64(hc)) & m32
+        v ^= v >> np.uint64(16)
+        r = (np.uint64(_SS_MIX_L) * np.uint64(pool[i_dst]) - np.uint64(_SS_MIX_R) * v) & m32  # (wraps modulo 2^64, then 2^32)
+        P.append(r ^ (r >> np.uint64(16)))
+    # ---- generate_state(4, uint64): 8 words cycling through the pool
+    hb = _SS_INIT_B
+    W = []
+    for i in range(8):
+        v = P[i & 3] ^ np.uint64(hb)
+        hb = (hb * _SS_MULT_B) & _M32
+        v = (v * np.uint64(hb)) & m32
+        W.append(v ^ (v >> np.uint64(16)))
+    val = [W[2 * k] | (W[2 * k + 1] << np.uint64(32)) for k in range(4)]  # little-endian uint64 view of the words
+    # ---- pcg64_set_seed: initstate = val[0] << 64 | val[1], initseq = val[2] << 64 | val[3];  inc = initseq << 1 | 1;
+    # state = ((0 * M + inc) + initstate) * M + inc  (mod 2^128) — in four 32-bit limbs
+    def limbs(hi: np.ndarray, lo: np.ndarray) -> list[np.ndarray]:
+        return [lo & m32, lo >> np.uint64(32), hi & m32, hi >> np.uint64(32)]
+
+    def add128(a: list, b: list) -> list:
+        out, carry = [], np.zeros_like(a[0])
+        for x, y in zip(a, b):
+            t = x + y + carry
+            out.append(t & m32)
+            carry = t >> np.uint64(32)
+        return out
+
+    def mul128_const(a: list, c: int) -> list:
+        cl = [(c >> (32 * k)) & _M32 for k in range(4)]
+        out, carry = [], np.zeros_like(a[0])
+        for k in range(4):  # limb k of the product: sum of a[i] * c[k - i], accumulated in two halves so nothing exceeds 2^64
+            lo_acc, hi_acc = carry & m32, carry >> np.uint64(32)
+            for i in range(k + 1):
+                t = a[i] * np.uint64(cl[k - i])
+                lo_acc = lo_acc + (t & m32)
+                hi_acc = hi_acc + (t >> np.uint64(32))
+            out.append(lo_acc & m32)
+            carry = hi_acc + (lo_acc >> np.uint64(32))
+        return out
+
+    inc_hi = (val[2] << np.uint64(1)) | (val[3] >> np.uint64(63))
+    inc_lo = (val[3] << np.uint64(1)) | np.uint64(1)
+    inc = limbs(inc_hi, inc_lo)
+    state = add128(mul128_const(add128(inc, limbs(val[0], val[1])), _PCG_MULT), inc)
+    out = np.empty((end - begin, 4), dtype=np.uint64)
+    out[:, 0] = state[2] | (state[3] << np.uint64(32))
+    out[:, 1] = state[0] | (state[1] << np.uint64(32))
+    out[:, 2] = inc_hi
+    out[:, 3] = inc_lo
     return out
 
 

@@ -246,3 +246,20 @@ def test_committed_profiles_belong_to_the_committed_kernels(monkeypatch):
                 "config", "roofline", "cpu_baseline"):
         assert key in line, key
     assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+
+
+def test_pcg64_states_vectorised_restatement_equals_numpy():
+    """`pcg64_states` restates SeedSequence(seed).spawn(n) + PCG64(child) in vectorised numpy (13 us per stream through numpy's
+    objects was a third of a default nhood call at 1e6 spots, half of config 5 with numpy's streams): `==` numpy's own states for
+    small, 32-, 64-, 128-bit and longer seeds, ranges in the middle of the spawn, and the generators those states continue."""
+    from squidpy_amd._utils import _pcg64_states_numpy, pcg64_states, spawn_generators
+
+    for seed in (0, 1, 42, 2**31 - 1, 2**32, 2**32 + 1, 2**64 + 5, 123456789012345678901234567890, 2**128 - 1, 2**130 + 7, 2**200 + 99):
+        for n, lo, hi in ((64, 0, 64), (300, 3, 290), (5000, 4000, 5000)):
+            np.testing.assert_array_equal(pcg64_states(seed, n, lo, hi), _pcg64_states_numpy(seed, n, lo, hi), err_msg=f"{seed} {n} {lo} {hi}")
+    np.testing.assert_array_equal(pcg64_states(9, 5), _pcg64_states_numpy(9, 5, 0, 5))   # short ranges: numpy itself
+    st = pcg64_states(77, 40)
+    for k, g in enumerate(spawn_generators(77, 40)):   # the reference's generators (_utils.py:240-241) start from exactly these states
+        s = g.bit_generator.state["state"]
+        assert (int(st[k, 0]) << 64 | int(st[k, 1])) == s["state"] and (int(st[k, 2]) << 64 | int(st[k, 3])) == s["inc"]
+    assert pcg64_states(None, 100).shape == (100, 4)
