@@ -224,6 +224,17 @@ struct sqgr_graph {
     };
     mutable PassList pass_lists[4];
     int pass_list(int J, int R, int w, const int2** out) const;
+    // The same lists in 4 bytes per entry (round 5: the pass kernel is bound by the bytes it pulls from L2 into L1, and at 8, 4,
+    // 2, 1 permutations per pass the 8-byte list entries are most of them): entry = (col - row) << 8 | (row - base of its group),
+    // one base spot per group of 4*J entries in `base` — spot indices, scaled by the plane width in the kernel.  Admissible when
+    // every group spans fewer than 256 rows and |col - row| < 2^23; state: 0 not tried, 1 built, -1 this graph does not fit (the
+    // 8-byte list is used).  One per J (the order R is fixed when it is built).
+    struct PackedList {
+        int J = 0, R = 0, state = 0;
+        sqgr::DevBuf<uint32_t> list, base;
+    };
+    mutable PackedList packed_lists[2];
+    int packed_list(int J, int R, const uint32_t** out_list, const uint32_t** out_base) const;  // *out_list == nullptr: not admissible
 };
 
 namespace sqgr {

@@ -389,6 +389,78 @@ int sqgr_graph::pass_list(int J, int R, int w, const int2** out) const {
     return SQGR_OK;
 }
 
+// one block per group of G = 4*J physical entries: the group's smallest row is its base; flag[0] != 0: some entry does not fit
+__global__ __launch_bounds__(256) void k_packed_list(const int2* __restrict__ src, uint32_t m, uint32_t J, uint32_t R,
+                                                    uint32_t* __restrict__ dst, uint32_t* __restrict__ base, int* __restrict__ flag) {
+    __shared__ uint32_t s_min;
+    const uint32_t G = 4 * J, p0 = blockIdx.x * G;
+    if (threadIdx.x == 0) s_min = 0xffffffffu;
+    __syncthreads();
+    int2 v = make_int2(0, 0);
+    bool real = false;
+    if (threadIdx.x < G) {
+        const uint32_t l = pass_list_logical(p0 + threadIdx.x, J, R);
+        real = l < m;
+        if (real) {
+            v = src[l];
+            atomicMin(&s_min, (uint32_t)v.x >> 4);
+        }
+    }
+    __syncthreads();
+    const uint32_t b = s_min == 0xffffffffu ? 0u : s_min;
+    if (threadIdx.x == 0) base[blockIdx.x] = b;
+    if (threadIdx.x >= G) return;
+    uint32_t e = 0;  // padding: the base row against itself (a valid spot; the kernel's tail logic adds 0 for it)
+    if (real) {
+        const uint32_t r = (uint32_t)v.x >> 4, c = (uint32_t)v.y >> 4;
+        const int32_t d = (int32_t)c - (int32_t)r;
+        if (r - b > 255u || d >= (1 << 23) || d < -(1 << 23)) atomicOr(flag, 1);
+        e = ((uint32_t)d << 8) | ((r - b) & 255u);
+    }
+    dst[p0 + threadIdx.x] = e;
+}
+
+int sqgr_graph::packed_list(int J, int R, const uint32_t** out_list, const uint32_t** out_base) const {
+    *out_list = *out_base = nullptr;
+    SQGR_TRY(ensure_half());
+    PackedList& pl = packed_lists[J == 32 ? 0 : 1];
+    if (pl.state == 0 || pl.J != J || pl.R != R) {
+        const bool is_half = sym_state == 1;
+        const int2* src = is_half ? half.p : coo.p;
+        const int64_t m = is_half ? n_half + n_self : nnz;
+        SQGR_HIP(hipSetDevice(ctx->device));
+        const int64_t G = 4 * (int64_t)J;
+        const int64_t groups = ceil_div(m, G) + ceil_div((int64_t)LIST_PAD, G) + 1;
+        pl.list.release();
+        pl.base.release();
+        SQGR_TRY(pl.list.alloc((size_t)(groups * G)));
+        SQGR_TRY(pl.base.alloc((size_t)groups));
+        DevBuf<int> flag;
+        SQGR_TRY(flag.alloc(1));
+        SQGR_HIP(hipMemsetAsync(flag.p, 0, 4, ctx->stream));
+        {
+            LaunchTimer t(ctx, "graph_packed_list");
+            k_packed_list<<<(unsigned)groups, 256, 0, ctx->stream>>>(src, (uint32_t)m, (uint32_t)J, (uint32_t)R, pl.list.p, pl.base.p, flag.p);
+            SQGR_HIP(hipGetLastError());
+        }
+        int h_flag = 1;
+        SQGR_HIP(hipMemcpyAsync(&h_flag, flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+        SQGR_HIP(hipStreamSynchronize(ctx->stream));
+        pl.J = J;
+        pl.R = R;
+        pl.state = h_flag ? -1 : 1;
+        if (h_flag) {
+            pl.list.release();
+            pl.base.release();
+        }
+    }
+    if (pl.state == 1) {
+        *out_list = pl.list.p;
+        *out_base = pl.base.p;
+    }
+    return SQGR_OK;
+}
+
 int sqgr_ctx::timer_id(const char* name) {
     auto it = timer_ids.find(name);
     if (it != timer_ids.end()) return it->second;

@@ -695,8 +695,10 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
 // SPLIT = 2 (203 <= K <= 256: not even one permutation's K*K counters fit): a block keeps the rows la of one HALF of the labels
 // only and skips the other edges' atomics — twice the blocks, every one of them walking the whole chunk; h + h^T is then formed
 // by k_reduce (sym bit 2), a block does not hold the transposed rows.
-template <int LPE, int NS, bool SELF, int SPLIT = 1>
-__global__ __launch_bounds__(COUNT_THREADS, 4) void k_count_pass(uint32_t nnz, const int2* __restrict__ coo,
+// PACK: the list in 4 bytes per entry (sqgr_graph::packed_list: (col - row) << 8 | row - base of the wavefront's group; spot indices,
+// scaled to plane offsets here) — half the list bytes through L2 -> L1, which is what bounds this kernel.
+template <int LPE, int NS, bool SELF, int SPLIT = 1, bool PACK = false>
+__global__ __launch_bounds__(COUNT_THREADS, 4) void k_count_pass(uint32_t nnz, const int2* __restrict__ coo, const uint32_t* __restrict__ gbase,
                                                                  const uint8_t* __restrict__ slab_all, int64_t n, int K,
                                                                  uint32_t edges_per_chunk, uint32_t self_begin, int add_transposed,
                                                                  int nchunks, uint32_t R, uint32_t* __restrict__ partial_all) {
@@ -751,35 +753,68 @@ __global__ __launch_bounds__(COUNT_THREADS, 4) void k_count_pass(uint32_t nnz, c
     const uint32_t dot_k = ((uint32_t)(K * B * 4) << 16) | (uint32_t)(B * 4);  // {hi: bytes per la row, lo: bytes per pair}
 
     struct Pairs { uint32_t r[U], c[U]; };
-    struct Loaded { int4 v[LPE == 1 ? 2 : 1]; };  // LPE 2: two entries; LPE 1: four entries
+    // what a lane loads per iteration: its U / LPE... entries — LPE 2: entries 2q, 2q + 1 of the quad's eight; LPE 1: its own four —
+    // as (row, col) offset pairs (8 bytes each) or PACKed words (4 bytes each) + the base spot of the wavefront's group
+    constexpr int NE = LPE == 1 ? 4 : 2;
+    struct Loaded { uint32_t w[PACK ? NE : 2 * NE]; uint32_t base; };
+    constexpr int LW = B == 8 ? 3 : (B == 4 ? 2 : (B == 2 ? 1 : 0));  // log2 of the plane's row width (PACK: spot -> byte offset)
     auto load_pair = [&](uint32_t e) {            // e: first edge of the block's iteration; physical entries 4 * slot .. + 3 of the wavefront's group
         Loaded L;
-        const int2* grp = coo + e + wave * (4 * J);
-        if constexpr (LPE == 2) {
-            L.v[0] = *reinterpret_cast<const int4*>(grp + lane * 2);  // the quad's 8 entries: lane q holds entries 2q, 2q + 1
+        L.base = 0;
+        if constexpr (PACK) {
+            const uint32_t* lst = reinterpret_cast<const uint32_t*>(coo) + e + wave * (4 * J) + lane * NE;
+            L.base = gbase[(e >> (LPE == 2 ? 7 : 8)) + wave];  // one word per group of 4*J entries: the same address in all 64 lanes
+            if constexpr (LPE == 2) {
+                const uint2 v = *reinterpret_cast<const uint2*>(lst);
+                L.w[0] = v.x; L.w[1] = v.y;
+            } else {
+                const uint4 v = *reinterpret_cast<const uint4*>(lst);
+                L.w[0] = v.x; L.w[1] = v.y; L.w[2] = v.z; L.w[3] = v.w;
+            }
         } else {
-            L.v[0] = *reinterpret_cast<const int4*>(grp + lane * 4);
-            L.v[1] = *reinterpret_cast<const int4*>(grp + lane * 4 + 2);
+            const int2* grp = coo + e + wave * (4 * J) + lane * NE;
+            const uint4 v = *reinterpret_cast<const uint4*>(grp);
+            L.w[0] = v.x; L.w[1] = v.y; L.w[2] = v.z; L.w[3] = v.w;
+            if constexpr (LPE == 1) {
+                const uint4 v2 = *reinterpret_cast<const uint4*>(grp + 2);
+                L.w[4] = v2.x; L.w[5] = v2.y; L.w[6] = v2.z; L.w[7] = v2.w;
+            }
         }
         return L;
     };
-#define SQGR_ADD_DPP(dst, src, sel)                                                                      \
-    asm("v_add_u32_dpp %0, %1, %2 quad_perm:[" sel "] row_mask:0xf bank_mask:0xf" : "=v"(dst) : "v"(src), "v"(qoff))
+    // quad_perm [0,0,2,2] = 0xA0, [1,1,3,3] = 0xF5: lanes {0, 1} of a quad handle its entries 0..3 (slot 2t), lanes {2, 3} entries 4..7
+#define SQGR_DPP(src, ctrl) (uint32_t)__builtin_amdgcn_mov_dpp((int)(src), ctrl, 0xf, 0xf, true)
+    auto unpack = [&](uint32_t word, uint32_t base, uint32_t& r_off, uint32_t& c_off) {
+        r_off = ((base + (word & 255u)) << LW) + qoff;
+        c_off = r_off + (uint32_t)(((int32_t)word >> 8) << LW);  // (two's complement: the shift of a negative difference is the intended product)
+    };
     auto spread = [&](const Loaded& L) {
         Pairs pr;
-        if constexpr (LPE == 2) {
-            // lanes {0, 1} of the quad handle its entries 0..3 (slot 2t), lanes {2, 3} its entries 4..7 (slot 2t + 1)
-            SQGR_ADD_DPP(pr.r[0], L.v[0].x, "0,0,2,2"); SQGR_ADD_DPP(pr.c[0], L.v[0].y, "0,0,2,2");
-            SQGR_ADD_DPP(pr.r[1], L.v[0].z, "0,0,2,2"); SQGR_ADD_DPP(pr.c[1], L.v[0].w, "0,0,2,2");
-            SQGR_ADD_DPP(pr.r[2], L.v[0].x, "1,1,3,3"); SQGR_ADD_DPP(pr.c[2], L.v[0].y, "1,1,3,3");
-            SQGR_ADD_DPP(pr.r[3], L.v[0].z, "1,1,3,3"); SQGR_ADD_DPP(pr.c[3], L.v[0].w, "1,1,3,3");
+        if constexpr (PACK) {
+            uint32_t e4[U];
+            if constexpr (LPE == 2) {
+                e4[0] = SQGR_DPP(L.w[0], 0xA0); e4[1] = SQGR_DPP(L.w[1], 0xA0);
+                e4[2] = SQGR_DPP(L.w[0], 0xF5); e4[3] = SQGR_DPP(L.w[1], 0xF5);
+            } else {
+                e4[0] = L.w[0]; e4[1] = L.w[1]; e4[2] = L.w[2]; e4[3] = L.w[3];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) unpack(e4[u], L.base, pr.r[u], pr.c[u]);
+        } else if constexpr (LPE == 2) {
+            pr.r[0] = SQGR_DPP(L.w[0], 0xA0) + qoff; pr.c[0] = SQGR_DPP(L.w[1], 0xA0) + qoff;
+            pr.r[1] = SQGR_DPP(L.w[2], 0xA0) + qoff; pr.c[1] = SQGR_DPP(L.w[3], 0xA0) + qoff;
+            pr.r[2] = SQGR_DPP(L.w[0], 0xF5) + qoff; pr.c[2] = SQGR_DPP(L.w[1], 0xF5) + qoff;
+            pr.r[3] = SQGR_DPP(L.w[2], 0xF5) + qoff; pr.c[3] = SQGR_DPP(L.w[3], 0xF5) + qoff;
         } else {
-            pr.r[0] = L.v[0].x; pr.c[0] = L.v[0].y; pr.r[1] = L.v[0].z; pr.c[1] = L.v[0].w;
-            pr.r[2] = L.v[1].x; pr.c[2] = L.v[1].y; pr.r[3] = L.v[1].z; pr.c[3] = L.v[1].w;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                pr.r[u] = L.w[2 * u];
+                pr.c[u] = L.w[2 * u + 1];
+            }
         }
         return pr;
     };
-#undef SQGR_ADD_DPP
+#undef SQGR_DPP
     auto gather_rows = [&](const Pairs& pr, uint32_t (&ra)[U], uint32_t (&rb)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {  // list entries of a pass list are byte offsets into a plane: B * spot
@@ -1321,42 +1356,48 @@ int sqgr_nhood::count_batches(int nb, int buf) {
         // order of the list inside a wavefront's group of entries (sqgr_graph::pass_list): R = 1 — a gather instruction covers
         // consecutive edges — unless SQGR_COUNT_PASS_R says 2 or 4 (experiments; 4 = the list as it is)
         static const int order_r = [] { const char* v = getenv("SQGR_COUNT_PASS_R"); const int r = v ? atoi(v) : 1; return (r == 2 || r == 4) ? r : 1; }();
+        // the list: 4 bytes per entry when the graph admits it (sqgr_graph::packed_list; SQGR_COUNT_PASS_PACK=0: never), else 8
+        static const bool want_pack = [] { const char* v = getenv("SQGR_COUNT_PASS_PACK"); return !(v && atoi(v) == 0); }();
         const int2* list = nullptr;
-        SQGR_TRY(g->pass_list(e >= 8 ? 32 : 64, order_r, e, &list));
+        const uint32_t *plist = nullptr, *pbase = nullptr;
+        // (measured at 1e6 spots, 2560 permutations per launch: 4 | 2 | 1 permutations per pass 2.33 -> 2.16, 7.46 -> 6.80, 7.88 -> 7.12 ms
+        //  — and 8 per pass 2.07 -> 2.14 ms: two lanes per edge unpack every entry twice; that width keeps the 8-byte list)
+        if (want_pack && e <= 4) SQGR_TRY(g->packed_list(64, order_r, &plist, &pbase));
+        const bool pack = plist != nullptr;
+        if (pack) list = reinterpret_cast<const int2*>(plist);
+        else SQGR_TRY(g->pass_list(e >= 8 ? 32 : 64, order_r, e, &list));
         const uint32_t step = (uint32_t)(COUNT_THREADS * 4 / (e >= 8 ? 2 : 1));             // edges per iteration of a block
         const uint32_t epc = (uint32_t)(ceil_div(ceil_div((int64_t)m, nblk), step) * step);  // whole iterations per chunk
         const int sp = split();
         const size_t lds = (size_t)((K + sp - 1) / sp) * K * e * 4;
         if (sp > 1 && half) sym_launch |= 4;  // h + h^T in k_reduce
+        const int addt = (half && sp == 1) ? 1 : 0;
         const dim3 grid(nblk * (16 / e) * sp, nb);
         LaunchTimer t(ctx, half ? "nhood_count_pass_half" : "nhood_count_pass");
-#define SQGR_PASS(LPE, NS)                                                                                                        \
+#define SQGR_PASS_K(LPE, NS, SELF, SPLIT, PACK)                                                                                   \
     do {                                                                                                                          \
-        if (self) {                                                                                                               \
-            SQGR_TRY(allow_lds(k_count_pass<LPE, NS, true>, lds));                                                                \
-            k_count_pass<LPE, NS, true><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, epc, self_begin, half ? 1 : 0, nblk, (uint32_t)order_r, partial.p); \
-        } else {                                                                                                                  \
-            SQGR_TRY(allow_lds(k_count_pass<LPE, NS, false>, lds));                                                               \
-            k_count_pass<LPE, NS, false><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, epc, self_begin, half ? 1 : 0, nblk, (uint32_t)order_r, partial.p); \
-        }                                                                                                                         \
+        SQGR_TRY(allow_lds((k_count_pass<LPE, NS, SELF, SPLIT, PACK>), lds));                                                     \
+        k_count_pass<LPE, NS, SELF, SPLIT, PACK><<<grid, COUNT_THREADS, lds, st>>>(m, list, pbase, slab_p, n, K, epc, self_begin, addt, nblk, \
+                                                                                   (uint32_t)order_r, partial.p);                \
+    } while (0)
+#define SQGR_PASS(LPE, NS, SPLIT)                                                  \
+    do {                                                                           \
+        if (self) {                                                                \
+            if (pack) SQGR_PASS_K(LPE, NS, true, SPLIT, true); else SQGR_PASS_K(LPE, NS, true, SPLIT, false);   \
+        } else {                                                                   \
+            if (pack) SQGR_PASS_K(LPE, NS, false, SPLIT, true); else SQGR_PASS_K(LPE, NS, false, SPLIT, false); \
+        }                                                                          \
     } while (0)
         switch (e) {
-            case 8: SQGR_PASS(2, 4); break;
-            case 4: SQGR_PASS(1, 4); break;
-            case 2: SQGR_PASS(1, 2); break;
+            case 8: SQGR_PASS(2, 4, 1); break;
+            case 4: SQGR_PASS(1, 4, 1); break;
+            case 2: SQGR_PASS(1, 2, 1); break;
             default:
-                if (sp == 1) {
-                    SQGR_PASS(1, 1);
-                } else if (self) {
-                    SQGR_TRY(allow_lds((k_count_pass<1, 1, true, 2>), lds));
-                    k_count_pass<1, 1, true, 2><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, epc, self_begin, 0, nblk, (uint32_t)order_r, partial.p);
-                } else {
-                    SQGR_TRY(allow_lds((k_count_pass<1, 1, false, 2>), lds));
-                    k_count_pass<1, 1, false, 2><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, epc, self_begin, 0, nblk, (uint32_t)order_r, partial.p);
-                }
+                if (sp == 1) SQGR_PASS(1, 1, 1); else SQGR_PASS(1, 1, 2);
                 break;
         }
 #undef SQGR_PASS
+#undef SQGR_PASS_K
     } else if (B == 32 || be() == 16) {
         // LDS-histogram kernels: on a structurally symmetric graph they walk the half list (see sqgr_graph::ensure_half)
         SQGR_TRY(g->ensure_half());

@@ -177,7 +177,7 @@ def test_all_cluster_count_regimes(L, ctx, k):
     np.testing.assert_array_equal(perms, ref.astype(np.uint32))
 
 
-@pytest.mark.parametrize("graph", ["hex", "hex+self", "knn"])
+@pytest.mark.parametrize("graph", ["hex", "hex+self", "knn", "gaps"])
 @pytest.mark.parametrize("k,width,blocks", [(60, 0, 0), (60, 4, 0), (71, 8, 5), (72, 0, 0), (100, 0, 0), (101, 2, 0), (102, 0, 0), (130, 1, 0), (30, 8, 0), (30, 4, 16),
                                              (30, 2, 0), (7, 1, 3), (202, 0, 0), (203, 0, 0), (231, 0, 5), (256, 0, 0)])
 def test_lds_pass_kernel_every_width_on_half_and_full_lists(L, ctx, graph, k, width, blocks):
@@ -190,6 +190,12 @@ def test_lds_pass_kernel_every_width_on_half_and_full_lists(L, ctx, graph, k, wi
     if graph == "knn":
         n = 21000
         adj = knn_graph(rng.random((n, 2)), 6)
+    elif graph == "gaps":  # one row in 40 has neighbours (anywhere): 256 list entries span > 255 rows — the 4-byte list entries
+        n = 24000          # (row - group base in 8 bits) do not fit this graph and the 8-byte list must take over
+        rows = np.repeat(np.arange(0, n, 40), 6)
+        adj = sp.csr_matrix((np.ones(rows.size, np.float32), (rows, rng.integers(0, n, rows.size))), shape=(n, n))
+        adj.sum_duplicates()
+        adj.sort_indices()
     else:
         adj = O.hex_grid_graph(150, 160)
         n = adj.shape[0]
@@ -202,7 +208,7 @@ def test_lds_pass_kernel_every_width_on_half_and_full_lists(L, ctx, graph, k, wi
     if width or blocks:
         plan.tune(width, blocks, 3)
     info = plan.info()
-    assert info["symmetric"] == (graph != "knn")
+    assert info["symmetric"] == (graph in ("hex", "hex+self"))
     n_perms = 50  # 3 batches of 16 per launch group -> two launch groups, the last batch partly filled
     _, _, perms = plan.run(11, 5, 5 + n_perms, None, return_perms=True)
     ref = O.nhood_perm_counts_philox(adj.indices, adj.indptr, labels, k, 11, 5, 5 + n_perms)
