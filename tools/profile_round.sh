@@ -8,10 +8,10 @@
 #   4. micro-benchmarks: float64 issue rates, gathers beside LDS atomics
 # <tag>_counters.json is stamped with the kernel sources' fingerprint; bench.py uses it only for that build and for the
 # workload key (spots, list edges, permutations per launch) it was taken on.
-#   usage: tools/profile_round.sh [tag]          (default tag r04; outputs under gpurun_out/prof_<tag>/ and profiles/)
+#   usage: tools/profile_round.sh [tag]          (default tag r05; outputs under gpurun_out/prof_<tag>/ and profiles/)
 # bench.py's final stdout line is the compact one: the summaries read the FULL record each profiled run writes (--detail-out).
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT $REPO/profiles

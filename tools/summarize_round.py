@@ -108,7 +108,10 @@ rep = {
 lagg = collect(("legs_sqa", "legs_fetch", "legs_write", "legs_tcp"))
 lb = bench_line("legs_sqa.log") or legs_bench or {}
 rep["legs"] = {"command": legs_cmd, "workload": (((lb.get("legs") or {}).get("co_occurrence") or {}).get("roofline") or {}).get("workload_key"),
-               "kernels": section(lagg, lambda k: "k_cooccur" in k or "k_pair_hist" in k or "k_knn" in k, after_first=True)}
+               "kernels": section(lagg, lambda k: "k_cooccur" in k or "k_pair_hist" in k or "k_knn" in k, after_first=True),
+               # the pass kernel of the nhood_K64 / K100 / K200 legs: one template instantiation each (<lanes per edge, atomics per edge and
+               # lane, self loops, row split, packed list>); a leg = a 64-permutation warm-up launch + the launches of 10 000 permutations
+               "nhood_pass_kernels": section(lagg, lambda k: "k_count_pass" in k, after_first=True)}
 nagg = collect(("npy_fetch", "npy_write"))
 nb = bench_line("npy_fetch.log") or {}
 rep["numpy"] = {"workload": (((nb.get("numpy_stream_mode") or {}).get("roofline")) or {}).get("workload_key"),
