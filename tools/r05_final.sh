@@ -1,0 +1,39 @@
+#!/bin/bash
+# final lease of round 5: the whole GPU suite, the driver's smoke, the profiles the bench line is priced with, the default bench
+# line, the two-rank bench through its own launcher, the stream table and the cluster-count sweep — ONE lease, one build
+set -u
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$REPO/gpurun_out/r05_final
+mkdir -p $OUT
+cd $REPO
+export TMPDIR=/tmp
+( time timeout 2400 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1 ) 2> $OUT/pytest_gpu.time; echo "rc=$?" >> $OUT/pytest_gpu.log; tail -4 $OUT/pytest_gpu.log; tail -3 $OUT/pytest_gpu.time
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
+bash tools/profile_round.sh r05 > $OUT/profile_round.log 2>&1; tail -3 $OUT/profile_round.log | cut -c1-200
+cp gpurun_out/prof_r05/r05_*.json gpurun_out/prof_r05/r05_*.txt profiles/ 2>/dev/null
+( time timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err ) 2> $OUT/bench.time; tail -3 $OUT/bench.time
+cp gpurun_out/bench_detail.json $OUT/bench_detail.json 2>/dev/null
+cp $OUT/bench_detail.json profiles/r05_bench_detail.json 2>/dev/null; tail -1 $OUT/bench.json > profiles/r05_bench.json
+# the driver's multi-GPU invocation, as far as one GPU can show it: `python bench.py --gpus 2` starts two ranks by itself
+timeout 600 python bench.py --gpus 2 --share-devices --steps 3 --warmup 1 --no-cpu-baseline --no-legs --no-secondary --no-numpy-leg --emulate-ranks 0 \
+  --detail-out $OUT/bench_gpus2_detail.json > $OUT/bench_gpus2.json 2> $OUT/bench_gpus2.err; tail -1 $OUT/bench_gpus2.json > profiles/r05_bench_gpus2_shared_device.json
+timeout 600 python tools/streams_table.py > profiles/r05_streams_table.json 2> $OUT/streams_table.err
+timeout 600 python tools/nhood_k_sweep.py 1000 2560 > profiles/r05_nhood_k_sweep.jsonl 2> $OUT/k_sweep.err
+timeout 300 python tools/numpy_call_breakdown.py > profiles/r05_numpy_call_breakdown.jsonl 2> $OUT/numpy_breakdown.err
+bash tools/pmc_pass.sh "30 64 100 200" > /dev/null 2>&1; cp gpurun_out/pmc_pass.txt profiles/r05_pmc_pass_kernel.txt
+cp $OUT/pytest_gpu.log profiles/r05_pytest_gpu.log
+python - $OUT/bench_detail.json $OUT/bench.json <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+line = open(sys.argv[2]).read().strip().splitlines()[-1]
+print("final line bytes:", len(line))
+r = d["roofline"]
+print("value", round(d["value"]), "roofline", r["bound"], r["achieved"], r["frac"], "fabric", r.get("fabric_frac"), "alg", r.get("algorithmic_frac"), "pmc:", d.get("pmc_profile"))
+print("moran", round(d["secondary"]["value"]), d["secondary"]["roofline"].get("frac"))
+for k, v in d.get("legs", {}).items():
+    rr = v.get("roofline") or {}
+    print(k, v.get("value"), v.get("unit"), "kernel_ms", v.get("kernel_ms") if not isinstance(v.get("kernel_ms"), dict) else "", "frac", rr.get("frac"), "cpu", (v.get("cpu_baseline") or {}).get("value"), v.get("moran"), v.get("geary"))
+n = d["numpy_stream_mode"]; print("numpy", n["value"], n["at_n_perms_1000"], n["roofline"]["frac"], n["roofline"].get("traffic_MB_per_perm"))
+print("cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["all_cores"].get("value"), "emulated", d.get("emulated_ranks", {}).get("shard_seconds"))
+PY
+tail -1 profiles/r05_bench_gpus2_shared_device.json | cut -c1-600
