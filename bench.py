@@ -872,7 +872,7 @@ def nhood_variant_legs(ctx, adj, graph, n: int, headline_value: float | None, pe
         legs[name] = {"value": perms / dt, "unit": "permutations/s", "clusters": K, "what": what,
                       "vs_k30": perms / dt / headline_value if headline_value else None,
                       "count_kernel": "+".join(k for k, _ in cnt), "count_us_per_perm": ms * 1e3 / perms, "perms_per_pass": info["perms_per_pass"],
-                      "list_edges": info["list_edges"], "symmetric_half_list": info["symmetric"], "kernel_ms": {k: round(v[1], 3) for k, v in kern.items() if v[0] > 0},
+                      "list_edges": info["list_edges"], "symmetric_half_list": info["symmetric"], "kernels_ms": {k: round(v[1], 3) for k, v in kern.items() if v[0] > 0},
                       "roofline": {"kernel": "+".join(k for k, _ in cnt), "bound": "hbm", "achieved": dram / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else None,
                                    "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": dram / (avg_ms * 1e-3) / HBM_PEAK if avg_ms > 0 else None, "traffic": dram,
                                    "frac_basis": "compulsory DRAM bytes per launch (slab once + partials once + edge list once) / HIP-event time"}}

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (what it writes under profiles/ stays on the box: tools/r05_collect.sh copies the lease's gpurun_out/ files into profiles/ afterwards)
 # final lease of round 5: the whole GPU suite, the driver's smoke, the profiles the bench line is priced with, the default bench
 # line, the two-rank bench through its own launcher, the stream table and the cluster-count sweep — ONE lease, one build
 set -u
@@ -17,10 +18,10 @@ cp $OUT/bench_detail.json profiles/r05_bench_detail.json 2>/dev/null; tail -1 $O
 # the driver's multi-GPU invocation, as far as one GPU can show it: `python bench.py --gpus 2` starts two ranks by itself
 timeout 600 python bench.py --gpus 2 --share-devices --steps 3 --warmup 1 --no-cpu-baseline --no-legs --no-secondary --no-numpy-leg --emulate-ranks 0 \
   --detail-out $OUT/bench_gpus2_detail.json > $OUT/bench_gpus2.json 2> $OUT/bench_gpus2.err; tail -1 $OUT/bench_gpus2.json > profiles/r05_bench_gpus2_shared_device.json
-timeout 600 python tools/streams_table.py > profiles/r05_streams_table.json 2> $OUT/streams_table.err
-timeout 600 python tools/nhood_k_sweep.py 1000 2560 > profiles/r05_nhood_k_sweep.jsonl 2> $OUT/k_sweep.err
-timeout 300 python tools/numpy_call_breakdown.py > profiles/r05_numpy_call_breakdown.jsonl 2> $OUT/numpy_breakdown.err
-bash tools/pmc_pass.sh "30 64 100 200" > /dev/null 2>&1; cp gpurun_out/pmc_pass.txt profiles/r05_pmc_pass_kernel.txt
+timeout 600 python tools/streams_table.py > gpurun_out/r05_streams_table.json 2> $OUT/streams_table.err
+timeout 600 python tools/nhood_k_sweep.py 1000 2560 > gpurun_out/r05_nhood_k_sweep.jsonl 2> $OUT/k_sweep.err
+timeout 300 python tools/numpy_call_breakdown.py > gpurun_out/r05_numpy_call_breakdown.jsonl 2> $OUT/numpy_breakdown.err
+bash tools/pmc_pass.sh "30 64 100 200" > /dev/null 2>&1; cp gpurun_out/pmc_pass.txt gpurun_out/r05_pmc_pass_kernel.txt
 cp $OUT/pytest_gpu.log profiles/r05_pytest_gpu.log
 python - $OUT/bench_detail.json $OUT/bench.json <<'PY'
 import json, sys

@@ -49,7 +49,10 @@ if legs_cmd:
     if legs_bench and legs_bench.get("legs"):
         for k, v in legs_bench["legs"].items():
             if "value" in v:
-                lines.append(f"{k}: {v['value']:.4g} {v['unit']} (kernel {v.get('kernel_ms', float('nan')):.2f} ms, wall {v.get('wall_s', float('nan')):.3f} s)")
+                km, ws = v.get("kernel_ms"), v.get("wall_s")
+                km = f"{km:.2f}" if isinstance(km, (int, float)) else "-"
+                ws = f"{ws:.3f}" if isinstance(ws, (int, float)) else "-"
+                lines.append(f"{k}: {v['value']:.4g} {v['unit']} (kernel {km} ms, wall {ws} s)")
 open(os.path.join(out, f"{tag}_rocprofv3_summary.txt"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
 
