@@ -1256,18 +1256,17 @@ struct sqgr_nhood {
     // layout of a batch's 16 * n slab bytes: 16 = rows [n][16]; 8 | 4 | 2 | 1 = 16 / w planes [n][w], one per pass (slab_store16)
     int plane_w() const { return (B == 16 && !wide() && be() > 0) ? be() : 16; }
     // 1024-thread blocks per batch of a launch with `nb` batches = edge chunks per batch (k_count_pass: times `passes()` blocks).
-    // nblk > 0: fixed by sqgr_nhood_tune.  Auto: ~8 blocks per CU over the whole launch, at least 32 per batch — measured on MI355X
-    // (tools/tune_sweep.sh): with 64 batches in flight 32-48 blocks per batch beat one block per CU by 15 % (fewer partial
-    // histograms to write and re-read: blocks * K*K*B*4 bytes per batch; longer edge runs per block).  With passes a chunk is walked
-    // by 16 / be blocks and its partial histogram is K*K*64 bytes whatever be is (2.5 MB at K = 200): at least 8 chunks, 32 / passes
-    // when that is more.
+    // nblk > 0: fixed by sqgr_nhood_tune.  Auto: ~4 blocks per CU over the whole launch, at least 8 per batch (one per XCD), whole
+    // XCD shares (a multiple of 8).  Round 2 had measured 32-48 blocks per batch as the best with 64 batches per launch; with the
+    // 160-batch launches of today fewer, longer chunks win — fewer partial histograms to write and re-read (blocks * K*K*64 bytes
+    // per batch), fewer ramps and tails (tools/nhood_k_sweep.py --sweep, round 5, permutations/s at 1e6 spots; blocks per batch 8 /
+    // 16 / 32 / 64: K = 30 953 k / 948 k / 921 k / 864 k — round 4's 32 was 6 % behind —, K = 64 687 k / 657 k / 602 k / 499 k,
+    // K = 100 605 k / 552 k / 450 k / 330 k, K = 200 230 k / 199 k / 149 k / 102 k).
     int blocks_for(int nb) const {
         if (nblk > 0) return nblk;
         const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
-        // rounded DOWN to a multiple of 8 (whole XCD shares): nb * blocks must not spill a few blocks into one more round of
-        // 2 blocks per CU — 49 batches x 42 blocks = 2058 blocks ran 5 rounds for 4.02 rounds of work
-        const int64_t fill = (((int64_t)8 * cus) / std::max(nb * passes(), 1)) & ~(int64_t)7;
-        return (int)std::max<int64_t>(std::max(8, 32 / passes()), std::min<int64_t>(cus, fill));
+        const int64_t fill = (((int64_t)4 * cus) / std::max(nb * passes(), 1)) & ~(int64_t)7;
+        return (int)std::max<int64_t>(8, std::min<int64_t>(cus, fill));
     }
     int nblk_launch = 0;  // blocks per batch of the launch in flight (count -> reduce)
     int sym_launch = 0;   // k_reduce mode of the launch in flight (0 full edge list, 1 half list, 2 half list with self loops)
@@ -1876,13 +1875,12 @@ int sqgr_nhood_run(sqgr_nhood* plan, uint64_t seed, int64_t perm_begin, int64_t 
     }
     return SQGR_OK;
     };
-    const int local_rc = local();
-    // the swap records of the bucketed replay (up to 36 GB at 1e6 spots x 8192 permutations per pass) belong to this run, not to
-    // the plan: back to the context's pool (parked up to SQGR_POOL_GB, the rest to the driver) — ADVICE r4
-    p->pcg_ws.recs.release();
-    p->pcg_ws.dir.release();
-    p->pcg_ws.nblk.release();
-    SQGR_TRY(comm_agree(p->comm, local_rc, st));
+    // (The swap records of the bucketed replay — up to 36 GB at 1e6 spots x 8192 permutations per pass — stay with the plan's
+    // workspace until the plan goes: releasing them after every run was tried for ADVICE r4 and made a persistent plan re-allocate
+    // 35 GB per run, more than the parked-buffer pool keeps; the driver then took seconds for some of those hipMallocs
+    // (bench.py's numpy leg: 61 k -> 3.9 k permutations/s in one lease).  The front ends create and close their plan per call, so
+    // a call gives the memory back either way; a caller that keeps a plan decides with sqgr_nhood_destroy / sqgr_ctx_trim.)
+    SQGR_TRY(comm_agree(p->comm, local(), st));
     // multi-GPU: the ranks ran disjoint permutation ranges; one RCCL all-reduce of the 2*K*K exact integer moments on the
     // device, then every rank copies out the global sums
     SQGR_TRY(comm_allreduce_i64_dev(p->comm, p->fin.p, (size_t)2 * K2, false, st));
@@ -2080,13 +2078,12 @@ static int run_pcg64_impl(sqgr_nhood* plan, const uint64_t* pcg_states, int64_t 
     }
     return SQGR_OK;
     };
-    const int local_rc = local();
-    // the swap records of the bucketed replay (up to 36 GB at 1e6 spots x 8192 permutations per pass) belong to this run, not to
-    // the plan: back to the context's pool (parked up to SQGR_POOL_GB, the rest to the driver) — ADVICE r4
-    p->pcg_ws.recs.release();
-    p->pcg_ws.dir.release();
-    p->pcg_ws.nblk.release();
-    SQGR_TRY(comm_agree(p->comm, local_rc, st));
+    // (The swap records of the bucketed replay — up to 36 GB at 1e6 spots x 8192 permutations per pass — stay with the plan's
+    // workspace until the plan goes: releasing them after every run was tried for ADVICE r4 and made a persistent plan re-allocate
+    // 35 GB per run, more than the parked-buffer pool keeps; the driver then took seconds for some of those hipMallocs
+    // (bench.py's numpy leg: 61 k -> 3.9 k permutations/s in one lease).  The front ends create and close their plan per call, so
+    // a call gives the memory back either way; a caller that keeps a plan decides with sqgr_nhood_destroy / sqgr_ctx_trim.)
+    SQGR_TRY(comm_agree(p->comm, local(), st));
     // multi-GPU: the ranks ran disjoint permutation ranges; one RCCL all-reduce of the 2*K*K exact integer moments on the
     // device, then every rank copies out the global sums
     SQGR_TRY(comm_allreduce_i64_dev(p->comm, p->fin.p, (size_t)2 * K2, false, st));
