@@ -1003,10 +1003,12 @@ def compact_line(detail: dict, detail_path: str | None = None) -> dict:
     line["pmc_profile"] = _short(detail.get("pmc_profile"), 120)
     line["detail"] = detail_path
 
-    def clip(obj):  # names, units and kernel labels are short by construction; nothing free-form may ever grow the line
+    limits = {"unit": 28, "bound": 24, "kind": 12, "dtype": 40, "data": 16, "scaling": 8}
+
+    def clip(obj, key=None):  # names, units and kernel labels are short by construction; nothing free-form may ever grow the line
         if isinstance(obj, dict):
-            return {k: (v if k in ("workload", "sample") and isinstance(v, str) else clip(v)) for k, v in obj.items()}
-        return _short(obj, 72) if isinstance(obj, str) else obj
+            return {k: (v if k in ("workload", "sample") and isinstance(v, str) else clip(v, k)) for k, v in obj.items()}
+        return _short(obj, limits.get(key, 72)) if isinstance(obj, str) else obj
 
     return clip(line)
 
