@@ -336,6 +336,38 @@ def test_numpy_streams_reproduced_on_device(L, ctx, golden):
     np.testing.assert_array_equal(zl, O.nhood_zscore(golden["nhood_count"], golden["nhood_perms_lib"]))
 
 
+@pytest.mark.parametrize("k", [60, 90, 130, 230])
+@pytest.mark.parametrize("libs", [0, 3])
+def test_default_streams_with_more_than_50_clusters(L, ctx, k, libs):
+    """numpy's streams + the pass kernel: the producers of the numpy path (`k_rows_to_slab` without libraries, `k_columns_to_slab`
+    with) write the label slab in PLANES of the pass width (8 / 4 / 2 / 1 at K = 60 / 90 / 130 / 230) — per-permutation counts
+    `==` the reference helper restated with numpy's own generators, z-scores of the DEFAULT front-end call `==` the reference's."""
+    import squidpy_amd as sq
+    from squidpy_amd._utils import pcg64_states
+
+    rng = np.random.default_rng(k + libs)
+    adata = hex_adata(60, 70, 5, seed=4, n_libs=libs)
+    n = adata.n_obs
+    lab = rng.integers(0, k, n).astype(np.int32)
+    lab[:k] = np.arange(k)
+    adata.obs["cluster"] = pd.Categorical.from_codes(lab, [f"c{i:03d}" for i in range(k)])
+    adj = adata.obsp["spatial_connectivities"]
+    lib = codes(adata, "library") if libs else None
+    P, seed = 37, 11
+    ref = O.nhood_perm_counts_numpy(adj.indices, adj.indptr, lab, k, seed, P, lib, libs)
+    g = L.Graph(ctx, adj, with_data=False)
+    plan = L.NhoodPlan(ctx, g, lab, k, lib, libs)
+    _, _, perms = plan.run_pcg64(pcg64_states(seed, P), return_perms=True)
+    np.testing.assert_array_equal(perms, ref.astype(np.uint32))
+    plan.close()
+    g.close()
+    res = sq.gr.nhood_enrichment(adata, "cluster", library_key="library" if libs else None, n_perms=P, seed=seed, copy=True)
+    want = O.nhood_zscore(res.counts, ref)
+    np.testing.assert_array_equal(np.isnan(res.zscore), np.isnan(want))
+    ok = np.isfinite(want)
+    np.testing.assert_array_equal(res.zscore[ok], want[ok])
+
+
 @pytest.mark.parametrize("segments", ["1", "7"])
 def test_numpy_mean_std_chain_is_cut_invariant(L, ctx, golden, segments, monkeypatch):
     """`perms.mean(0)` / `perms.std(0)` of gr/_nhood.py:231 are formed on the device as two CHAINS of running sums in permutation
