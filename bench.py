@@ -1032,6 +1032,7 @@ def launch_ranks(cmd: list[str], n: int, extra_env: dict | None = None, timeout_
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), **(extra_env or {}))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL between processes needs dmabuf IPC on this driver
+        env.setdefault("NCCL_SOCKET_IFNAME", "lo")           # one node: RCCL's bootstrap over loopback (a box without another interface has none to pick)
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0) or None))
     deadline = None if timeout_s is None else time.monotonic() + timeout_s
     import threading
