@@ -980,22 +980,24 @@ __device__ __forceinline__ uint32_t row_higher(uint32_t key, const RowSources& s
     return hp;
 }
 
-// grid (buckets * 2 halves of the 64 lanes, groups of 64 permutations, segments); 32 threads = the two lane groups of a half.
+// grid (buckets, groups of 64 permutations); 64 threads = a whole wavefront = the four lane groups of a bucket's 64 lists (round 5:
+// 32 threads — two lane groups, half of every wave instruction masked off — until then; the step array, 432 of a thread's 1010
+// bytes of LDS, now lives in a global scratch array shaped like the lists: fire-and-forget stores during the turns, read back by
+// the last pass — 36 KiB per workgroup, four per CU = 16 lane groups in flight instead of 10).
 // "Class c takes the best lane that holds it" = one wave ballot of the holders + each lane's mask of the better lanes of its row.
-__global__ __launch_bounds__(32) void k_bucket_order_steps(int m, int nb, const uint32_t* __restrict__ len, const uint32_t* __restrict__ off,
+__global__ __launch_bounds__(64) void k_bucket_order_steps(int m, int nb, const uint32_t* __restrict__ len, const uint32_t* __restrict__ off,
                                                            const uint64_t* __restrict__ base, const uint32_t* __restrict__ src,
-                                                           uint32_t* __restrict__ dst, const uint16_t* __restrict__ nlen) {
-    __shared__ uint8_t cnt[256 * 32];            // [cell][t] pairs of the cell not yet placed
-    __shared__ uint8_t cur[256 * 32];            // [cell][t] slot of the cell's next pair, counted from the start of its pool
-    __shared__ uint16_t pstart[17 * 32];         // [zc][t] pairs in the pools below zc; [16]: all
-    __shared__ uint16_t amask[16 * 32];          // [zc][t] Y classes pool (lane, zc) still holds
-    __shared__ uint8_t stp[STEP_SEG * 32];       // [slot][t] the step given to the lane's pair of that slot, bits 0..7
-    __shared__ uint32_t stp8[STEP_SEG / 32 * 32];  // [slot / 32][t] bit slot % 32: bit 8 of that step
-    __shared__ int saturated[2];                 // per lane group
+                                                           uint32_t* __restrict__ dst, const uint16_t* __restrict__ nlen,
+                                                           uint16_t* __restrict__ stp_scr) {
+    __shared__ uint8_t cnt[256 * 64];            // [cell][t] pairs of the cell not yet placed
+    __shared__ uint8_t cur[256 * 64];            // [cell][t] slot of the cell's next pair, counted from the start of its pool
+    __shared__ uint16_t pstart[17 * 64];         // [zc][t] pairs in the pools below zc; [16]: all
+    __shared__ uint16_t amask[16 * 64];          // [zc][t] Y classes pool (lane, zc) still holds
+    __shared__ int saturated[4];                 // per lane group
     const int t = threadIdx.x, r = t & 15;
-    const int lane = group_lane((int)(blockIdx.x & 1u) * 2 + (t >> 4), r);
+    const int lane = group_lane(t >> 4, r);
     const int64_t pg = blockIdx.y;
-    const size_t bk = (size_t)pg * nb + (blockIdx.x >> 1);
+    const size_t bk = (size_t)pg * nb + blockIdx.x;
     const int L = (int)len[bk];
     if (L == 0) return;
     // A lane group whose longest list fits STEP_SEG rows is scheduled here, in one piece; the others keep the rotation schedule in
@@ -1012,10 +1014,10 @@ __global__ __launch_bounds__(32) void k_bucket_order_steps(int m, int nb, const 
     const size_t row0 = ((size_t)base[pg] + off[bk]) * 64;
     const uint32_t* a = src + row0 + lane;
     uint32_t* d = dst + row0 + lane;
+    uint16_t* stp = stp_scr + row0 + lane;       // [slot * 64]: the step given to the lane's pair of that slot (slots < the lane's pairs <= L)
     const uint32_t pad = (uint32_t)m;
-    for (int i = t; i < 256 * 8; i += 32) reinterpret_cast<uint32_t*>(cnt)[i] = 0;
-    for (int i = t; i < STEP_SEG; i += 32) stp8[i] = 0;
-    if (t < 2) saturated[t] = 0;
+    for (int i = t; i < 256 * 16; i += 64) reinterpret_cast<uint32_t*>(cnt)[i] = 0;
+    if (t < 4) saturated[t] = 0;
     __syncthreads();
     // --- thread = lane: the cells of its list
     uint32_t rem = 0;
@@ -1027,7 +1029,7 @@ __global__ __launch_bounds__(32) void k_bucket_order_steps(int m, int nb, const 
 #pragma unroll
         for (int u = 0; u < 16; ++u)
             if (mine && (e[u] & 0xffffu) < pad) {
-                const int cell = ((((e[u] & 15u) << 4) | ((e[u] >> 16) & 15u))) * 32 + t;
+                const int cell = ((((e[u] & 15u) << 4) | ((e[u] >> 16) & 15u))) * 64 + t;
                 const uint32_t c = cnt[cell];
                 sat |= c == 255u;
                 cnt[cell] = (uint8_t)(c + 1u);
@@ -1041,18 +1043,18 @@ __global__ __launch_bounds__(32) void k_bucket_order_steps(int m, int nb, const 
             uint32_t mask = 0, ps = 0;
 #pragma unroll
             for (int y = 0; y < 16; ++y) {
-                const uint32_t c = cnt[(zc * 16 + y) * 32 + t];
-                cur[(zc * 16 + y) * 32 + t] = (uint8_t)ps;
+                const uint32_t c = cnt[(zc * 16 + y) * 64 + t];
+                cur[(zc * 16 + y) * 64 + t] = (uint8_t)ps;
                 ps += c;
                 mask |= c ? (1u << y) : 0u;
             }
             sat |= ps > 255u;
-            amask[zc * 32 + t] = (uint16_t)mask;
-            pstart[zc * 32 + t] = (uint16_t)run;
+            amask[zc * 64 + t] = (uint16_t)mask;
+            pstart[zc * 64 + t] = (uint16_t)run;
             run += ps;
             cand |= mask ? (1u << zc) : 0u;
         }
-        pstart[16 * 32 + t] = (uint16_t)run;
+        pstart[16 * 64 + t] = (uint16_t)run;
     }
     if (sat) saturated[t >> 4] = 1;
     __syncthreads();
@@ -1066,33 +1068,34 @@ __global__ __launch_bounds__(32) void k_bucket_order_steps(int m, int nb, const 
     if (!__builtin_amdgcn_ballot_w64(mine_sched)) return;
     uint32_t cdeg = 0;  // thread r of a row also keeps class r: the pairs of that class all 16 lanes still hold
 #pragma unroll
-    for (int l2 = 0; l2 < 16; ++l2) cdeg += (uint32_t)pstart[(r + 1) * 32 + (t & 16) + l2] - (uint32_t)pstart[r * 32 + (t & 16) + l2];
+    for (int l2 = 0; l2 < 16; ++l2) cdeg += (uint32_t)pstart[(r + 1) * 64 + (t & 48) + l2] - (uint32_t)pstart[r * 64 + (t & 48) + l2];
     RowSources rs;
     rs.bit[0] = 0;
-#define SQGR_SRC(N) rs.bit[N] = 1u << row_ror<N>((uint32_t)t);
+#define SQGR_SRC(N) rs.bit[N] = 1u << (row_ror<N>((uint32_t)t) & 31u);  // (one bit per lane of the own row: distinct within a row)
     SQGR_ROW_OTHERS(SQGR_SRC)
 #undef SQGR_SRC
     uint32_t sig_lo = 0, sig_hi = 0;  // the classes, fullest first, 4 bits each
     uint32_t zpos = 0;                // (byte address of) the lane's place in its row by pairs left, most first
-    const uint32_t rowbase = (uint32_t)(t & 16);
+    const uint32_t rowbase = (uint32_t)(t & 48);
     // "The classes in turn each take the best lane that holds them": the lanes' holdings are moved to their places in order of
     // preference (ds_permute), 16 wave ballots give every class's holders in that order, the turns are scalar arithmetic on the
     // masks (lowest set bit = best holder still free, one 16-bit half per lane group), and the lanes read their class back.
-    auto take_turns = [&](const uint32_t (&holders)[16], uint32_t (&won)[16]) {
-        uint32_t free_places = 0xffffffffu;
+    auto take_turns = [&](const uint64_t (&holders)[16], uint64_t (&won)[16]) {
+        uint64_t free_places = ~0ull;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const uint32_t h = holders[i] & free_places, h0 = h & 0xffffu, h1 = h & 0xffff0000u;
-            won[i] = (h0 & (0u - h0)) | (h1 & (0u - h1));
+            const uint64_t h = holders[i] & free_places;
+            const uint64_t f0 = h & 0xffffull, f1 = h & 0xffff0000ull, f2 = h & 0xffff00000000ull, f3 = h & 0xffff000000000000ull;
+            won[i] = (f0 & (0ull - f0)) | (f1 & (0ull - f1)) | (f2 & (0ull - f2)) | (f3 & (0ull - f3));
             free_places &= ~won[i];
         }
     };
     uint32_t zkeep = 16;  // the lane's Z class of the current four steps
     // The steps of a lane group: its own longest list — NOT the bucket's rows (the longest of all 64 lanes): the schedule of a group
     // must not depend on the other groups (split invariance); the rows past it hold padding pairs.
-    const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane((int)(mine_sched ? horizon : 0u), 0);
-    const uint32_t h1 = (uint32_t)__builtin_amdgcn_readlane((int)(mine_sched ? horizon : 0u), 16);
-    const int steps = (int)max(h0, h1);
+    const uint32_t hz = mine_sched ? horizon : 0u;
+    const int steps = (int)max(max((uint32_t)__builtin_amdgcn_readlane((int)hz, 0), (uint32_t)__builtin_amdgcn_readlane((int)hz, 16)),
+                               max((uint32_t)__builtin_amdgcn_readlane((int)hz, 32), (uint32_t)__builtin_amdgcn_readlane((int)hz, 48)));
     if (mine_sched)
         for (int k = (int)horizon; k < L; ++k) d[(size_t)k * 64] = (pad + (((uint32_t)r - pad) & 15u)) | ((uint32_t)r << 16);
     for (int k = 0; k < steps; ++k) {
@@ -1106,16 +1109,17 @@ __global__ __launch_bounds__(32) void k_bucket_order_steps(int m, int nb, const 
             sig_hi = row_or(rank >= 8 ? (uint32_t)r << (4 * (rank - 8)) : 0u);
             zpos = (rowbase + (uint32_t)__builtin_popcount(row_higher((rem << 4) | (uint32_t)(15 - r), rs))) << 2;
             const uint32_t held = (uint32_t)__builtin_amdgcn_ds_permute((int)zpos, (int)(rem ? cand : 0u));  // (by place)
-            uint32_t zi[16], holders[16], won[16];
+            uint32_t zi[16];
+            uint64_t holders[16], won[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 zi[i] = ((i < 8 ? sig_lo : sig_hi) >> (4 * (i & 7))) & 15u;
-                holders[i] = (uint32_t)__builtin_amdgcn_ballot_w64(((held >> zi[i]) & 1u) != 0);
+                holders[i] = __builtin_amdgcn_ballot_w64(((held >> zi[i]) & 1u) != 0);
             }
             take_turns(holders, won);
             uint32_t zp = 16;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) zp = __builtin_amdgcn_inverse_ballot_w64((uint64_t)won[i]) ? zi[i] : zp;
+            for (int i = 0; i < 16; ++i) zp = __builtin_amdgcn_inverse_ballot_w64(won[i]) ? zi[i] : zp;
             zkeep = (uint32_t)__builtin_amdgcn_ds_bpermute((int)zpos, (int)zp);
         }
         uint32_t myz = (rem && zkeep < 16 && ((cand >> zkeep) & 1u)) ? zkeep : 16u;
@@ -1124,20 +1128,20 @@ __global__ __launch_bounds__(32) void k_bucket_order_steps(int m, int nb, const 
         const uint32_t zused = row_or(active ? (1u << myz) : 0u);
         cdeg -= ((zused >> r) & 1u) && cdeg ? 1u : 0u;
         // Y side: the classes in turn (rotating start) each take the lane with the fewest alternatives among the lanes whose pool holds them
-        const uint32_t av = active ? (uint32_t)amask[myz * 32 + t] : 0u;
+        const uint32_t av = active ? (uint32_t)amask[myz * 64 + t] : 0u;
         uint32_t myy = 16;
         {
             const uint32_t ykey = active ? (((17u - (uint32_t)__builtin_popcount(av)) << 4) | (uint32_t)(15 - r)) : (uint32_t)(15 - r);
             const uint32_t ypos = (rowbase + (uint32_t)__builtin_popcount(row_higher(ykey, rs))) << 2;
             const uint32_t held = (uint32_t)__builtin_amdgcn_ds_permute((int)ypos, (int)av);
             const uint32_t y0 = (uint32_t)(k * 5);
-            uint32_t holders[16], won[16];
+            uint64_t holders[16], won[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) holders[i] = (uint32_t)__builtin_amdgcn_ballot_w64(((held >> ((y0 + (uint32_t)i) & 15u)) & 1u) != 0);
+            for (int i = 0; i < 16; ++i) holders[i] = __builtin_amdgcn_ballot_w64(((held >> ((y0 + (uint32_t)i) & 15u)) & 1u) != 0);
             take_turns(holders, won);
             uint32_t yp = 16;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) yp = __builtin_amdgcn_inverse_ballot_w64((uint64_t)won[i]) ? ((y0 + (uint32_t)i) & 15u) : yp;
+            for (int i = 0; i < 16; ++i) yp = __builtin_amdgcn_inverse_ballot_w64(won[i]) ? ((y0 + (uint32_t)i) & 15u) : yp;
             myy = (uint32_t)__builtin_amdgcn_ds_bpermute((int)ypos, (int)yp);
         }
         const bool unas = active && myy == 16;
@@ -1146,17 +1150,16 @@ __global__ __launch_bounds__(32) void k_bucket_order_steps(int m, int nb, const 
         const uint32_t idle = row_or(active ? 0u : (1u << r));
         const uint32_t yused = row_or(active ? (1u << myy) : 0u);
         if (active) {
-            const int cell = (int)(myz * 16 + myy) * 32 + t;
-            const uint32_t c = cnt[cell], slot = (uint32_t)pstart[myz * 32 + t] + cur[cell];
+            const int cell = (int)(myz * 16 + myy) * 64 + t;
+            const uint32_t c = cnt[cell], slot = (uint32_t)pstart[myz * 64 + t] + cur[cell];
             cnt[cell] = (uint8_t)(c - 1u);
             cur[cell] = (uint8_t)(cur[cell] + 1u);
             if (c == 1u) {
                 const uint32_t nav = av & ~(1u << myy);
-                amask[myz * 32 + t] = (uint16_t)nav;
+                amask[myz * 64 + t] = (uint16_t)nav;
                 if (!nav) cand &= ~(1u << myz);
             }
-            stp[slot * 32 + t] = (uint8_t)k;
-            if (k & 256) stp8[(slot >> 5) * 32 + t] |= 1u << (slot & 31u);
+            stp[(size_t)slot * 64] = (uint16_t)k;
             --rem;
         } else if (mine_sched && (uint32_t)k < horizon) {
             const uint32_t nth = (uint32_t)__builtin_popcount(idle & ((1u << r) - 1u));  // (at least as many free classes as idle lanes)
@@ -1164,6 +1167,7 @@ __global__ __launch_bounds__(32) void k_bucket_order_steps(int m, int nb, const 
             d[(size_t)k * 64] = (pad + ((zc - pad) & 15u)) | (yc << 16);
         }
     }
+    __threadfence_block();  // the step array is read back by the lane that wrote it
     __syncthreads();
     // --- every pair to its step: the cursors now stand at the end of their cells
     for (int k0 = 0; k0 < Ls; k0 += 16) {
@@ -1174,11 +1178,11 @@ __global__ __launch_bounds__(32) void k_bucket_order_steps(int m, int nb, const 
         for (int u = 0; u < 16; ++u)
             if (mine_sched && (e[u] & 0xffffu) < pad) {
                 const uint32_t zc = e[u] & 15u;
-                const int cell = (int)((zc << 4) | ((e[u] >> 16) & 15u)) * 32 + t;
+                const int cell = (int)((zc << 4) | ((e[u] >> 16) & 15u)) * 64 + t;
                 const uint32_t within = (uint32_t)cur[cell] - 1u;
                 cur[cell] = (uint8_t)within;
-                const uint32_t slot = (uint32_t)pstart[zc * 32 + t] + (within & 0xffu);
-                const uint32_t k = (uint32_t)stp[slot * 32 + t] | (((stp8[(slot >> 5) * 32 + t] >> (slot & 31u)) & 1u) << 8);
+                const uint32_t slot = (uint32_t)pstart[zc * 64 + t] + (within & 0xffu);
+                const uint32_t k = (uint32_t)stp[(size_t)slot * 64];
                 d[(size_t)k * 64] = e[u];
             }
     }
@@ -1571,6 +1575,7 @@ struct PermLists : sqgr::CtxCache {
     // lists
     DevBuf<uint32_t> b_len, b_off, b_total, lists, lists_raw;
     DevBuf<uint16_t> n_len;                  // [group][a][b][lane] pairs in the lane's list (the schedule kernels choose by them)
+    DevBuf<uint16_t> stp_scr;                // scratch of k_bucket_order_steps, shaped like the lists: the step given to every pair
     DevBuf<uint32_t> x_len, x_off, x_lists;  // exception lists (see k_exc_offsets), when the lists serve RMODE 3
     DevBuf<uint64_t> b_base;
     bool matches(int64_t n_, int64_t pc_, int64_t perm0_, int m_, int nch_, int kind_, uint64_t seed_, const uint64_t* st_, int split_,
@@ -1661,6 +1666,7 @@ static int build_perm_lists(sqgr_ctx* ctx, PermLists* pl, const int32_t* idx, in
     if (joint) {  // out of place: the lists as built -> lists_raw, scheduled -> lists
         SQGR_TRY(pl->n_len.ensure((size_t)npg * nb * 64));
         if (pl->lists_raw.n < (size_t)rows * 64 || !pl->lists_raw.p) SQGR_TRY(pl->lists_raw.alloc_pooled((size_t)rows * 64 + (size_t)rows * 4));
+        if (order == 3 && (pl->stp_scr.n < (size_t)rows * 64 || !pl->stp_scr.p)) SQGR_TRY(pl->stp_scr.alloc_pooled((size_t)rows * 64 + (size_t)rows * 4));
         fill_to = pl->lists_raw.p;
     }
     k_bucket_fill<<<dim3((unsigned)nch, (unsigned)npg), 64, cnt_lds + (size_t)nch * sizeof(uint32_t), st>>>(idx, n, pc, m, nch, split, pl->b_len.p, pl->b_off.p,
@@ -1671,8 +1677,8 @@ static int build_perm_lists(sqgr_ctx* ctx, PermLists* pl, const int32_t* idx, in
     if (joint) {
         // the step schedule takes the lane groups whose longest list fits STEP_SEG rows, the rotation schedule the others (in segments)
         if (order == 3 && rows_max[1] > 0)
-            k_bucket_order_steps<<<dim3((unsigned)nb * 2u, (unsigned)npg), 32, 0, st>>>(m, nb, pl->b_len.p, pl->b_off.p, pl->b_base.p, pl->lists_raw.p,
-                                                                                      pl->lists.p, pl->n_len.p);
+            k_bucket_order_steps<<<dim3((unsigned)nb, (unsigned)npg), 64, 0, st>>>(m, nb, pl->b_len.p, pl->b_off.p, pl->b_base.p, pl->lists_raw.p,
+                                                                                 pl->lists.p, pl->n_len.p, pl->stp_scr.p);
         const int longer_than = order == 3 ? STEP_SEG : 0;
         const int segs = (int64_t)rows_max[1] > longer_than ? (int)ceil_div((int64_t)rows_max[1], (int64_t)ORDER_SEG) : 0;
         if (segs > 0)
