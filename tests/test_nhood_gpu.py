@@ -108,6 +108,22 @@ def test_injected_numpy_permutations_reproduce_reference_zscore(L, ctx, golden):
     np.testing.assert_array_equal(z, golden["nhood_zscore"])
 
 
+@pytest.mark.parametrize("k", [30, 60, 100, 150, 220, 256])
+def test_injected_permutations_in_every_cluster_count_regime(L, ctx, k):
+    """`sqgr_nhood_counts_batch` (host-drawn label vectors: the `rng="numpy-host"` route and what INTEGRATION.md offers a maintainer who
+    keeps numpy's shuffles on the host) hands the labels to the count kernels through `k_transpose_labels` — rows for K <= 50, planes
+    of the pass width above: 37 injected vectors (a partly filled last batch) `==` the reference kernel per vector."""
+    rng = np.random.default_rng(k)
+    adj = O.hex_grid_graph(37, 41)
+    n = adj.shape[0]
+    lab = rng.integers(0, k, size=(37, n))
+    g = L.Graph(ctx, adj, with_data=False)
+    got = L.nhood_counts_batch(ctx, g, lab, k)
+    for p in range(37):
+        np.testing.assert_array_equal(got[p], O.nhood_counts(adj.indices, adj.indptr, lab[p], k), err_msg=f"vector {p}")
+    g.close()
+
+
 @pytest.mark.parametrize("n", [1, 7, 49, 300, 5000])
 def test_device_shuffle_matches_oracle_generator(L, ctx, n):
     rng = np.random.default_rng(n)
