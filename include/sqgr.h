@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SQGR_ABI_VERSION 4
+#define SQGR_ABI_VERSION 5
 
 typedef enum sqgr_status {
     SQGR_OK = 0,
@@ -54,10 +54,15 @@ int sqgr_ctx_create(int device, sqgr_ctx** out_ctx);
 int sqgr_ctx_destroy(sqgr_ctx* ctx);
 int sqgr_ctx_sync(sqgr_ctx* ctx);
 /* Device buffers of 64 MB and more are parked per device when their owner lets go of them and reused by the next request of
- * about that size (bounded by SQGR_POOL_GB, default 32 GB; other HIP users of the process see parked memory as taken).
+ * about that size (bounded by SQGR_POOL_GB, default a quarter of the device memory — the oldest parked buffers go first; other HIP users of the process see parked memory as taken).
  * sqgr_ctx_trim synchronises the device and returns parked buffers of ctx's device to the driver until at most keep_bytes
  * stay parked (0: everything). */
 int sqgr_ctx_trim(sqgr_ctx* ctx, int64_t keep_bytes);
+/* What the library asked of the HIP allocator since it was loaded (process-wide, all devices): out[0..count) <-
+ * {hipMalloc calls, bytes of the successful ones, ns spent inside hipMalloc, hipFree calls, ns spent inside hipFree, requests
+ * served by a parked buffer, buffers parked, pool flushes}; slots past 8 read 0.  bench.py prints the differences over its timed
+ * regions next to the kernel times, and `a second call allocates nothing` is a test (tests/test_autocorr_gpu.py). */
+int sqgr_debug_counters(int64_t* out, int32_t count);
 /* name[0..len) <- device name, *cu_count <- compute units, *hbm_bytes <- total device memory */
 int sqgr_ctx_device_info(sqgr_ctx* ctx, char* name, int len, int* cu_count, int64_t* hbm_bytes);
 

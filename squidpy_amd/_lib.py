@@ -33,6 +33,7 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "sqgr_ctx_destroy": (C.c_int, [C.c_void_p]),
     "sqgr_ctx_trim": (C.c_int, [C.c_void_p, C.c_int64]),
     "sqgr_ctx_sync": (C.c_int, [C.c_void_p]),
+    "sqgr_debug_counters": (C.c_int, [c_i64p, C.c_int32]),
     "sqgr_ctx_device_info": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), c_i64p]),
     "sqgr_timer_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "sqgr_timer_reset": (C.c_int, [C.c_void_p]),
@@ -95,7 +96,7 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
 }
 
 
-ABI_VERSION = 4  # SQGR_ABI_VERSION of include/sqgr.h
+ABI_VERSION = 5  # SQGR_ABI_VERSION of include/sqgr.h
 
 
 class SqgrError(RuntimeError):
@@ -187,6 +188,13 @@ class Context:
         _check(self.lib, self.lib.sqgr_ctx_device_info(self.h, buf, 256, C.byref(cu), C.byref(mem)))
         return {"name": buf.value.decode(), "cu_count": cu.value, "hbm_bytes": mem.value}
 
+    def alloc_counters(self) -> dict[str, int]:
+        """What the library has asked of the HIP allocator so far (process-wide): ``sqgr_debug_counters``."""
+        out = np.zeros(8, dtype=np.int64)
+        _check(self.lib, self.lib.sqgr_debug_counters(out.ctypes.data_as(c_i64p), 8))
+        names = ("mallocs", "malloc_bytes", "malloc_ns", "frees", "free_ns", "pool_hits", "pool_parks", "pool_flushes")
+        return {k: int(v) for k, v in zip(names, out)}
+
     # ---- kernel timers (HIP events on this context's stream)
     def trim(self, keep_bytes: int = 0) -> None:
         """Hand parked device buffers (``SQGR_POOL_GB``) back to the driver until at most ``keep_bytes`` stay parked."""
@@ -219,7 +227,7 @@ _default_ctx: dict[int, Context] = {}
 
 
 def trim_device_memory(keep_bytes: int = 0) -> None:
-    """Hand the device buffers libsqgr keeps parked between calls (``SQGR_POOL_GB``, default 32 GB per GPU) back to the driver —
+    """Hand the device buffers libsqgr keeps parked between calls (``SQGR_POOL_GB``, default a quarter of the GPU's memory) back to the driver —
     for processes that share the GPU with other HIP users (torch, a second library).  Resident graphs and plans stay."""
     for ctx in _default_ctx.values():
         ctx.trim(keep_bytes)

@@ -1560,6 +1560,20 @@ struct sqgr_autocorr {
     int rs_main = 0;         // the class of r0
     double rs_main_val = 0.0;
     DevBuf<double> rtab_x;   // r_c - r0
+    // what crosses PCIe per call — the observed scores in, G x 4 reductions out — goes through ONE persistent device block
+    // [score | sum | std | var | n_ge] and its pinned twin, both made with the plan: no allocation, no pageable-copy staging and
+    // one copy each way per sqgr_autocorr_perm_stats (round 5: three hipMalloc / hipFree and five pageable copies per call)
+    DevBuf<double> stat_dev;
+    double* stat_host = nullptr;
+    int ensure_stat() {
+        if (stat_dev.p && stat_host) return SQGR_OK;
+        SQGR_TRY(stat_dev.alloc((size_t)5 * G));
+        SQGR_HIP(hipHostMalloc(reinterpret_cast<void**>(&stat_host), (size_t)5 * G * sizeof(double), hipHostMallocDefault));
+        return SQGR_OK;
+    }
+    ~sqgr_autocorr() {
+        if (stat_host) (void)hipHostFree(stat_host);
+    }
 };
 
 // The bucket lists depend on the permutations alone: every feature block of a call (and the next call with the same seed)
@@ -1973,6 +1987,7 @@ static int autocorr_create(sqgr_ctx* ctx, const sqgr_graph* g, const double* val
             }
         }
     }
+    if ((rc = h->ensure_stat())) return fail(rc);
     *out = h;
     return SQGR_OK;
 }
@@ -2162,11 +2177,12 @@ int sqgr_autocorr_scores(sqgr_autocorr* h, int32_t mode, double* out_scores) {
         SQGR_TRY(column_sum(h, 0, h->Zt.p, h->Yt.p, h->tmpG.p));
     else
         SQGR_TRY(column_sum(h, 3, h->Zt.p, nullptr, h->tmpG.p));
-    SQGR_TRY(h->sims.ensure((size_t)h->G));
-    k_scores<<<(unsigned)ceil_div(h->G, 256), 256, 0, st>>>(mode, h->G, h->n, h->W, h->tmpG.p, h->z2ss.p, h->isconst.p, h->sims.p);
+    SQGR_TRY(h->ensure_stat());
+    k_scores<<<(unsigned)ceil_div(h->G, 256), 256, 0, st>>>(mode, h->G, h->n, h->W, h->tmpG.p, h->z2ss.p, h->isconst.p, h->stat_dev.p);
     SQGR_HIP(hipGetLastError());
-    SQGR_HIP(hipMemcpyAsync(out_scores, h->sims.p, (size_t)h->G * 8, hipMemcpyDeviceToHost, st));
+    SQGR_HIP(hipMemcpyAsync(h->stat_host, h->stat_dev.p, (size_t)h->G * 8, hipMemcpyDeviceToHost, st));
     SQGR_HIP(hipStreamSynchronize(st));
+    memcpy(out_scores, h->stat_host, (size_t)h->G * 8);
     return SQGR_OK;
 }
 
@@ -2319,22 +2335,23 @@ int sqgr_autocorr_perm_stats(sqgr_autocorr* h, int32_t mode, const int32_t* perm
     SQGR_TRY(h->sims_all.ensure((size_t)P * G));
     SQGR_TRY(autocorr_perms(h, mode, perm_idx, pcg_states, seed, (perm_idx || pcg_states) ? 0 : perm_begin, (perm_idx || pcg_states) ? P : perm_end,
                             nullptr, h->sims_all.p));
-    DevBuf<double> d_score, d_out;  // d_out: sum | std | var
-    DevBuf<long long> d_ge;
-    SQGR_TRY(d_score.alloc((size_t)G));
-    SQGR_TRY(d_out.alloc((size_t)3 * G));
-    SQGR_TRY(d_ge.alloc((size_t)G));
-    SQGR_HIP(hipMemcpyAsync(d_score.p, score, (size_t)G * 8, hipMemcpyHostToDevice, st));
+    SQGR_TRY(h->ensure_stat());
+    double* d = h->stat_dev.p;  // [score | sum | std | var | n_ge]
+    static_assert(sizeof(long long) == sizeof(double), "the n_ge column shares the block");
+    memcpy(h->stat_host, score, (size_t)G * 8);
+    SQGR_HIP(hipMemcpyAsync(d, h->stat_host, (size_t)G * 8, hipMemcpyHostToDevice, st));
     {
         LaunchTimer t(ctx, "autocorr_perm_stats");
-        k_perm_stats<<<(unsigned)ceil_div(G, 256), 256, 0, st>>>(h->sims_all.p, P, G, d_score.p, d_ge.p, d_out.p, d_out.p + G, d_out.p + 2 * G, only_feature ? 1 : 0);
+        k_perm_stats<<<(unsigned)ceil_div(G, 256), 256, 0, st>>>(h->sims_all.p, P, G, d, reinterpret_cast<long long*>(d + 4 * G), d + G, d + 2 * G, d + 3 * G,
+                                                                 only_feature ? 1 : 0);
         SQGR_HIP(hipGetLastError());
     }
-    SQGR_HIP(hipMemcpyAsync(out_ge, d_ge.p, (size_t)G * 8, hipMemcpyDeviceToHost, st));
-    SQGR_HIP(hipMemcpyAsync(out_sum, d_out.p, (size_t)G * 8, hipMemcpyDeviceToHost, st));
-    SQGR_HIP(hipMemcpyAsync(out_std, d_out.p + G, (size_t)G * 8, hipMemcpyDeviceToHost, st));
-    SQGR_HIP(hipMemcpyAsync(out_var, d_out.p + 2 * G, (size_t)G * 8, hipMemcpyDeviceToHost, st));
+    SQGR_HIP(hipMemcpyAsync(h->stat_host + G, d + G, (size_t)4 * G * 8, hipMemcpyDeviceToHost, st));
     SQGR_HIP(hipStreamSynchronize(st));
+    memcpy(out_sum, h->stat_host + G, (size_t)G * 8);
+    memcpy(out_std, h->stat_host + 2 * G, (size_t)G * 8);
+    memcpy(out_var, h->stat_host + 3 * G, (size_t)G * 8);
+    memcpy(out_ge, h->stat_host + 4 * G, (size_t)G * 8);
     return SQGR_OK;
 }
 

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -112,6 +113,14 @@ struct LaunchTimer {
 // buffers back on request — other HIP users of the process see parked memory as taken); flushed when any
 // hipMalloc of the library fails (which is then retried) and when a context is destroyed.
 constexpr size_t POOL_MIN_BYTES = (size_t)64 << 20;
+// Every device allocation of the library goes through dev_malloc / dev_free (sqgr_ctx.hip): counted and timed, so that a caller
+// — bench.py's legs, the "a second call allocates nothing" tests — can see what a call asked of the driver (sqgr_debug_counters).
+struct AllocStats {
+    std::atomic<int64_t> mallocs{0}, malloc_bytes{0}, malloc_ns{0}, frees{0}, free_ns{0}, pool_hits{0}, pool_parks{0}, pool_flushes{0};
+};
+extern AllocStats g_alloc_stats;
+hipError_t dev_malloc(void** p, size_t bytes);
+hipError_t dev_free(void* p);
 void* pool_take(size_t bytes, size_t* capacity);  // a parked buffer of [bytes, 1.5 * bytes] on the current device, or NULL
 void pool_give(void* p, size_t capacity);         // parks p or frees it
 void pool_flush();                                // frees everything parked on the current device
@@ -128,7 +137,7 @@ struct DevBuf {
     ~DevBuf() { release(); }
     void release() {
         if (p && pooled_bytes) pool_give(p, pooled_bytes);
-        else if (p) (void)hipFree(p);
+        else if (p) (void)dev_free(p);
         p = nullptr;
         n = 0;
         pooled_bytes = 0;
@@ -146,7 +155,7 @@ struct DevBuf {
                     if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
                 }
                 if (e != hipSuccess) {
-                    (void)hipFree(q);
+                    (void)dev_free(q);
                     set_error("reusing a parked buffer failed: %s", hipGetErrorString(e));
                     return SQGR_ERR_HIP;
                 }
@@ -156,11 +165,11 @@ struct DevBuf {
                 return SQGR_OK;
             }
         }
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), bytes);
+        hipError_t e = dev_malloc(reinterpret_cast<void**>(&p), bytes);
         if (e == hipErrorOutOfMemory) {  // give the parked buffers back to the driver and try once more
             (void)hipGetLastError();
             pool_flush();
-            e = hipMalloc(reinterpret_cast<void**>(&p), bytes);
+            e = dev_malloc(reinterpret_cast<void**>(&p), bytes);
         }
         if (e != hipSuccess) {
             p = nullptr;
@@ -179,9 +188,12 @@ struct DevBuf {
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// zero entries behind the nhood edge lists (sqgr_graph::coo / half): the count kernels' look-ahead loads stay in bounds
-// (six iterations of the widest one — one lane per edge, 4096 edges per iteration of a block — and a lane's own four edges)
-constexpr int LIST_PAD = 6 * 4096 + 64;
+// zero entries behind the nhood edge lists (sqgr_graph::coo / half): the count kernels' look-ahead loads stay in bounds.  A block's
+// sweep runs ceil((T + 2) / 3) * 3 stages and stage t loads the entries of iteration t + 2: the last load ends at e0 + (T + 6) * STEP
+// with e0 + T * STEP < m + STEP for the tail chunk — SEVEN iterations past the list's end for the widest kernel (one lane per edge,
+// STEP = 4096 edges per iteration of a block), plus a lane's own four edges.  (Round 5 padded six: ADVICE r5, a third of all graph
+// sizes read up to 30 KB past the allocation — values never consumed, but an out-of-bounds read all the same.)
+constexpr int LIST_PAD = 7 * 4096 + 64;
 
 // device-side collectives of an sqgr_comm (sqgr_comm.hip); no-ops for a NULL communicator or a single rank
 int comm_allreduce_i64_dev(sqgr_comm* c, int64_t* dev_buf, size_t count, bool op_max, hipStream_t st);

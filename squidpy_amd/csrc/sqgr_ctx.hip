@@ -3,6 +3,7 @@
 
 #include "sqgr_common.h"
 
+#include <chrono>
 #include <cstdlib>
 #include <mutex>
 
@@ -48,6 +49,27 @@ void roctx_pop() {
     if (roctx_api().pop) (void)roctx_api().pop();
 }
 
+// ---- counted device allocations (declared in sqgr_common.h)
+AllocStats g_alloc_stats;
+static inline int64_t now_ns() {
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+hipError_t dev_malloc(void** p, size_t bytes) {
+    const int64_t t0 = now_ns();
+    const hipError_t e = hipMalloc(p, bytes);
+    g_alloc_stats.malloc_ns += now_ns() - t0;
+    g_alloc_stats.mallocs += 1;
+    if (e == hipSuccess) g_alloc_stats.malloc_bytes += (int64_t)bytes;
+    return e;
+}
+hipError_t dev_free(void* p) {
+    const int64_t t0 = now_ns();
+    const hipError_t e = hipFree(p);
+    g_alloc_stats.free_ns += now_ns() - t0;
+    g_alloc_stats.frees += 1;
+    return e;
+}
+
 // ---- parked device buffers (declared in sqgr_common.h)
 struct PoolEntry {
     int device;
@@ -57,10 +79,26 @@ struct PoolEntry {
 static std::mutex g_pool_mutex;
 static std::vector<PoolEntry> g_pool;
 
-static size_t pool_limit() {
+// Cap of the parked bytes per device: SQGR_POOL_GB, else a quarter of the device's memory (72 GB of the MI355X's 288).  Round 5's
+// fixed 32 GB could not hold config 3's 16 GB expression matrix next to what earlier calls had parked: the matrix went back to the
+// driver after every call and came back through hipMalloc — which, for memory that has been used before, costs ~30 ms per GB on
+// this stack (round 6, counters of bench.py's config-3 leg: 0.7 ms for the first 16 GB of a fresh box, 513 ms for the second).
+static size_t pool_limit(int dev) {
     const char* e = getenv("SQGR_POOL_GB");
-    const double gb = (e && *e) ? atof(e) : 32.0;  // (config 3 in full parks ~25 GB: the 16 GB matrix and one 2048-gene block)
-    return gb <= 0.0 ? 0 : (size_t)(gb * (double)((size_t)1 << 30));
+    if (e && *e) {
+        const double gb = atof(e);
+        return gb <= 0.0 ? 0 : (size_t)(gb * (double)((size_t)1 << 30));
+    }
+    static std::map<int, size_t> by_dev;  // (under g_pool_mutex)
+    auto it = by_dev.find(dev);
+    if (it != by_dev.end()) return it->second;
+    size_t total = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) total = prop.totalGlobalMem;
+    else (void)hipGetLastError();
+    const size_t lim = total ? total / 4 : (size_t)32 << 30;
+    by_dev[dev] = lim;
+    return lim;
 }
 
 void* pool_take(size_t bytes, size_t* capacity) {
@@ -74,6 +112,7 @@ void* pool_take(size_t bytes, size_t* capacity) {
     void* p = g_pool[best].p;
     *capacity = g_pool[best].cap;
     g_pool.erase(g_pool.begin() + best);
+    g_alloc_stats.pool_hits += 1;
     return p;
 }
 
@@ -91,15 +130,32 @@ static bool owner_device(const void* p, int* dev) {
 void pool_give(void* p, size_t capacity) {
     int dev = 0;
     if (capacity >= POOL_MIN_BYTES && owner_device(p, &dev)) {
-        std::lock_guard<std::mutex> lock(g_pool_mutex);
-        size_t held = 0;
-        for (const PoolEntry& e : g_pool) held += e.device == dev ? e.cap : 0;
-        if (held + capacity <= pool_limit()) {
-            g_pool.push_back({dev, p, capacity});
-            return;
+        std::vector<void*> evicted;
+        bool parked = false;
+        {
+            std::lock_guard<std::mutex> lock(g_pool_mutex);
+            const size_t limit = pool_limit(dev);
+            if (capacity <= limit) {
+                size_t held = 0;
+                for (const PoolEntry& e : g_pool) held += e.device == dev ? e.cap : 0;
+                // the newest buffer is the likeliest to be asked for again (the next feature block, the next call): when the cap is
+                // reached the OLDEST parked buffers of the device go back to the driver, not the one just released (round 5 refused
+                // the newcomer: whatever the first legs of a process had parked stayed, everything later was freed and re-allocated)
+                for (size_t k = 0; k < g_pool.size() && held + capacity > limit;) {
+                    if (g_pool[k].device != dev) { ++k; continue; }
+                    held -= g_pool[k].cap;
+                    evicted.push_back(g_pool[k].p);
+                    g_pool.erase(g_pool.begin() + (long)k);
+                }
+                g_pool.push_back({dev, p, capacity});
+                g_alloc_stats.pool_parks += 1;
+                parked = true;
+            }
         }
+        for (void* q : evicted) (void)dev_free(q);
+        if (parked) return;
     }
-    (void)hipFree(p);
+    (void)dev_free(p);
 }
 
 void pool_trim(int dev, size_t keep_bytes) {  // frees the largest parked buffers of `dev` until at most keep_bytes stay parked
@@ -113,7 +169,7 @@ void pool_trim(int dev, size_t keep_bytes) {  // frees the largest parked buffer
             if (big < 0 || g_pool[k].cap > g_pool[big].cap) big = k;
         }
         if (big < 0 || held <= keep_bytes) return;
-        (void)hipFree(g_pool[big].p);
+        (void)dev_free(g_pool[big].p);
         g_pool.erase(g_pool.begin() + big);
     }
 }
@@ -121,6 +177,7 @@ void pool_trim(int dev, size_t keep_bytes) {  // frees the largest parked buffer
 void pool_flush() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return;
+    g_alloc_stats.pool_flushes += 1;
     pool_trim(dev, 0);
 }
 
@@ -563,10 +620,10 @@ int sqgr_ctx::scratch_get(int slot, size_t bytes, void** out) {
     auto& sc = scratch[(size_t)slot];
     if (bytes == 0) bytes = 8;
     if (sc.second < bytes) {
-        if (sc.first) (void)hipFree(sc.first);
+        if (sc.first) (void)sqgr::dev_free(sc.first);
         sc = {nullptr, 0};
         const size_t want = bytes + bytes / 4;  // head-room: point counts of successive calls vary a little
-        hipError_t e = hipMalloc(&sc.first, want);
+        hipError_t e = sqgr::dev_malloc(&sc.first, want);
         if (e != hipSuccess) {
             sc.first = nullptr;
             sqgr::set_error("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
@@ -592,7 +649,7 @@ int sqgr_ctx_destroy(sqgr_ctx* ctx) {
     delete ctx->autocorr_lists;
     ctx->autocorr_lists = nullptr;
     for (auto& sc : ctx->scratch)
-        if (sc.first) (void)hipFree(sc.first);
+        if (sc.first) (void)sqgr::dev_free(sc.first);
     (void)hipStreamDestroy(ctx->stream);
     (void)hipStreamDestroy(ctx->stream2);
     delete ctx;
@@ -604,6 +661,15 @@ int sqgr_ctx_trim(sqgr_ctx* ctx, int64_t keep_bytes) {
     SQGR_HIP(hipSetDevice(ctx->device));
     SQGR_HIP(hipDeviceSynchronize());  // nothing of a previous owner may be in flight when a parked buffer goes back to the driver
     sqgr::pool_trim(ctx->device, (size_t)keep_bytes);
+    return SQGR_OK;
+}
+
+int sqgr_debug_counters(int64_t* out, int32_t count) {
+    SQGR_REQUIRE(out && count >= 0, "out is NULL or count < 0");
+    const sqgr::AllocStats& a = sqgr::g_alloc_stats;
+    const int64_t v[8] = {a.mallocs.load(), a.malloc_bytes.load(), a.malloc_ns.load(), a.frees.load(),
+                          a.free_ns.load(), a.pool_hits.load(), a.pool_parks.load(), a.pool_flushes.load()};
+    for (int i = 0; i < count; ++i) out[i] = i < 8 ? v[i] : 0;
     return SQGR_OK;
 }
 

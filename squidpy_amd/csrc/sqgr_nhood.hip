@@ -494,7 +494,7 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
     // offset pairs of iteration k+2 are in flight (every load gets a full processing phase of slack).
     constexpr int U = 4;
     constexpr uint32_t STEP = (COUNT_THREADS / 4) * U;
-    static_assert(6 * STEP + U <= LIST_PAD, "look-ahead exceeds the padding of the edge lists");
+    static_assert(7 * STEP + U <= LIST_PAD, "look-ahead exceeds the padding of the edge lists");
     using Row = typename std::conditional<B == 16, uint32_t, uint2>::type;
     // offsets of the 4 edges' label rows for THIS lane: the quad broadcast rides on the add of the lane's byte offset inside
     // the row (v_add_u32 with a DPP quad_perm source: one instruction instead of a broadcast and an add)
@@ -661,7 +661,9 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
     // __syncthreads() is a "soft" wait it drops when it sees no pending LDS operation — the barrier was reached with atomics still
     // in flight (found in round 5 on the pass kernel below: one increment in ~5e5 cells lost now and then; this kernel had the
     // same barrier without a wait in its ISA, never caught by a test).  The wait is explicit.
+#ifndef SQGR_DEBUG_NO_FLUSH_WAIT  // (tools/soak_negative.sh builds without it to show that tests/test_soak_gpu.py catches the race)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     __syncthreads();
     uint32_t* dst = partial_all + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * hist_words;
     if (add_transposed) {  // half list: the block's contribution to count = h + h^T is formed here, out of LDS
@@ -709,7 +711,7 @@ __global__ __launch_bounds__(COUNT_THREADS, 4) void k_count_pass(uint32_t nnz, c
     constexpr int U = 4;
     constexpr uint32_t J = 64 / LPE;           // edge slots of a wavefront
     constexpr uint32_t STEP = (COUNT_THREADS / LPE) * U;
-    static_assert(6 * STEP + 2 * U <= LIST_PAD, "look-ahead exceeds the padding of the edge lists");
+    static_assert(7 * STEP + 2 * U <= LIST_PAD, "look-ahead exceeds the padding of the edge lists");
     const int tid = threadIdx.x;
     // block -> (chunk, pass[, half]): XCD x takes the x-th eighth of the chunks and runs the P blocks of a chunk back to back
     int chunk, pass;
@@ -890,7 +892,9 @@ __global__ __launch_bounds__(COUNT_THREADS, 4) void k_count_pass(uint32_t nnz, c
         else
             sweep(std::true_type{});
     }
+#ifndef SQGR_DEBUG_NO_FLUSH_WAIT
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the inline-asm atomics are invisible to the compiler's wait counts (see k_count)
+#endif
     __syncthreads();
     // the chunk's partial histogram is [16 / B planes][pair][B] (k_reduce's slot order): a block writes ONE contiguous run — its
     // plane, or its half of the plane's rows (first version: [pair][16] with the pass's B columns scattered into it — 4 bytes

@@ -16,9 +16,9 @@ d = json.loads(open(f"{out}/{tag}_bench.json").read().strip().splitlines()[-1])
 c = sqlite3.connect(f"{out}/{tag}_results.db")
 t0 = c.execute("select min(start) from regions").fetchone()[0]
 lines = [f"HIP API trace of `python bench.py --no-cpu-baseline --no-numpy-leg` (rocprofv3 --hip-runtime-trace), env SQGR_POOL_GB={__import__('os').environ.get('SQGR_POOL_GB', 'default')}",
-         f"config 3 end to end (s): moran {d['legs']['config3_full']['moran']['runs_s']}, geary {d['legs']['config3_full']['geary']['runs_s']}", "",
+         f"config 3 end to end (s): {d['legs'].get('config3_full')}; secondary: {d.get('secondary', {}).get('value')} genes/s, {d.get('secondary', {}).get('ms_per_step')} ms/step", "",
          "longest single calls:"]
-for name, start, dur in c.execute("select name, start, end - start from regions order by 3 desc limit 8"):
+for name, start, dur in c.execute("select name, start, end - start from regions order by 3 desc limit 24"):
     args = dict((r[0], r[1]) for r in c.execute("select name, value from region_args where id = (select id from regions where start = ? and name = ?)", (start, name)))
     lines.append(f"  {dur / 1e6:9.1f} ms  {name:28s} at t = {(start - t0) / 1e9:6.2f} s  {('size ' + args['size']) if 'size' in args else ''}")
 lines += ["", "totals per function:"]
