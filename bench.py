@@ -907,12 +907,12 @@ def nhood_variant_legs(ctx, adj, graph, n: int, headline_value: float | None, pe
         ms = sum(v[1] for _, v in cnt)
         per_launch = perms / max(launches, 1)
         avg_ms = ms / max(launches, 1)
-        dram = float(n) * per_launch + float(info["blocks_per_batch"]) * info["hist_words"] * 4.0 * (per_launch / 16.0) + 8.0 * info["list_edges"]
+        dram = float(n) * per_launch + float(info["blocks_per_batch"]) * info["partial_bytes_per_chunk"] * (per_launch / 16.0) + 8.0 * info["list_edges"]
         legs[name] = {"value": perms / dt, "unit": "permutations/s", "clusters": K, "what": what, "steps": reps,
                       "wall_ms_per_step": dt * 1e3, "kernel_sum_ms_per_step": sum(v[1] for v in kern.values()),
                       "timed_hipMalloc_calls": a1["mallocs"] - a0["mallocs"],
                       "vs_k30": perms / dt / headline_value if headline_value else None,
-                      "count_kernel": "+".join(k for k, _ in cnt), "count_us_per_perm": ms * 1e3 / perms, "perms_per_pass": info["perms_per_pass"],
+                      "count_kernel": "+".join(k for k, _ in cnt), "count_us_per_perm": ms * 1e3 / perms, "perms_per_pass": info["perms_per_pass"], "counter_mode": info["counter_mode"], "blocks_per_batch": info["blocks_per_batch"],
                       "list_edges": info["list_edges"], "symmetric_half_list": info["symmetric"], "kernels_ms": {k: round(v[1], 3) for k, v in kern.items() if v[0] > 0},
                       "roofline": {"kernel": "+".join(k for k, _ in cnt), "bound": "hbm", "achieved": dram / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else None,
                                    "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": dram / (avg_ms * 1e-3) / HBM_PEAK if avg_ms > 0 else None, "traffic": dram,

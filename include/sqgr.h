@@ -157,10 +157,13 @@ int sqgr_nhood_run_pcg64(sqgr_nhood* plan, const uint64_t* pcg_states, int64_t n
  * `(count - mean) / std` is Squidpy's z-score for the seed — without moving the n_perms*K*K counts to the host. */
 int sqgr_nhood_run_pcg64_stats(sqgr_nhood* plan, const uint64_t* pcg_states, int64_t n_perms, double* out_mean, double* out_std);
 
-/* Launch geometry of a plan, int64[8]: {permutations per pass over the edge list (16|32), batches per launch group,
- * count blocks per batch, edges of the list the count kernel walks (the half list r < c + self loops on a structurally
- * symmetric graph, else nnz), 0 full list | 1 half list | 2 half list with self loops, LDS histogram words per block,
- * self loops, permutations per group of the label generator}.  bench.py derives its per-kernel ceilings from these. */
+/* Launch geometry of a plan, int64[12]: {width of the label slab's rows (16|32 permutations), batches per launch group,
+ * edge chunks (count blocks) per batch, edges of the list the count kernel walks (the half list r < c + self loops on a structurally
+ * symmetric graph, else nnz), 0 full list | 1 half list | 2 half list with self loops, accumulator slots per batch (K*K x row
+ * width), self loops, permutations per group of the label generator, permutations per PASS over the edge list (16 | 8 | 4 | 2 | 1;
+ * 32 for 32-wide rows; 0: device-scope counters), row halves per pass (2: 203 <= K <= 256 with 32-bit counters), counter mode
+ * (0: 32-bit counters on K*K pairs; 1: 16-bit on K*K pairs; 2: 16-bit on the K (K + 1) / 2 unordered pairs of a symmetric
+ * graph), bytes of one chunk's partial histograms}.  bench.py derives its per-kernel ceilings from these. */
 int sqgr_nhood_info(sqgr_nhood* plan, int64_t* out_info);
 
 /* Attaches (comm != NULL) or detaches an RCCL communicator: see "multi-GPU" above. */

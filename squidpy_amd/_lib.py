@@ -446,12 +446,13 @@ class NhoodPlan:
 
     def info(self) -> dict[str, Any]:
         """Launch geometry (``sqgr_nhood_info``)."""
-        v = np.zeros(8, dtype=np.int64)
+        v = np.zeros(12, dtype=np.int64)
         _check(self.ctx.lib, self.ctx.lib.sqgr_nhood_info(self.h, _ptr(v, c_i64p)))
         return {
-            "perms_per_pass": int(v[0]), "batches_per_launch": int(v[1]), "blocks_per_batch": int(v[2]), "list_edges": int(v[3]),
+            "slab_width": int(v[0]), "perms_per_pass": int(v[8]), "row_halves": int(v[9]), "counter_mode": int(v[10]),
+            "batches_per_launch": int(v[1]), "blocks_per_batch": int(v[2]), "list_edges": int(v[3]),
             "symmetric": int(v[4]) != 0, "self_loops": int(v[6]), "hist_words": int(v[5]), "generator_group": int(v[7]),
-            "partial_bytes_per_launch": int(v[1]) * int(v[2]) * int(v[5]) * 4,
+            "partial_bytes_per_chunk": int(v[11]), "partial_bytes_per_launch": int(v[1]) * int(v[2]) * int(v[11]),
         }
 
     def set_comm(self, comm: "Comm | None") -> None:

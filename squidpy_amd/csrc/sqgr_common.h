@@ -207,6 +207,7 @@ int comm_world(const sqgr_comm* c);
 struct sqgr_graph {
     sqgr_ctx* ctx = nullptr;
     int64_t n = 0, nnz = 0;
+    int64_t max_row_len = 0;        // most stored entries of one row (the 16-bit count kernels bound a counter with it)
     sqgr::DevBuf<int64_t> indptr;   // [n+1]
     sqgr::DevBuf<int32_t> indices;  // [nnz]
     sqgr::DevBuf<int32_t> erow;     // [nnz] row of every stored edge (COO expansion, built on device)

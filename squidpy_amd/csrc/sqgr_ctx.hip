@@ -3,6 +3,7 @@
 
 #include "sqgr_common.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <mutex>
@@ -748,8 +749,11 @@ static int graph_create_impl(sqgr_ctx* ctx, int64_t n, int64_t nnz, const int64_
     SQGR_REQUIRE(indptr && (indices || nnz == 0), "indptr/indices is NULL");
     SQGR_REQUIRE(indptr[0] == 0 && indptr[n] == nnz, "indptr[0]=%lld indptr[n]=%lld inconsistent with nnz=%lld",
                  (long long)indptr[0], (long long)indptr[n], (long long)nnz);
-    for (int64_t i = 0; i < n; ++i)
+    int64_t max_row_len = 0;
+    for (int64_t i = 0; i < n; ++i) {
         SQGR_REQUIRE(indptr[i] <= indptr[i + 1], "indptr not monotone at row %lld", (long long)i);
+        max_row_len = std::max(max_row_len, indptr[i + 1] - indptr[i]);
+    }
     for (int64_t e = 0; e < nnz; ++e)
         SQGR_REQUIRE(indices[e] >= 0 && indices[e] < n, "indices[%lld]=%d out of [0,%lld)", (long long)e, indices[e],
                      (long long)n);
@@ -763,6 +767,7 @@ static int graph_create_impl(sqgr_ctx* ctx, int64_t n, int64_t nnz, const int64_
     g->ctx = ctx;
     g->n = n;
     g->nnz = nnz;
+    g->max_row_len = max_row_len;
     int rc = SQGR_OK;
     do {
         if ((rc = g->indptr.alloc((size_t)n + 1)) != SQGR_OK) break;

@@ -441,7 +441,17 @@ __device__ __forceinline__ uint32_t pair_index(uint32_t la, uint32_t lb, uint32_
 // DOT2 (B = 16): the counter address in TWO instructions per (edge, permutation): v_perm_b32 with a PER-LANE selector picks the
 // staggered label byte of both rows into the 16-bit halves (la << 16 | lb) — the selector carries the lane's rotation, so no
 // v_alignbit — and v_dot2_u32_u16 forms la * (K << 6) + lb * 64 + bank offset in one VOP3P.
-template <int B, int MIN_WAVES, bool SELF, bool DOT2 = false, int DBG = 0>  // DBG (developer probes, bit mask): 1 no atomics, 2 no row gathers, 4 no list loads
+// CM (round 6; 16 permutations per pass, DOT2 addressing): how the block keeps its counters.  0: one 32-bit word per (pair,
+// permutation), K*K pairs — K <= 50.  1 | 2: 16-BIT counters, two permutations per `ds_add_u32` word (the lane's increment is 1 or
+// 1 << 16: which half its permutation owns) — twice the pairs per KB of LDS; the host cuts the edge list so that no block can
+// carry a counter past 65 535 (at most 65 535 / weight edges per block).  2 additionally keeps ONE cell per UNORDERED label pair
+// (the half list of a structurally symmetric graph: count = h + h^T needs {la, lb} only) at cell = hi * (hi + 1) / 2 + lo —
+// K (K + 1) / 2 cells: 16 permutations fit up to K = 100 (mode 1, directed graphs: K = 71).  The sorted pair costs two
+// instructions on the packed labels t = la << 16 | lb: min(t, t rotated by 16) = lo << 16 | hi as 32-bit integers; the quadratic
+// term rides in the multiplier of the dot product: v_mad_u32_u16 forms {hi: bytes per cell, lo: (hi + 1) * bytes per cell / 2}
+// and v_dot2_u32_u16 multiplies it with {hi: lo, lo: hi} — five instructions per counter address instead of two.
+// The block's partial is then the LDS image itself (16-bit counters, no h + h^T pass): k_reduce16 expands it.
+template <int B, int MIN_WAVES, bool SELF, bool DOT2 = false, int DBG = 0, int CM = 0>  // DBG (developer probes, bit mask): 1 no atomics, 2 no row gathers, 4 no list loads
 __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz, const int2* __restrict__ coo,
                                                                     const uint8_t* __restrict__ slab_all, int64_t n, int K,
                                                                     int hist_words, uint32_t edges_per_block,
@@ -452,7 +462,8 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
     // shares the CU (SQGR_NHOOD_STREAMS=2), issue priority keeps the LDS pipe fed
     __builtin_amdgcn_s_setprio(3);
     constexpr int BPL = B / 4;  // label bytes per lane
-    constexpr int LOGW = (B == 32) ? 7 : 6;  // log2(bytes of one pair's B counters)
+    constexpr int LOGW = CM ? 5 : ((B == 32) ? 7 : 6);  // log2(bytes of one pair's B counters)
+    static_assert(CM == 0 || (DOT2 && B == 16 && DBG == 0), "16-bit counters: the dot2 path at 16 permutations per pass");
     const int tid = threadIdx.x;
     for (int i = tid; i < hist_words; i += COUNT_THREADS) hist[i] = 0;
     __syncthreads();
@@ -468,7 +479,12 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
     const uint32_t rot = (el & (BPL - 1)) * 8;  // bits to rotate right
     uint32_t bank_ofs[BPL];                      // byte offset of this lane's counter inside a pair, per step
 #pragma unroll
-    for (int s = 0; s < BPL; ++s) bank_ofs[s] = (q * BPL + ((s + el) & (BPL - 1))) * 4;
+    for (int s = 0; s < BPL; ++s) {
+        const uint32_t byte = (s + el) & (BPL - 1);
+        bank_ofs[s] = CM ? (q * (BPL / 2) + (byte >> 1)) * 4 : (q * BPL + byte) * 4;  // CM: permutations 2w, 2w + 1 share word w
+    }
+    // CM: the half of the word the lane's permutation owns alternates with the step ((s + el) & 1): two shift amounts per lane
+    const uint32_t half_sh0 = CM ? 16u * (el & 1u) : 0u, half_sh1 = CM ? 16u * ((el + 1u) & 1u) : 0u;
     const uint32_t qoff = q * BPL;
     char* hist_bytes = reinterpret_cast<char*>(hist);
     static_assert(!DOT2 || B == 16, "the dot2 address path is written for 16 permutations per pass");
@@ -476,6 +492,7 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
 #pragma unroll
     for (int s = 0; s < BPL; ++s) sel[s] = 0x0c000c00u | ((4u + ((s + el) & 3u)) << 16) | ((s + el) & 3u);
     const uint32_t dot_k = ((uint32_t)K << (LOGW + 16)) | (1u << LOGW);  // {hi: K << 6, lo: 64}
+    constexpr uint32_t tri_k = (1u << (LOGW + 16)) | (1u << (LOGW - 1));   // CM 2: {hi: bytes per cell, lo: half of them} (+ hi * half)
     uint32_t dbg_acc = 0;
     const uint32_t dbg_lin = (uint32_t)((((size_t)blockIdx.x * 40503u) % (size_t)(n - 4096)) * 16) + tid * 4;
     if constexpr (DOT2) {
@@ -569,12 +586,29 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
                 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
                 uint32_t addr[4];
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    addr[s] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(la[0], lb[0], sel[s])),
-                                                     __builtin_bit_cast(u16x2, dot_k), bank_ofs[s], false);
+                for (int s = 0; s < 4; ++s) {
+                    const uint32_t t = __builtin_amdgcn_perm(la[0], lb[0], sel[s]);  // la << 16 | lb
+                    if constexpr (CM == 2) {
+                        const uint32_t tr = __builtin_amdgcn_alignbit(t, t, 16);     // lb << 16 | la
+                        const uint32_t m = t < tr ? t : tr;                          // lo << 16 | hi
+                        uint32_t mul;                                                // {hi: bytes per cell, lo: (hi + 1) * bytes per cell / 2}
+                        asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(mul) : "v"(m), "v"(1u << (LOGW - 1)), "v"(tri_k));
+                        addr[s] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, m), __builtin_bit_cast(u16x2, mul), bank_ofs[s], false);
+                    } else {
+                        addr[s] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, t), __builtin_bit_cast(u16x2, dot_k), bank_ofs[s], false);
+                    }
+                }
                 // (the LDS offset of the histogram is folded into bank_ofs: no per-atomic base add)
                 if constexpr ((DBG & 1) != 0) {  // keep the address arithmetic alive, drop the atomics
                     asm volatile("" : : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]) : "memory");
+                    continue;
+                }
+                if constexpr (CM != 0) {
+                    const uint32_t inc0 = inc << half_sh0, inc1 = inc << half_sh1;  // (loop-invariant in whole blocks: `inc` is a constant there)
+                    asm volatile("ds_add_u32 %0, %4\n\tds_add_u32 %1, %5\n\tds_add_u32 %2, %4\n\tds_add_u32 %3, %5"
+                                 :
+                                 : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(inc0), "v"(inc1)
+                                 : "memory");
                     continue;
                 }
                 asm volatile("ds_add_u32 %0, %4\n\tds_add_u32 %1, %4\n\tds_add_u32 %2, %4\n\tds_add_u32 %3, %4"
@@ -666,6 +700,10 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
 #endif
     __syncthreads();
     uint32_t* dst = partial_all + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * hist_words;
+    if constexpr (CM != 0) {  // the partial is the LDS image: 16-bit counters [cell][16], expanded (and h + h^T resolved) by k_reduce16
+        for (int i = tid; i < hist_words; i += COUNT_THREADS) dst[i] = hist[i];
+        return;
+    }
     if (add_transposed) {  // half list: the block's contribution to count = h + h^T is formed here, out of LDS
         constexpr int LOGB = (B == 32) ? 5 : 4;
         for (int i = tid; i < hist_words; i += COUNT_THREADS) {
@@ -699,13 +737,17 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
 // by k_reduce (sym bit 2), a block does not hold the transposed rows.
 // PACK: the list in 4 bytes per entry (sqgr_graph::packed_list: (col - row) << 8 | row - base of the wavefront's group; spot indices,
 // scaled to plane offsets here) — half the list bytes through L2 -> L1, which is what bounds this kernel.
-template <int LPE, int NS, bool SELF, int SPLIT = 1, bool PACK = false>
+// CM: the counter modes of k_count — 1: 16-bit counters on K*K pairs, 2: 16-bit counters on the K (K + 1) / 2 unordered pairs of a
+// symmetric graph's half list — at 8 | 4 | 2 permutations per pass: 8 up to K = 142 (mode 1: 101), 4 up to 201 (143), 2 up to 285
+// (202); the partial of a block is its LDS image (`cells` cells of B 16-bit counters), written as one contiguous run.
+template <int LPE, int NS, bool SELF, int SPLIT = 1, bool PACK = false, int CM = 0>
 __global__ __launch_bounds__(COUNT_THREADS, 4) void k_count_pass(uint32_t nnz, const int2* __restrict__ coo, const uint32_t* __restrict__ gbase,
                                                                  const uint8_t* __restrict__ slab_all, int64_t n, int K,
                                                                  uint32_t edges_per_chunk, uint32_t self_begin, int add_transposed,
-                                                                 int nchunks, uint32_t R, uint32_t* __restrict__ partial_all) {
+                                                                 int nchunks, uint32_t R, uint32_t* __restrict__ partial_all, int cells) {
     extern __shared__ uint32_t hist[];
     static_assert((LPE == 2 || LPE == 1) && (NS == 4 || NS == 2 || NS == 1) && (NS == 4 || LPE == 1) && (SPLIT == 1 || NS == 1), "shape");
+    static_assert(CM == 0 || (NS >= 2 && SPLIT == 1), "16-bit counters: two permutations per word, whole histograms");
     constexpr int B = NS == 4 ? LPE * 4 : NS;  // permutations per pass
     constexpr int P = (16 / B) * SPLIT;        // blocks per chunk and batch of 16: passes x row halves
     constexpr int U = 4;
@@ -727,7 +769,7 @@ __global__ __launch_bounds__(COUNT_THREADS, 4) void k_count_pass(uint32_t nnz, c
     pass /= SPLIT;
     const int Kh = (K + SPLIT - 1) / SPLIT, a0 = half * Kh;          // this block's rows of the histogram: la in [a0, a0 + rows)
     const int rows = min(Kh, K - a0);
-    const int hist_words = rows * K * B;
+    const int hist_words = CM ? cells * (B / 2) : rows * K * B;
     for (int i = tid; i < hist_words; i += COUNT_THREADS) hist[i] = 0;
     __syncthreads();
     const uint8_t* slab = slab_all + (size_t)blockIdx.y * n * 16 + (size_t)pass * n * B;  // the pass's plane [n][B] (slab_store16)
@@ -749,10 +791,15 @@ __global__ __launch_bounds__(COUNT_THREADS, 4) void k_count_pass(uint32_t nnz, c
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const uint32_t byte = (s + el) & (NS - 1);
-        bank_ofs[s] = (d * NS + byte) * 4 + lds_base - (uint32_t)(a0 * K * B * 4);  // (wraps; row a0 lands on the first counter)
+        bank_ofs[s] = CM ? ((d * NS + byte) >> 1) * 4 + lds_base                       // permutations 2w, 2w + 1 of the pass share word w
+                         : (d * NS + byte) * 4 + lds_base - (uint32_t)(a0 * K * B * 4);  // (wraps; row a0 lands on the first counter)
         sel[s] = 0x0c000c00u | ((4u + base_byte + byte) << 16) | (base_byte + byte);  // b row byte -> bits 0..7, a row byte -> bits 16..23
     }
-    const uint32_t dot_k = ((uint32_t)(K * B * 4) << 16) | (uint32_t)(B * 4);  // {hi: bytes per la row, lo: bytes per pair}
+    constexpr uint32_t CB = CM ? B * 2 : B * 4;  // bytes of one pair's (cell's) B counters
+    const uint32_t dot_k = ((uint32_t)(K * CB) << 16) | CB;  // {hi: bytes per la row, lo: bytes per pair}
+    constexpr uint32_t tri_k = (CB << 16) | (CB / 2);         // CM 2: {hi: bytes per cell, lo: half of them} (+ hi * half: see k_count)
+    // CM: which half of its word the lane's permutation of step s owns alternates with s ((s + el) & 1)
+    const uint32_t half_sh0 = CM ? 16u * (el & 1u) : 0u, half_sh1 = CM ? 16u * ((el + 1u) & 1u) : 0u;
 
     struct Pairs { uint32_t r[U], c[U]; };
     // what a lane loads per iteration: its U / LPE... entries — LPE 2: entries 2q, 2q + 1 of the quad's eight; LPE 1: its own four —
@@ -845,10 +892,28 @@ __global__ __launch_bounds__(COUNT_THREADS, 4) void k_count_pass(uint32_t nnz, c
             }
             uint32_t addr[NS];
 #pragma unroll
-            for (int s = 0; s < NS; ++s)
-                addr[s] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(row_a[u], row_b[u], sel[s])),
-                                                 __builtin_bit_cast(u16x2, dot_k), bank_ofs[s], false);
-            if constexpr (NS == 4)
+            for (int s = 0; s < NS; ++s) {
+                const uint32_t t = __builtin_amdgcn_perm(row_a[u], row_b[u], sel[s]);  // la << 16 | lb
+                if constexpr (CM == 2) {
+                    const uint32_t tr = __builtin_amdgcn_alignbit(t, t, 16);
+                    const uint32_t m = t < tr ? t : tr;  // lo << 16 | hi
+                    uint32_t mul;
+                    asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(mul) : "v"(m), "v"(CB / 2), "v"(tri_k));
+                    addr[s] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, m), __builtin_bit_cast(u16x2, mul), bank_ofs[s], false);
+                } else {
+                    addr[s] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, t), __builtin_bit_cast(u16x2, dot_k), bank_ofs[s], false);
+                }
+            }
+            if constexpr (CM != 0) {
+                const uint32_t inc0 = inc << half_sh0, inc1 = inc << half_sh1;
+                if constexpr (NS == 4)
+                    asm volatile("ds_add_u32 %0, %4\n\tds_add_u32 %1, %5\n\tds_add_u32 %2, %4\n\tds_add_u32 %3, %5"
+                                 :
+                                 : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(inc0), "v"(inc1)
+                                 : "memory");
+                else
+                    asm volatile("ds_add_u32 %0, %2\n\tds_add_u32 %1, %3" : : "v"(addr[0]), "v"(addr[1]), "v"(inc0), "v"(inc1) : "memory");
+            } else if constexpr (NS == 4)
                 asm volatile("ds_add_u32 %0, %4\n\tds_add_u32 %1, %4\n\tds_add_u32 %2, %4\n\tds_add_u32 %3, %4"
                              :
                              : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(inc)
@@ -899,6 +964,11 @@ __global__ __launch_bounds__(COUNT_THREADS, 4) void k_count_pass(uint32_t nnz, c
     // the chunk's partial histogram is [16 / B planes][pair][B] (k_reduce's slot order): a block writes ONE contiguous run — its
     // plane, or its half of the plane's rows (first version: [pair][16] with the pass's B columns scattered into it — 4 bytes
     // per 64-byte line at B = 1, 7.4 GB of write traffic per 2560 permutations at K = 200 instead of 3.3)
+    if constexpr (CM != 0) {  // the LDS image: [cell][B] 16-bit counters of this pass's plane (k_reduce16 expands them)
+        uint32_t* dst16 = partial_all + ((size_t)blockIdx.y * nchunks + chunk) * ((size_t)cells * 8) + (size_t)pass * hist_words;
+        for (int i = tid; i < hist_words; i += COUNT_THREADS) dst16[i] = hist[i];
+        return;
+    }
     uint32_t* dst = partial_all + ((size_t)blockIdx.y * nchunks + chunk) * ((size_t)K * K * 16) + (size_t)pass * K * K * B + (size_t)a0 * K * B;
     const float inv_k = 1.0f / (float)K;  // pair / K without an integer division: (pair + 0.5) / K is at least 0.5 / K away from an
                                           // integer, the float product is off by < 2^-22 * K (pair < 2^16, K <= 256)
@@ -985,6 +1055,89 @@ __global__ __launch_bounds__(256) void k_reduce(const uint32_t* __restrict__ par
     acc_sum[slot] += d;
     acc_sq[slot] += (uint64_t)(d * d);
     if (perms_out) perms_out[(size_t)(p - perm_begin) * K2 + pair] = (uint32_t)c;
+}
+
+// Reduction of the 16-bit partials (counter modes 1 and 2 of k_count / k_count_pass): per (batch, chunk) the blocks wrote
+// [16 / PW planes][cell][PW] uint16 — cells = K*K (mode 1) or K (K + 1) / 2 unordered pairs at cell = hi * (hi + 1) / 2 + lo (TRI).  ONE
+// thread owns a cell of a batch: it sums the cell's 16 permutations over the chunks (PW / 2 words per plane and chunk: 32 contiguous
+// bytes per lane at PW = 16), turns them into the counts they stand for, and adds the batch's sum of d = count - shift and of d^2
+// to ONE accumulator slot per ordered pair (acc[batch][pair]: private, no atomics, bit-reproducible) — 16 times fewer accumulator
+// bytes than k_reduce's slot per (pair, permutation), which at K = 200 were as many as the partials themselves.
+// TRI: count[a][b] = count[b][a] = T{a,b} for a != b, count[a][a] = 2 T{a,a} (an edge inside a cluster is one half-list entry and
+// two entries of the full scan); `doubled` (half list with self loops: half edges weigh 2, self loops 1): count[a][b] = T{a,b} / 2,
+// count[a][a] = T{a,a} — every T{a,b}, a != b, is even by construction.
+template <bool TRI, int PW>
+__global__ __launch_bounds__(256) void k_reduce16(const uint32_t* __restrict__ partial_all, int nblk, int cells, int K, int doubled,
+                                                  const int64_t* __restrict__ shift, int64_t perm_batch0, int64_t perm_begin, int64_t perm_end,
+                                                  int64_t* __restrict__ acc_sum, uint64_t* __restrict__ acc_sq, uint32_t* __restrict__ perms_out) {
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    const int batch = blockIdx.y;
+    if (cell >= cells) return;
+    const int K2 = K * K;
+    const size_t words = (size_t)cells * 8;  // 32-bit words of one chunk's partial
+    uint32_t c[16];  // (a count is < 2^32 by the interface: uint32 per-permutation counts)
+#pragma unroll
+    for (int b = 0; b < 16; ++b) c[b] = 0;
+    const uint32_t* src = partial_all + (size_t)batch * nblk * words + (size_t)cell * (PW / 2);
+#pragma unroll 2
+    for (int k = 0; k < nblk; ++k, src += words) {
+#pragma unroll
+        for (int plane = 0; plane < 16 / PW; ++plane) {
+            const uint32_t* q = src + (size_t)plane * cells * (PW / 2);
+            uint32_t w[PW / 2];
+            if constexpr (PW == 16) {
+                const uint4 v0 = *reinterpret_cast<const uint4*>(q), v1 = *reinterpret_cast<const uint4*>(q + 4);
+                w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w; w[4] = v1.x; w[5] = v1.y; w[6] = v1.z; w[7] = v1.w;
+            } else if constexpr (PW == 8) {
+                const uint4 v0 = *reinterpret_cast<const uint4*>(q);
+                w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w;
+            } else if constexpr (PW == 4) {
+                const uint2 v0 = *reinterpret_cast<const uint2*>(q);
+                w[0] = v0.x; w[1] = v0.y;
+            } else {
+                w[0] = *q;
+            }
+#pragma unroll
+            for (int i = 0; i < PW / 2; ++i) {
+                c[plane * PW + 2 * i] += w[i] & 0xffffu;
+                c[plane * PW + 2 * i + 1] += w[i] >> 16;
+            }
+        }
+    }
+    int pa[2], npairs = 1;
+    bool diag = false;
+    if constexpr (TRI) {
+        int hi = (int)((sqrtf(8.0f * (float)cell + 1.0f) - 1.0f) * 0.5f);
+        while (hi * (hi + 1) / 2 > cell) --hi;
+        while ((hi + 1) * (hi + 2) / 2 <= cell) ++hi;
+        const int lo = cell - hi * (hi + 1) / 2;
+        diag = lo == hi;
+        npairs = diag ? 1 : 2;
+        pa[0] = lo * K + hi;
+        pa[1] = hi * K + lo;
+    } else {
+        pa[0] = pa[1] = cell;
+    }
+    const int64_t p0 = perm_batch0 + (int64_t)batch * 16;
+    for (int t = 0; t < npairs; ++t) {
+        const int64_t sh = shift[pa[t]];
+        int64_t sum = 0;
+        uint64_t sq = 0;
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            const int64_t p = p0 + b;
+            if (p >= perm_end || p < perm_begin) continue;
+            uint32_t cnt = c[b];
+            if constexpr (TRI) cnt = diag ? (doubled ? cnt : 2 * cnt) : (doubled ? cnt >> 1 : cnt);
+            const int64_t d = (int64_t)cnt - sh;
+            sum += d;
+            sq += (uint64_t)(d * d);
+            if (perms_out) perms_out[(size_t)(p - perm_begin) * K2 + pa[t]] = cnt;
+        }
+        const size_t slot = (size_t)batch * K2 + pa[t];
+        acc_sum[slot] += sum;
+        acc_sq[slot] += sq;
+    }
 }
 
 // thread per slot j of a batch: sums the slot over the batches (coalesced whatever the plane width), then adds into its pair's
@@ -1239,46 +1392,93 @@ struct sqgr_nhood {
     DevBuf<uint32_t> perms_dev;
     DevBuf<uint8_t> stage;
 
-    int hist_words() const { return K2 * B; }
-    // permutations of the 16-wide slab whose K*K histograms fit LDS together: 16 -> k_count; 8, 4, 2, 1 -> that many per PASS of
-    // k_count_pass (16 / be passes per batch); 0: not even one (K > 202) -> device-scope counters (k_count_global).
+    int hist_words() const { return K2 * B; }  // accumulator slots of a batch: every ordered pair x every permutation of the slab row
+    // Counter mode of the LDS count kernels above 50 clusters (round 6; see k_count): 0 — 32-bit counters on K*K pairs (what
+    // K <= 50 keeps, and what serves one permutation per pass: a tune / SQGR_COUNT_PASS_B cap of 1, directed graphs above 202
+    // clusters); 1 — 16-bit counters on K*K pairs (directed graphs); 2 — 16-bit counters on the K (K + 1) / 2 unordered pairs
+    // (structurally symmetric graphs: the half list).  Needs g->ensure_half() to have run (ensure_workspace, sqgr_nhood_info).
+    int max_label_count = 0;  // largest cluster of the base labels (0: unknown — injected label vectors)
+    int pass_cap = 16;
+    int cap() const {
+        static const int env_cap = [] { const char* e = getenv("SQGR_COUNT_PASS_B"); return e ? std::max(atoi(e), 1) : 16; }();
+        return std::min(pass_cap, env_cap);
+    }
+    int cm() const {
+        static const bool off = [] { const char* e = getenv("SQGR_COUNT_C16"); return e && atoi(e) == 0; }();
+        if (off || wide() || B != 16 || !g || (size_t)K2 * 16 * 4 <= LDS_BUDGET || cap() < 2) return 0;
+        const bool sym = g->sym_state == 1;
+        const size_t c = sym ? (size_t)K * (K + 1) / 2 : (size_t)K2;
+        if (c * 2 * 2 > LDS_BUDGET) return 0;  // not even two permutations (a directed graph above 202 clusters)
+        return sym ? 2 : 1;
+    }
+    int cells() const { return cm() == 2 ? K * (K + 1) / 2 : K2; }
+    // permutations of the 16-wide slab whose histograms fit LDS together: 16 -> k_count; 8, 4, 2, 1 -> that many per PASS of
+    // k_count_pass (16 / be passes per batch); 0: not even one (32-bit counters, K > 202) -> device-scope counters (k_count_global).
     // sqgr_nhood_tune(perms_per_pass = 8|4|2|1) / SQGR_COUNT_PASS_B cap it (tests: every pass width on one input; experiments:
     // fewer permutations per pass, more blocks per CU).
-    int pass_cap = 16;
     int be() const {
-        static const int env_cap = [] { const char* e = getenv("SQGR_COUNT_PASS_B"); return e ? std::max(atoi(e), 1) : 16; }();
-        const int cap = std::min(pass_cap, env_cap);
+        if (cm()) {
+            for (int b : {16, 8, 4, 2})
+                if ((size_t)cells() * b * 2 <= LDS_BUDGET && b <= cap()) return b;
+        }
         for (int b : {16, 8, 4, 2, 1})
-            if ((size_t)K2 * b * 4 <= LDS_BUDGET && b <= cap) return b;
+            if ((size_t)K2 * b * 4 <= LDS_BUDGET && b <= cap()) return b;
         if (!wide() && (size_t)((K + 1) / 2) * K * 4 <= LDS_BUDGET) return 1;  // half of the rows per block (split() == 2)
         return 0;
     }
-    int split() const { return (B == 16 && !wide() && be() == 1 && (size_t)K2 * 4 > LDS_BUDGET) ? 2 : 1; }
+    int split() const { return (B == 16 && !wide() && !cm() && be() == 1 && (size_t)K2 * 4 > LDS_BUDGET) ? 2 : 1; }
     int partial_w() const { return (B == 16 && !wide() && be() > 0 && be() < 16) ? be() : B; }  // plane width of partials and accumulator slots
     bool lds_path() const { return !wide() && (B == 32 || be() > 0); }  // block-local LDS histograms, (half) edge list
     int passes() const { return (B == 16 && !wide() && be() > 0) ? (16 / be()) * split() : 1; }
     // layout of a batch's 16 * n slab bytes: 16 = rows [n][16]; 8 | 4 | 2 | 1 = 16 / w planes [n][w], one per pass (slab_store16)
     int plane_w() const { return (B == 16 && !wide() && be() > 0) ? be() : 16; }
+    // 32-bit words of ONE block-partial set of a batch's chunk: K*K*B counters, or (16-bit modes) cells x 16 half words
+    size_t part_words() const { return cm() ? (size_t)cells() * 8 : (size_t)hist_words(); }
+    // accumulator slots of a batch and their plane width (k_finalize): one per (pair, permutation) — or, 16-bit modes, one per pair
+    int acc_words() const { return cm() ? K2 : hist_words(); }
+    int acc_pw() const { return cm() ? 1 : partial_w(); }
+    // 16-bit counters: the most edges one block may count — no counter can pass 65 535 whatever the labels are (a block's cell
+    // receives at most weight x edges; weight 2 on half lists with self loops) — in whole iterations of the kernel that runs
+    uint32_t edge_step() const { return be() == 16 ? 1024u : (be() == 8 ? 2048u : 4096u); }
+    int64_t list_edges() const { return g ? ((lds_path() && g->sym_state == 1) ? g->n_half + g->n_self : g->nnz) : 0; }
+    // ... unless the labels themselves bound it: a cell {a, b} receives only list entries with an endpoint in cluster a, at most
+    // (size of a) x (longest row) of them, and a shuffle keeps the cluster sizes.  That argument needs every one of the slab's 16
+    // columns to BE a shuffle of the base labels: `columns_valid` — true inside sqgr_nhood_run only (the device generator always
+    // fills whole rows; the numpy-stream and injected-label paths leave the columns past the last permutation stale).
+    bool columns_valid = false;
+    int64_t chunk_cap(bool relaxed) const {
+        if (!cm()) return 0;
+        const uint32_t w = (g->sym_state == 1 && g->n_self > 0) ? 2u : 1u;
+        if (relaxed && max_label_count > 0 && (int64_t)max_label_count * std::max<int64_t>(g->max_row_len, 1) * w <= 65535) return 0;
+        return (int64_t)(65535u / w / edge_step()) * edge_step();
+    }
     // 1024-thread blocks per batch of a launch with `nb` batches = edge chunks per batch (k_count_pass: times `passes()` blocks).
     // nblk > 0: fixed by sqgr_nhood_tune.  Auto: ~4 blocks per CU over the whole launch, at least 8 per batch (one per XCD), whole
     // XCD shares (a multiple of 8).  Round 2 had measured 32-48 blocks per batch as the best with 64 batches per launch; with the
     // 160-batch launches of today fewer, longer chunks win — fewer partial histograms to write and re-read (blocks * K*K*64 bytes
     // per batch), fewer ramps and tails (tools/nhood_k_sweep.py --sweep, round 5, permutations/s at 1e6 spots; blocks per batch 8 /
     // 16 / 32 / 64: K = 30 953 k / 948 k / 921 k / 864 k — round 4's 32 was 6 % behind —, K = 64 687 k / 657 k / 602 k / 499 k,
-    // K = 100 605 k / 552 k / 450 k / 330 k, K = 200 230 k / 199 k / 149 k / 102 k).
-    int blocks_for(int nb) const {
-        if (nblk > 0) return nblk;
-        const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
-        const int64_t fill = (((int64_t)4 * cus) / std::max(nb * passes(), 1)) & ~(int64_t)7;
-        return (int)std::max<int64_t>(8, std::min<int64_t>(cus, fill));
+    // K = 100 605 k / 552 k / 450 k / 330 k, K = 200 230 k / 199 k / 149 k / 102 k).  16-bit counters: at least list / chunk_cap().
+    int blocks_for(int nb, bool relaxed = false) const {
+        int want = nblk;
+        if (want <= 0) {
+            const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
+            const int64_t fill = (((int64_t)4 * cus) / std::max(nb * passes(), 1)) & ~(int64_t)7;
+            want = (int)std::max<int64_t>(8, std::min<int64_t>(cus, fill));
+        }
+        if (const int64_t capn = chunk_cap(relaxed)) {
+            const int64_t need = ceil_div(std::max<int64_t>(list_edges(), 1), capn);
+            if (need > want) want = (int)(nblk > 0 ? need : ceil_div(need, 8) * 8);
+        }
+        return want;
     }
     int nblk_launch = 0;  // blocks per batch of the launch in flight (count -> reduce)
     int sym_launch = 0;   // k_reduce mode of the launch in flight (0 full edge list, 1 half list, 2 half list with self loops)
     int partial_blocks(int nb) const { return lds_path() ? blocks_for(nb) : 1; }
-    size_t partial_words() const {  // largest nb * blocks_for(nb) * hist_words over the launches this plan can issue
+    size_t partial_words() const {  // largest nb * blocks_for(nb) * part_words over the launches this plan can issue
         size_t m = 0;
         for (int nb = 1; nb <= nbatch; ++nb) m = std::max(m, (size_t)nb * partial_blocks(nb));
-        return m * (size_t)hist_words();
+        return m * part_words();
     }
     int resolve_tuning();
     int ensure_workspace(bool need_perms);
@@ -1287,6 +1487,7 @@ struct sqgr_nhood {
 };
 
 int sqgr_nhood::resolve_tuning() {
+    if (g && !wide()) SQGR_TRY(g->ensure_half());  // the counter mode (cm()) and with it every size below depend on the graph's symmetry
     if (wide()) {  // K*K*16 device-scope counters per batch: at most ~1 GiB of them in flight
         B = 16;
         const int64_t cap = std::max<int64_t>(1, ((int64_t)1 << 30) / ((int64_t)K2 * 16 * 4));
@@ -1322,8 +1523,8 @@ int sqgr_nhood::ensure_workspace(bool need_perms) {
     }
     (void)hw;
     SQGR_TRY(partial.ensure(partial_words()));
-    SQGR_TRY(acc_sum.ensure((size_t)nbatch * hw));
-    SQGR_TRY(acc_sq.ensure((size_t)nbatch * hw));
+    SQGR_TRY(acc_sum.ensure((size_t)nbatch * acc_words()));
+    SQGR_TRY(acc_sq.ensure((size_t)nbatch * acc_words()));
     SQGR_TRY(shift.ensure((size_t)K2));
     SQGR_TRY(fin.ensure((size_t)2 * K2));
     (void)need_perms;
@@ -1335,11 +1536,13 @@ int sqgr_nhood::count_batches(int nb, int buf) {
     const int64_t nnz = g->nnz;
     hipStream_t st = ctx->stream;
     const int hw = hist_words();
-    const int nblk = blocks_for(nb);  // shadows the tuning member on purpose: everything below is per launch
-    nblk_launch = partial_blocks(nb);
+    const int nblk = blocks_for(nb, columns_valid);  // shadows the tuning member on purpose: everything below is per launch
+    nblk_launch = lds_path() ? nblk : 1;             // (the workspace is sized for partial_blocks(nb) >= nblk)
     sym_launch = 0;
+    const int mode = cm();            // 0: 32-bit counters; 1 | 2: 16-bit counters (K*K | unordered pairs), reduced by k_reduce16
+    const int ncell = cells();
     if (nnz == 0) {  // no edges: every count is zero
-        SQGR_HIP(hipMemsetAsync(partial.p, 0, (size_t)nb * nblk_launch * hw * 4, st));
+        SQGR_HIP(hipMemsetAsync(partial.p, 0, (size_t)nb * nblk_launch * part_words() * 4, st));
         return SQGR_OK;
     }
     if (wide()) {
@@ -1372,34 +1575,43 @@ int sqgr_nhood::count_batches(int nb, int buf) {
         const uint32_t step = (uint32_t)(COUNT_THREADS * 4 / (e >= 8 ? 2 : 1));             // edges per iteration of a block
         const uint32_t epc = (uint32_t)(ceil_div(ceil_div((int64_t)m, nblk), step) * step);  // whole iterations per chunk
         const int sp = split();
-        const size_t lds = (size_t)((K + sp - 1) / sp) * K * e * 4;
+        const size_t lds = mode ? (size_t)ncell * e * 2 : (size_t)((K + sp - 1) / sp) * K * e * 4;
         if (sp > 1 && half) sym_launch |= 4;  // h + h^T in k_reduce
         const int addt = (half && sp == 1) ? 1 : 0;
         const dim3 grid(nblk * (16 / e) * sp, nb);
-        LaunchTimer t(ctx, half ? "nhood_count_pass_half" : "nhood_count_pass");
-#define SQGR_PASS_K(LPE, NS, SELF, SPLIT, PACK)                                                                                   \
-    do {                                                                                                                          \
-        SQGR_TRY(allow_lds((k_count_pass<LPE, NS, SELF, SPLIT, PACK>), lds));                                                     \
-        k_count_pass<LPE, NS, SELF, SPLIT, PACK><<<grid, COUNT_THREADS, lds, st>>>(m, list, pbase, slab_p, n, K, epc, self_begin, addt, nblk, \
-                                                                                   (uint32_t)order_r, partial.p);                \
+        SQGR_REQUIRE(!mode || chunk_cap(columns_valid) == 0 || (int64_t)epc * (self ? 2 : 1) <= 65535, "internal: %u edges per block overflow a 16-bit counter", epc);
+        SQGR_REQUIRE(mode != 2 || half, "internal: unordered-pair counters on a full edge list");
+        LaunchTimer t(ctx, mode ? (half ? "nhood_count_pass16_half" : "nhood_count_pass16") : (half ? "nhood_count_pass_half" : "nhood_count_pass"));
+#define SQGR_PASS_K(LPE, NS, SELF, SPLIT, PACK, CM)                                                                                  \
+    do {                                                                                                                             \
+        SQGR_TRY(allow_lds((k_count_pass<LPE, NS, SELF, SPLIT, PACK, CM>), lds));                                                    \
+        k_count_pass<LPE, NS, SELF, SPLIT, PACK, CM><<<grid, COUNT_THREADS, lds, st>>>(m, list, pbase, slab_p, n, K, epc, self_begin, addt, nblk, \
+                                                                                       (uint32_t)order_r, partial.p, ncell);        \
     } while (0)
-#define SQGR_PASS(LPE, NS, SPLIT)                                                  \
-    do {                                                                           \
-        if (self) {                                                                \
-            if (pack) SQGR_PASS_K(LPE, NS, true, SPLIT, true); else SQGR_PASS_K(LPE, NS, true, SPLIT, false);   \
-        } else {                                                                   \
-            if (pack) SQGR_PASS_K(LPE, NS, false, SPLIT, true); else SQGR_PASS_K(LPE, NS, false, SPLIT, false); \
-        }                                                                          \
+#define SQGR_PASS_C(LPE, NS, SPLIT, CM)                                                    \
+    do {                                                                                   \
+        if (self) {                                                                        \
+            if (pack) SQGR_PASS_K(LPE, NS, true, SPLIT, true, CM); else SQGR_PASS_K(LPE, NS, true, SPLIT, false, CM);   \
+        } else {                                                                           \
+            if (pack) SQGR_PASS_K(LPE, NS, false, SPLIT, true, CM); else SQGR_PASS_K(LPE, NS, false, SPLIT, false, CM); \
+        }                                                                                  \
+    } while (0)
+#define SQGR_PASS(LPE, NS)                                  \
+    do {                                                    \
+        if (mode == 2) SQGR_PASS_C(LPE, NS, 1, 2);          \
+        else if (mode == 1) SQGR_PASS_C(LPE, NS, 1, 1);     \
+        else SQGR_PASS_C(LPE, NS, 1, 0);                    \
     } while (0)
         switch (e) {
-            case 8: SQGR_PASS(2, 4, 1); break;
-            case 4: SQGR_PASS(1, 4, 1); break;
-            case 2: SQGR_PASS(1, 2, 1); break;
+            case 8: SQGR_PASS(2, 4); break;
+            case 4: SQGR_PASS(1, 4); break;
+            case 2: SQGR_PASS(1, 2); break;
             default:
-                if (sp == 1) SQGR_PASS(1, 1, 1); else SQGR_PASS(1, 1, 2);
+                if (sp == 1) SQGR_PASS_C(1, 1, 1, 0); else SQGR_PASS_C(1, 1, 2, 0);
                 break;
         }
 #undef SQGR_PASS
+#undef SQGR_PASS_C
 #undef SQGR_PASS_K
     } else if (B == 32 || be() == 16) {
         // LDS-histogram kernels: on a structurally symmetric graph they walk the half list (see sqgr_graph::ensure_half)
@@ -1411,8 +1623,30 @@ int sqgr_nhood::count_batches(int nb, int buf) {
         const bool self = half && g->n_self > 0;
         sym_launch = self ? 2 : 0;  // the blocks' partials already hold h + h^T; half lists with self loops are in doubled units
         const uint32_t epb = (uint32_t)(ceil_div(ceil_div((int64_t)m, nblk), 1024) * 1024);  // whole iterations of a block
-        const size_t lds = (size_t)hw * 4;
+        const size_t lds = mode ? (size_t)ncell * 32 : (size_t)hw * 4;
         const dim3 grid(nblk, nb);
+        if (mode) {  // 51 <= K <= 100 (71 on directed graphs): 16-bit counters, all 16 permutations in one pass
+            SQGR_REQUIRE(chunk_cap(columns_valid) == 0 || (int64_t)epb * (self ? 2 : 1) <= 65535, "internal: %u edges per block overflow a 16-bit counter", epb);
+            SQGR_REQUIRE(mode != 2 || half, "internal: unordered-pair counters on a full edge list");
+            const int pw16 = ncell * 8;  // 32-bit words of a block's partial = its LDS image
+            LaunchTimer t(ctx, half ? "nhood_count_c16_half" : "nhood_count_c16");
+#define SQGR_COUNT16(MW, SELF, CM)                                                                                             \
+    do {                                                                                                                       \
+        SQGR_TRY(allow_lds((k_count<16, MW, SELF, true, 0, CM>), lds));                                                        \
+        k_count<16, MW, SELF, true, 0, CM><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, pw16, epb, self_begin, 0, partial.p); \
+    } while (0)
+#define SQGR_COUNT16_S(MW, CM) \
+    do { if (self) SQGR_COUNT16(MW, true, CM); else SQGR_COUNT16(MW, false, CM); } while (0)
+            if (lds * 2 <= LDS_BUDGET) {
+                if (mode == 2) SQGR_COUNT16_S(8, 2); else SQGR_COUNT16_S(8, 1);
+            } else {
+                if (mode == 2) SQGR_COUNT16_S(4, 2); else SQGR_COUNT16_S(4, 1);
+            }
+#undef SQGR_COUNT16_S
+#undef SQGR_COUNT16
+            SQGR_HIP(hipGetLastError());
+            return SQGR_OK;
+        }
 #define SQGR_COUNT(BB, MW, SELF) \
     k_count<BB, MW, SELF><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, hw, epb, self_begin, half ? 1 : 0, partial.p)
 #define SQGR_COUNT_D(BB, MW, SELF) \
@@ -1474,6 +1708,26 @@ int sqgr_nhood::count_batches(int nb, int buf) {
 int sqgr_nhood::reduce_batches(int nb, int64_t perm_batch0, int64_t perm_begin, int64_t perm_end, uint32_t* perms_out_dev) {
     const int hw = hist_words();
     LaunchTimer t(ctx, "nhood_reduce");
+    if (const int mode = cm()) {  // 16-bit partials: [planes][cell][pw] -> one accumulator slot per ordered pair and batch
+        const int ncell = cells(), pw = partial_w();
+        const dim3 grid((unsigned)ceil_div(ncell, 256), nb);
+        const int dbl = (sym_launch & 2) ? 1 : 0;
+#define SQGR_RED16(TRI, PW)                                                                                                                    \
+    k_reduce16<TRI, PW><<<grid, 256, 0, ctx->stream>>>(partial.p, nblk_launch, ncell, K, dbl, shift.p, perm_batch0, perm_begin, perm_end, acc_sum.p, \
+                                                       acc_sq.p, perms_out_dev)
+#define SQGR_RED16_W(TRI)                                \
+    switch (pw) {                                        \
+        case 16: SQGR_RED16(TRI, 16); break;             \
+        case 8: SQGR_RED16(TRI, 8); break;               \
+        case 4: SQGR_RED16(TRI, 4); break;               \
+        default: SQGR_RED16(TRI, 2); break;              \
+    }
+        if (mode == 2) { SQGR_RED16_W(true) } else { SQGR_RED16_W(false) }
+#undef SQGR_RED16_W
+#undef SQGR_RED16
+        SQGR_HIP(hipGetLastError());
+        return SQGR_OK;
+    }
     int nsum = nblk_launch;
     if ((sym_launch & 4) && nblk_launch > 1) {  // the transposed reads are scattered: do them once per slot, not once per chunk
         k_sum_chunks<<<dim3((unsigned)ceil_div(hw, 256), nb), 256, 0, ctx->stream>>>(partial.p, nblk_launch, hw);
@@ -1628,6 +1882,13 @@ static int nhood_build(sqgr_ctx* ctx, const sqgr_graph* g, int64_t n, const int3
             if (labels) hist[(size_t)l * K + labels[i]]++;
         }
         if (rc != SQGR_OK) break;
+        if (labels) {
+            for (int k = 0; k < K; ++k) {
+                int64_t tot = 0;
+                for (int l = 0; l < p->n_libs; ++l) tot += hist[(size_t)l * K + k];
+                p->max_label_count = (int)std::max<int64_t>(p->max_label_count, tot);
+            }
+        }
         std::vector<uint32_t> cum((size_t)p->n_libs * p->kpad, 0xFFFFFFFFu);
         std::vector<LibDom> doms((size_t)p->n_libs);
         size_t blk_total = 0;
@@ -1832,7 +2093,7 @@ int sqgr_nhood_run(sqgr_nhood* plan, uint64_t seed, int64_t perm_begin, int64_t 
     // that a rank that fails here never leaves its peers waiting inside the all-reduce
     auto local = [&]() -> int {
     SQGR_TRY(p->ensure_workspace(out_perms != nullptr));
-    const int B = p->B, hw = p->hist_words();
+    const int B = p->B, hw = p->acc_words();
     const int64_t per_launch = (int64_t)p->nbatch * B;
     if (shift)
         SQGR_HIP(hipMemcpyAsync(p->shift.p, shift, (size_t)K2 * 8, hipMemcpyHostToDevice, st));
@@ -1866,14 +2127,17 @@ int sqgr_nhood_run(sqgr_nhood* plan, uint64_t seed, int64_t perm_begin, int64_t 
         SQGR_TRY(launch_shuffle(p, nb, buf, sa));
         SQGR_HIP(hipEventRecord(p->ev_shuffled[buf], sa));
         SQGR_HIP(hipStreamWaitEvent(st, p->ev_shuffled[buf], 0));
-        SQGR_TRY(p->count_batches(nb, buf));
+        p->columns_valid = p->has_labels;  // every column of every row is a shuffle of the base labels (see chunk_cap)
+        const int rc_count = p->count_batches(nb, buf);
+        p->columns_valid = false;
+        SQGR_TRY(rc_count);
         SQGR_TRY(p->reduce_batches(nb, p0, perm_begin, perm_end, out_perms ? p->perms_dev.p : nullptr));
         SQGR_HIP(hipEventRecord(p->ev_counted[buf], st));
     }
     {
         LaunchTimer t(ctx, "nhood_finalize");
         SQGR_HIP(hipMemsetAsync(p->fin.p, 0, (size_t)2 * K2 * 8, st));
-        k_finalize<<<(unsigned)ceil_div(hw, 256), 256, 0, st>>>(p->acc_sum.p, p->acc_sq.p, p->nbatch, hw, p->partial_w(), K2, p->fin.p,
+        k_finalize<<<(unsigned)ceil_div(hw, 256), 256, 0, st>>>(p->acc_sum.p, p->acc_sq.p, p->nbatch, hw, p->acc_pw(), K2, p->fin.p,
                                                                reinterpret_cast<uint64_t*>(p->fin.p + K2));
         SQGR_HIP(hipGetLastError());
     }
@@ -1933,7 +2197,7 @@ int sqgr_nhood_counts_batch(sqgr_ctx* ctx, const sqgr_graph* g, const uint8_t* l
     int rc = SQGR_OK;
     do {
         if ((rc = p->ensure_workspace(true)) != SQGR_OK) break;
-        const int B = p->B, K2 = p->K2, hw = p->hist_words();
+        const int B = p->B, K2 = p->K2, hw = p->acc_words();
         const int64_t per_launch = (int64_t)p->nbatch * B;
         hipStream_t st = ctx->stream;
         if ((rc = p->stage.ensure((size_t)per_launch * n)) != SQGR_OK) break;
@@ -1983,7 +2247,7 @@ static int run_pcg64_impl(sqgr_nhood* plan, const uint64_t* pcg_states, int64_t 
     const int K2 = p->K2;
     auto local = [&]() -> int {  // this rank's own part; its outcome is agreed on in front of the collective (see sqgr_nhood_run)
     SQGR_TRY(p->ensure_workspace(keep_perms));
-    const int B = p->B, hw = p->hist_words();
+    const int B = p->B, hw = p->acc_words();
     const int64_t n = p->n;
     if (shift)
         SQGR_HIP(hipMemcpyAsync(p->shift.p, shift, (size_t)K2 * 8, hipMemcpyHostToDevice, st));
@@ -2076,7 +2340,7 @@ static int run_pcg64_impl(sqgr_nhood* plan, const uint64_t* pcg_states, int64_t 
     {
         LaunchTimer t(ctx, "nhood_finalize");
         SQGR_HIP(hipMemsetAsync(p->fin.p, 0, (size_t)2 * K2 * 8, st));
-        k_finalize<<<(unsigned)ceil_div(hw, 256), 256, 0, st>>>(p->acc_sum.p, p->acc_sq.p, p->nbatch, hw, p->partial_w(), K2, p->fin.p,
+        k_finalize<<<(unsigned)ceil_div(hw, 256), 256, 0, st>>>(p->acc_sum.p, p->acc_sq.p, p->nbatch, hw, p->acc_pw(), K2, p->fin.p,
                                                                reinterpret_cast<uint64_t*>(p->fin.p + K2));
         SQGR_HIP(hipGetLastError());
     }
@@ -2176,12 +2440,16 @@ int sqgr_nhood_info(sqgr_nhood* plan, int64_t* out_info) {
     const bool half = lds_path && p->g->sym_state == 1;
     out_info[0] = p->B;
     out_info[1] = p->nbatch;
-    out_info[2] = p->partial_blocks(p->nbatch);
+    out_info[2] = lds_path ? p->blocks_for(p->nbatch, p->has_labels) : 1;  // (what sqgr_nhood_run launches; the other entry points may cut finer)
     out_info[3] = p->g ? (half ? p->g->n_half + p->g->n_self : p->g->nnz) : 0;
     out_info[4] = half ? (p->g->n_self > 0 ? 2 : 1) : 0;
     out_info[5] = p->hist_words();
     out_info[6] = half ? p->g->n_self : 0;
     out_info[7] = FEISTEL_GROUP;
+    out_info[8] = lds_path ? (p->B == 32 ? 32 : p->be()) : 0;   // permutations per pass over the edge list (0: device-scope counters)
+    out_info[9] = p->split();
+    out_info[10] = p->cm();
+    out_info[11] = (int64_t)p->part_words() * 4;                // bytes of one chunk's partial histograms (all passes)
     return SQGR_OK;
 }
 

@@ -59,7 +59,7 @@ def measure(K, tune=None, reps=2):
     ks = {k: [v[0], round(v[1], 3)] for k, v in rep.items() if k.startswith("nhood") and v[0] > 0}
     cnt_ms = sum(v[1] for k, v in ks.items() if k.startswith("nhood_count"))
     rec = {"K": K, "tune": tune, "perms": P, "perms_per_s": round(P / dt), "count_us_per_perm": round(cnt_ms * 1e3 / P, 4),
-           "blocks_per_batch": info["blocks_per_batch"], "batches_per_launch": info["batches_per_launch"], "list_edges": info["list_edges"], "kernels": ks}
+           "perms_per_pass": info["perms_per_pass"], "counter_mode": info["counter_mode"], "blocks_per_batch": info["blocks_per_batch"], "batches_per_launch": info["batches_per_launch"], "list_edges": info["list_edges"], "kernels": ks}
     print(json.dumps(rec), flush=True)
     plan.close() if hasattr(plan, "close") else None
     return rec
