@@ -186,6 +186,13 @@ def label_permutations(n: int, seed: int, perms: np.ndarray, lib: int = 0, x: np
     return grouped_permutation_batch(n, group_keys(seed, perms // FEISTEL_GROUP, lib), sigma_keys(seed, perms, lib), x)
 
 
+def independent_label_permutations(n: int, seed: int, perms: np.ndarray, lib: int = 0) -> np.ndarray:
+    """(len(perms), n) label-shuffle permutations of the INDEPENDENT variant of the device generator (SQGR_SHUFFLE_INDEPENDENT=1,
+    sqgr_nhood.hip: k_shuffle_indep): every permutation its own 8-round bijection keyed by ``round_keys(seed, perm, lib)`` — no
+    group bijection shared by 16 permutations, no sigma network."""
+    return permutation_batch(n, round_keys(seed, np.asarray(perms, dtype=np.int64), lib))
+
+
 def permutation(n: int, rk: np.ndarray) -> np.ndarray:
     """pi with pi[i] = image of i under the cycle-walked bijection of [0, n); int64 (n,)."""
     return permutation_batch(n, np.asarray(rk)[None, :])[0]

@@ -40,7 +40,11 @@ constexpr size_t LDS_BUDGET = 160 * 1024;
 // instruction of the label shuffle):
 //   group keys : [g][lib][8]   g < B/16: the 8 round keys of group perm_row/16 + g in both halves
 //   sigma keys : [t][lib][2]   t < B/2 : the 2 round keys of permutations perm_row + 2t (low half) and + 2t + 1 (high half)
-__host__ __device__ constexpr int key_words_per_row(int B, int n_libs) { return n_libs * ((B / FEISTEL_GROUP) * 8 + (B / 2) * 2); }
+// (a row of 16 never takes fewer than 64 words: the independent-bijection variant of the generator, k_shuffle_indep, keeps the 8
+// round keys of each of its 8 permutation pairs there)
+__host__ __device__ constexpr int key_words_per_row(int B, int n_libs) {
+    return n_libs * ((B / FEISTEL_GROUP) * 8 + (B / 2) * 2) < (B / 2) * 8 ? (B / 2) * 8 : n_libs * ((B / FEISTEL_GROUP) * 8 + (B / 2) * 2);
+}
 
 __global__ void k_keygen(uint64_t seed, int64_t perm0, int nrows, int B, int n_libs, uint32_t* __restrict__ keys) {
     const int items = B / FEISTEL_GROUP + B / 2;  // per (row, library)
@@ -65,6 +69,22 @@ __global__ void k_keygen(uint64_t seed, int64_t perm0, int nrows, int B, int n_l
         o[0] = (ra[0] & 0xFFFFu) | (rb[0] << 16);
         o[1] = (ra[1] & 0xFFFFu) | (rb[1] << 16);
     }
+}
+
+// keys of the INDEPENDENT variant (SQGR_SHUFFLE_INDEPENDENT=1, bench.py's `nhood_independent_bijections` leg): every permutation
+// its own 8-round bijection, keyed like a row permutation of spatial_autocorr (round_keys: Philox counter words j = 0, 1) —
+// [pair t < 8][round r < 8] per row of 16, permutation perm_row + 2t in the low half, + 2t + 1 in the high half
+__global__ void k_keygen_indep(uint64_t seed, int64_t perm0, int nrows, uint32_t* __restrict__ keys) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= (int64_t)nrows * 8) return;
+    const int64_t row = t / 8;
+    const int pair = (int)(t % 8);
+    uint32_t ra[8], rb[8];
+    round_keys(seed, (uint64_t)(perm0 + row * 16 + 2 * pair), 0u, ra);
+    round_keys(seed, (uint64_t)(perm0 + row * 16 + 2 * pair + 1), 0u, rb);
+    uint32_t* out = keys + row * key_words_per_row(16, 1) + pair * 8;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) out[r] = (ra[r] & 0xFFFFu) | (rb[r] << 16);
 }
 
 // ---------------------------------------------------------------------------------------------- label shuffle
@@ -264,6 +284,89 @@ __global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __re
         slab_store16(slab_all + (size_t)row0 * n * 16, n, i, pw, outA[0], outA[1], outA[2], outA[3]);
         if (store1) slab_store16(slab_all + (size_t)row1 * n * 16, n, i, pw, outB[0], outB[1], outB[2], outB[3]);
     }
+    }
+}
+
+// The generator WITHOUT its shortcut (what do 16 independent bijections cost?): slab label b of row `row` =
+// label_at_rank(pi_p(rank_i)) with pi_p the full 8-round bijection of permutation p = perm_row + b itself — no group bijection
+// shared by 16 permutations, no 2-round sigma network.  Two permutations per packed evaluation, 8 evaluations of 8 rounds per spot
+// and row (the two-level kernel: half an evaluation of 8 rounds + 8 of 2).  Same label look-up (block table, sentinel, exact
+// route), same slab layout; no libraries.  Restated in oracle/devrng.py (independent_label_permutations).
+template <bool SMALLK>
+__global__ __launch_bounds__(256) void k_shuffle_indep(int64_t n, const uint32_t* __restrict__ cum, int kpad, int blk_words, int K,
+                                                       const uint32_t* __restrict__ keys, LibDom dom0, uint8_t* __restrict__ slab_all, int pw) {
+    extern __shared__ uint32_t s_lds[];
+    uint32_t* s_cum = s_lds + blk_words;
+    for (int t = threadIdx.x; t < kpad; t += 256) s_cum[t] = cum[t];
+    for (int t = threadIdx.x; t < blk_words; t += 256) s_lds[t] = cum[kpad + t];
+    __syncthreads();
+    const int row = blockIdx.y;
+    const uint32_t* krow = keys + (size_t)row * key_words_per_row(16, 1);
+    const uint32_t zero = 0;
+    const uint32_t sent_add = (uint32_t)(128 - K) * 0x01010101u;
+    const FeistelDomain dom = dom0.dom;
+    const uint32_t* tab = s_cum + 1;
+    typedef __attribute__((address_space(3))) const uint32_t lds_word;
+    auto blk_at = [&](uint32_t byte_off) { return *reinterpret_cast<lds_word*>((uintptr_t)byte_off); };
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t x0 = (uint32_t)i;
+        const uint32_t a0 = x0 / dom.B, b0 = x0 - a0 * dom.B;
+        uint32_t out[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            uint32_t word = 0, apk[2], bpk[2];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const uint32_t* const pk[1] = {krow + (w * 2 + jj) * 8};
+                u16x2 ga = (u16x2)((unsigned short)a0), gb = (u16x2)((unsigned short)b0);
+                bool need0 = true, need1 = true;
+                do {  // the bijection, cycle-walked per half
+                    u16x2 na[1] = {ga}, nb[1] = {gb};
+                    feistel_rounds<1>(na, nb, dom, pk);
+                    if (need0) { ga.x = na[0].x; gb.x = nb[0].x; }
+                    if (need1) { ga.y = na[0].y; gb.y = nb[0].y; }
+                    need0 = __umul24((uint32_t)ga.x, dom.B) + (uint32_t)gb.x >= dom.n;
+                    need1 = __umul24((uint32_t)ga.y, dom.B) + (uint32_t)gb.y >= dom.n;
+                } while (need0 | need1);
+                apk[jj] = __builtin_bit_cast(uint32_t, ga);
+                bpk[jj] = __builtin_bit_cast(uint32_t, gb);
+                const uint32_t a4 = apk[jj] << 2;
+                const uint32_t e0 = blk_at(a4 & 0xFFFFu);
+                const uint32_t e1 = blk_at(a4 >> 16);
+                if (jj == 0) {
+                    put_label<0, 0>(word, e0, bpk[jj], zero);
+                    put_label<1, 1>(word, e1, bpk[jj], zero);
+                } else {
+                    put_label<2, 0>(word, e0, bpk[jj], zero);
+                    put_label<3, 1>(word, e1, bpk[jj], zero);
+                }
+            }
+            bool sentinel;
+            if constexpr (SMALLK) {
+                sentinel = ((word + sent_add) & 0x80808080u) != 0;
+            } else {
+                const uint32_t k = (uint32_t)K;
+                sentinel = k > 255u || (word & 0xFFu) >= k || ((word >> 8) & 0xFFu) >= k || ((word >> 16) & 0xFFu) >= k || (word >> 24) >= k;
+            }
+            if (sentinel) {  // a block the two-field table form cannot describe: rank against the boundaries (the image is < n already)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (K <= 255 && ((word >> (8 * j)) & 0xFFu) < (uint32_t)K) continue;
+                    const int jj = j >> 1, sh = (j & 1) * 16;
+                    const uint32_t a = (apk[jj] >> sh) & 0xFFFFu, b = (bpk[jj] >> sh) & 0xFFFFu;
+                    const uint32_t x = a * dom.B + b;
+                    const uint32_t e = blk_at(a * 4u);
+                    uint32_t l = (e & 0xFFFFu) + (b >= (e >> 16) ? 1u : 0u);
+                    if (l >= (uint32_t)K) {
+                        l = 0;
+                        while (x >= tab[l]) ++l;
+                    }
+                    word = (word & ~(0xFFu << (8 * j))) | (l << (8 * j));
+                }
+            }
+            out[w] = word;
+        }
+        slab_store16(slab_all + (size_t)row * n * 16, n, i, pw, out[0], out[1], out[2], out[3]);
     }
 }
 
@@ -1367,6 +1470,7 @@ struct sqgr_nhood {
     DevBuf<uint64_t> pcg_states;
     PcgWorkspace pcg_ws;        // jump-ahead table and row workspace of the numpy-compatible shuffle (sqgr_pcg.hip)
     bool has_labels = false;
+    bool independent = false;   // sqgr_nhood_run under SQGR_SHUFFLE_INDEPENDENT=1: one 8-round bijection per permutation
     // tuning
     int B = 16;
     int nblk = 0;
@@ -2057,6 +2161,16 @@ static int launch_shuffle_raw(sqgr_nhood* p, int B, int nb, const uint32_t* keys
         SQGR_HIP(hipGetLastError());
         return SQGR_OK;
     }
+    if (p->independent) {  // every permutation its own 8-round bijection (bench.py's `nhood_independent_bijections`; keys: k_keygen_indep)
+        if (B != 16 || p->has_libs) {
+            set_error("SQGR_SHUFFLE_INDEPENDENT: 16 permutations per row and no libraries only");
+            return SQGR_ERR_UNSUPPORTED;
+        }
+        if (p->K <= 126) k_shuffle_indep<true><<<dim3(gx, nb), 256, lds, st>>>(p->n, p->cum.p, p->kpad, p->blk_bytes, p->K, keys, p->dom0, slab, pw);
+        else k_shuffle_indep<false><<<dim3(gx, nb), 256, lds, st>>>(p->n, p->cum.p, p->kpad, p->blk_bytes, p->K, keys, p->dom0, slab, pw);
+        SQGR_HIP(hipGetLastError());
+        return SQGR_OK;
+    }
     const unsigned gy = (unsigned)(B == 32 ? nb : (nb + 1) / 2);  // 16-permutation rows are shuffled in pairs
 #define SQGR_SHUFFLE(BB, LIBS, SK)                                                                                               \
     k_shuffle<BB, LIBS, SK><<<dim3(gx, gy), 256, lds, st>>>(p->n, p->cum.p, p->kpad, p->blk_bytes, p->K, keys, p->dom0, p->n_libs, nb, \
@@ -2091,6 +2205,11 @@ int sqgr_nhood_run(sqgr_nhood* plan, uint64_t seed, int64_t perm_begin, int64_t 
     const int64_t nperm = perm_end - perm_begin;
     // this rank's own part (everything in front of the collective); with a communicator its outcome is agreed on first, so
     // that a rank that fails here never leaves its peers waiting inside the all-reduce
+    {   // SQGR_SHUFFLE_INDEPENDENT=1: the generator without its shared group bijection (read at every call; see k_shuffle_indep)
+        const char* e = getenv("SQGR_SHUFFLE_INDEPENDENT");
+        p->independent = e && atoi(e) == 1;
+        SQGR_REQUIRE(!p->independent || (p->B == 16 && !p->has_libs && !p->wide()), "SQGR_SHUFFLE_INDEPENDENT needs 16-wide rows, K <= 256 and no libraries");
+    }
     auto local = [&]() -> int {
     SQGR_TRY(p->ensure_workspace(out_perms != nullptr));
     const int B = p->B, hw = p->acc_words();
@@ -2121,7 +2240,10 @@ int sqgr_nhood_run(sqgr_nhood* plan, uint64_t seed, int64_t perm_begin, int64_t 
         {
             LaunchTimer t(ctx, "nhood_keygen", sa);
             const int64_t nk = (int64_t)nb * p->n_libs * (B / FEISTEL_GROUP + B / 2);
-            k_keygen<<<(unsigned)ceil_div(nk, 256), 256, 0, sa>>>(seed, p0, nb, B, p->n_libs, p->keys.p + (size_t)buf * p->keys_stride());
+            if (p->independent)
+                k_keygen_indep<<<(unsigned)ceil_div((int64_t)nb * 8, 256), 256, 0, sa>>>(seed, p0, nb, p->keys.p + (size_t)buf * p->keys_stride());
+            else
+                k_keygen<<<(unsigned)ceil_div(nk, 256), 256, 0, sa>>>(seed, p0, nb, B, p->n_libs, p->keys.p + (size_t)buf * p->keys_stride());
             SQGR_HIP(hipGetLastError());
         }
         SQGR_TRY(launch_shuffle(p, nb, buf, sa));
@@ -2170,8 +2292,16 @@ int sqgr_nhood_shuffled_labels(sqgr_nhood* plan, uint64_t seed, int64_t perm, ui
     hipStream_t st = ctx->stream;
     const int B = p->B;
     const int64_t perm_row = perm - perm % FEISTEL_GROUP;  // rows start at group boundaries of the global index
-    k_keygen<<<(unsigned)ceil_div((int64_t)p->n_libs * (B / FEISTEL_GROUP + B / 2), 256), 256, 0, st>>>(seed, perm_row, 1, B, p->n_libs,
-                                                                                                       p->keys.p);
+    {
+        const char* e = getenv("SQGR_SHUFFLE_INDEPENDENT");
+        p->independent = e && atoi(e) == 1;
+        SQGR_REQUIRE(!p->independent || (B == 16 && !p->has_libs && !p->wide()), "SQGR_SHUFFLE_INDEPENDENT needs 16-wide rows, K <= 256 and no libraries");
+    }
+    if (p->independent)
+        k_keygen_indep<<<1, 256, 0, st>>>(seed, perm_row, 1, p->keys.p);
+    else
+        k_keygen<<<(unsigned)ceil_div((int64_t)p->n_libs * (B / FEISTEL_GROUP + B / 2), 256), 256, 0, st>>>(seed, perm_row, 1, B, p->n_libs,
+                                                                                                           p->keys.p);
     SQGR_HIP(hipGetLastError());
     SQGR_TRY(launch_shuffle(p, 1, 0, st));
     std::vector<uint8_t> rows((size_t)p->n * B);

@@ -40,3 +40,25 @@ def test_strong_scaling_shards_config5s_range(tmp_path):
     one = _bench("--gpus", "1", "--scaling", "strong", "--total-perms", "1000", "--detail-out", str(tmp_path / "one.json"), *SMALL)
     assert two["n_gpus"] == 2 and two["config"]["perms_per_step_per_gpu"] == 500
     assert two["check"] == one["check"]
+
+
+def test_gpus_8_at_the_nodes_size_on_one_gpu(tmp_path):
+    """The driver's 8-GPU invocation, as far as one GPU can show it: `bench.py --gpus 8` starts EIGHT ranks of itself;
+    their all-reduced moments are one rank's over the same global permutation range."""
+    flags = ["--no-legs", "--no-secondary", "--no-cpu-baseline", "--no-numpy-leg", "--emulate-ranks", "0", "--rows", "120", "--cols", "150", "--steps", "2", "--warmup", "1"]
+    eight = _bench("--gpus", "8", "--share-devices", "--perms-per-step", "1024", "--detail-out", str(tmp_path / "eight.json"), *flags)
+    one = _bench("--gpus", "1", "--perms-per-step", "8192", "--detail-out", str(tmp_path / "one.json"), *flags)
+    assert eight["n_gpus"] == 8 and eight["config"]["ranks_on_devices"] == [0] * 8 and eight["config"]["perms_per_step_per_gpu"] == 1024
+    assert eight["check"]["perm_range"] == one["check"]["perm_range"] == [8192, 3 * 8192]
+    assert eight["check"]["moments_sha16"] == one["check"]["moments_sha16"]
+
+
+def test_strong_scaling_shards_config5_into_8_x_12500(tmp_path):
+    """BASELINE config 5 in full — 1e6 spots, 30 clusters, 100 000 permutations per step — cut into the 8 rank shards of a node."""
+    flags = ["--no-legs", "--no-secondary", "--no-cpu-baseline", "--no-numpy-leg", "--emulate-ranks", "0", "--steps", "2", "--warmup", "1", "--scaling", "strong",
+             "--total-perms", "100000"]
+    eight = _bench("--gpus", "8", "--share-devices", "--detail-out", str(tmp_path / "eight.json"), *flags)
+    one = _bench("--gpus", "1", "--detail-out", str(tmp_path / "one.json"), *flags)
+    assert eight["n_gpus"] == 8 and eight["scaling"] == "strong" and eight["config"]["perms_per_step_per_gpu"] == 12500
+    assert eight["config"]["perms_per_step"] == 100000 and "1000000 spots" in eight["config"]["workload"]
+    assert eight["check"] == one["check"] and eight["check"]["perm_range"] == [100000, 300000]

@@ -252,3 +252,17 @@ def test_permutation_test_moments_and_group_covariance_vs_numpy_streams():
     s, ss = z.sum(1), (z**2).sum(1)
     within = ((s**2 - ss) / (16 * 15)).mean(0)  # average correlation of two distinct permutations of a group, per cell
     assert np.abs(within).max() < 5.0 / math.sqrt(G * 120), np.abs(within).max()
+
+
+def test_independent_label_permutations_are_bijections_of_their_own():
+    """The restatement of the generator's independent variant (sqgr_nhood.hip: k_shuffle_indep): every row a permutation of [0, n),
+    keyed by the permutation index alone — rows of one 16-group share nothing, and differ from the two-level generator's."""
+    n = 1234
+    perms = np.arange(16, 48)
+    pi = D.independent_label_permutations(n, 5, perms)
+    assert pi.shape == (32, n)
+    for row in pi:
+        assert np.array_equal(np.sort(row), np.arange(n))
+    assert len({row.tobytes() for row in pi}) == 32
+    np.testing.assert_array_equal(pi[3], D.permutation(n, D.round_keys(5, np.array([19]))[0]))
+    assert not np.array_equal(pi, D.label_permutations(n, 5, perms))

@@ -178,6 +178,34 @@ def test_philox_library_shuffle_bit_exact_vs_oracle(L, ctx, golden):
             assert np.array_equal(np.sort(got[libs == c]), np.sort(labels[libs == c]))
 
 
+@pytest.mark.parametrize("k", [5, 30, 100, 200, 256])
+def test_independent_bijection_variant_bit_exact_vs_oracle(L, ctx, k, monkeypatch):
+    """SQGR_SHUFFLE_INDEPENDENT=1 (bench.py's `nhood_independent_bijections` leg: what the generator costs WITHOUT the group
+    bijection that 16 permutations share): every permutation its own 8-round bijection — the label vectors and the per-permutation
+    counts `==` oracle/devrng.py's restatement (independent_label_permutations), in every counter layout."""
+    monkeypatch.setenv("SQGR_SHUFFLE_INDEPENDENT", "1")
+    rng = np.random.default_rng(k)
+    adj = O.hex_grid_graph(61, 57)
+    n = adj.shape[0]
+    labels = rng.integers(0, k, n).astype(np.int32)
+    labels[:k] = np.arange(k)
+    g = L.Graph(ctx, adj, with_data=False)
+    plan = L.NhoodPlan(ctx, g, labels, k)
+    perms = np.arange(3, 3 + 40)
+    pi = devrng.independent_label_permutations(n, 9, perms)
+    srt = np.sort(labels)
+    for j in (0, 1, 12, 13, 29, 39):
+        np.testing.assert_array_equal(plan.shuffled_labels(9, int(perms[j])), srt[pi[j]], err_msg=f"permutation {perms[j]}")
+    _, _, got = plan.run(9, 3, 43, None, return_perms=True)
+    for j in range(40):
+        np.testing.assert_array_equal(got[j], O.nhood_counts(adj.indices, adj.indptr, srt[pi[j]], k), err_msg=f"permutation {perms[j]}")
+    monkeypatch.delenv("SQGR_SHUFFLE_INDEPENDENT")
+    two_level = plan.shuffled_labels(9, 3)   # the default generator is another arrangement of the same multiset
+    assert not np.array_equal(two_level, srt[pi[0]]) and np.array_equal(np.sort(two_level), srt)
+    plan.close()
+    g.close()
+
+
 @pytest.mark.parametrize("k", [2, 30, 46, 60, 100, 150, 210, 256])
 def test_all_cluster_count_regimes(L, ctx, k):
     """K decides which count kernel runs (LDS B=16, narrower LDS passes, device atomics): all bit-exact."""
@@ -195,9 +223,15 @@ def test_all_cluster_count_regimes(L, ctx, k):
 
 @pytest.mark.parametrize("graph", ["hex", "hex+self", "knn", "gaps"])
 @pytest.mark.parametrize("k,width,blocks", [(60, 0, 0), (60, 4, 0), (71, 8, 5), (72, 0, 0), (100, 0, 0), (101, 2, 0), (102, 0, 0), (130, 1, 0), (30, 8, 0), (30, 4, 16),
-                                             (30, 2, 0), (7, 1, 3), (202, 0, 0), (203, 0, 0), (231, 0, 5), (256, 0, 0)])
+                                             (30, 2, 0), (7, 1, 3), (202, 0, 0), (203, 0, 0), (231, 0, 5), (256, 0, 0),
+                                             # round 6: the 16-bit counter layouts at every width they run at (16 | 8 | 4 | 2) and at the
+                                             # cluster counts where a width ends (symmetric: 100 | 142 | 201; directed: 71 | 101 | 143 | 202)
+                                             (60, 8, 0), (60, 2, 3), (100, 8, 0), (100, 4, 3), (142, 0, 0), (143, 0, 0), (150, 2, 0), (201, 0, 0), (64, 1, 0)])
 def test_lds_pass_kernel_every_width_on_half_and_full_lists(L, ctx, graph, k, width, blocks):
-    """51 <= K <= 202 clusters count in PASSES of 8 | 4 | 2 | 1 of the slab's 16 permutations (k_count_pass: the machinery of the
+    """Above 50 clusters the counters of a block are 16 bits wide, two permutations per LDS word, on the unordered label pairs of a
+    symmetric graph's half list (16 permutations per pass up to K = 100, 8 to 142, 4 to 201, 2 to 256) or on all K*K pairs of a
+    directed graph's full list (16 to 71, 8 to 101, 4 to 143, 2 to 202); one permutation per pass (a cap of 1; directed graphs above
+    202 clusters) and every forced width at K <= 50 keep the 32-bit counters of rounds 1-5 (k_count_pass: the machinery of the
     K <= 50 kernel at 2 | 1 lanes per edge).  Every width — the one K selects (width 0) and narrower ones forced through
     `tune` — on the symmetric half list without and with self loops (weights 2 and 1, halved sums) and on a directed kNN
     graph (full list); chunks cut so that whole-iteration blocks, a ragged last chunk and empty chunks all occur; chunk counts
@@ -225,6 +259,16 @@ def test_lds_pass_kernel_every_width_on_half_and_full_lists(L, ctx, graph, k, wi
         plan.tune(width, blocks, 3)
     info = plan.info()
     assert info["symmetric"] == (graph in ("hex", "hex+self"))
+    sym = info["symmetric"]
+    if k > 50 and width != 1:  # which layout and pass width K selects (csrc/sqgr_nhood.hip: sqgr_nhood::cm / be)
+        lim = (100, 142, 201, 285) if sym else (71, 101, 143, 202)
+        want = next((w for w, top in zip((16, 8, 4, 2), lim) if k <= top and (not width or w <= width)), None)
+        if want is None:
+            assert info["counter_mode"] == 0
+        else:
+            assert (info["counter_mode"], info["perms_per_pass"]) == (2 if sym else 1, want), info
+    else:
+        assert info["counter_mode"] == 0
     n_perms = 50  # 3 batches of 16 per launch group -> two launch groups, the last batch partly filled
     _, _, perms = plan.run(11, 5, 5 + n_perms, None, return_perms=True)
     ref = O.nhood_perm_counts_philox(adj.indices, adj.indptr, labels, k, 11, 5, 5 + n_perms)
