@@ -684,6 +684,43 @@ def config4_legs(ctx, ceil: dict, with_cpu: bool, counters: dict) -> dict:
         "metric": "co_occurrence ordered pair evaluations/sec (1e6 points x 30 clusters x 49 thresholds)",
         "value": pairs / wall, "unit": "pairs/s", "wall_s": wall, "kernel_ms": kms, "roofline": roof,
     }
+    # ---- the same cloud with the intervals users pass: 50 edges up to 20 spot spacings — tile pairs beyond the last
+    # threshold are skipped (k_co_candidates), the dense sweep of the same thresholds (SQGR_COOCCUR_SPARSE=0) is timed beside it
+    short = np.linspace(0.0, 2000.0, num=50, dtype=np.float32)  # (the synthetic hex grid's spot spacing is 100)
+    thr2s = short[1:] ** 2
+    _lib.cooccur_counts(ctx, sp[:8192, 0], sp[:8192, 1], labels[:8192], N_CLS, thr2s)
+    res = {}
+    saved = os.environ.get("SQGR_COOCCUR_SPARSE")
+    try:
+        for route, env in (("near", None), ("dense", "0")):
+            if env is None:
+                os.environ.pop("SQGR_COOCCUR_SPARSE", None)
+            else:
+                os.environ["SQGR_COOCCUR_SPARSE"] = env
+            ctx.sync()
+            ctx.timer_enable(True)
+            ctx.timer_reset()
+            t0 = time.perf_counter()
+            c = _lib.cooccur_counts(ctx, sp[:, 0], sp[:, 1], labels, N_CLS, thr2s)
+            w = time.perf_counter() - t0
+            kk = ctx.timer_report()
+            ctx.timer_enable(False)
+            res[route] = {"wall_s": w, "kernel_ms": {name: round(v[1], 3) for name, v in kk.items() if name.startswith("cooccur") and v[0] > 0}, "counts": c}
+    finally:
+        if saved is None:
+            os.environ.pop("SQGR_COOCCUR_SPARSE", None)
+        else:
+            os.environ["SQGR_COOCCUR_SPARSE"] = saved
+    same = bool(np.array_equal(res["near"]["counts"], res["dense"]["counts"]))
+    near_ms, dense_ms = sum(res["near"]["kernel_ms"].values()), sum(res["dense"]["kernel_ms"].values())
+    out["co_occurrence_short_radii"] = {
+        "metric": "co_occurrence wall seconds, 1e6 points x 30 clusters, interval = linspace(0, 20 spot spacings, 50)", "unit": "s", "value": res["near"]["wall_s"],
+        "kernel_ms": near_ms, "kernels_ms": res["near"]["kernel_ms"], "dense_wall_s": res["dense"]["wall_s"], "dense_kernel_ms": dense_ms,
+        "kernel_speedup_vs_dense": dense_ms / near_ms if near_ms > 0 else None, "wall_speedup_vs_dense": res["dense"]["wall_s"] / res["near"]["wall_s"],
+        "counts_equal_dense": same, "pairs_counted": int(res["near"]["counts"][:, :, -1].sum()),
+        "note": "the wall time includes the host's counting sort (by cluster and Hilbert cell), the upload and the copy-out; `kernel_ms` = candidate lists + sweep",
+    }
+    assert same, "short-radius co_occurrence differs from the dense sweep"
     # ---- Ripley L (gr/_ripley.py:212-227): float64 pair counts per cluster, 50 radii
     from scipy.spatial import ConvexHull
 
@@ -1039,6 +1076,11 @@ def compact_line(detail: dict, detail_path: str | None = None) -> dict:
     if "geary_c" not in legs and detail.get("geary_c"):
         legs["geary_c"] = detail["geary_c"]
     out_legs = {}
+    cs = legs.get("co_occurrence_short_radii")
+    if cs:
+        out_legs["co_occurrence_short_radii"] = {"value": _sig(cs.get("value"), 4), "unit": "s", "kernel_ms": _sig(cs.get("kernel_ms"), 4),
+                                                 "kernel_speedup_vs_dense": _sig(cs.get("kernel_speedup_vs_dense"), 4),
+                                                 "wall_speedup_vs_dense": _sig(cs.get("wall_speedup_vs_dense"), 4), "counts_equal_dense": cs.get("counts_equal_dense")}
     for name in ("co_occurrence", "ripley_L", "ripley_G", "geary_general", "moran_p100", "geary_c"):
         rec = _leg(legs.get(name), extra=("kernel_ms", "speedup_vs_gather_kernel", "wall_ms_per_step", "kernel_sum_ms_per_step", "wall_over_kernels"))
         if rec and (legs.get(name) or {}).get("FAILED"):

@@ -137,3 +137,48 @@ def test_interval_batches_reproduce_the_full_counts(L, ctx):
     for cuts in ((0, 8, 23), (0, 1, 2, 11, 22, 23)):
         parts = [L.cooccur_counts(ctx, xy[:, 0], xy[:, 1], lab, k, thr[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
         np.testing.assert_array_equal(np.concatenate(parts, axis=2), full)
+
+
+@pytest.mark.parametrize("fma", [False, True])
+@pytest.mark.parametrize("n,k,l,rmax,near", [(30000, 4, 12, 40.0, True), (200000, 30, 49, 25.0, True), (40000, 3, 150, 60.0, True), (300000, 200, 9, 10.0, True),
+                                              (20000, 30, 49, 25.0, False)])
+def test_short_radii_skip_tile_pairs_and_change_no_count(L, ctx, n, k, l, rmax, near, fma, monkeypatch):
+    """Explicit short radii (what users pass: a few spot diameters): clusters are tiled along a Hilbert curve and tile pairs whose
+    bounding boxes lie beyond the largest threshold are skipped (csrc/sqgr_cooccur.hip: k_co_candidates) — exact.  The route the
+    library picks by itself `==` the dense sweep (SQGR_COOCCUR_SPARSE=0) `==` the oracle; lattice coordinates put many pairs
+    exactly on a threshold and exactly on a box edge.  `near` = False: so few points per cluster that a tile spans the cloud and
+    most tile pairs stay — the library keeps the dense sweep.  /root/reference/src/squidpy/gr/_ppatterns.py:283-310, 407-413."""
+    rng = np.random.default_rng(n + k)
+    x = (rng.integers(0, 2000, n) * 0.5).astype(np.float32)   # half-integer lattice: exact ties with thresholds
+    y = (rng.integers(0, 1400, n) * 0.5).astype(np.float32)
+    labs = rng.integers(0, k, n).astype(np.int32)
+    thr = np.linspace(0.5, rmax, l, dtype=np.float32) ** 2
+    ctx.timer_enable(True)
+    ctx.timer_reset()
+    got = L.cooccur_counts(ctx, x, y, labs, k, thr, fma=fma)
+    kern = ctx.timer_report()
+    ctx.timer_enable(False)
+    assert any(name.startswith("cooccur_pairs_near") and v[0] > 0 for name, v in kern.items()) == near, kern   # which route ran
+    monkeypatch.setenv("SQGR_COOCCUR_SPARSE", "0")
+    dense = L.cooccur_counts(ctx, x, y, labs, k, thr, fma=fma)
+    np.testing.assert_array_equal(got, dense)
+    if n <= 30000:
+        np.testing.assert_array_equal(got, O.occur_count(x, y, thr, labs, k))   # (half-integer coordinates: every product is exact, fused or not)
+    monkeypatch.delenv("SQGR_COOCCUR_SPARSE")
+    parts = sum(L.cooccur_counts(ctx, x, y, labs, k, thr, fma=fma, shard_index=s, shard_count=3) for s in range(3))
+    np.testing.assert_array_equal(parts, got)
+
+
+def test_short_radii_forced_on_a_long_interval_and_degenerate_clouds(L, ctx, monkeypatch):
+    """SQGR_COOCCUR_SPARSE=1 forces the candidate lists whatever the radius (every tile pair stays: the lists are then complete);
+    a cloud on a line (zero extent in y) and one of identical points go through it too."""
+    monkeypatch.setenv("SQGR_COOCCUR_SPARSE", "1")
+    rng = np.random.default_rng(1)
+    n, k = 5000, 5
+    labs = rng.integers(0, k, n).astype(np.int32)
+    for x, y in ((rng.random(n).astype(np.float32) * 100, rng.random(n).astype(np.float32) * 100),
+                 (rng.random(n).astype(np.float32) * 100, np.zeros(n, np.float32)),
+                 (np.full(n, 3.0, np.float32), np.full(n, 4.0, np.float32))):
+        thr = np.linspace(1, 150, 20, dtype=np.float32) ** 2
+        got = L.cooccur_counts(ctx, x, y, labs, k, thr)
+        np.testing.assert_array_equal(got, O.occur_count(x, y, thr, labs, k))
