@@ -1418,13 +1418,32 @@ __global__ __launch_bounds__(64) void k_numpy_chain(const uint32_t* __restrict__
     if (c >= K2) return;
     const uint32_t* col = perms + c;
     double a = acc[c];
-    if (mean == nullptr) {
-        for (int64_t q = 0; q < count; ++q) a += (double)col[(size_t)q * K2];
-    } else {
-        const double m = mean[c];
-        for (int64_t q = 0; q < count; ++q) {
+    const bool second = mean != nullptr;
+    const double m = second ? mean[c] : 0.0;
+    // the additions are a dependent chain, the loads are not: 16 of them in flight per trip (round 5 waited one global-memory
+    // latency per permutation: 5 ms of a 138 ms call at 8192 permutations); the order of the additions is unchanged
+    constexpr int U = 16;
+    int64_t q = 0;
+    for (; q + U <= count; q += U) {
+        uint32_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = col[(size_t)(q + u) * K2];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (second) {
+                const double d = (double)v[u] - m;
+                a += d * d;
+            } else {
+                a += (double)v[u];
+            }
+        }
+    }
+    for (; q < count; ++q) {
+        if (second) {
             const double d = (double)col[(size_t)q * K2] - m;
             a += d * d;
+        } else {
+            a += (double)col[(size_t)q * K2];
         }
     }
     acc[c] = a;

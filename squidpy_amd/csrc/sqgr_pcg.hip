@@ -474,7 +474,8 @@ __global__ __launch_bounds__(64) void k_pcg_shuffle_wave(int64_t n, int64_t row_
 // per chunk at 1e6 positions).  Traffic per permutation: ranges 16 phases x ~0.5 MB x 2 + records 2 x 4.3 MB.
 constexpr int PCGB_MAX_RANGES = 64;   // ranges per library (lane r of the generator wave keeps range r's cursors)
 constexpr int PCGB_RING = 128;        // staging ring per range (records)
-constexpr int PCGB_SLOTS = 3328;      // conflict tags of the apply kernel (two buffers: rounds alternate)
+constexpr int PCGB_SLOTS = 3328;      // conflict tags of the apply kernel at 65536-position windows (two buffers: rounds alternate); shorter
+                                      // windows leave more of the 160 KB of LDS to the tags: PcgBucketGeom::slots
 constexpr int PCGB_CHUNK_BLOCKS = 32; // 64-record blocks per chunk of the apply kernel: two records per lane
 constexpr int PCGB_THREADS = 1024;
 
@@ -483,6 +484,7 @@ struct PcgBucketGeom {
     int n_ranges;          // max over libraries of ceil(m / S)
     int bcap;              // blocks per phase: S / 64 + n_ranges (rounded up when S < 64)
     int phases;            // phases of all libraries of one permutation
+    int slots;             // conflict tags per buffer of the apply kernel (two buffers)
 };
 
 __device__ __forceinline__ uint32_t lane_get(uint32_t v, uint32_t src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src); }
@@ -682,7 +684,8 @@ __global__ __launch_bounds__(PCGB_THREADS) void k_pcg_apply_bucketed(int64_t row
     uint8_t* const Xw = s_dyn;                                            // the phase's window: positions [f*S, (f+1)*S)
     uint8_t* const Xr = s_dyn + S;                                        // one range r < f
     uint32_t* const tags = reinterpret_cast<uint32_t*>(s_dyn + 2 * (size_t)S);  // [2][PCGB_SLOTS]: rounds alternate between the buffers
-    uint32_t* const blist = tags + 2 * PCGB_SLOTS;                     // [bcap] block | count << 16, sorted by (range, ordinal)
+    const uint32_t SLOTS = (uint32_t)geo.slots;
+    uint32_t* const blist = tags + 2 * SLOTS;                             // [bcap] block | count << 16, sorted by (range, ordinal)
     __shared__ uint32_t s_wave_any[2][PCGB_THREADS / 64];                 // per round parity and wave: a record is still pending
     __shared__ uint32_t s_hist[PCGB_MAX_RANGES], s_start[PCGB_MAX_RANGES + 1];
     __shared__ uint8_t s_dirty[PCGB_MAX_RANGES];                          // range already written to the row (else: still base_pos)
@@ -693,7 +696,7 @@ __global__ __launch_bounds__(PCGB_THREADS) void k_pcg_apply_bucketed(int64_t row
         const uint32_t* const dir_p = dir + (size_t)p * geo.phases * geo.bcap;
         const uint32_t* const nblk_p = nblk + (size_t)p * geo.phases;
         uint8_t* const row = R + p * row_stride;
-        for (int k = tid; k < 2 * PCGB_SLOTS; k += PCGB_THREADS) tags[k] = 0u;
+        for (uint32_t k = L; k < 2 * SLOTS; k += PCGB_THREADS) tags[k] = 0u;
         uint32_t epoch = 0;
         for (int l = 0; l < n_libs; ++l) {
             const uint32_t off = lib_off[l];
@@ -713,7 +716,7 @@ __global__ __launch_bounds__(PCGB_THREADS) void k_pcg_apply_bucketed(int64_t row
                 __syncthreads();
                 // the conflict tags hold (epoch << 11 | index): epoch restarts with every phase — a phase has at most S / 2048 chunks of
                 // <= 2048 rounds each, far below 2^21, so the epoch field cannot wrap whatever the array length
-                for (int k = tid; k < 2 * PCGB_SLOTS; k += PCGB_THREADS) tags[k] = 0u;
+                for (uint32_t k = L; k < 2 * SLOTS; k += PCGB_THREADS) tags[k] = 0u;
                 epoch = 0;
                 pcgb_copy_in(Xw, (s_dirty[f] ? row : base_pos) + off + ((size_t)f << logS), wlen, tid);
                 if (tid < PCGB_MAX_RANGES) s_hist[tid] = 0u;
@@ -805,8 +808,8 @@ __global__ __launch_bounds__(PCGB_THREADS) void k_pcg_apply_bucketed(int64_t row
                     const uint32_t rec_na = load_recs(rr_n, c0_n, have_na), rec_nb = load_recs(rr_n, c0_n + 16u, have_nb);
                     bool pend_a = have_a, pend_b = have_b;
                     const uint32_t ja = rec_a & 0xffffu, ia = rec_a >> 16, jb = rec_b & 0xffffu, ib = rec_b >> 16;
-                    const uint32_t hja = __umulhi(ja * 2654435761u, (uint32_t)PCGB_SLOTS), hia = __umulhi(ia * 2654435761u, (uint32_t)PCGB_SLOTS);
-                    const uint32_t hjb = __umulhi(jb * 2654435761u, (uint32_t)PCGB_SLOTS), hib = __umulhi(ib * 2654435761u, (uint32_t)PCGB_SLOTS);
+                    const uint32_t hja = __umulhi(ja * 2654435761u, SLOTS), hia = __umulhi(ia * 2654435761u, SLOTS);
+                    const uint32_t hjb = __umulhi(jb * 2654435761u, SLOTS), hib = __umulhi(ib * 2654435761u, SLOTS);
                     // ONE barrier per round: the tags of consecutive rounds live in different buffers (a fast wave's claims of round
                     // k + 1 cannot disturb a slow wave still reading round k; the barrier of round k + 1 protects the buffer's
                     // re-use in round k + 2), and so do the per-wave "still pending" words.  Tag = epoch | 2047 - index in the chunk.
@@ -816,7 +819,7 @@ __global__ __launch_bounds__(PCGB_THREADS) void k_pcg_apply_bucketed(int64_t row
                     // instead of ~160, but every lane then issues every LDS operation of every round: 94 ms.)
                     for (;;) {
                         ++epoch;
-                        uint32_t* const T = tags + (epoch & 1u) * PCGB_SLOTS;
+                        uint32_t* const T = tags + (epoch & 1u) * SLOTS;
                         const uint32_t mine_a = (epoch << 11) | (2047u - L), mine_b = (epoch << 11) | (1023u - L);
                         if (pend_a) atomicMax(&T[hja], mine_a);
                         if (pend_b) atomicMax(&T[hjb], mine_b);
@@ -1015,7 +1018,15 @@ static int pcg_shuffle_rows_bucketed(sqgr_ctx* ctx, PcgWorkspace& ws, int64_t n,
     SQGR_TRY(ws.dir.ensure((size_t)sub * geo.phases * geo.bcap));
     SQGR_TRY(ws.nblk.ensure((size_t)sub * geo.phases));
     const size_t lds_g = (size_t)geo.n_ranges * PCGB_RING * 4;
-    const size_t lds_a = 2 * (size_t)S + (size_t)2 * PCGB_SLOTS * 4 + (size_t)geo.bcap * 4;
+    // conflict tags: what the two windows and the block list leave of the LDS (SQGR_PCG_BUCKET_SLOTS: experiments), at least 3328
+    {
+        const int64_t room = ((int64_t)160 << 10) - 2 * S - (int64_t)geo.bcap * 4 - 2048;  // (2 KB: the kernel's static LDS)
+        int64_t slots = std::max<int64_t>(PCGB_SLOTS, std::min<int64_t>(room / 8, 16384));
+        if (const char* e = getenv("SQGR_PCG_BUCKET_SLOTS"))
+            if (atoi(e) >= 64) slots = std::min<int64_t>(atoi(e), std::max<int64_t>(room / 8, PCGB_SLOTS));
+        geo.slots = (int)slots;
+    }
+    const size_t lds_a = 2 * (size_t)S + (size_t)2 * geo.slots * 4 + (size_t)geo.bcap * 4;
     SQGR_TRY(pcg_allow_lds(k_pcg_draws_bucketed, lds_g));
     SQGR_TRY(pcg_allow_lds(k_pcg_apply_bucketed, lds_a));
     const std::string name_g = std::string(timer_name) + "_draws", name_a = std::string(timer_name) + "_apply";

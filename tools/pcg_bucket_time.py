@@ -16,10 +16,12 @@ st = pcg64_states(0, P)
 res = {}
 for kern in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["bucket", "wave"]):
     os.environ["SQGR_PCG_KERNEL"] = kern.split(":")[0]
-    if ":" in kern:
-        os.environ["SQGR_PCG_BUCKET_LOGS"] = kern.split(":")[1]
-    else:
-        os.environ.pop("SQGR_PCG_BUCKET_LOGS", None)
+    parts = kern.split(":")   # bucket[:logS[:tag slots]]
+    for var, idx in (("SQGR_PCG_BUCKET_LOGS", 1), ("SQGR_PCG_BUCKET_SLOTS", 2)):
+        if len(parts) > idx and parts[idx]:
+            os.environ[var] = parts[idx]
+        else:
+            os.environ.pop(var, None)
     plan = L.NhoodPlan(ctx, g, labels, 30)
     plan.run_pcg64(st[:256])
     ctx.timer_enable(True); ctx.timer_reset()
