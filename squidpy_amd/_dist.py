@@ -209,14 +209,27 @@ class SocketGroup:
                     if not ok:  # not one of ours: drop it and keep waiting for the real ranks
                         conn.close()
                         continue
-                    if w != self.world or not 0 < r < self.world or r in by_rank:
+                    if w != self.world or not 0 < r < self.world:
                         conn.close()
                         raise RuntimeError(f"rendezvous: unexpected peer (rank {r} of {w}) for a {self.world}-rank group")
                     try:
                         conn.sendall(b"\x01")  # the rank keeps dialling until it has read this: a hello that came too late is re-sent
-                    except OSError:
+                        # ... and confirms that it has: a rank that gave up waiting for this byte (the hub was busy with silent
+                        # connections in front of it), closed and dialled again leaves a buffered hello on a dead socket — the write
+                        # above "succeeds" on it, the read below does not, and the dead connection is never registered
+                        conn.settimeout(_HELLO_TIMEOUT_S)
+                        if _recv_exact(conn, 1) != b"\x02":
+                            raise ConnectionError("no confirmation")
+                        conn.settimeout(_TIMEOUT_S)
+                    except (ConnectionError, OSError):
                         conn.close()
                         continue
+                    # the same rank twice all the same (a redial that crossed a confirmation): the newest dial wins
+                    if r in by_rank:
+                        try:
+                            by_rank[r].close()
+                        except OSError:
+                            pass
                     by_rank[r] = conn
             finally:
                 srv.close()
@@ -240,6 +253,7 @@ class SocketGroup:
                     s.settimeout(2.0 * _HELLO_TIMEOUT_S + 5.0)
                     if _recv_exact(s, 1) != b"\x01":
                         raise ConnectionError("rendezvous: the hub did not acknowledge the hello")
+                    s.sendall(b"\x02")  # confirmation: this socket is the one the rank keeps
                     s.settimeout(_TIMEOUT_S)
                     self._hub = s
                     break

@@ -1700,6 +1700,8 @@ int sqgr_nhood::count_batches(int nb, int buf) {
         const int sp = split();
         const size_t lds = mode ? (size_t)ncell * e * 2 : (size_t)((K + sp - 1) / sp) * K * e * 4;
         if (sp > 1 && half) sym_launch |= 4;  // h + h^T in k_reduce
+        // (k_sum_chunks adds a batch's chunk partials in 32 bits: a pair's total, in doubled units with self loops, must fit — ADVICE r5)
+        SQGR_REQUIRE(sp == 1 || (uint64_t)m * (self ? 2u : 1u) < ((uint64_t)1 << 32), "edge list too long for the 32-bit chunk sums of the split-row path (%u entries)", m);
         const int addt = (half && sp == 1) ? 1 : 0;
         const dim3 grid(nblk * (16 / e) * sp, nb);
         SQGR_REQUIRE(!mode || chunk_cap(columns_valid) == 0 || (int64_t)epc * (self ? 2 : 1) <= 65535, "internal: %u edges per block overflow a 16-bit counter", epc);

@@ -7,6 +7,7 @@ validates, uploads and turns exact integer moments into z-scores."""
 from __future__ import annotations
 
 import math
+import warnings
 from typing import Any, NamedTuple
 
 import numpy as np
@@ -80,7 +81,7 @@ def nhood_enrichment(
     show_progress_bar: bool = True,
     *,
     table_key: str | None = None,
-    rng: str = "numpy",
+    rng: str | None = None,
     device: int | None = None,
 ) -> NhoodEnrichmentResult | None:
     """Compute neighborhood enrichment by permutation test (drop-in for ``squidpy.gr.nhood_enrichment``).
@@ -92,7 +93,10 @@ def nhood_enrichment(
     Extra keyword-only parameters
     -----------------------------
     rng
-        ``"numpy"`` (default since round 5): the reference's own streams (``SeedSequence(seed).spawn(n_perms)`` -> PCG64 ->
+        ``None`` = ``"numpy"`` (the default since round 5 — a BREAKING change against rounds 1-4, whose default was ``"philox"``:
+        the z-scores of a given ``seed`` are now Squidpy's, not the device generator's; a default call that is large enough for the
+        17x slower stream to matter — ``n_obs * n_perms >= 5e9`` — says so once, and so does a multi-rank call that has to gather
+        the per-permutation counts through the host).  ``"numpy"``: the reference's own streams (``SeedSequence(seed).spawn(n_perms)`` -> PCG64 ->
         ``Generator.shuffle``, gr/_nhood.py:213, 530-539) are reproduced bit for bit *on the GPU* (LCG jump-ahead draws; long
         arrays replay the swaps phase by phase through LDS, ``csrc/sqgr_pcg.hip``), and the z-score is formed with the
         reference's float64 ``perms.mean/std``: a default call returns **Squidpy's z-scores for that ``seed``, exactly**
@@ -115,8 +119,16 @@ def nhood_enrichment(
     _assert_categorical_obs(adata, cluster_key)
     _assert_connectivity_key(adata, connectivity_key)
     assert_positive(n_perms, name="n_perms")
+    rng_defaulted = rng is None
+    rng = "numpy" if rng is None else rng
     if rng not in ("philox", "numpy", "numpy-host"):
         raise ValueError(f"Invalid option `{rng}` for `rng`. Valid options are: `['philox', 'numpy', 'numpy-host']`.")
+    if rng_defaulted and adata.n_obs * n_perms >= DEFAULT_STREAM_NOTICE_WORK:
+        warnings.warn(
+            f"nhood_enrichment: {n_perms} permutations of {adata.n_obs} observations with the default `rng='numpy'` (Squidpy's own PCG64 streams, "
+            "reproduced on the GPU: ~60 k permutations/s at 1e6 spots).  `rng='philox'` runs the same test ~17x faster with the device "
+            "generator (same null distribution, other digits); pass `rng='numpy'` explicitly to keep Squidpy's numbers without this note.",
+            UserWarning, stacklevel=2)
 
     adj = adata.obsp[connectivity_key]
     int_clust, n_cls = category_codes(adata.obs[cluster_key])
@@ -154,6 +166,11 @@ def nhood_enrichment(
                 mean, std = plan.run_pcg64_stats(pcg64_states(seed, n_perms))
                 perms = None
             else:
+                if n_perms * n_cls * n_cls >= HOST_GATHER_NOTICE_ENTRIES:
+                    warnings.warn(
+                        f"nhood_enrichment(rng='numpy') on {world} ranks without a device communicator: the {n_perms} x {n_cls} x {n_cls} per-permutation counts "
+                        "are gathered through the host side channel on every rank (RCCL between the ranks' GPUs — one process per GPU — keeps them on the "
+                        "device; `rng='philox'` all-reduces 2 K^2 integers instead).", UserWarning, stacklevel=2)
                 _, _, perms = plan.run_pcg64(pcg64_states(seed, n_perms, lo, hi), return_perms=True)
         finally:
             plan.close()
@@ -212,6 +229,8 @@ def _broadcast_seed(key: int) -> int:
     return int(_dist.broadcast_object(int(key), src=0))
 
 
+DEFAULT_STREAM_NOTICE_WORK = 5_000_000_000   # n_obs * n_perms from which a DEFAULTED `rng` (numpy's streams, ~17x slower than "philox") is pointed out
+HOST_GATHER_NOTICE_ENTRIES = 64_000_000      # n_perms * K * K from which the host gather of several ranks' per-permutation counts is pointed out
 PROGRESS_STEP = 40_960  # permutations per progress update: 16 launch groups of 2560
 MAX_DEVICE_SHUFFLE_CLUSTERS = 2048  # batched permutation kernels: uint8 labels + LDS counters up to 256 clusters, uint16 labels + device-scope
 # counters up to 2048 (K*K*16 counters per batch); beyond that the any-K edge-pair kernel counts host-drawn numpy shuffles

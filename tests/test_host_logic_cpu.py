@@ -263,3 +263,50 @@ def test_pcg64_states_vectorised_restatement_equals_numpy():
         s = g.bit_generator.state["state"]
         assert (int(st[k, 0]) << 64 | int(st[k, 1])) == s["state"] and (int(st[k, 2]) << 64 | int(st[k, 3])) == s["inc"]
     assert pcg64_states(None, 100).shape == (100, 4)
+
+
+def test_rendezvous_survives_a_dial_that_gave_up_before_the_acknowledgement():
+    """a rank that closes its first dial and dials again left a buffered hello on a dead socket; the hub registered that
+    socket (its acknowledgement write to a closed peer succeeds) and then refused the redial as an `unexpected peer` — or, in a
+    two-rank group, left the accept loop with the dead connection.  The rank now confirms the acknowledgement and a connection
+    that cannot is never registered."""
+    import os
+    import socket
+    import struct
+    import threading
+    import time
+
+    from squidpy_amd import _dist as D
+
+    key = f"redial_{os.getpid()}_{time.monotonic_ns()}"
+    box: dict = {}
+
+    def hub():
+        try:
+            box["g0"] = D.SocketGroup(0, 2, key=key)
+        except Exception as exc:  # pragma: no cover
+            box["err"] = exc
+
+    t = threading.Thread(target=hub)
+    t.start()
+    path = os.path.join(D._rendezvous_dir(), f"rdzv_{key}")
+    for _ in range(400):
+        if os.path.exists(path) and open(path).read().strip().count(" ") == 1:
+            break
+        time.sleep(0.01)
+    port, token = open(path).read().split()
+    s = socket.create_connection(("127.0.0.1", int(port)))
+    s.sendall(struct.pack("<ii", 1, 2) + bytes.fromhex(token))   # a genuine hello ...
+    s.close()                                                      # ... of a rank that gives up before it is acknowledged
+    time.sleep(0.1)
+    g1 = D.SocketGroup(1, 2, key=key)                              # the redial
+    t.join(60)
+    assert "err" not in box and "g0" in box, box.get("err")
+    out: dict = {}
+    t = threading.Thread(target=lambda: out.setdefault("a", box["g0"].allgather_bytes(b"zero")))
+    t.start()
+    assert g1.allgather_bytes(b"one") == [b"zero", b"one"]
+    t.join(30)
+    assert out["a"] == [b"zero", b"one"]
+    g1.close()
+    box["g0"].close()
