@@ -60,14 +60,14 @@ PERMS_PER_STEP = 10_000
 HBM_PEAK = 8.0e12   # B/s, MI355X_MICROARCH.md
 L2_PEAK = 34.5e12   # B/s aggregate L2 bandwidth, MI355X_MICROARCH.md §L2
 LDS_READ_PEAK = 256 * 256 * 2.4e9  # B/s: 256 B/clk/CU (ds_read_b64/b128, MI355X_MICROARCH.md §LDS) x 256 CUs x 2.4 GHz
-PROFILE_TAG = "r05"
+PROFILE_TAG = "r06"
 
 
 # --------------------------------------------------------------------------------------------- measured ceilings
 def _profile(name: str) -> str:
     """profiles/<tag>_<name> of this round; an earlier round's file only while this round's lease has not produced its own (the
     `source` / `ceiling_source` fields of the record say which file was read)."""
-    for tag in (PROFILE_TAG, "r04", "r03", "r02"):
+    for tag in (PROFILE_TAG, "r05", "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{tag}_{name}")
         if os.path.exists(path):
             return path
