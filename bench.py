@@ -623,7 +623,7 @@ def config3_full_leg(with_cpu_value: float | None) -> dict:
 
 
 # --------------------------------------------------------------------------------------------- config-4 legs
-def config4_legs(ctx, ceil: dict, with_cpu: bool, counters: dict) -> dict:
+def config4_legs(ctx, ceil: dict, with_cpu: bool, counters: dict, short_radii: bool = True) -> dict:
     """co_occurrence, Ripley L and Ripley G on BASELINE config 4's shape: 1e6 points (hex grid + N(0,5) jitter), 30 clusters,
     50 interval edges (49 thresholds) / 50 Ripley radii.  Unit of work = one ORDERED pair evaluation.  Neither HBM
     nor MFMA bounds these kernels: the pair kernels are VALU-issue bound, priced against the measured issue rate of their own
@@ -684,43 +684,44 @@ def config4_legs(ctx, ceil: dict, with_cpu: bool, counters: dict) -> dict:
         "metric": "co_occurrence ordered pair evaluations/sec (1e6 points x 30 clusters x 49 thresholds)",
         "value": pairs / wall, "unit": "pairs/s", "wall_s": wall, "kernel_ms": kms, "roofline": roof,
     }
-    # ---- the same cloud with the intervals users pass: 50 edges up to 20 spot spacings — tile pairs beyond the last
-    # threshold are skipped (k_co_candidates), the dense sweep of the same thresholds (SQGR_COOCCUR_SPARSE=0) is timed beside it
-    short = np.linspace(0.0, 2000.0, num=50, dtype=np.float32)  # (the synthetic hex grid's spot spacing is 100)
-    thr2s = short[1:] ** 2
-    _lib.cooccur_counts(ctx, sp[:8192, 0], sp[:8192, 1], labels[:8192], N_CLS, thr2s)
-    res = {}
-    saved = os.environ.get("SQGR_COOCCUR_SPARSE")
-    try:
-        for route, env in (("near", None), ("dense", "0")):
-            if env is None:
+    if short_radii:
+        # ---- the same cloud with the intervals users pass: 50 edges up to 20 spot spacings — tile pairs beyond the last
+        # threshold are skipped (k_co_candidates), the dense sweep of the same thresholds (SQGR_COOCCUR_SPARSE=0) is timed beside it
+        short = np.linspace(0.0, 2000.0, num=50, dtype=np.float32)  # (the synthetic hex grid's spot spacing is 100)
+        thr2s = short[1:] ** 2
+        _lib.cooccur_counts(ctx, sp[:8192, 0], sp[:8192, 1], labels[:8192], N_CLS, thr2s)
+        res = {}
+        saved = os.environ.get("SQGR_COOCCUR_SPARSE")
+        try:
+            for route, env in (("near", None), ("dense", "0")):
+                if env is None:
+                    os.environ.pop("SQGR_COOCCUR_SPARSE", None)
+                else:
+                    os.environ["SQGR_COOCCUR_SPARSE"] = env
+                ctx.sync()
+                ctx.timer_enable(True)
+                ctx.timer_reset()
+                t0 = time.perf_counter()
+                c = _lib.cooccur_counts(ctx, sp[:, 0], sp[:, 1], labels, N_CLS, thr2s)
+                w = time.perf_counter() - t0
+                kk = ctx.timer_report()
+                ctx.timer_enable(False)
+                res[route] = {"wall_s": w, "kernel_ms": {name: round(v[1], 3) for name, v in kk.items() if name.startswith("cooccur") and v[0] > 0}, "counts": c}
+        finally:
+            if saved is None:
                 os.environ.pop("SQGR_COOCCUR_SPARSE", None)
             else:
-                os.environ["SQGR_COOCCUR_SPARSE"] = env
-            ctx.sync()
-            ctx.timer_enable(True)
-            ctx.timer_reset()
-            t0 = time.perf_counter()
-            c = _lib.cooccur_counts(ctx, sp[:, 0], sp[:, 1], labels, N_CLS, thr2s)
-            w = time.perf_counter() - t0
-            kk = ctx.timer_report()
-            ctx.timer_enable(False)
-            res[route] = {"wall_s": w, "kernel_ms": {name: round(v[1], 3) for name, v in kk.items() if name.startswith("cooccur") and v[0] > 0}, "counts": c}
-    finally:
-        if saved is None:
-            os.environ.pop("SQGR_COOCCUR_SPARSE", None)
-        else:
-            os.environ["SQGR_COOCCUR_SPARSE"] = saved
-    same = bool(np.array_equal(res["near"]["counts"], res["dense"]["counts"]))
-    near_ms, dense_ms = sum(res["near"]["kernel_ms"].values()), sum(res["dense"]["kernel_ms"].values())
-    out["co_occurrence_short_radii"] = {
-        "metric": "co_occurrence wall seconds, 1e6 points x 30 clusters, interval = linspace(0, 20 spot spacings, 50)", "unit": "s", "value": res["near"]["wall_s"],
-        "kernel_ms": near_ms, "kernels_ms": res["near"]["kernel_ms"], "dense_wall_s": res["dense"]["wall_s"], "dense_kernel_ms": dense_ms,
-        "kernel_speedup_vs_dense": dense_ms / near_ms if near_ms > 0 else None, "wall_speedup_vs_dense": res["dense"]["wall_s"] / res["near"]["wall_s"],
-        "counts_equal_dense": same, "pairs_counted": int(res["near"]["counts"][:, :, -1].sum()),
-        "note": "the wall time includes the host's counting sort (by cluster and Hilbert cell), the upload and the copy-out; `kernel_ms` = candidate lists + sweep",
-    }
-    assert same, "short-radius co_occurrence differs from the dense sweep"
+                os.environ["SQGR_COOCCUR_SPARSE"] = saved
+        same = bool(np.array_equal(res["near"]["counts"], res["dense"]["counts"]))
+        near_ms, dense_ms = sum(res["near"]["kernel_ms"].values()), sum(res["dense"]["kernel_ms"].values())
+        out["co_occurrence_short_radii"] = {
+            "metric": "co_occurrence wall seconds, 1e6 points x 30 clusters, interval = linspace(0, 20 spot spacings, 50)", "unit": "s", "value": res["near"]["wall_s"],
+            "kernel_ms": near_ms, "kernels_ms": res["near"]["kernel_ms"], "dense_wall_s": res["dense"]["wall_s"], "dense_kernel_ms": dense_ms,
+            "kernel_speedup_vs_dense": dense_ms / near_ms if near_ms > 0 else None, "wall_speedup_vs_dense": res["dense"]["wall_s"] / res["near"]["wall_s"],
+            "counts_equal_dense": same, "pairs_counted": int(res["near"]["counts"][:, :, -1].sum()),
+            "note": "the wall time includes the host's counting sort (by cluster and Hilbert cell), the upload and the copy-out; `kernel_ms` = candidate lists + sweep",
+        }
+        assert same, "short-radius co_occurrence differs from the dense sweep"
     # ---- Ripley L (gr/_ripley.py:212-227): float64 pair counts per cluster, 50 radii
     from scipy.spatial import ConvexHull
 
@@ -1216,6 +1217,8 @@ def main() -> None:
     ap.add_argument("--no-secondary", action="store_true", help="skip the Moran's I genes/sec leg")
     ap.add_argument("--no-legs", action="store_true", help="skip the co_occurrence / Ripley L legs (config 4)")
     ap.add_argument("--no-numpy-leg", action="store_true", help="skip the bit-compatible numpy-stream leg")
+    ap.add_argument("--no-short-radii", action="store_true", help="skip the co_occurrence short-radii leg (tools/profile_round.sh: the PMC totals of "
+                    "the co-occurrence kernel then belong to the config-4 sweep alone)")
     ap.add_argument("--no-config3-full", action="store_true", help="skip BASELINE config 3 in full through the front end (builds a 16 GB host matrix)")
     ap.add_argument("--emulate-ranks", type=int, default=8,
                     help="projection for a node this box does not have: run the N rank shards of BASELINE config 5 (--total-perms permutations, strong "
@@ -1331,7 +1334,7 @@ def main() -> None:
             geary = autocorr_leg(ctx, "geary", world, fence, reduce_max, max(1, min(args.steps, 10)), with_cpu, counters, graph_kind="hex")
     legs = None
     if world == 1 and not args.no_legs:
-        legs = config4_legs(ctx, ceil, not args.no_cpu_baseline, counters)
+        legs = config4_legs(ctx, ceil, not args.no_cpu_baseline, counters, short_radii=not args.no_short_radii)
         if geary is not None:
             legs["geary_c"] = geary
         if not args.no_secondary:
@@ -1545,6 +1548,7 @@ def main() -> None:
             "fabric_traffic": fab.get("traffic_bytes_per_launch"), "fabric_GBps": fab.get("traffic_GBps"), "fabric_frac": fab.get("traffic_frac_of_hbm_peak"),
             "traffic_source": fab.get("traffic_source"),
             "launches": dom["launches"], "avg_launch_ms": dom["avg_launch_ms"], "perms_per_launch": perms_per_launch,
+            "workload_key": workload,   # (tools/summarize_round.py stamps the PMC profile with it; kernel_counters() matches on it)
             "ms_per_step": dom["total_ms"] / args.steps, "share_of_kernel_time": dom["total_ms"] / gpu_ms if gpu_ms > 0 else None,
             "step_dram_frac": step_dram_frac, "step_dram_bytes": step_bytes,
             "dram_frac_by_kernel": {k: r["dram_frac"] for k, r in per_kernel.items()},

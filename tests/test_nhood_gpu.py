@@ -206,6 +206,27 @@ def test_independent_bijection_variant_bit_exact_vs_oracle(L, ctx, k, monkeypatc
     g.close()
 
 
+@pytest.mark.parametrize("k,n_libs", [(60, 3), (120, 2), (220, 4)])
+def test_device_generator_with_libraries_above_50_clusters(L, ctx, k, n_libs):
+    """The 16-bit counter layouts keep their chunks long when the LABELS bound a counter (largest cluster x longest row x weight
+    <= 65 535: every slab column is a shuffle of the base labels) — per-library shuffles keep the cluster sizes too.  Per-permutation
+    counts `==` the oracle's restatement of `_shuffle_group` with the device generator (gr/_utils.py:185-213), a ragged range."""
+    rng = np.random.default_rng(k * 31 + n_libs)
+    adj = O.hex_grid_graph(90, 80)
+    n = adj.shape[0]
+    labels = rng.integers(0, k, n).astype(np.int32)
+    libs = rng.integers(0, n_libs, n).astype(np.int32)
+    g = L.Graph(ctx, adj, with_data=False)
+    plan = L.NhoodPlan(ctx, g, labels, k, libs, n_libs)
+    info = plan.info()
+    assert info["counter_mode"] == 2 and info["blocks_per_batch"] == 8, info   # the labels bound every counter: no extra chunks
+    _, _, got = plan.run(21, 7, 7 + 35, None, return_perms=True)
+    ref = O.nhood_perm_counts_philox(adj.indices, adj.indptr, labels, k, 21, 7, 7 + 35, libs, n_libs)
+    np.testing.assert_array_equal(got, ref.astype(np.uint32))
+    plan.close()
+    g.close()
+
+
 @pytest.mark.parametrize("k", [2, 30, 46, 60, 100, 150, 210, 256])
 def test_all_cluster_count_regimes(L, ctx, k):
     """K decides which count kernel runs (LDS B=16, narrower LDS passes, device atomics): all bit-exact."""

@@ -67,6 +67,21 @@ while (it < ITERS) if ITERS else (time.time() - t0 < budget):
     labs = rng.integers(0, kk, m).astype(np.int32)
     thr = np.sort(rng.random(int(rng.integers(1, 30))) * 60).astype(np.float32) ** 2
     assert np.array_equal(L.cooccur_counts(ctx, x, y, labs, kk, thr), O.occur_count(x, y, thr, labs, kk)), ("cooc", m, kk)
+    # ... and short radii on a cloud large enough for the candidate-list route (round 6): near route == forced dense sweep, three shards
+    mm = int(rng.choice([17000, 40000, 90000])); kq = int(rng.choice([1, 3, 12, 80])); ext = float(rng.choice([100.0, 3000.0]))
+    xq = (rng.random(mm) * ext).astype(np.float32); yq = (rng.random(mm) * ext * rng.choice([0.02, 0.7, 1.0])).astype(np.float32)
+    if rng.random() < 0.3: xq = np.round(xq)                          # ties with thresholds and box edges
+    lq = rng.integers(0, kq, mm).astype(np.int32)
+    tq = (np.sort(rng.random(int(rng.integers(1, 60)))) * ext * rng.choice([0.005, 0.03, 0.15])).astype(np.float32) ** 2
+    fq = bool(rng.random() < 0.3)
+    note('  cooc short mm', mm, 'kq', kq, 'L', len(tq), 'fma', fq)
+    near = L.cooccur_counts(ctx, xq, yq, lq, kq, tq, fma=fq)
+    os.environ["SQGR_COOCCUR_SPARSE"] = "0"
+    dense = L.cooccur_counts(ctx, xq, yq, lq, kq, tq, fma=fq)
+    os.environ.pop("SQGR_COOCCUR_SPARSE")
+    assert np.array_equal(near, dense), ("cooc short radii", mm, kq, len(tq), fq)
+    ns = int(rng.integers(2, 5))
+    assert np.array_equal(sum(L.cooccur_counts(ctx, xq, yq, lq, kq, tq, fma=fq, shard_index=r, shard_count=ns) for r in range(ns)), near), ("cooc short shards", mm, ns)
     note('  pairs')
     pts = np.stack([x, y], 1).astype(np.float64); sup = np.linspace(0, 40, int(rng.integers(2, 40)))
     assert np.array_equal(L.pair_counts(ctx, pts, sup), O.pair_counts_bruteforce(pts, sup)), ("pairs", m)

@@ -18,7 +18,7 @@ rm -rf $OUT; mkdir -p $OUT $REPO/profiles
 cd /tmp && export TMPDIR=/tmp
 CMD="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-numpy-leg --no-legs --emulate-ranks 0 --detail-out $OUT/stats_detail.json"
 PMC="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-numpy-leg --no-legs --emulate-ranks 0 --detail-out $OUT/pmc_detail.json"
-LEGS="python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-numpy-leg --no-secondary --emulate-ranks 0 --detail-out $OUT/legs_detail.json"
+LEGS="python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-numpy-leg --no-secondary --no-short-radii --emulate-ranks 0 --detail-out $OUT/legs_detail.json"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/stats.log 2>&1
 timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $PMC > $OUT/fetch.log 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $PMC > $OUT/write.log 2>&1
