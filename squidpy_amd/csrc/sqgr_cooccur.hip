@@ -479,8 +479,9 @@ extern "C" int sqgr_cooccur_counts(sqgr_ctx* ctx, const float* x, const float* y
         n_chunks = (int64_t)chunks.size();
         // not worth it when most tile pairs stay (a radius that reaches across the tiles): the dense sweep has no lists to walk
         const double dense_pairs = 0.5 * 4.0 * (double)T * (double)T / (double)shard_count;  // (in quarter tiles)
-        if (n_cand >= (int64_t)(0.5 * dense_pairs) || n_cand >= ((int64_t)1 << 31) || n_chunks == 0) {
-            if (!getenv("SQGR_COOCCUR_SPARSE") || n_chunks == 0 || n_cand >= ((int64_t)1 << 31)) sparse = false;
+        const int64_t cand_cap = (int64_t)500 << 20;  // 2 GB of candidate entries at most (the dense sweep needs no list at all)
+        if (n_cand >= (int64_t)(0.5 * dense_pairs) || n_cand >= cand_cap || n_chunks == 0) {
+            if (!getenv("SQGR_COOCCUR_SPARSE") || n_chunks == 0 || n_cand >= cand_cap) sparse = false;
         }
         if (const char* e = getenv("SQGR_COOCCUR_DEBUG"))
             if (atoi(e))
