@@ -674,15 +674,6 @@ __device__ __forceinline__ void pcgb_copy_out(uint8_t* __restrict__ dst, const u
     }
 }
 
-#ifdef SQGR_PCG_EXPERIMENT_COUNT_ROUNDS  // (variant builds of tools/pcg_rounds.sh: how many barrier rounds the replay kernels run)
-__device__ unsigned long long g_pcg_rounds[2];
-extern "C" int sqgr_debug_pcg_rounds(unsigned long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pcg_rounds), sizeof(g_pcg_rounds)) == hipSuccess ? 0 : -2;
-}
-#define SQGR_COUNT_ROUND(k) do { if (tid == 0) atomicAdd(&g_pcg_rounds[k], 1ull); } while (0)
-#else
-#define SQGR_COUNT_ROUND(k) do { } while (0)
-#endif
 __global__ __launch_bounds__(PCGB_THREADS) void k_pcg_apply_bucketed(int64_t row_stride, int n_libs, const uint32_t* __restrict__ lib_off,
                                                                      const uint32_t* __restrict__ lib_phase, const uint8_t* __restrict__ base_pos,
                                                                      int64_t P, PcgBucketGeom geo, const uint32_t* __restrict__ recs,
@@ -828,7 +819,6 @@ __global__ __launch_bounds__(PCGB_THREADS) void k_pcg_apply_bucketed(int64_t row
                     // instead of ~160, but every lane then issues every LDS operation of every round: 94 ms.)
                     for (;;) {
                         ++epoch;
-                        SQGR_COUNT_ROUND(0);
                         uint32_t* const T = tags + (epoch & 1u) * SLOTS;
                         const uint32_t mine_a = (epoch << 11) | (2047u - L), mine_b = (epoch << 11) | (1023u - L);
                         if (pend_a) atomicMax(&T[hja], mine_a);
@@ -888,268 +878,6 @@ __global__ __launch_bounds__(PCGB_THREADS) void k_pcg_apply_bucketed(int64_t row
         }
         __syncthreads();
     }
-}
-
-// global loads whose waits are placed by hand (k_pcg_apply_stream): the compiler's wait-count pass neither sees them nor waits for them
-#define SQGR_VM_LOAD_U32(DST, PTR) asm volatile("global_load_dword %0, %1, off" : "=v"(DST) : "v"(PTR) : "memory")
-// ... into a register that stays RESERVED from one load to the next (in-out operand): a load that is never waited for lands at any
-// later time, and the compiler must not have put anything else into its destination by then
-#define SQGR_VM_TOUCH_U32(DST, PTR) asm volatile("global_load_dword %0, %1, off" : "+v"(DST) : "v"(PTR) : "memory")
-// The same replay with the records STREAMED through the record slots (round 6): k_pcg_apply_bucketed works in chunks of 2048 records
-// and a chunk ends when its last record has gone — ~3.2 rounds of which the first retires three records in four, plus one round that
-// only finds out that nothing is left; every round costs the same instructions however few records it still serves, and the kernel
-// is bound by instruction issue.  Here a slot whose record has gone takes the next record of the list in the round after (the free
-// slots of the 16 wavefronts are counted through the round's own barrier), so every round claims for ~1200 records instead of ~465.
-// The order argument is unchanged: records enter in list order, so everything in front of a record in flight is in flight or done.
-__global__ __launch_bounds__(PCGB_THREADS) void k_pcg_apply_stream(int64_t row_stride, int n_libs, const uint32_t* __restrict__ lib_off,
-                                                                     const uint32_t* __restrict__ lib_phase, const uint8_t* __restrict__ base_pos,
-                                                                     int64_t P, PcgBucketGeom geo, const uint32_t* __restrict__ recs,
-                                                                     const uint32_t* __restrict__ dir, const uint32_t* __restrict__ nblk,
-                                                                     uint8_t* __restrict__ R) {
-    extern __shared__ unsigned char s_dyn[];
-    const uint32_t logS = (uint32_t)geo.logS, S = 1u << logS;
-    uint8_t* const Xw = s_dyn;                                            // the phase's window: positions [f*S, (f+1)*S)
-    uint8_t* const Xr = s_dyn + S;                                        // one range r < f
-    uint32_t* const tags = reinterpret_cast<uint32_t*>(s_dyn + 2 * (size_t)S);  // [2][PCGB_SLOTS]: rounds alternate between the buffers
-    const uint32_t SLOTS = (uint32_t)geo.slots;
-    uint32_t* const blist = tags + 2 * SLOTS;                             // [bcap] block | count << 16, sorted by (range, ordinal)
-    __shared__ uint32_t s_cnt[2][PCGB_THREADS / 64];                      // per round parity and wave: free record slots | a record is pending << 16
-    __shared__ uint32_t s_hist[PCGB_MAX_RANGES], s_start[PCGB_MAX_RANGES + 1];
-    __shared__ uint8_t s_dirty[PCGB_MAX_RANGES];                          // range already written to the row (else: still base_pos)
-    const int tid = threadIdx.x;
-    const uint32_t L = (uint32_t)tid;
-    uint32_t pf = 0;  // destination of the list touches (see SQGR_VM_TOUCH_U32): reserved for the whole kernel
-    for (int64_t p = blockIdx.x; p < P; p += gridDim.x) {
-        const uint32_t* const rec_p = recs + (size_t)p * geo.phases * geo.bcap * 64;
-        const uint32_t* const dir_p = dir + (size_t)p * geo.phases * geo.bcap;
-        const uint32_t* const nblk_p = nblk + (size_t)p * geo.phases;
-        uint8_t* const row = R + p * row_stride;
-        for (uint32_t k = L; k < 2 * SLOTS; k += PCGB_THREADS) tags[k] = 0u;
-        uint32_t epoch = 0;
-        for (int l = 0; l < n_libs; ++l) {
-            const uint32_t off = lib_off[l];
-            const uint32_t m = lib_off[l + 1] - off;
-            if (m == 0u) continue;
-            if (m == 1u) {
-                if (tid == 0) row[off] = base_pos[off];
-                continue;
-            }
-            const uint32_t F = (m + S - 1u) >> logS;
-            __syncthreads();
-            if (tid < PCGB_MAX_RANGES) s_dirty[tid] = 0;
-            for (uint32_t ff = F; ff-- > 0u;) {
-                const uint32_t f = ff;
-                const uint32_t ph = lib_phase[l] + f;
-                const uint32_t wlen = min(S, m - (f << logS));
-                __syncthreads();
-                // the conflict tags hold (epoch << 11 | index): epoch restarts with every phase — a phase has at most S / 2048 chunks of
-                // <= 2048 rounds each, far below 2^21, so the epoch field cannot wrap whatever the array length
-                for (uint32_t k = L; k < 2 * SLOTS; k += PCGB_THREADS) tags[k] = 0u;
-                epoch = 0;
-                pcgb_copy_in(Xw, (s_dirty[f] ? row : base_pos) + off + ((size_t)f << logS), wlen, tid);
-                if (tid < PCGB_MAX_RANGES) s_hist[tid] = 0u;
-                __syncthreads();
-                const uint32_t nb = nblk_p[ph];
-                for (uint32_t t = L; t < nb; t += PCGB_THREADS) atomicAdd(&s_hist[dir_p[(size_t)ph * geo.bcap + t] & 0xffu], 1u);
-                __syncthreads();
-                if (tid == 0) {
-                    uint32_t acc = 0;
-                    for (uint32_t r = 0; r <= f; ++r) {
-                        s_start[r] = acc;
-                        acc += s_hist[r];
-                    }
-                    s_start[f + 1] = acc;
-                }
-                __syncthreads();
-                for (uint32_t t = L; t < nb; t += PCGB_THREADS) {
-                    const uint32_t e = dir_p[(size_t)ph * geo.bcap + t];
-                    blist[s_start[e & 0xffu] + (e >> 16)] = t | (((e >> 8) & 0xffu) << 16);
-                }
-                __syncthreads();
-                // Ranges in processing order: rr = 0 is the window range f, rr >= 1 is range rr - 1.  The records of a range are
-                // STREAMED through the workgroup's 2048 record slots (two per lane): a slot whose record has gone takes the next record
-                // of the list — in list order, so that at any time every record in front of a record in flight is in flight itself or
-                // done — instead of waiting for the last record of a 2048-record chunk.  Priority = the record's index in its list.
-                auto range_of = [&](uint32_t rr) { return rr == 0u ? f : rr - 1u; };
-                auto next_range = [&](uint32_t rr) {  // first rr' > rr with records (f + 1: none)
-                    for (++rr; rr <= f && s_hist[range_of(rr)] == 0u; ++rr) {}
-                    return rr;
-                };
-                uint4 pre0, pre1, pre2, pre3;  // the next range's bytes (16-byte pieces tid, tid + 1024, ...): S <= 65536 = 4 x 1024 x 16
-                pre0 = pre1 = pre2 = pre3 = make_uint4(0u, 0u, 0u, 0u);
-                auto range_src = [&](uint32_t rr) { return (s_dirty[range_of(rr)] ? row : base_pos) + off + ((size_t)range_of(rr) << logS); };
-                const uint32_t n16 = S >> 4;
-#define SQGR_PCGB_PREFETCH(RR, OK)                                                                            \
-    do {                                                                                                      \
-        OK = false;                                                                                           \
-        const uint32_t rr__ = (RR);                                                                           \
-        if (rr__ <= f && rr__ != 0u && S >= 16u) {                                                            \
-            const uint4* src__ = reinterpret_cast<const uint4*>(range_src(rr__));                             \
-            if ((reinterpret_cast<uintptr_t>(src__) & 15u) == 0u) {                                           \
-                if ((uint32_t)tid < n16) pre0 = src__[tid];                                                   \
-                if ((uint32_t)tid + 1024u < n16) pre1 = src__[tid + 1024];                                    \
-                if ((uint32_t)tid + 2048u < n16) pre2 = src__[tid + 2048];                                    \
-                if ((uint32_t)tid + 3072u < n16) pre3 = src__[tid + 3072];                                    \
-                OK = true;                                                                                    \
-            }                                                                                                 \
-        }                                                                                                     \
-    } while (0)
-                const uint32_t wave = L >> 6, lane = L & 63u;
-                bool pre_ok = false;
-                for (uint32_t rr = s_hist[f] != 0u ? 0u : next_range(0u); rr <= f; rr = next_range(rr)) {
-                    const uint32_t r = range_of(rr), nbr = s_hist[r];
-                    const bool internal = rr == 0u;
-                    uint8_t* const X2 = internal ? Xw : Xr;
-                    if (!internal) {  // entering range r
-                        if (pre_ok) {
-                            uint4* dst = reinterpret_cast<uint4*>(Xr);
-                            if ((uint32_t)tid < n16) dst[tid] = pre0;
-                            if ((uint32_t)tid + 1024u < n16) dst[tid + 1024] = pre1;
-                            if ((uint32_t)tid + 2048u < n16) dst[tid + 2048] = pre2;
-                            if ((uint32_t)tid + 3072u < n16) dst[tid + 3072] = pre3;
-                        } else {
-                            pcgb_copy_in(Xr, range_src(rr), S, tid);
-                        }
-                        __syncthreads();
-                    }
-                    SQGR_PCGB_PREFETCH(next_range(rr), pre_ok);  // in flight while this range is replayed
-                    if (epoch >= 0x6000u) {  // (15 epoch bits per phase: out of reach for random draws — a list would have to serialise thousands of records)
-                        __syncthreads();
-                        for (uint32_t k = L; k < 2 * SLOTS; k += PCGB_THREADS) tags[k] = 0u;
-                        epoch = 0;
-                        __syncthreads();
-                    }
-                    // the list: nbr blocks in time order, all of 64 records but the last
-                    const uint32_t* const bl = blist + s_start[r];
-                    const uint32_t R = (nbr - 1u) * 64u + (bl[nbr - 1u] >> 16);
-                    auto rec_ptr = [&](uint32_t idx) {  // record idx of the list
-                        return rec_p + ((size_t)ph * geo.bcap + (bl[idx >> 6] & 0xffffu)) * 64 + (idx & 63u);
-                    };
-                    // the list that follows (its head is touched while this one drains: see `pf` below)
-                    const uint32_t rr_nx = next_range(rr);
-                    const uint32_t* const bl_nx = rr_nx <= f ? blist + s_start[range_of(rr_nx)] : bl;
-                    const uint32_t R_nx = rr_nx <= f ? (s_hist[range_of(rr_nx)] - 1u) * 64u + (bl_nx[s_hist[range_of(rr_nx)] - 1u] >> 16) : 0u;
-                    // Every round issues exactly THREE global loads per lane, in this order and on every path — a record for slot a, one
-                    // for slot b (a record the slot takes, or any valid address), and a touch `pf` of the list ~2 rounds ahead — and the top
-                    // of the next round waits with `s_waitcnt vmcnt(1)`: for the two records, not for the youngest load, the touch.  The
-                    // records then come out of L2 / L1, where a touch two rounds old has put their lines, instead of HBM (a first version
-                    // loaded the records alone, one round ahead: 1.5 us per round against 0.7, all of it HBM latency; with compiler-managed
-                    // loads the wait-count pass puts vmcnt(0) on the loop's back edge, which waits for the touch as well — hence the
-                    // inline-asm loads, which it does not see, and the hand-placed waits).  No other vector-memory operation is issued
-                    // inside the round loop; loads and stores around it are older than the loop's first wait or younger than its last.
-                    auto touch_idx = [&](uint32_t from) {  // lane L touches every second record of [from, from + 2048): 64 lines of 128 bytes
-                        const uint32_t t = from + 2u * L;
-                        return t < R ? rec_p + ((size_t)ph * geo.bcap + (bl[t >> 6] & 0xffffu)) * 64 + (t & 63u)
-                                     : (t - R < R_nx ? rec_p + ((size_t)ph * geo.bcap + (bl_nx[(t - R) >> 6] & 0xffffu)) * 64 + ((t - R) & 63u)
-                                                     : rec_p + ((size_t)ph * geo.bcap + (bl[0] & 0xffffu)) * 64);
-                    };
-                    // first fill, known without counting: wave w takes records [128 w, 128 w + 128), its a slots the first 64
-                    uint32_t cursor = min(R, 2u * PCGB_THREADS);
-                    uint32_t idx_a = wave * 128u + lane, idx_b = idx_a + 64u;
-                    bool load_a = idx_a < R, load_b = idx_b < R, pend_a = false, pend_b = false;
-                    uint32_t ld_a, ld_b;
-                    SQGR_VM_LOAD_U32(ld_a, rec_ptr(load_a ? idx_a : 0u));
-                    SQGR_VM_LOAD_U32(ld_b, rec_ptr(load_b ? idx_b : 0u));
-                    SQGR_VM_TOUCH_U32(pf, touch_idx(2u * PCGB_THREADS));
-                    uint32_t ja = 0, ia = 0, jb = 0, ib = 0, hja = 0, hia = 0, hjb = 0, hib = 0;
-                    for (;;) {
-                        // records loaded in the last round enter the game (the touch issued behind them stays in flight)
-                        asm volatile("s_waitcnt vmcnt(1)" : "+v"(ld_a), "+v"(ld_b) : : "memory");
-                        if (load_a) {
-                            ja = ld_a & 0xffffu; ia = ld_a >> 16;
-                            hja = __umulhi(ja * 2654435761u, SLOTS); hia = __umulhi(ia * 2654435761u, SLOTS);
-                            pend_a = true; load_a = false;
-                        }
-                        if (load_b) {
-                            jb = ld_b & 0xffffu; ib = ld_b >> 16;
-                            hjb = __umulhi(jb * 2654435761u, SLOTS); hib = __umulhi(ib * 2654435761u, SLOTS);
-                            pend_b = true; load_b = false;
-                        }
-                        ++epoch;
-                        SQGR_COUNT_ROUND(1);
-                        uint32_t* const T = tags + (epoch & 1u) * SLOTS;
-                        // tag = epoch | 131071 - index in the list (a list has at most bcap * 64 < 2^17 records): the earliest pending record wins its slot
-                        const uint32_t mine_a = (epoch << 17) | (0x1ffffu - idx_a), mine_b = (epoch << 17) | (0x1ffffu - idx_b);
-                        if (pend_a) atomicMax(&T[hja], mine_a);
-                        if (pend_b) atomicMax(&T[hjb], mine_b);
-                        const unsigned long long fa = __ballot(!pend_a), fb = __ballot(!pend_b);
-                        const uint32_t nfa = (uint32_t)__popcll(fa), nfb = (uint32_t)__popcll(fb);
-                        const bool wave_pending = (nfa + nfb) != 128u;
-                        if (lane == 0u) s_cnt[epoch & 1u][wave] = (nfa + nfb) | (wave_pending ? 0x10000u : 0u);
-                        __syncthreads();
-                        const uint32_t cw = s_cnt[epoch & 1u][lane & (PCGB_THREADS / 64 - 1)];
-                        const bool any_pending = __ballot((cw >> 16) != 0u) != 0ull;  // uniform over the workgroup: every wave reads all 16 words
-                        uint32_t ta = 0, tb = 0, tia = 0, tib = 0;
-                        uint8_t va_i = 0, va_j = 0, vb_i = 0, vb_j = 0;
-                        if (pend_a) {
-                            ta = T[hja];
-                            va_i = Xw[ia];
-                            va_j = X2[ja];
-                        }
-                        if (pend_b) tb = T[hjb];
-                        if (internal) {
-                            if (pend_a) tia = T[hia];
-                            if (pend_b) tib = T[hib];
-                        }
-                        // refill: the free slots of the whole workgroup take the next records in list order (wave by wave, a slots first)
-                        uint32_t base = 0, total = 0;
-#pragma unroll
-                        for (int w = 0; w < PCGB_THREADS / 64; ++w) {
-                            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cw, w) & 0xffffu;
-                            base += (uint32_t)w < wave ? c : 0u;
-                            total += c;
-                        }
-                        const bool issued = cursor < R && total != 0u;
-                        const uint32_t ra = cursor + base + __builtin_amdgcn_mbcnt_hi((uint32_t)(fa >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fa, 0u));
-                        const uint32_t rb = cursor + base + nfa + __builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0u));
-                        load_a = !pend_a && ra < R;
-                        load_b = !pend_b && rb < R;
-                        idx_a = load_a ? ra : idx_a;
-                        idx_b = load_b ? rb : idx_b;
-                        cursor = min(R, cursor + total);
-                        {
-                            const uint32_t* const pa = rec_ptr(load_a ? ra : 0u);   // (all three unconditional: see above)
-                            const uint32_t* const pb = rec_ptr(load_b ? rb : 0u);
-                            const uint32_t* const pt = touch_idx(cursor + 2u * PCGB_THREADS);
-                            SQGR_VM_LOAD_U32(ld_a, pa);
-                            SQGR_VM_LOAD_U32(ld_b, pb);
-                            SQGR_VM_TOUCH_U32(pf, pt);
-                        }
-                        if (!any_pending && !issued) break;  // uniform: nothing in flight, nothing left to hand out
-                        bool go_a = pend_a && ta == mine_a, go_b = pend_b && tb == mine_b;
-                        // window range: no earlier pending record may write to this record's i position
-                        if (internal) {
-                            go_a = go_a && ((tia >> 17) != epoch || (0x1ffffu - (tia & 0x1ffffu)) >= (0x1ffffu - (mine_a & 0x1ffffu)));
-                            go_b = go_b && ((tib >> 17) != epoch || (0x1ffffu - (tib & 0x1ffffu)) >= (0x1ffffu - (mine_b & 0x1ffffu)));
-                        }
-                        if (go_a) {
-                            Xw[ia] = va_j;
-                            X2[ja] = va_i;
-                            pend_a = false;
-                        }
-                        if (go_b) {  // (a lane's two records share no position when both go: one slot per j, the i check for the rest)
-                            vb_i = Xw[ib];
-                            vb_j = X2[jb];
-                            Xw[ib] = vb_j;
-                            X2[jb] = vb_i;
-                            pend_b = false;
-                        }
-                    }
-                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ld_a), "+v"(ld_b), "+v"(pf) : : "memory");  // nothing of this range stays in flight
-                    if (!internal) {
-                        __syncthreads();
-                        pcgb_copy_out(row + off + ((size_t)r << logS), Xr, S, tid);
-                        if (tid == 0) s_dirty[r] = 1;
-                        __syncthreads();
-                    }
-                }
-#undef SQGR_PCGB_PREFETCH
-                pcgb_copy_out(row + off + ((size_t)f << logS), Xw, wlen, tid);  // positions of this phase are final
-            }
-        }
-        __syncthreads();
-    }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf) : : "memory");
 }
 
 // rows R[q][row_stride] (bytes) -> columns W[pos * stride + q]
@@ -1301,7 +1029,6 @@ static int pcg_shuffle_rows_bucketed(sqgr_ctx* ctx, PcgWorkspace& ws, int64_t n,
     const size_t lds_a = 2 * (size_t)S + (size_t)2 * geo.slots * 4 + (size_t)geo.bcap * 4;
     SQGR_TRY(pcg_allow_lds(k_pcg_draws_bucketed, lds_g));
     SQGR_TRY(pcg_allow_lds(k_pcg_apply_bucketed, lds_a));
-    SQGR_TRY(pcg_allow_lds(k_pcg_apply_stream, lds_a));
     const std::string name_g = std::string(timer_name) + "_draws", name_a = std::string(timer_name) + "_apply";
     const int cus = std::max(ctx->cu_count, 1);
     const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, ((size_t)160 << 10) / (lds_a + 1024)));
@@ -1317,13 +1044,8 @@ static int pcg_shuffle_rows_bucketed(sqgr_ctx* ctx, PcgWorkspace& ws, int64_t n,
         {
             LaunchTimer t(ctx, name_a.c_str(), st);
             const unsigned grid = (unsigned)std::min<int64_t>(qc, (int64_t)cus * wg_per_cu);
-            static const bool chunked = [] { const char* e = getenv("SQGR_PCG_APPLY"); return e && strcmp(e, "chunks") == 0; }();  // (round 4's kernel)
-            if (chunked)
-                k_pcg_apply_bucketed<<<grid, PCGB_THREADS, lds_a, st>>>(n_pad, n_libs, lib_off_dev, ws.lib_phase.p, base_pos_dev, qc, geo, ws.recs.p, ws.dir.p,
-                                                                        ws.nblk.p, ws.rows.p + (size_t)q0 * n_pad);
-            else
-                k_pcg_apply_stream<<<grid, PCGB_THREADS, lds_a, st>>>(n_pad, n_libs, lib_off_dev, ws.lib_phase.p, base_pos_dev, qc, geo, ws.recs.p, ws.dir.p,
-                                                                      ws.nblk.p, ws.rows.p + (size_t)q0 * n_pad);
+            k_pcg_apply_bucketed<<<grid, PCGB_THREADS, lds_a, st>>>(n_pad, n_libs, lib_off_dev, ws.lib_phase.p, base_pos_dev, qc, geo, ws.recs.p, ws.dir.p,
+                                                                    ws.nblk.p, ws.rows.p + (size_t)q0 * n_pad);
             SQGR_HIP(hipGetLastError());
         }
     }

@@ -16,9 +16,7 @@ st = pcg64_states(0, P)
 res = {}
 for kern in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["bucket", "wave"]):
     os.environ["SQGR_PCG_KERNEL"] = kern.split(":")[0]
-    parts = kern.split(":")   # bucket[:logS[:tag slots[:chunks]]] ("chunks": round 4's replay kernel — read once per process: one kernel per run)
-    if len(parts) > 3 and parts[3]:
-        os.environ["SQGR_PCG_APPLY"] = parts[3]
+    parts = kern.split(":")   # bucket[:logS[:tag slots]]
     for var, idx in (("SQGR_PCG_BUCKET_LOGS", 1), ("SQGR_PCG_BUCKET_SLOTS", 2)):
         if len(parts) > idx and parts[idx]:
             os.environ[var] = parts[idx]
