@@ -330,7 +330,7 @@ int sqgr_radius_self(sqgr_ctx* ctx, const double* xy, int64_t n, double radius, 
  * (formed by the caller in float64, the same IEEE addition the reference performs per comparison).
  *   data: the (n_cells x n_genes) float64 matrix as CSC columns of its stored entries (colptr int64[n_genes+1],
  *         rowidx int32 ascending inside a column, values) — zeros need not be stored, they do not change a sum.
- *   clustering int32[n_cells] in [0,K), 2 <= K <= 2048 (more than 256 clusters run in cluster tiles of 255 on 16-bit labels); inv_counts float64[K].
+ *   clustering int32[n_cells] in [0,K), 2 <= K <= 65535 (more than 256 clusters run in cluster tiles of 255 on 16-bit labels); inv_counts float64[K].
  *   pcg_states == NULL: device generator keyed by (seed, global permutation index) — the result for a permutation
  *         range does not depend on how ranges are split over calls or GPUs.
  *   pcg_states != NULL: numpy streams; (perm_end-perm_begin) rows [state_hi,state_lo,inc_hi,inc_lo] of the PCG64

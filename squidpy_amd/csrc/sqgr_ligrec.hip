@@ -203,7 +203,7 @@ int sqgr_ligrec_counts(sqgr_ctx* ctx, int64_t n_cells, int32_t n_genes, int32_t 
     SQGR_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     ShufflerGuard sh;
-    SQGR_TRY(label_shuffler_create(ctx, n_cells, clustering, K, &sh.s));  // validates the labels, K in [2, 2048]
+    SQGR_TRY(label_shuffler_create(ctx, n_cells, clustering, K, &sh.s));  // validates the labels, K in [2, 65535]
     // more than 256 clusters: 16-bit labels from the generators, the group sums in cluster tiles of at most 255 (+ one bucket
     // for the cells of the other tiles), the same permutation behind every tile
     const bool wide = label_shuffler_wide(sh.s);

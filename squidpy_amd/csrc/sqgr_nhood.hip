@@ -377,10 +377,11 @@ template <bool HAS_LIBS>
 __global__ __launch_bounds__(256) void k_shuffle16(int64_t n, const uint32_t* __restrict__ cum, int kpad, int blk_words, int K,
                                                    const uint32_t* __restrict__ keys, LibDom dom0, int n_libs,
                                                    const int32_t* __restrict__ lib_of, const int32_t* __restrict__ rank_of,
-                                                   const LibDom* __restrict__ libdoms, uint16_t* __restrict__ slab_all) {
+                                                   const LibDom* __restrict__ libdoms, uint16_t* __restrict__ slab_all, int tab_lds) {
     extern __shared__ uint32_t s_lds[];
     uint32_t* s_cum = s_lds + blk_words;
-    for (int t = threadIdx.x; t < n_libs * kpad; t += 256) s_cum[t] = cum[t];
+    if (tab_lds)  // (else: the boundaries stay in global memory — sqgr_nhood::tab_lds)
+        for (int t = threadIdx.x; t < n_libs * kpad; t += 256) s_cum[t] = cum[t];
     for (int t = threadIdx.x; t < blk_words; t += 256) s_lds[t] = cum[n_libs * kpad + t];
     __syncthreads();
     constexpr int B = 16;
@@ -397,6 +398,7 @@ __global__ __launch_bounds__(256) void k_shuffle16(int64_t n, const uint32_t* __
         }
         const FeistelDomain dom = ld.dom;
         const uint32_t* tab = s_cum + lib * kpad + 1;  // tab[k] = cum[k + 1]
+        const uint32_t* gtab = cum + lib * kpad + 1;   // the same table where it lies in global memory (tab_lds == 0)
         const uint32_t* blk = s_lds + ld.aoff;
         uint32_t ga = x0 / dom.B, gb = x0 - ga * dom.B;
         const uint32_t* gk = kg + (size_t)lib * 8;
@@ -426,9 +428,16 @@ __global__ __launch_bounds__(256) void k_shuffle16(int64_t n, const uint32_t* __
             uint32_t l = (e & 0xFFFFu) + (b >= (e >> 16) ? 1u : 0u);
             if (l >= (uint32_t)K) {  // largest l with cum[l] <= x  <=>  first l with x < tab[l]
                 uint32_t lo = 0, hi = (uint32_t)K - 1u;
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (x < tab[mid]) hi = mid; else lo = mid + 1;
+                if (tab_lds) {
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (x < tab[mid]) hi = mid; else lo = mid + 1;
+                    }
+                } else {
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (x < gtab[mid]) hi = mid; else lo = mid + 1;
+                    }
                 }
                 l = lo;
             }
@@ -1506,6 +1515,7 @@ struct sqgr_nhood {
     }
     size_t keys_stride() const { return (size_t)nbatch * key_words_per_row(B, n_libs); }
     bool wide() const { return K > 256; }  // 16-bit labels, device-scope counters
+    bool tab_lds = true;                   // the label-boundary table fits LDS next to the block table (nhood_build)
     size_t slab_stride() const { return (size_t)nbatch * n * B * (wide() ? 2 : 1); }  // bytes
     DevBuf<uint32_t> partial;
     DevBuf<int64_t> acc_sum;
@@ -1963,8 +1973,11 @@ static int nhood_build(sqgr_ctx* ctx, const sqgr_graph* g, int64_t n, const int3
     *out_plan = nullptr;
     SQGR_REQUIRE(!g || g->ctx == ctx, "graph belongs to a different context");
     SQGR_REQUIRE(K >= 2, "Expected at least `2` clusters, found `%d`.", K);
-    if (K > 2048) {
-        set_error("K=%d > 2048 clusters is not supported by the batched permutation kernels", K);
+    // with a graph: K*K*16 device-scope counters per batch bound the cluster count; the label generators alone (ligrec's
+    // shuffler: no graph) address 16-bit labels
+    if (K > (g ? 2048 : 65535)) {
+        set_error(g ? "K=%d > 2048 clusters is not supported by the batched permutation kernels"
+                    : "K=%d > 65535 clusters: the label generators write 16-bit labels", K);
         return SQGR_ERR_UNSUPPORTED;
     }
     if (n > (int64_t)1 << 27 || (g && g->nnz > (int64_t)0xFFF00000u)) {
@@ -2028,7 +2041,10 @@ static int nhood_build(sqgr_ctx* ctx, const sqgr_graph* g, int64_t n, const int3
             blk_total += doms[l].dom.A;
         }
         p->blk_bytes = (int)blk_total;
-        if ((size_t)p->n_libs * p->kpad * 4 + blk_total * 4 > 150 * 1024) {
+        // the boundary table rides in LDS next to the block table when both fit; the 16-bit generator (more than 256 labels)
+        // otherwise reads the boundaries of its exact route from global memory (thousands of clusters: ligrec's shuffler)
+        p->tab_lds = (size_t)p->n_libs * p->kpad * 4 + blk_total * 4 <= 150 * 1024;
+        if (!p->tab_lds && (K <= 256 || blk_total * 4 > 150 * 1024)) {
             set_error("library/label tables (%zu bytes) exceed the LDS budget of the shuffle kernel",
                       (size_t)p->n_libs * p->kpad * 4 + blk_total * 4);
             rc = SQGR_ERR_UNSUPPORTED;
@@ -2163,7 +2179,7 @@ static int launch_shuffle_raw(sqgr_nhood* p, int B, int nb, const uint32_t* keys
     if (env_blocks && atoi(env_blocks) > 0) per_cu = atoi(env_blocks);
     gx = std::min<unsigned>(gx, (unsigned)(per_cu * std::max(p->ctx->cu_count, 1)) / (unsigned)std::max(nb, 1) + 1);
     LaunchTimer t(p->ctx, p->wide() ? "nhood_shuffle16" : "nhood_shuffle", st);
-    const size_t lds = (size_t)p->n_libs * p->kpad * 4 + (size_t)p->blk_bytes * 4;
+    const size_t lds = (p->tab_lds ? (size_t)p->n_libs * p->kpad * 4 : 0) + (size_t)p->blk_bytes * 4;
     if (p->wide()) {
         if (B != 16) {
             set_error("more than 256 clusters: 16 permutations per pass only");
@@ -2173,11 +2189,11 @@ static int launch_shuffle_raw(sqgr_nhood* p, int B, int nb, const uint32_t* keys
         if (p->has_libs) {
             SQGR_TRY(allow_lds(k_shuffle16<true>, lds));
             k_shuffle16<true><<<dim3(gx, nb), 256, lds, st>>>(p->n, p->cum.p, p->kpad, p->blk_bytes, p->K, keys, p->dom0, p->n_libs, p->lib_of.p,
-                                                              p->rank_of.p, p->libs.p, slab16);
+                                                              p->rank_of.p, p->libs.p, slab16, p->tab_lds ? 1 : 0);
         } else {
             SQGR_TRY(allow_lds(k_shuffle16<false>, lds));
             k_shuffle16<false><<<dim3(gx, nb), 256, lds, st>>>(p->n, p->cum.p, p->kpad, p->blk_bytes, p->K, keys, p->dom0, p->n_libs, p->lib_of.p,
-                                                               p->rank_of.p, p->libs.p, slab16);
+                                                               p->rank_of.p, p->libs.p, slab16, p->tab_lds ? 1 : 0);
         }
         SQGR_HIP(hipGetLastError());
         return SQGR_OK;
@@ -2620,10 +2636,6 @@ namespace sqgr {
 
 int label_shuffler_create(sqgr_ctx* ctx, int64_t n, const int32_t* labels, int K, LabelShuffler** out) {
     SQGR_REQUIRE(ctx && labels && out && n > 0, "ctx/labels/out is NULL or n <= 0");
-    if (K > 2048) {
-        set_error("K=%d > 2048 clusters: the label generators address at most 2048 label boundaries", K);
-        return SQGR_ERR_UNSUPPORTED;
-    }
     SQGR_HIP(hipSetDevice(ctx->device));
     sqgr_nhood* plan = nullptr;
     SQGR_TRY(nhood_build(ctx, nullptr, n, labels, K, nullptr, 0, &plan));

@@ -18,7 +18,7 @@ int label_shuffler_philox(LabelShuffler* s, uint64_t seed, int64_t perm0, int nb
 // q < pc.  states_dev: pc rows [state_hi, state_lo, inc_hi, inc_lo] on the device.
 int label_shuffler_pcg64(LabelShuffler* s, const uint64_t* states_dev, int64_t pc, int64_t stride, uint8_t* W, hipStream_t st);
 
-// More than 256 labels (K <= 2048): 16-bit label rows of 16 permutations, slab16[(q*n + i)*16 + b] = label of item i in
+// More than 256 labels (K <= 65535 without a graph): 16-bit label rows of 16 permutations, slab16[(q*n + i)*16 + b] = label of item i in
 // permutation perm0 + q*16 + b (device generator; keys_ws: nb * label_shuffler_key_words16() words) or in the permutation
 // generator q*16 + b yields (numpy streams; labels of generators >= pc are 0).
 bool label_shuffler_wide(const LabelShuffler* s);

@@ -260,8 +260,8 @@ class PermutationTest:
         the device, i.e. Squidpy's p-values for that ``seed``; ``rng='philox'`` shuffles with the device generator keyed by
         ``(seed, permutation)`` (throughput mode, another stream).
 
-        Limits of the GPU path: at most ``2048`` clusters among the requested cluster pairs (``NotImplementedError`` beyond;
-        the reference has no limit; more than 256 run in cluster tiles of 255 on 16-bit labels); a subset that resolves to a single cluster is computed on the host like the reference does."""
+        Limits of the GPU path: at most ``65535`` clusters among the requested cluster pairs (16-bit labels; ``NotImplementedError``
+        beyond; the reference has no limit; more than 256 run in cluster tiles of 255); a subset that resolves to a single cluster is computed on the host like the reference does."""
         assert_positive(n_perms, name="n_perms")
         _assert_categorical_obs(self._adata, key=cluster_key)
         if rng not in ("philox", "numpy"):
@@ -373,10 +373,10 @@ class PermutationTest:
         means = np.where(nonzero, (m_rec + m_lig) / 2.0, 0.0)
         obs = m_rec + m_lig
 
-        if n_cls > 2048:
+        if n_cls > 65535:
             raise NotImplementedError(
-                f"`{n_cls}` clusters: the label generators of the GPU path address at most `2048` clusters per call (there is no CPU "
-                "fallback); restrict `clusters` to at most 2048."
+                f"`{n_cls}` clusters: the label generators of the GPU path write 16-bit labels, at most `65535` clusters per call "
+                "(there is no CPU fallback); restrict `clusters`."
             )
         if n_cls == 1:
             # A cluster subset that resolves to ONE cluster (e.g. clusters=[("A", "A")]): the reference has no check here and

@@ -112,6 +112,30 @@ def test_more_than_256_clusters_in_tiles(L, ctx):
     np.testing.assert_array_equal(got, sum(parts))
 
 
+@pytest.mark.parametrize("k", [3000, 40000])
+def test_thousands_of_clusters(L, ctx, k):
+    """More than 2048 clusters (the reference has no limit, gr/_ligrec.py:616-673): the shufflers address 16-bit labels; at
+    40 000 clusters the label-boundary table no longer fits LDS next to the block table and the device generator's exact
+    route reads it from global memory.  Counts and group means bit for bit like the oracle's, both generators."""
+    n, g = 45000, 4
+    data, cl, inter, cp = _problem(n, g, k, seed=77, density=0.6, n_inter=6, pairs=[(0, 1)])
+    rng = np.random.default_rng(8)
+    cp = np.stack([rng.integers(0, k, 400), rng.integers(0, k, 400)], axis=1).astype(np.int32)
+    cp[:4] = [(0, k - 1), (k - 1, 0), (254, 255), (2048, 2049)]
+    pre = O.ligrec_prepare(data, cl, inter, cp, threshold=0.0)
+    labels = O.ligrec_perm_labels_numpy(cl, 11, 20)
+    want = O.ligrec_score_permutations(data, labels, pre["inv_counts"], pre["mean_obs"], inter, cp, pre["valid"])
+    got, groups = _device_counts(L, ctx, data, cl, k, inter, cp, pre, pcg_states=pcg64_states(11, 20), perm_begin=0, perm_end=20, return_first_groups=True)
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(groups, O.ligrec_group_means(data, labels[0], pre["inv_counts"]))
+    assert want.sum() > 0
+    labels = O.ligrec_perm_labels_philox(cl, 5, 3, 3 + 20)
+    want = O.ligrec_score_permutations(data, labels, pre["inv_counts"], pre["mean_obs"], inter, cp, pre["valid"])
+    got, groups = _device_counts(L, ctx, data, cl, k, inter, cp, pre, seed=5, perm_begin=3, perm_end=23, return_first_groups=True)
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(groups, O.ligrec_group_means(data, labels[0], pre["inv_counts"]))
+
+
 def test_permutation_ranges_add_up(L, ctx):
     """Sharding invariance: counts over [0, P) equal the sum over any split (what the multi-GPU path relies on)."""
     data, cl, inter, cp = _problem(350, 8, 6, seed=9)
