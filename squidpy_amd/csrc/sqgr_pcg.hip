@@ -880,6 +880,450 @@ __global__ __launch_bounds__(PCGB_THREADS) void k_pcg_apply_bucketed(int64_t row
     }
 }
 
+// ---- the replay with exact claims (round 6): bitmaps instead of hashed tags, contested records deferred ------------------
+// k_pcg_apply_bucketed's rounds are spent on FALSE conflicts: 2048 records claim 3328 hashed tag slots, 46 % lose the first round
+// to a record with another position, ~4.4 barrier rounds per chunk — while only 3-6 % of a chunk's records really share a
+// position with another record of the chunk.  This kernel claims positions EXACTLY, one bit per position of the window (8 KB):
+//   claim   every record ORs the bit(s) of its position(s) into the claim bitmap A (ds_or_rtn); a record that finds a bit already
+//           set knows it is contested and sets the bit(s) in the poison bitmap B — which also tells the first arriver;
+//   apply   (behind a barrier) a record with none of its positions in B swaps at once — it is the only record of the chunk on
+//           them and every earlier record on them has gone; the others are DEFERRED: appended to a queue in LDS with their
+//           time index (chunk << 11 | slot), their positions stay poisoned, so later records that touch them queue up behind
+//           them (a queued record and a later unqueued one never share a position: they commute);
+//   drain   when the list ends (the range's bytes leave LDS) or the queue is half full: the queued records go in the priority
+//           rounds of the old kernel (hashed tags, atomic max of epoch | earliest time index, the i-side rule of the window
+//           range) — a few hundred records on 2 x 1024 slots (they alias the claim bitmap, which is all zero between chunks);
+//           each clears its words of B.
+// A chunk costs two barrier intervals instead of ~4.4 rounds, a list one drain of ~4-6 rounds.  A record that finds the queue
+// full stays with its lane and joins the drain that follows at once (slots a / b of the drain: robust for any stream).
+constexpr int PCGQ_CAP = 1024;     // queue entries (4 + 2 bytes each)
+constexpr int PCGQ_SLOTS = 1024;   // conflict tags per buffer of a drain (two buffers = the 8 KB of the claim bitmap at S = 65536)
+constexpr int PCGQ_TAG_BYTES = 2 * PCGQ_SLOTS * 4;
+constexpr int PCGQ_NSUB = 4;       // chunks per super-chunk of record loads
+
+__host__ __device__ inline uint32_t pcgq_bitmap_bytes(uint32_t S) { return S / 8u < 16u ? 16u : S / 8u; }
+__host__ __device__ inline uint32_t pcgq_claim_bytes(uint32_t S) { return pcgq_bitmap_bytes(S) < (uint32_t)PCGQ_TAG_BYTES ? (uint32_t)PCGQ_TAG_BYTES : pcgq_bitmap_bytes(S); }
+static size_t pcgq_lds_bytes(uint32_t S, int bcap) {
+    return 2 * (size_t)S + pcgq_claim_bytes(S) + pcgq_bitmap_bytes(S) + (size_t)PCGQ_CAP * 6 + (size_t)bcap * 4;
+}
+
+#ifdef SQGR_PCG_PROFILE
+// developer build (tools/pcg_profile.sh): shader-clock time per section, counts of chunks / drains / drain rounds / queued records
+__device__ unsigned long long g_pcgq_prof[16];
+#define PCGQ_T0() unsigned long long t0__ = __builtin_amdgcn_s_memtime()
+#define PCGQ_ACC(SLOT)                                                          \
+    do {                                                                        \
+        const unsigned long long t1__ = __builtin_amdgcn_s_memtime();           \
+        if (tid == 0) atomicAdd(&g_pcgq_prof[SLOT], t1__ - t0__);               \
+        t0__ = t1__;                                                            \
+    } while (0)
+#define PCGQ_CNT(SLOT, V)                                                       \
+    do {                                                                        \
+        if (tid == 0) atomicAdd(&g_pcgq_prof[SLOT], (unsigned long long)(V));   \
+    } while (0)
+#else
+#define PCGQ_T0() do {} while (0)
+#define PCGQ_ACC(SLOT) do {} while (0)
+#define PCGQ_CNT(SLOT, V) do {} while (0)
+#endif
+
+__global__ __launch_bounds__(PCGB_THREADS) void k_pcg_apply_claims(int64_t row_stride, int n_libs, const uint32_t* __restrict__ lib_off,
+                                                                   const uint32_t* __restrict__ lib_phase, const uint8_t* __restrict__ base_pos,
+                                                                   int64_t P, PcgBucketGeom geo, const uint32_t* __restrict__ recs,
+                                                                   const uint32_t* __restrict__ dir, const uint32_t* __restrict__ nblk,
+                                                                   uint8_t* __restrict__ R) {
+    extern __shared__ unsigned char s_dyn[];
+    const uint32_t logS = (uint32_t)geo.logS, S = 1u << logS;
+    uint8_t* const Xw = s_dyn;                                                   // the phase's window: positions [f*S, (f+1)*S)
+    uint8_t* const Xr = s_dyn + S;                                               // one range r < f
+    uint32_t* const A = reinterpret_cast<uint32_t*>(s_dyn + 2 * (size_t)S);      // claim bitmap of the chunk; a drain's tags [2][PCGQ_SLOTS]
+    uint32_t* const Bm = A + pcgq_claim_bytes(S) / 4;                            // poison bitmap: positions of the queued records
+    uint32_t* const Qrec = Bm + pcgq_bitmap_bytes(S) / 4;                        // queue: records ...
+    uint16_t* const Qprio = reinterpret_cast<uint16_t*>(Qrec + PCGQ_CAP);        // ... and their time index (chunk << 11 | slot)
+    uint32_t* const blist = reinterpret_cast<uint32_t*>(Qprio + PCGQ_CAP);       // [bcap] block | count << 16, sorted by (range, ordinal)
+    __shared__ uint32_t s_wave_any[2][PCGB_THREADS / 64];
+    __shared__ uint32_t s_hist[PCGB_MAX_RANGES], s_start[PCGB_MAX_RANGES + 1];
+    __shared__ uint8_t s_dirty[PCGB_MAX_RANGES];
+    __shared__ uint32_t s_qcount, s_spill;
+    const int tid = threadIdx.x;
+    const uint32_t L = (uint32_t)tid;
+    const uint32_t claim_words = pcgq_claim_bytes(S) / 4, bm_words = pcgq_bitmap_bytes(S) / 4;
+    for (int64_t p = blockIdx.x; p < P; p += gridDim.x) {
+        const uint32_t* const rec_p = recs + (size_t)p * geo.phases * geo.bcap * 64;
+        const uint32_t* const dir_p = dir + (size_t)p * geo.phases * geo.bcap;
+        const uint32_t* const nblk_p = nblk + (size_t)p * geo.phases;
+        uint8_t* const row = R + p * row_stride;
+        __syncthreads();
+        for (uint32_t k = L; k < claim_words + bm_words; k += PCGB_THREADS) A[k] = 0u;  // (Bm follows A)
+        if (tid == 0) {
+            s_qcount = 0u;
+            s_spill = 0u;
+        }
+        for (int l = 0; l < n_libs; ++l) {
+            const uint32_t off = lib_off[l];
+            const uint32_t m = lib_off[l + 1] - off;
+            if (m == 0u) continue;
+            if (m == 1u) {
+                if (tid == 0) row[off] = base_pos[off];
+                continue;
+            }
+            const uint32_t F = (m + S - 1u) >> logS;
+            __syncthreads();
+            if (tid < PCGB_MAX_RANGES) s_dirty[tid] = 0;
+            for (uint32_t ff = F; ff-- > 0u;) {
+                const uint32_t f = ff;
+                const uint32_t ph = lib_phase[l] + f;
+                const uint32_t wlen = min(S, m - (f << logS));
+                __syncthreads();
+                PCGQ_T0();
+                pcgb_copy_in(Xw, (s_dirty[f] ? row : base_pos) + off + ((size_t)f << logS), wlen, tid);
+                if (tid < PCGB_MAX_RANGES) s_hist[tid] = 0u;
+                __syncthreads();
+                const uint32_t nb = nblk_p[ph];
+                for (uint32_t t = L; t < nb; t += PCGB_THREADS) atomicAdd(&s_hist[dir_p[(size_t)ph * geo.bcap + t] & 0xffu], 1u);
+                __syncthreads();
+                if (tid == 0) {
+                    uint32_t acc = 0;
+                    for (uint32_t r = 0; r <= f; ++r) {
+                        s_start[r] = acc;
+                        acc += s_hist[r];
+                    }
+                    s_start[f + 1] = acc;
+                }
+                __syncthreads();
+                for (uint32_t t = L; t < nb; t += PCGB_THREADS) {
+                    const uint32_t e = dir_p[(size_t)ph * geo.bcap + t];
+                    blist[s_start[e & 0xffu] + (e >> 16)] = t | (((e >> 8) & 0xffu) << 16);
+                }
+                __syncthreads();
+                // (range order, the two software pipelines — next chunk's records, next range's bytes — as in k_pcg_apply_bucketed)
+                auto range_of = [&](uint32_t rr) { return rr == 0u ? f : rr - 1u; };
+                auto next_range = [&](uint32_t rr) {
+                    for (++rr; rr <= f && s_hist[range_of(rr)] == 0u; ++rr) {}
+                    return rr;
+                };
+                uint4 pre0, pre1, pre2, pre3;
+                pre0 = pre1 = pre2 = pre3 = make_uint4(0u, 0u, 0u, 0u);
+                auto range_src = [&](uint32_t rr) { return (s_dirty[range_of(rr)] ? row : base_pos) + off + ((size_t)range_of(rr) << logS); };
+                const uint32_t n16 = S >> 4;
+#define SQGR_PCGQ_PREFETCH(RR, OK)                                                                            \
+    do {                                                                                                      \
+        OK = false;                                                                                           \
+        const uint32_t rr__ = (RR);                                                                           \
+        if (rr__ <= f && rr__ != 0u && S >= 16u) {                                                            \
+            const uint4* src__ = reinterpret_cast<const uint4*>(range_src(rr__));                             \
+            if ((reinterpret_cast<uintptr_t>(src__) & 15u) == 0u) {                                           \
+                if ((uint32_t)tid < n16) pre0 = src__[tid];                                                   \
+                if ((uint32_t)tid + 1024u < n16) pre1 = src__[tid + 1024];                                    \
+                if ((uint32_t)tid + 2048u < n16) pre2 = src__[tid + 2048];                                    \
+                if ((uint32_t)tid + 3072u < n16) pre3 = src__[tid + 3072];                                    \
+                OK = true;                                                                                    \
+            }                                                                                                 \
+        }                                                                                                     \
+    } while (0)
+                // The records of a list are loaded a SUPER-CHUNK (PCGQ_NSUB chunks) at a time, the next super-chunk's loads issued
+                // right behind the wait for this one's: a chunk is two short barrier intervals, far less than an HBM round trip, and
+                // the compiler's wait for conditionally issued loads is vmcnt(0) — with one chunk in flight per wait (the shape of
+                // k_pcg_apply_bucketed) every chunk paid the whole latency.
+                uint32_t rr = s_hist[f] != 0u ? 0u : next_range(0u), c0 = 0;
+                auto load_super = [&](uint32_t rrx, uint32_t s0, uint32_t (&out)[2 * PCGQ_NSUB], uint32_t& hv) {
+                    hv = 0u;
+                    const bool any = rrx <= f;
+                    const uint32_t r = any ? range_of(rrx) : 0u;
+                    const uint32_t nbr = any ? s_hist[r] : 0u, st0 = s_start[r];
+#pragma unroll
+                    for (int q = 0; q < 2 * PCGQ_NSUB; ++q) {  // sub-chunk q / 2: record a (blocks s0 + 32 (q/2) + wave) | b (+ 16)
+                        const uint32_t bi = s0 + 16u * (uint32_t)q + (L >> 6);
+                        const bool in = bi < nbr;
+                        const uint32_t e = blist[in ? st0 + bi : 0u];
+                        const bool ok = in && (L & 63u) < (e >> 16);
+                        const uint32_t* src = rec_p + ((size_t)ph * geo.bcap + (e & 0xffffu)) * 64 + (L & 63u);
+                        const uint32_t v = *(ok ? src : rec_p);  // unconditional load: the eight of them issue back to back
+                        out[q] = ok ? v : 0u;
+                        hv |= ok ? (1u << q) : 0u;
+                    }
+                };
+                uint32_t cur[2 * PCGQ_NSUB], nxt[2 * PCGQ_NSUB], cur_hv = 0u, nxt_hv = 0u;
+                load_super(rr, c0, cur, cur_hv);
+                PCGQ_ACC(0);
+                bool pre_ok = false;
+                uint32_t seq = 0;  // chunks since the last drain (5 bits of the time index)
+                while (rr <= f) {
+                    const uint32_t r = range_of(rr), nbr = s_hist[r];
+                    const bool internal = rr == 0u;
+                    uint8_t* const X2 = internal ? Xw : Xr;
+                    const bool last_super = c0 + PCGQ_NSUB * PCGB_CHUNK_BLOCKS >= nbr;
+                    const uint32_t rr_n = last_super ? next_range(rr) : rr, c0_n = last_super ? 0u : c0 + PCGQ_NSUB * PCGB_CHUNK_BLOCKS;
+                    if (c0 == 0u) {  // entering range r
+#if defined(SQGR_PCG_ABLATE) && (SQGR_PCG_ABLATE & 2)
+                        if (false) {
+#else
+                        if (!internal) {
+#endif
+                            if (pre_ok) {
+                                uint4* dst = reinterpret_cast<uint4*>(Xr);
+                                if ((uint32_t)tid < n16) dst[tid] = pre0;
+                                if ((uint32_t)tid + 1024u < n16) dst[tid + 1024] = pre1;
+                                if ((uint32_t)tid + 2048u < n16) dst[tid + 2048] = pre2;
+                                if ((uint32_t)tid + 3072u < n16) dst[tid + 3072] = pre3;
+                            } else {
+                                pcgb_copy_in(Xr, range_src(rr), S, tid);
+                            }
+                        }
+#if !(defined(SQGR_PCG_ABLATE) && (SQGR_PCG_ABLATE & 2))
+                        SQGR_PCGQ_PREFETCH(next_range(rr), pre_ok);  // in flight while this range is replayed
+#endif
+                        PCGQ_ACC(1);
+                    }
+                    // touch this super-chunk's records (the wait lands here), then put the next one's loads in flight
+                    {
+                        uint32_t acc = cur_hv;
+#pragma unroll
+                        for (int q = 0; q < 2 * PCGQ_NSUB; ++q) acc |= cur[q];
+                        asm volatile("" ::"v"(acc));
+                    }
+                    PCGQ_ACC(12);
+                    load_super(rr_n, c0_n, nxt, nxt_hv);
+                    PCGQ_ACC(13);
+                    auto chunk = [&](const uint32_t rec_a, const uint32_t rec_b, const bool have_a, const bool have_b, const bool last_chunk) {
+                        const uint32_t ja = rec_a & 0xffffu, ia = rec_a >> 16, jb = rec_b & 0xffffu, ib = rec_b >> 16;
+                        // a swap of a position with itself changes nothing and claims nothing
+#if defined(SQGR_PCG_ABLATE) && (SQGR_PCG_ABLATE & 4)  // timing experiment (wrong results): no record claims or swaps anything
+                        const bool act_a = have_a && ia == 0x12345u, act_b = have_b && ib == 0x12345u;
+#else
+                        const bool act_a = have_a && !(internal && ia == ja), act_b = have_b && !(internal && ib == jb);
+#endif
+                        const uint32_t wja = ja >> 5, bja = 1u << (ja & 31u), wia = ia >> 5, bia = 1u << (ia & 31u);
+                        const uint32_t wjb = jb >> 5, bjb = 1u << (jb & 31u), wib = ib >> 5, bib = 1u << (ib & 31u);
+                        // ---- claim
+                        bool conf_a = false, conf_b = false;
+                        {
+                            uint32_t oja = 0, oia = 0, ojb = 0, oib = 0;
+                            if (act_a) oja = atomicOr(&A[wja], bja);
+                            if (act_b) ojb = atomicOr(&A[wjb], bjb);
+                            if (internal) {
+                                if (act_a) oia = atomicOr(&A[wia], bia);
+                                if (act_b) oib = atomicOr(&A[wib], bib);
+                            }
+                            conf_a = ((oja & bja) | (oia & bia)) != 0u;
+                            conf_b = ((ojb & bjb) | (oib & bib)) != 0u;
+                            if (conf_a) {
+                                atomicOr(&Bm[wja], bja);
+                                if (internal) atomicOr(&Bm[wia], bia);
+                            }
+                            if (conf_b) {
+                                atomicOr(&Bm[wjb], bjb);
+                                if (internal) atomicOr(&Bm[wib], bib);
+                            }
+                        }
+                        __syncthreads();  // (also: the range's bytes stored above are in place)
+                        PCGQ_ACC(2);
+                        PCGQ_CNT(8, 1);
+                        // ---- apply or defer
+                        bool def_a = false, def_b = false;
+                        if (act_a) {
+                            uint32_t pb = Bm[wja] & bja;
+                            if (internal) pb |= Bm[wia] & bia;
+                            def_a = conf_a || pb != 0u;
+                            A[wja] = 0u;
+                            if (internal) A[wia] = 0u;
+                            if (!def_a) {
+                                const uint8_t vi = Xw[ia], vj = X2[ja];
+                                Xw[ia] = vj;
+                                X2[ja] = vi;
+                            } else if (!conf_a && internal) {  // queued behind a poisoned position: its other position is poisoned too
+                                atomicOr(&Bm[wja], bja);
+                                atomicOr(&Bm[wia], bia);
+                            }
+                        }
+                        if (act_b) {  // after this lane's own record a (had they shared a position, both would be deferred)
+                            uint32_t pb = Bm[wjb] & bjb;
+                            if (internal) pb |= Bm[wib] & bib;
+                            def_b = conf_b || pb != 0u;
+                            A[wjb] = 0u;
+                            if (internal) A[wib] = 0u;
+                            if (!def_b) {
+                                const uint8_t vi = Xw[ib], vj = X2[jb];
+                                Xw[ib] = vj;
+                                X2[jb] = vi;
+                            } else if (!conf_b && internal) {
+                                atomicOr(&Bm[wjb], bjb);
+                                atomicOr(&Bm[wib], bib);
+                            }
+                        }
+                        const uint32_t prio_a = (seq << 11) | L, prio_b = (seq << 11) | (1024u + L);
+                        bool sp_a = false, sp_b = false;  // deferred, but the queue was full: the record stays with the lane
+                        {
+                            const uint64_t ma = __ballot(def_a), mb = __ballot(def_b);
+                            if ((ma | mb) != 0ull) {
+                                const uint32_t na = (uint32_t)__popcll(ma), nq2 = na + (uint32_t)__popcll(mb);
+                                uint32_t base = 0;
+                                if ((L & 63u) == 0u) base = atomicAdd(&s_qcount, nq2);
+                                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                                if (def_a) {
+                                    const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(ma >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ma, 0u));
+                                    if (slot < (uint32_t)PCGQ_CAP) {
+                                        Qrec[slot] = rec_a;
+                                        Qprio[slot] = (uint16_t)prio_a;
+                                    } else {
+                                        sp_a = true;
+                                    }
+                                }
+                                if (def_b) {
+                                    const uint32_t slot = base + na + __builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0u));
+                                    if (slot < (uint32_t)PCGQ_CAP) {
+                                        Qrec[slot] = rec_b;
+                                        Qprio[slot] = (uint16_t)prio_b;
+                                    } else {
+                                        sp_b = true;
+                                    }
+                                }
+                                if (sp_a || sp_b) s_spill = 1u;
+                            }
+                        }
+                        __syncthreads();
+                        PCGQ_ACC(3);
+                        const uint32_t qc = s_qcount;
+                        const bool spill = s_spill != 0u;
+                        ++seq;
+                        if (qc == 0u && !spill) {
+                            seq = 0;  // nothing is queued: the time index restarts
+                        } else if (last_chunk || qc > (uint32_t)PCGQ_CAP / 2u || spill || seq == 32u) {
+                            // ---- drain: the queued records (lane L: entry L) and the spilled ones in priority rounds
+                            const uint32_t nq = min(qc, (uint32_t)PCGQ_CAP);
+                            PCGQ_CNT(9, 1);
+                            PCGQ_CNT(11, qc);
+                            const bool was_q = L < nq;
+                            const uint32_t rec_q = was_q ? Qrec[L] : 0u;
+                            const uint32_t prio_q = was_q ? (uint32_t)Qprio[L] : 0u;
+                            const uint32_t jq = rec_q & 0xffffu, iq = rec_q >> 16;
+                            const uint32_t hjq = __umulhi(jq * 2654435761u, (uint32_t)PCGQ_SLOTS), hiq = __umulhi(iq * 2654435761u, (uint32_t)PCGQ_SLOTS);
+                            const uint32_t hja = __umulhi(ja * 2654435761u, (uint32_t)PCGQ_SLOTS), hia = __umulhi(ia * 2654435761u, (uint32_t)PCGQ_SLOTS);
+                            const uint32_t hjb = __umulhi(jb * 2654435761u, (uint32_t)PCGQ_SLOTS), hib = __umulhi(ib * 2654435761u, (uint32_t)PCGQ_SLOTS);
+                            bool pend_q = was_q, pend_a = sp_a, pend_b = sp_b;
+                            const bool any_sp = spill;  // uniform over the workgroup
+                            uint32_t ep = 0;
+#if defined(SQGR_PCG_ABLATE) && (SQGR_PCG_ABLATE & 1)  // timing experiment (wrong results): the drain without its rounds
+                            pend_q = pend_a = pend_b = false;
+#endif
+                            // wavefronts without a record (lane L holds queue entry L: all but the first few) only keep the barriers
+                            // company — out of the way of the SIMDs' instruction issue
+                            if ((L & ~63u) >= nq && !any_sp) {
+                                for (;;) {
+                                    ++ep;
+                                    if ((L & 63u) == 0u) s_wave_any[ep & 1u][L >> 6] = 0u;
+                                    __syncthreads();
+                                    const uint32_t wa = s_wave_any[ep & 1u][L & (PCGB_THREADS / 64 - 1)];
+                                    if (__ballot(wa != 0u) == 0ull) break;
+                                }
+                            } else
+                            for (;;) {
+                                ++ep;
+                                PCGQ_CNT(10, 1);
+                                uint32_t* const T = A + (ep & 1u) * PCGQ_SLOTS;
+                                const uint32_t mine_q = (ep << 16) | (0xffffu - prio_q);
+                                const uint32_t mine_a = (ep << 16) | (0xffffu - prio_a), mine_b = (ep << 16) | (0xffffu - prio_b);
+                                if (pend_q) atomicMax(&T[hjq], mine_q);
+                                if (any_sp) {
+                                    if (pend_a) atomicMax(&T[hja], mine_a);
+                                    if (pend_b) atomicMax(&T[hjb], mine_b);
+                                }
+                                const bool wave_pending = __ballot(pend_q || pend_a || pend_b) != 0ull;
+                                if ((L & 63u) == 0u) s_wave_any[ep & 1u][L >> 6] = wave_pending ? 1u : 0u;
+                                __syncthreads();
+                                const uint32_t wa = s_wave_any[ep & 1u][L & (PCGB_THREADS / 64 - 1)];
+                                uint32_t tq = 0, tiq = 0;
+                                if (pend_q) {
+                                    tq = T[hjq];
+                                    if (internal) tiq = T[hiq];
+                                }
+                                if (__ballot(wa != 0u) == 0ull) break;  // uniform over the workgroup
+                                // a record goes when it is the earliest pending record on its j slot and — window range — no earlier
+                                // pending record writes to its i position
+                                bool go_q = pend_q && tq == mine_q;
+                                if (internal) go_q = go_q && ((tiq >> 16) != ep || (0xffffu - (tiq & 0xffffu)) >= prio_q);
+                                if (go_q) {  // (and clears its words of the poison bitmap: all of B's bits belong to drained records)
+                                    const uint8_t vi = Xw[iq], vj = X2[jq];
+                                    Xw[iq] = vj;
+                                    X2[jq] = vi;
+                                    Bm[jq >> 5] = 0u;
+                                    if (internal) Bm[iq >> 5] = 0u;
+                                    pend_q = false;
+                                }
+                                if (any_sp) {  // (a lane's spilled records are later than every queued one it could share a position with)
+                                    uint32_t ta = 0, tia = 0, tb = 0, tib = 0;
+                                    if (pend_a) {
+                                        ta = T[hja];
+                                        if (internal) tia = T[hia];
+                                    }
+                                    if (pend_b) {
+                                        tb = T[hjb];
+                                        if (internal) tib = T[hib];
+                                    }
+                                    bool go_a = pend_a && ta == mine_a, go_b = pend_b && tb == mine_b;
+                                    if (internal) {
+                                        go_a = go_a && ((tia >> 16) != ep || (0xffffu - (tia & 0xffffu)) >= prio_a);
+                                        go_b = go_b && ((tib >> 16) != ep || (0xffffu - (tib & 0xffffu)) >= prio_b);
+                                    }
+                                    if (go_a) {
+                                        const uint8_t vi = Xw[ia], vj = X2[ja];
+                                        Xw[ia] = vj;
+                                        X2[ja] = vi;
+                                        Bm[wja] = 0u;
+                                        if (internal) Bm[wia] = 0u;
+                                        pend_a = false;
+                                    }
+                                    if (go_b) {
+                                        const uint8_t vi = Xw[ib], vj = X2[jb];
+                                        Xw[ib] = vj;
+                                        X2[jb] = vi;
+                                        Bm[wjb] = 0u;
+                                        if (internal) Bm[wib] = 0u;
+                                        pend_b = false;
+                                    }
+                                }
+                            }
+                            // the tags go back to zero — the region is the claim bitmap again (the last round registered nothing and what a
+                            // slow wavefront still reads of it is not used: no barrier in front)
+                            for (uint32_t k = L; k < 2u * PCGQ_SLOTS; k += PCGB_THREADS) A[k] = 0u;
+                            if (tid == 0) {
+                                s_qcount = 0u;
+                                s_spill = 0u;
+                            }
+                            seq = 0;
+                            __syncthreads();
+                            PCGQ_ACC(4);
+                        }
+                    };
+#pragma unroll
+                    for (int t = 0; t < PCGQ_NSUB; ++t) {
+                        if (t > 0 && c0 + (uint32_t)t * PCGB_CHUNK_BLOCKS >= nbr) break;  // uniform
+                        chunk(cur[2 * t], cur[2 * t + 1], (cur_hv >> (2 * t)) & 1u, (cur_hv >> (2 * t + 1)) & 1u,
+                              c0 + (uint32_t)(t + 1) * PCGB_CHUNK_BLOCKS >= nbr);
+                    }
+                    if (last_super && !internal) {
+#if !(defined(SQGR_PCG_ABLATE) && (SQGR_PCG_ABLATE & 2))  // timing experiment (wrong results): ranges neither loaded nor stored
+                        pcgb_copy_out(row + off + ((size_t)r << logS), Xr, S, tid);
+#endif
+                        if (tid == 0) s_dirty[r] = 1;
+                        __syncthreads();
+                        PCGQ_ACC(5);
+                    }
+                    rr = rr_n;
+                    c0 = c0_n;
+#pragma unroll
+                    for (int q = 0; q < 2 * PCGQ_NSUB; ++q) cur[q] = nxt[q];
+                    cur_hv = nxt_hv;
+                }
+#undef SQGR_PCGQ_PREFETCH
+                pcgb_copy_out(row + off + ((size_t)f << logS), Xw, wlen, tid);  // positions of this phase are final
+                PCGQ_ACC(6);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // rows R[q][row_stride] (bytes) -> columns W[pos * stride + q]
 __global__ __launch_bounds__(256) void k_rows_to_columns_u8(int64_t n, int64_t row_stride, const uint8_t* __restrict__ R, int64_t P,
                                                             int64_t stride, uint8_t* __restrict__ W) {
@@ -1026,9 +1470,13 @@ static int pcg_shuffle_rows_bucketed(sqgr_ctx* ctx, PcgWorkspace& ws, int64_t n,
             if (atoi(e) >= 64) slots = std::min<int64_t>(atoi(e), std::max<int64_t>(room / 8, PCGB_SLOTS));
         geo.slots = (int)slots;
     }
-    const size_t lds_a = 2 * (size_t)S + (size_t)2 * geo.slots * 4 + (size_t)geo.bcap * 4;
+    // replay kernel: exact claims + deferred queue (default), or rounds 4-5's hashed tags (SQGR_PCG_APPLY=tags)
+    const char* apply_env = getenv("SQGR_PCG_APPLY");  // (read at every call: tools/pcg_bucket_time.py compares the two)
+    const bool use_claims = !(apply_env && strcmp(apply_env, "tags") == 0);
+    const size_t lds_a = use_claims ? pcgq_lds_bytes((uint32_t)S, geo.bcap) : 2 * (size_t)S + (size_t)2 * geo.slots * 4 + (size_t)geo.bcap * 4;
     SQGR_TRY(pcg_allow_lds(k_pcg_draws_bucketed, lds_g));
-    SQGR_TRY(pcg_allow_lds(k_pcg_apply_bucketed, lds_a));
+    if (use_claims) SQGR_TRY(pcg_allow_lds(k_pcg_apply_claims, lds_a));
+    else SQGR_TRY(pcg_allow_lds(k_pcg_apply_bucketed, lds_a));
     const std::string name_g = std::string(timer_name) + "_draws", name_a = std::string(timer_name) + "_apply";
     const int cus = std::max(ctx->cu_count, 1);
     const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, ((size_t)160 << 10) / (lds_a + 1024)));
@@ -1044,8 +1492,27 @@ static int pcg_shuffle_rows_bucketed(sqgr_ctx* ctx, PcgWorkspace& ws, int64_t n,
         {
             LaunchTimer t(ctx, name_a.c_str(), st);
             const unsigned grid = (unsigned)std::min<int64_t>(qc, (int64_t)cus * wg_per_cu);
-            k_pcg_apply_bucketed<<<grid, PCGB_THREADS, lds_a, st>>>(n_pad, n_libs, lib_off_dev, ws.lib_phase.p, base_pos_dev, qc, geo, ws.recs.p, ws.dir.p,
-                                                                    ws.nblk.p, ws.rows.p + (size_t)q0 * n_pad);
+            if (use_claims) {
+#ifdef SQGR_PCG_PROFILE
+                unsigned long long zero[16] = {0};
+                SQGR_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_pcgq_prof), zero, sizeof zero));
+#endif
+                k_pcg_apply_claims<<<grid, PCGB_THREADS, lds_a, st>>>(n_pad, n_libs, lib_off_dev, ws.lib_phase.p, base_pos_dev, qc, geo, ws.recs.p, ws.dir.p,
+                                                                      ws.nblk.p, ws.rows.p + (size_t)q0 * n_pad);
+#ifdef SQGR_PCG_PROFILE
+                unsigned long long prof[16];
+                SQGR_HIP(hipStreamSynchronize(st));
+                SQGR_HIP(hipMemcpyFromSymbol(prof, HIP_SYMBOL(g_pcgq_prof), sizeof prof));
+                fprintf(stderr, "pcgq profile (%lld permutations; shader clocks per permutation): phase setup %.0f, range entry %.0f, record wait %.0f, "
+                        "record issue %.0f, claim %.0f, apply %.0f, drain %.0f, range out %.0f, window out %.0f | per permutation: chunks %.1f, drains %.1f, "
+                        "drain rounds %.1f, queued %.1f\n", (long long)qc, prof[0] / (double)qc, prof[1] / (double)qc, prof[12] / (double)qc,
+                        prof[13] / (double)qc, prof[2] / (double)qc, prof[3] / (double)qc, prof[4] / (double)qc, prof[5] / (double)qc, prof[6] / (double)qc,
+                        prof[8] / (double)qc, prof[9] / (double)qc, prof[10] / (double)qc, prof[11] / (double)qc);
+#endif
+            }
+            else
+                k_pcg_apply_bucketed<<<grid, PCGB_THREADS, lds_a, st>>>(n_pad, n_libs, lib_off_dev, ws.lib_phase.p, base_pos_dev, qc, geo, ws.recs.p, ws.dir.p,
+                                                                        ws.nblk.p, ws.rows.p + (size_t)q0 * n_pad);
             SQGR_HIP(hipGetLastError());
         }
     }
