@@ -655,6 +655,239 @@ __global__ __launch_bounds__(64) void k_pcg_draws_bucketed(int n_libs, const uin
     }
 }
 
+// ---- the draw generator, 128 raw draws per trip (round 6) ---------------------------------------------------------------
+// k_pcg_draws_bucketed spends most of a trip on bookkeeping that does not depend on the number of draws (uniform branches,
+// cursor updates, the stream position: ~250 instructions of which 12 are the 128-bit multiply) and computes every LCG state in
+// two lanes, one per 32-bit half.  Here lane l advances to state l + 1 once and takes BOTH halves — slot 2l (low half) and
+// slot 2l + 1 (high half), numpy's order — so a trip consumes 128 draws (127 when the low half of the first state was used
+// before: after a full trip the stream always stands at a state boundary).  The acceptance, the running count, the phase
+// crossings and the time order of the records appended to a range's list are the ones of the 64-draw kernel, on pairs of lane
+// masks: slot (l, h) comes before (l', h') when l < l' or l == l' and h < h'.
+constexpr int PCGW_TAB2 = 65;     // jump distances 0..64
+// One wavefront per permutation is bound by the latencies of its own instruction stream, so the kernel lives on occupancy (measured:
+// 8 KB more LDS per wavefront cost the 64-draw kernel 49.7 -> 73.4 ms per 8192 permutations).  LDS per wavefront here: a 64-record
+// ring per range (a block goes out the moment it is complete, so a ring never holds more than one) + two lane masks per range +
+// the step list of the one-by-one path = 4.9 KB at 16 ranges (64-draw kernel: 10 KB); the jump constants of lane l never change
+// (state l + 1 of every trip) and stay in registers.
+
+__device__ __forceinline__ uint64_t pcgw_draw2(const U128& s, const U128& a, const U128& d, U128& sk) {
+    sk = add128(mul128_lo(a, s), d);
+    const uint64_t x = sk.hi ^ sk.lo;
+    const unsigned rot = (unsigned)(sk.hi >> 58);
+    return (x >> rot) | (x << ((64u - rot) & 63u));
+}
+// consume `used` slots starting at slot `half`: lane dq - 1 holds state dq
+__device__ __forceinline__ void pcgw_advance2(U128& s, uint32_t& half, const U128& sk, uint32_t used) {
+    const uint32_t hu = half + used;
+    const uint32_t dq = hu >> 1;
+    if (dq > 0u) {
+        s.hi = readlane64(sk.hi, (int)dq - 1);
+        s.lo = readlane64(sk.lo, (int)dq - 1);
+    }
+    half = hu & 1u;
+}
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {  // bits of m below this lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+static size_t pcg_draws2_lds_bytes(int n_ranges) { return (size_t)n_ranges * (64 * 4 + 2 * 8); }
+
+__global__ __launch_bounds__(64) void k_pcg_draws_bucketed2(int n_libs, const uint32_t* __restrict__ lib_off, const uint32_t* __restrict__ lib_phase,
+                                                            const uint64_t* __restrict__ states, const uint64_t* __restrict__ jump, int64_t P,
+                                                            PcgBucketGeom geo, uint32_t* __restrict__ recs, uint32_t* __restrict__ dir,
+                                                            uint32_t* __restrict__ nblk, int force_slow) {
+    extern __shared__ uint32_t s_stage[];  // [n_ranges][64], then the lane masks
+    unsigned long long* const s_lanes0 = reinterpret_cast<unsigned long long*>(s_stage + (size_t)geo.n_ranges * 64);  // per range: lanes whose slot-0 ...
+    unsigned long long* const s_lanes1 = s_lanes0 + geo.n_ranges;                                                     // ... | slot-1 record goes there
+    __shared__ uint32_t sJ[128];
+    const int lane = threadIdx.x;
+    if (lane < geo.n_ranges) {
+        s_lanes0[lane] = 0ull;
+        s_lanes1[lane] = 0ull;
+    }
+    const uint32_t logS = (uint32_t)geo.logS, SM = (1u << logS) - 1u;
+    const int64_t p = blockIdx.x;
+    if (p >= P) return;
+    U128 s, inc;
+    s.hi = states[4 * p + 0];
+    s.lo = states[4 * p + 1];
+    inc.hi = states[4 * p + 2];
+    inc.lo = states[4 * p + 3];
+    U128 ja, jd;  // state_(l+1) = ja * s + jd: A_(l+1) and G_(l+1) * inc
+    {
+        U128 g;
+        ja.hi = jump[4 * (lane + 1) + 0];
+        ja.lo = jump[4 * (lane + 1) + 1];
+        g.hi = jump[4 * (lane + 1) + 2];
+        g.lo = jump[4 * (lane + 1) + 3];
+        jd = mul128_lo(g, inc);
+    }
+    uint32_t* const rec_p = recs + (size_t)p * geo.phases * geo.bcap * 64;
+    uint32_t* const dir_p = dir + (size_t)p * geo.phases * geo.bcap;
+    uint32_t* const nblk_p = nblk + (size_t)p * geo.phases;
+    uint32_t c_cnt = 0, c_ord = 0;  // lane r: range r's staged records (< 64 between appends), blocks flushed in this phase
+    uint32_t nb = 0;   // blocks written in the current phase (uniform)
+    uint32_t ph = 0;   // global index of the current phase (uniform)
+    auto flush_block = [&](uint32_t r0, uint32_t count) {  // uniform arguments
+        const uint32_t v = s_stage[r0 * 64u + (uint32_t)lane];
+        uint32_t* dst = rec_p + ((size_t)ph * geo.bcap + nb) * 64;
+        const uint32_t ordinal = lane_get(c_ord, r0);
+        if ((uint32_t)lane < count) dst[lane] = v;
+        if (lane == 0) dir_p[(size_t)ph * geo.bcap + nb] = r0 | (count << 8) | (ordinal << 16);
+        if ((uint32_t)lane == r0) ++c_ord;
+        ++nb;
+    };
+    auto end_phase = [&](uint32_t f) {  // the partial blocks of ranges 0..f, then the phase's block count
+        for (uint32_t r0 = 0; r0 <= f; ++r0) {
+            const uint32_t cnt = lane_get(c_cnt, r0);
+            if (cnt > 0u) flush_block(r0, cnt);
+        }
+        if (lane == 0) nblk_p[ph] = nb;
+        c_cnt = 0;
+        c_ord = 0;
+        nb = 0;
+    };
+    // append the slot-0 / slot-1 records of the lanes with in0 / in1 set to their ranges' rings in slot order.  A range may receive up
+    // to 128 records on top of the < 64 it holds: they go in passes of one block — write the records that fall into the block being
+    // filled, send the complete blocks out, go on with the next 64 positions.
+    auto append = [&](bool in0, uint32_t iloc0, uint32_t jj0, bool in1, uint32_t iloc1, uint32_t jj1) {
+        const uint32_t r0 = jj0 >> logS, r1 = jj1 >> logS;
+        const unsigned long long bit = 1ull << lane;
+        if (in0) atomicOr(&s_lanes0[r0], bit);
+        if (in1) atomicOr(&s_lanes1[r1], bit);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        unsigned long long a0 = 0ull, a1 = 0ull, b0 = 0ull, b1 = 0ull;
+        if (in0) {
+            a0 = s_lanes0[r0];
+            a1 = s_lanes1[r0];
+        }
+        if (in1) {
+            b0 = s_lanes0[r1];
+            b1 = s_lanes1[r1];
+        }
+        unsigned long long own0 = 0ull, own1 = 0ull;
+        if (lane < geo.n_ranges) {
+            own0 = s_lanes0[lane];
+            own1 = s_lanes1[lane];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (lane < geo.n_ranges) {  // re-armed for the next call
+            s_lanes0[lane] = 0ull;
+            s_lanes1[lane] = 0ull;
+        }
+        // position in the range's list counted from the start of the block being filled: records staged + slots before this one
+        const uint32_t pos0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(r0 << 2), (int)c_cnt) + mbcnt64(a0) + mbcnt64(a1);
+        const uint32_t pos1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(r1 << 2), (int)c_cnt) + mbcnt64(b0) + mbcnt64(b1) + (uint32_t)((b0 >> lane) & 1ull);
+        const uint32_t rec0 = (jj0 & SM) | (iloc0 << 16), rec1 = (jj1 & SM) | (iloc1 << 16);
+        uint32_t tot = c_cnt + (uint32_t)__popcll(own0) + (uint32_t)__popcll(own1);  // lane r: range r's records, staged + new
+        for (uint32_t base = 0;; base += 64u) {
+            if (in0 && pos0 - base < 64u) s_stage[r0 * 64u + (pos0 - base)] = rec0;
+            if (in1 && pos1 - base < 64u) s_stage[r1 * 64u + (pos1 - base)] = rec1;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the rings are read back by other lanes of this wave
+            uint64_t full = __ballot(tot >= base + 64u);
+            if (full == 0ull) break;
+            for (; full != 0ull; full &= full - 1ull) flush_block((uint32_t)__builtin_ctzll(full), 64u);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        c_cnt = tot & 63u;
+    };
+    uint32_t half = 0;
+    U128 sk;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    uint64_t raw = pcgw_draw2(s, ja, jd, sk);
+    for (int l = 0; l < n_libs; ++l) {
+        const uint32_t off = lib_off[l];
+        const uint32_t m = lib_off[l + 1] - off;
+        if (m < 2) continue;
+        uint32_t mask = m - 1;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        uint32_t i = m - 1;
+        uint32_t f_cur = i >> logS;
+        ph = lib_phase[l] + f_cur;
+        while (i >= 1) {
+            uint32_t used = 128u - half, nacc = 0, it = i;
+            bool valid0 = false, valid1 = false;
+            uint32_t ipos0 = 0, ipos1 = 0, jj0 = 0, jj1 = 0;
+            const bool general = force_slow || i < 320u || (mask >> 1) >= i - 128u;
+            if (!general) {
+                // the bound stays above i - 128 and the mask cannot change: a candidate <= i - 128 is accepted, one > i rejected
+                // whatever happened before it; the few in between are decided in slot order from the running count
+                const uint32_t c0 = (uint32_t)raw & mask, c1 = (uint32_t)(raw >> 32) & mask;
+                const bool live0 = !(lane == 0 && half != 0u);  // slot 0 of the first state was consumed before
+                const bool sure0 = live0 && c0 <= i - 128u, sure1 = c1 <= i - 128u;
+                uint64_t amb0 = __ballot(live0 && !sure0 && c0 <= i), amb1 = __ballot(!sure1 && c1 <= i);
+                uint64_t acc0 = __ballot(sure0), acc1 = __ballot(sure1);
+                while ((amb0 | amb1) != 0ull) {
+                    const uint32_t l0 = amb0 ? (uint32_t)__builtin_ctzll(amb0) : 64u, l1 = amb1 ? (uint32_t)__builtin_ctzll(amb1) : 64u;
+                    if (l0 <= l1) {  // slot (l0, 0) comes before slot (l1, 1)
+                        const uint64_t below = (1ull << l0) - 1ull;
+                        const uint32_t before = (uint32_t)__popcll(acc0 & below) + (uint32_t)__popcll(acc1 & below);
+                        if (lane_get(c0, l0) <= i - before) acc0 |= 1ull << l0;
+                        amb0 &= amb0 - 1ull;
+                    } else {
+                        const uint64_t below = (1ull << l1) - 1ull;
+                        const uint32_t before = (uint32_t)__popcll(acc0 & (below | (1ull << l1))) + (uint32_t)__popcll(acc1 & below);
+                        if (lane_get(c1, l1) <= i - before) acc1 |= 1ull << l1;
+                        amb1 &= amb1 - 1ull;
+                    }
+                }
+                valid0 = (acc0 >> lane) & 1ull;
+                valid1 = (acc1 >> lane) & 1ull;
+                const uint32_t t0 = mbcnt64(acc0) + mbcnt64(acc1), t1 = t0 + (valid0 ? 1u : 0u);
+                nacc = (uint32_t)__popcll(acc0) + (uint32_t)__popcll(acc1);
+                it = i - nacc;
+                ipos0 = i - t0;
+                ipos1 = i - t1;
+                jj0 = c0;
+                jj1 = c1;
+            } else {
+                uint32_t t = 0;
+                const uint32_t rlo = (uint32_t)raw, rhi = (uint32_t)(raw >> 32);
+                for (uint32_t dd = half; dd < 128u; ++dd) {  // slot dd = 2 * lane + (high half ? 1 : 0)
+                    const uint32_t c = ((dd & 1u) ? lane_get(rhi, dd >> 1) : lane_get(rlo, dd >> 1)) & mask;
+                    if (c <= it) {
+                        if (lane == 0) sJ[t] = c;
+                        ++t;
+                        --it;
+                        if ((mask >> 1) >= it) mask >>= 1;
+                        if (it == 0u) {
+                            used = dd + 1u - half;
+                            break;
+                        }
+                    }
+                }
+                nacc = t;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                valid0 = 2u * (uint32_t)lane < nacc;       // step 2 * lane ...
+                valid1 = 2u * (uint32_t)lane + 1u < nacc;  // ... and step 2 * lane + 1 of the trip
+                ipos0 = i - 2u * (uint32_t)lane;
+                ipos1 = ipos0 - 1u;
+                jj0 = valid0 ? sJ[2 * lane] : 0u;
+                jj1 = valid1 ? sJ[2 * lane + 1] : 0u;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+            if (nacc > 0u) {
+                const uint32_t f_last = (it + 1u) >> logS;  // phase of the trip's last step
+                for (uint32_t f = f_cur;; --f) {
+                    append(valid0 && (ipos0 >> logS) == f, ipos0 & SM, jj0, valid1 && (ipos1 >> logS) == f, ipos1 & SM, jj1);
+                    if (f == f_last) break;
+                    end_phase(f);
+                    --ph;
+                }
+                f_cur = f_last;
+            }
+            i = it;
+            if (i >= 1u && (i >> logS) != f_cur) {  // the next step opens a new phase
+                end_phase(f_cur);
+                --ph;
+                f_cur = i >> logS;
+            }
+            pcgw_advance2(s, half, sk, used);
+            raw = pcgw_draw2(s, ja, jd, sk);
+        }
+        end_phase(f_cur);  // f_cur == 0 here: the library's last phase
+    }
+}
+
 __device__ __forceinline__ void pcgb_copy_in(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t len, int tid) {
     if ((reinterpret_cast<uintptr_t>(src) & 15u) == 0u) {
         const uint32_t n16 = len >> 4;
@@ -899,7 +1132,14 @@ __global__ __launch_bounds__(PCGB_THREADS) void k_pcg_apply_bucketed(int64_t row
 constexpr int PCGQ_CAP = 1024;     // queue entries (4 + 2 bytes each)
 constexpr int PCGQ_SLOTS = 1024;   // conflict tags per buffer of a drain (two buffers = the 8 KB of the claim bitmap at S = 65536)
 constexpr int PCGQ_TAG_BYTES = 2 * PCGQ_SLOTS * 4;
-constexpr int PCGQ_NSUB = 4;       // chunks per super-chunk of record loads
+#ifndef SQGR_PCGQ_NSUB
+#define SQGR_PCGQ_NSUB 2
+#endif
+#ifndef SQGR_PCGQ_DRAIN_AT
+#define SQGR_PCGQ_DRAIN_AT (PCGQ_CAP / 2)
+#endif
+constexpr int PCGQ_NSUB = SQGR_PCGQ_NSUB;  // chunks per super-chunk of record loads
+constexpr int PCGQ_DRAIN_AT = SQGR_PCGQ_DRAIN_AT;  // queue length that triggers a drain before the list ends
 
 __host__ __device__ inline uint32_t pcgq_bitmap_bytes(uint32_t S) { return S / 8u < 16u ? 16u : S / 8u; }
 __host__ __device__ inline uint32_t pcgq_claim_bytes(uint32_t S) { return pcgq_bitmap_bytes(S) < (uint32_t)PCGQ_TAG_BYTES ? (uint32_t)PCGQ_TAG_BYTES : pcgq_bitmap_bytes(S); }
@@ -1188,7 +1428,7 @@ __global__ __launch_bounds__(PCGB_THREADS) void k_pcg_apply_claims(int64_t row_s
                         ++seq;
                         if (qc == 0u && !spill) {
                             seq = 0;  // nothing is queued: the time index restarts
-                        } else if (last_chunk || qc > (uint32_t)PCGQ_CAP / 2u || spill || seq == 32u) {
+                        } else if (last_chunk || qc > (uint32_t)PCGQ_DRAIN_AT || spill || seq == 32u) {
                             // ---- drain: the queued records (lane L: entry L) and the spilled ones in priority rounds
                             const uint32_t nq = min(qc, (uint32_t)PCGQ_CAP);
                             PCGQ_CNT(9, 1);
@@ -1358,10 +1598,11 @@ using namespace sqgr;
 // A_k = M^k and G_k = 1 + M + ... + M^(k-1) (mod 2^128) of PCG64's LCG, k = 0..PCGW_TAB-1, as [A_hi, A_lo, G_hi, G_lo]
 static int ensure_pcg_jump(DevBuf<uint64_t>& buf) {
     if (buf.p) return SQGR_OK;
-    std::vector<uint64_t> t((size_t)PCGW_TAB * 4);
+    constexpr int TAB = PCGW_TAB2 > PCGW_TAB ? PCGW_TAB2 : PCGW_TAB;  // (k_pcg_draws_bucketed2 jumps up to 64 states ahead)
+    std::vector<uint64_t> t((size_t)TAB * 4);
     const unsigned __int128 M = ((unsigned __int128)0x2360ED051FC65DA4ull << 64) | (unsigned __int128)0x4385DF649FCCF645ull;
     unsigned __int128 A = 1, G = 0;
-    for (int k = 0; k < PCGW_TAB; ++k) {
+    for (int k = 0; k < TAB; ++k) {
         t[4 * k + 0] = (uint64_t)(A >> 64);
         t[4 * k + 1] = (uint64_t)A;
         t[4 * k + 2] = (uint64_t)(G >> 64);
@@ -1461,7 +1702,11 @@ static int pcg_shuffle_rows_bucketed(sqgr_ctx* ctx, PcgWorkspace& ws, int64_t n,
     SQGR_TRY(ws.recs.ensure((size_t)sub * rec_words));
     SQGR_TRY(ws.dir.ensure((size_t)sub * geo.phases * geo.bcap));
     SQGR_TRY(ws.nblk.ensure((size_t)sub * geo.phases));
-    const size_t lds_g = (size_t)geo.n_ranges * PCGB_RING * 4;
+    // generator: 128 draws per trip (default), or rounds 4-5's 64 (SQGR_PCG_DRAWS=64)
+    const char* draws_env = getenv("SQGR_PCG_DRAWS");
+    const bool draws128 = !(draws_env && atoi(draws_env) == 64);
+    size_t lds_g = draws128 ? pcg_draws2_lds_bytes(geo.n_ranges) : (size_t)geo.n_ranges * PCGB_RING * 4;
+    if (const char* e = getenv("SQGR_PCG_LDS_PAD")) lds_g += (size_t)atoi(e);  // occupancy experiments
     // conflict tags: what the two windows and the block list leave of the LDS (SQGR_PCG_BUCKET_SLOTS: experiments), at least 3328
     {
         const int64_t room = ((int64_t)160 << 10) - 2 * S - (int64_t)geo.bcap * 4 - 2048;  // (2 KB: the kernel's static LDS)
@@ -1474,7 +1719,8 @@ static int pcg_shuffle_rows_bucketed(sqgr_ctx* ctx, PcgWorkspace& ws, int64_t n,
     const char* apply_env = getenv("SQGR_PCG_APPLY");  // (read at every call: tools/pcg_bucket_time.py compares the two)
     const bool use_claims = !(apply_env && strcmp(apply_env, "tags") == 0);
     const size_t lds_a = use_claims ? pcgq_lds_bytes((uint32_t)S, geo.bcap) : 2 * (size_t)S + (size_t)2 * geo.slots * 4 + (size_t)geo.bcap * 4;
-    SQGR_TRY(pcg_allow_lds(k_pcg_draws_bucketed, lds_g));
+    if (draws128) SQGR_TRY(pcg_allow_lds(k_pcg_draws_bucketed2, lds_g));
+    else SQGR_TRY(pcg_allow_lds(k_pcg_draws_bucketed, lds_g));
     if (use_claims) SQGR_TRY(pcg_allow_lds(k_pcg_apply_claims, lds_a));
     else SQGR_TRY(pcg_allow_lds(k_pcg_apply_bucketed, lds_a));
     const std::string name_g = std::string(timer_name) + "_draws", name_a = std::string(timer_name) + "_apply";
@@ -1485,8 +1731,12 @@ static int pcg_shuffle_rows_bucketed(sqgr_ctx* ctx, PcgWorkspace& ws, int64_t n,
         SQGR_HIP(hipMemsetAsync(ws.nblk.p, 0, (size_t)qc * geo.phases * 4, st));
         {
             LaunchTimer t(ctx, name_g.c_str(), st);
-            k_pcg_draws_bucketed<<<(unsigned)qc, 64, lds_g, st>>>(n_libs, lib_off_dev, ws.lib_phase.p, states_dev + 4 * q0, ws.jump.p, qc, geo, ws.recs.p,
-                                                                  ws.dir.p, ws.nblk.p, pcg_force_slow());
+            if (draws128)
+                k_pcg_draws_bucketed2<<<(unsigned)qc, 64, lds_g, st>>>(n_libs, lib_off_dev, ws.lib_phase.p, states_dev + 4 * q0, ws.jump.p, qc, geo,
+                                                                       ws.recs.p, ws.dir.p, ws.nblk.p, pcg_force_slow());
+            else
+                k_pcg_draws_bucketed<<<(unsigned)qc, 64, lds_g, st>>>(n_libs, lib_off_dev, ws.lib_phase.p, states_dev + 4 * q0, ws.jump.p, qc, geo, ws.recs.p,
+                                                                      ws.dir.p, ws.nblk.p, pcg_force_slow());
             SQGR_HIP(hipGetLastError());
         }
         {

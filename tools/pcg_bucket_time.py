@@ -17,6 +17,7 @@ res = {}
 for kern in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["bucket", "wave"]):
     os.environ["SQGR_PCG_KERNEL"] = kern.split(":")[0].replace("bucket-tags", "bucket")
     os.environ["SQGR_PCG_APPLY"] = "tags" if kern.startswith("bucket-tags") else "claims"   # replay kernel: rounds 4-5's hashed tags | exact claims
+    os.environ["SQGR_PCG_DRAWS"] = "64" if kern.startswith("bucket-tags") else "128"        # generator: 64 | 128 draws per trip
     parts = kern.split(":")   # bucket[-tags][:logS[:tag slots]]
     for var, idx in (("SQGR_PCG_BUCKET_LOGS", 1), ("SQGR_PCG_BUCKET_SLOTS", 2)):
         if len(parts) > idx and parts[idx]:
