@@ -485,6 +485,7 @@ struct PcgBucketGeom {
     int bcap;              // blocks per phase: S / 64 + n_ranges (rounded up when S < 64)
     int phases;            // phases of all libraries of one permutation
     int slots;             // conflict tags per buffer of the apply kernel (two buffers)
+    int qcap;              // k_pcg_apply_claims: queue entries in use (<= PCGQ_CAP; SQGR_PCG_QUEUE_CAP: tests of the spill path)
 };
 
 __device__ __forceinline__ uint32_t lane_get(uint32_t v, uint32_t src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src); }
@@ -1135,11 +1136,7 @@ constexpr int PCGQ_TAG_BYTES = 2 * PCGQ_SLOTS * 4;
 #ifndef SQGR_PCGQ_NSUB
 #define SQGR_PCGQ_NSUB 2
 #endif
-#ifndef SQGR_PCGQ_DRAIN_AT
-#define SQGR_PCGQ_DRAIN_AT (PCGQ_CAP / 2)
-#endif
 constexpr int PCGQ_NSUB = SQGR_PCGQ_NSUB;  // chunks per super-chunk of record loads
-constexpr int PCGQ_DRAIN_AT = SQGR_PCGQ_DRAIN_AT;  // queue length that triggers a drain before the list ends
 
 __host__ __device__ inline uint32_t pcgq_bitmap_bytes(uint32_t S) { return S / 8u < 16u ? 16u : S / 8u; }
 __host__ __device__ inline uint32_t pcgq_claim_bytes(uint32_t S) { return pcgq_bitmap_bytes(S) < (uint32_t)PCGQ_TAG_BYTES ? (uint32_t)PCGQ_TAG_BYTES : pcgq_bitmap_bytes(S); }
@@ -1188,6 +1185,7 @@ __global__ __launch_bounds__(PCGB_THREADS) void k_pcg_apply_claims(int64_t row_s
     const int tid = threadIdx.x;
     const uint32_t L = (uint32_t)tid;
     const uint32_t claim_words = pcgq_claim_bytes(S) / 4, bm_words = pcgq_bitmap_bytes(S) / 4;
+    const uint32_t qcap = (uint32_t)geo.qcap;  // a drain starts when the queue is half full; a record that finds it full stays with its lane
     for (int64_t p = blockIdx.x; p < P; p += gridDim.x) {
         const uint32_t* const rec_p = recs + (size_t)p * geo.phases * geo.bcap * 64;
         const uint32_t* const dir_p = dir + (size_t)p * geo.phases * geo.bcap;
@@ -1402,7 +1400,7 @@ __global__ __launch_bounds__(PCGB_THREADS) void k_pcg_apply_claims(int64_t row_s
                                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                                 if (def_a) {
                                     const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(ma >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ma, 0u));
-                                    if (slot < (uint32_t)PCGQ_CAP) {
+                                    if (slot < qcap) {
                                         Qrec[slot] = rec_a;
                                         Qprio[slot] = (uint16_t)prio_a;
                                     } else {
@@ -1411,7 +1409,7 @@ __global__ __launch_bounds__(PCGB_THREADS) void k_pcg_apply_claims(int64_t row_s
                                 }
                                 if (def_b) {
                                     const uint32_t slot = base + na + __builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0u));
-                                    if (slot < (uint32_t)PCGQ_CAP) {
+                                    if (slot < qcap) {
                                         Qrec[slot] = rec_b;
                                         Qprio[slot] = (uint16_t)prio_b;
                                     } else {
@@ -1428,9 +1426,9 @@ __global__ __launch_bounds__(PCGB_THREADS) void k_pcg_apply_claims(int64_t row_s
                         ++seq;
                         if (qc == 0u && !spill) {
                             seq = 0;  // nothing is queued: the time index restarts
-                        } else if (last_chunk || qc > (uint32_t)PCGQ_DRAIN_AT || spill || seq == 32u) {
+                        } else if (last_chunk || qc > qcap / 2u || spill || seq == 32u) {
                             // ---- drain: the queued records (lane L: entry L) and the spilled ones in priority rounds
-                            const uint32_t nq = min(qc, (uint32_t)PCGQ_CAP);
+                            const uint32_t nq = min(qc, qcap);
                             PCGQ_CNT(9, 1);
                             PCGQ_CNT(11, qc);
                             const bool was_q = L < nq;
@@ -1657,7 +1655,9 @@ static bool pcg_use_bucket(int64_t n, int64_t n_lib_max) {
     const char* e = getenv("SQGR_PCG_KERNEL");
     if (e && strcmp(e, "bucket") == 0) return ceil_div(n_lib_max, (int64_t)1 << pcg_bucket_logs(n_lib_max)) <= PCGB_MAX_RANGES;
     if (e && (strcmp(e, "wave") == 0 || strcmp(e, "lane") == 0)) return false;
-    return n >= ((int64_t)1 << 17) && ceil_div(n_lib_max, (int64_t)1 << 16) <= PCGB_MAX_RANGES;
+    // (round 6, tools/pcg_threshold_time.py: with the 128-draw generator and the claims replay the pipeline wins from ~65 000
+    // positions on — 1e5 positions x 10 000 permutations 17.5 ms against the wave kernel's 23.9, 80 000: 15.5 / 18.1, 40 000: 4.5 / 4.5)
+    return n >= ((int64_t)1 << 16) && ceil_div(n_lib_max, (int64_t)1 << 16) <= PCGB_MAX_RANGES;
 }
 
 static int pcg_shuffle_rows_bucketed(sqgr_ctx* ctx, PcgWorkspace& ws, int64_t n, int64_t n_pad, int n_libs, const uint32_t* lib_off_dev,
@@ -1716,6 +1716,9 @@ static int pcg_shuffle_rows_bucketed(sqgr_ctx* ctx, PcgWorkspace& ws, int64_t n,
         geo.slots = (int)slots;
     }
     // replay kernel: exact claims + deferred queue (default), or rounds 4-5's hashed tags (SQGR_PCG_APPLY=tags)
+    geo.qcap = PCGQ_CAP;
+    if (const char* e = getenv("SQGR_PCG_QUEUE_CAP"))
+        if (atoi(e) >= 2 && atoi(e) <= PCGQ_CAP) geo.qcap = atoi(e);
     const char* apply_env = getenv("SQGR_PCG_APPLY");  // (read at every call: tools/pcg_bucket_time.py compares the two)
     const bool use_claims = !(apply_env && strcmp(apply_env, "tags") == 0);
     const size_t lds_a = use_claims ? pcgq_lds_bytes((uint32_t)S, geo.bcap) : 2 * (size_t)S + (size_t)2 * geo.slots * 4 + (size_t)geo.bcap * 4;

@@ -569,6 +569,44 @@ def test_numpy_shuffle_bucketed_replay_agrees_with_numpy(L, ctx, logs, monkeypat
     np.testing.assert_array_equal(perms, want.astype(np.uint32))
 
 
+@pytest.mark.parametrize(
+    "env",
+    [
+        {"SQGR_PCG_QUEUE_CAP": "4"},                              # the replay's queue overflows at once: records stay with their lanes (spill path), a drain per chunk
+        {"SQGR_PCG_QUEUE_CAP": "64"},
+        {"SQGR_PCG_FORCE_SLOW": "1"},                             # the generator's one-by-one path on every trip (128 slots in order)
+        {"SQGR_PCG_APPLY": "tags", "SQGR_PCG_DRAWS": "64"},       # rounds 4-5's kernels stay selectable and correct
+        {"SQGR_PCG_APPLY": "tags"},                               # 128-draw generator + hashed-tag replay
+        {"SQGR_PCG_DRAWS": "64"},                                 # 64-draw generator + claims replay
+    ],
+    ids=lambda e: ",".join(f"{k[9:].lower()}={v}" for k, v in e.items()),
+)
+def test_numpy_shuffle_replay_variants_agree_with_numpy(L, ctx, env, monkeypatch):
+    """Round 6's generator (128 draws per trip, one 64-record ring per range) and replay (exact claims, deferred queue, priority
+    drains): the paths a production run hardly takes — a full queue, the one-by-one acceptance — and the old kernels behind their
+    switches, against numpy's own shuffles: production geometry on 70 001 and 200 001 positions, 4096-position phases on 33 000."""
+    from squidpy_amd._utils import pcg64_states
+
+    monkeypatch.setenv("SQGR_PCG_KERNEL", "bucket")
+    for k_, v in env.items():
+        monkeypatch.setenv(k_, v)
+    for n, logs in ((33000, "12"), (70001, None), (200001, None)):
+        if logs:
+            monkeypatch.setenv("SQGR_PCG_BUCKET_LOGS", logs)
+        else:
+            monkeypatch.delenv("SQGR_PCG_BUCKET_LOGS", raising=False)
+        P, k = 5, 251
+        labels = (np.arange(n) * 7919 % k).astype(np.int32)
+        ring = sp.csr_matrix((np.ones(n, np.float32), (np.arange(n), (np.arange(n) + 1) % n)), shape=(n, n))
+        g = L.Graph(ctx, ring)
+        plan = L.NhoodPlan(ctx, g, labels, k)
+        _, _, perms = plan.run_pcg64(pcg64_states(n + 1, P), return_perms=True)
+        ref = O.nhood_perm_counts_numpy(ring.indices, ring.indptr, labels, k, n + 1, P)
+        np.testing.assert_array_equal(perms, ref.astype(np.uint32), err_msg=f"n={n} {env}")
+        plan.close()
+        g.close()
+
+
 def test_skewed_cluster_sizes(L, ctx):
     """SURVEY §8d skewed variant: Dirichlet(0.5) cluster proportions (a few huge clusters, some almost empty, one
     empty) concentrate the count kernel's LDS atomics on few counters and make label boundaries fall inside single
