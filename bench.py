@@ -851,10 +851,11 @@ def config4_legs(ctx, ceil: dict, with_cpu: bool, counters: dict, short_radii: b
 def numpy_stream_leg(ctx, plan, shift, n: int, counters: dict) -> dict:
     """The test with numpy's own PCG64 streams reproduced bit for bit on the GPU (`rng="numpy"` — the mode whose z-scores ARE
     Squidpy's for a seed).  Round 4: the swaps of `Generator.shuffle` are replayed in a cache-friendly order (csrc/sqgr_pcg.hip,
-    proof of the order: oracle/pcg_bucket.py): `k_pcg_draws_bucketed` generates the draws (one wave per permutation) into
-    time-ordered lists per (64 K-step phase, 64 KB range), `k_pcg_apply_bucketed` (one workgroup per permutation) streams window
-    and ranges through LDS in coalesced 64 KB pieces.  Algorithmic traffic per permutation of n bytes: records 2 x 4.3 n, ranges
-    ~17 n, rows in and out 2 n — against 128 n + for the one-random-sector-per-swap-side kernel of rounds 1-3."""
+    proof of the order: oracle/pcg_bucket.py): `k_pcg_draws_bucketed2` generates the draws (one wave per permutation, 128 raw
+    draws per trip since round 6) into time-ordered lists per (64 K-step phase, 64 KB range), `k_pcg_apply_claims` (one workgroup
+    per permutation; round 6: exact position claims in an LDS bitmap, contested records deferred and drained once per list) streams
+    window and ranges through LDS in coalesced 64 KB pieces.  Algorithmic traffic per permutation of n bytes: records 2 x 4.3 n,
+    ranges ~17 n, rows in and out 2 n — against 128 n + for the one-random-sector-per-swap-side kernel of rounds 1-3."""
     from squidpy_amd._utils import pcg64_states
 
     res, kern = {}, {}
@@ -876,18 +877,18 @@ def numpy_stream_leg(ctx, plan, shift, n: int, counters: dict) -> dict:
     # each range r < f read and written once per phase (sum_f f * 64 KB * 2), every window read and written once, the row -> slab pass
     phases = -(-n // 65536)
     alg_bytes = (2.0 * phases * (1024 + phases) * 256 + 2.0 * 65536 * phases * (phases - 1) / 2 + 2.0 * n + 2.0 * n) if bucketed else 2.0 * (n - 1) * 64.0
-    roof = {"kernel": "nhood_pcg64_shuffle_draws + _apply (k_pcg_draws_bucketed, k_pcg_apply_bucketed)" if bucketed else "nhood_pcg64_shuffle (k_pcg_shuffle_wave)",
+    roof = {"kernel": "nhood_pcg64_shuffle_draws + _apply (k_pcg_draws_bucketed2, k_pcg_apply_claims)" if bucketed else "nhood_pcg64_shuffle (k_pcg_shuffle_wave)",
             "bound": "hbm", "achieved": 8192 * alg_bytes / (ms_shuffle * 1e-3) / 1e9 if ms_shuffle > 0 else None, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": 8192 * alg_bytes / (ms_shuffle * 1e-3) / HBM_PEAK if ms_shuffle > 0 else None, "traffic": None,
             "algorithmic_bytes_per_perm": alg_bytes, "workload_key": {"spots": n, "perms": 8192},
             "swap_steps_per_s": 8192 * (n - 1) / (ms_shuffle * 1e-3) if ms_shuffle > 0 else None,
             "note": "`achieved` = algorithmic bytes of the bucketed replay (records, ranges, windows: all coalesced) / time of the two shuffle kernels; the "
             "measured traffic (`traffic`, `traffic_MB_per_perm`, `traffic_frac`) replaces it when the committed PMC profile matches.  Neither kernel is "
-            "HBM-bound: the draw generator is bound by VALU issue (PCG64 jump-ahead: 128-bit multiplies, ~170 wave-instructions per 64 raw draws), the "
-            "replay by instruction issue and LDS latency inside its barrier rounds (PMC: ~100 % issue-active with 4 waves per SIMD; ~5 rounds per chunk of "
-            "2048 swaps) — the HBM figure says how far the traffic is from mattering, which was the defect of the kernel it replaces (0.44 of peak on 152 MB "
-            "per permutation)"}
-    names = ("k_pcg_draws_bucketed", "k_pcg_apply_bucketed", "k_rows_to_slab", "k_pcg_shuffle_wave", "k_rows_to_columns", "k_columns_to_slab")
+            "HBM-bound yet: the draw generator (one wavefront per permutation) is bound by the latencies of its own instruction stream and lives on "
+            "occupancy (4.9 KB of LDS per wavefront; 8 KB more cost the 64-draw kernel 49.7 -> 73.4 ms), the replay by its barrier intervals (two per "
+            "chunk of 2048 swaps + ~6 per drain; ablation of round 6: skeleton 23 %, range traffic 15-20 %, claims and swaps 25 %, drains 20 %) — the "
+            "ranges' 17 MB per permutation put its HBM floor at ~36 ms per 8192 permutations (54 measured)"}
+    names = ("k_pcg_draws_bucketed", "k_pcg_apply_bucketed", "k_pcg_apply_claims", "k_rows_to_slab", "k_pcg_shuffle_wave", "k_rows_to_columns", "k_columns_to_slab")
     cn = counters.get("numpy", {})
     if cn and cn.get("workload") == {"spots": n, "perms": 8192} and ms_shuffle > 0:
         fetch = sum((rec.get("FETCH_SIZE_bytes_timed_total") or 0.0) for name, rec in cn.get("kernels", {}).items() if any(x in name for x in names))

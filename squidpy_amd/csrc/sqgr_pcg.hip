@@ -1442,6 +1442,18 @@ __global__ __launch_bounds__(PCGB_THREADS) void k_pcg_apply_claims(int64_t row_s
                             const bool any_sp = spill;  // uniform over the workgroup
                             uint32_t ep = 0;
 #if defined(SQGR_PCG_ABLATE) && (SQGR_PCG_ABLATE & 1)  // timing experiment (wrong results): the drain without its rounds
+                            if (pend_q) {
+                                Bm[jq >> 5] = 0u;
+                                if (internal) Bm[iq >> 5] = 0u;
+                            }
+                            if (pend_a) {
+                                Bm[wja] = 0u;
+                                if (internal) Bm[wia] = 0u;
+                            }
+                            if (pend_b) {
+                                Bm[wjb] = 0u;
+                                if (internal) Bm[wib] = 0u;
+                            }
                             pend_q = pend_a = pend_b = false;
 #endif
                             // wavefronts without a record (lane L holds queue entry L: all but the first few) only keep the barriers

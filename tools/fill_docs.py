@@ -49,6 +49,7 @@ try:
 except OSError:
     pass
 big = nb.get((1000000, 8192), {})
+small = nb.get((1000000, 1000), {})
 kern = d.get("kernels", {})
 cs, co = legs.get("co_occurrence_short_radii", {}), legs.get("co_occurrence", {})
 ind = legs.get("nhood_independent_bijections", {})
@@ -76,6 +77,7 @@ vals = {
     "KSWEEP": "\n".join(rows),
     "NUMPY": k(npy.get("value", 0), 1), "NUMPY1K": k(npy.get("at_n_perms_1000", 0), 1),
     "DRAWMS": f"{big.get('kernels_ms', {}).get('nhood_pcg64_shuffle_draws', 0):.1f}", "APPLYMS": f"{big.get('kernels_ms', {}).get('nhood_pcg64_shuffle_apply', 0):.1f}",
+    "DRAWMS1K": f"{small.get('kernels_ms', {}).get('nhood_pcg64_shuffle_draws', 0):.1f}",
     "NPCALLMS": f"{big.get('call_ms', 0):.0f}", "CHAINMS": f"{big.get('kernels_ms', {}).get('nhood_numpy_mean_std', 0):.2f}",
     "MORAN": k(sec["value"], 1), "MORANMS": f"{sec['ms_per_step']:.1f}", "MORANWK": f"{sec['wall_over_kernels']:.3f}",
     "DOTMS": f"{sec['roofline']['avg_launch_ms']:.1f}", "LISTMS": f"{sec['roofline']['list_build_ms_per_launch']:.1f}",

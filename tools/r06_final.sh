@@ -25,7 +25,7 @@ timeout 300 python tools/numpy_call_breakdown.py > gpurun_out/r06_numpy_call_bre
 # geometry sweep, the soak tests' negative control, the driver's launcher invocation at the node's size on this one GPU
 SQGR_COUNT_C16=0 timeout 600 python tools/nhood_k_sweep.py 1000 2560 --K=51 --K=64 --K=100 --K=150 --K=200 --K=256 > gpurun_out/r06_nhood_k_sweep_c16_off.jsonl 2> $OUT/k_sweep_off.err
 timeout 600 python tools/nhood_k_sweep.py 1000 2560 --graph=knn --K=30 --K=64 --K=100 --K=200 > gpurun_out/r06_nhood_k_sweep_knn.jsonl 2> $OUT/k_sweep_knn.err
-( for P in 8192 1000; do timeout 600 python tools/pcg_bucket_time.py $P bucket,bucket:15,bucket:15:4096,bucket:14,bucket:16:2048 2>&1 | grep -v Warn; done ) > gpurun_out/r06_pcg_geometry_sweep.txt 2>&1
+timeout 900 bash tools/pcg_ablation.sh > /dev/null 2>&1  # numpy-stream kernels old against new, occupancy, the replay kernel's ablation -> gpurun_out/r06_pcg_replay_ablation.txt
 bash tools/soak_negative.sh > /dev/null 2>&1; cp gpurun_out/soak_negative.txt gpurun_out/r06_soak_negative_run.txt
 timeout 900 python bench.py --gpus 8 --share-devices --steps 3 --warmup 1 --no-cpu-baseline --no-legs --no-secondary --no-numpy-leg --emulate-ranks 0 --scaling strong --total-perms 100000 \
   --detail-out $OUT/bench_gpus8_detail.json > $OUT/bench_gpus8.json 2> $OUT/bench_gpus8.err; tail -1 $OUT/bench_gpus8.json > gpurun_out/r06_bench_gpus8_shared_device.json
