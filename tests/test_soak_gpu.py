@@ -121,3 +121,31 @@ def test_soak_piled_up_counters(L, ctx, k, width, self_loops):
     g = L.Graph(ctx, adj, with_data=False)
     _soak(L, ctx, adj, g, k, width, 320, 150, labels=np.zeros(n, dtype=np.int32))
     g.close()
+
+
+def test_numpy_stream_replay_is_the_same_on_every_launch(L, ctx, c5_graph, monkeypatch):
+    """Round 6's numpy-stream kernels (k_pcg_draws_bucketed2 + k_pcg_apply_claims) resolve contested swaps through LDS atomics whose
+    arrival order differs from launch to launch (which record of a chunk claims a position first; which of two deferred records
+    reaches the queue first): the rows must not.  1024 permutations of config 5's 1e6 positions, six launches — the moments of
+    the counts `array_equal` on every launch and equal to those of rounds 4-5's kernels (hashed-tag replay, 64-draw generator),
+    which the stream tests pin to numpy's own shuffles."""
+    from squidpy_amd._utils import pcg64_states
+
+    adj, g = c5_graph
+    n, k, P = adj.shape[0], 30, 1024
+    labels = np.random.default_rng(5).integers(0, k, n).astype(np.int32)
+    states = pcg64_states(77, P)
+    monkeypatch.setenv("SQGR_PCG_APPLY", "tags")
+    monkeypatch.setenv("SQGR_PCG_DRAWS", "64")
+    plan = L.NhoodPlan(ctx, g, labels, k)
+    ref1, ref2, _ = plan.run_pcg64(states)
+    plan.close()
+    assert int(ref1.sum()) == int(adj.nnz) * P
+    monkeypatch.delenv("SQGR_PCG_APPLY")
+    monkeypatch.delenv("SQGR_PCG_DRAWS")
+    plan = L.NhoodPlan(ctx, g, labels, k)
+    for it in range(6):
+        s1, s2, _ = plan.run_pcg64(states)
+        np.testing.assert_array_equal(s1, ref1, err_msg=f"launch {it}")
+        np.testing.assert_array_equal(s2, ref2, err_msg=f"launch {it}")
+    plan.close()
