@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SQGR_ABI_VERSION 5
+#define SQGR_ABI_VERSION 6
 
 typedef enum sqgr_status {
     SQGR_OK = 0,
@@ -215,6 +215,14 @@ int sqgr_matrix_create(sqgr_ctx* ctx, const double* x, int64_t n_rows, int64_t n
  * wider host matrix: x points at the first wanted element, rows are `ld` elements apart (ld >= n_cols); value_bytes 4 | 8. */
 int sqgr_matrix_create_dense(sqgr_ctx* ctx, const void* x, int32_t value_bytes, int64_t n_rows, int64_t n_cols, int64_t ld,
                              sqgr_matrix** out);
+/* The same matrix filled while its first feature blocks are being worked on (ABI v6): `sqgr_matrix_alloc_dense` reserves the
+ * device array; `sqgr_matrix_upload_columns(m, x, ld, col0, n_cols)` copies columns [col0, col0 + n_cols) — x points at the first
+ * row's element of column col0 of the host matrix, rows `ld` elements apart — on the context's COPY stream and waits for that
+ * stream only, so it may run on another host thread than the statistics (config 3: 16 GB cross PCIe in 0.29 s, hidden behind the
+ * 0.58 s of the ten feature blocks).  A column range must be uploaded before sqgr_autocorr_create_cols reads it: the caller's
+ * business (squidpy_amd: DeviceMatrix.wait_columns). */
+int sqgr_matrix_alloc_dense(sqgr_ctx* ctx, int32_t value_bytes, int64_t n_rows, int64_t n_cols, sqgr_matrix** out);
+int sqgr_matrix_upload_columns(sqgr_matrix* m, const void* x, int64_t ld, int64_t col0, int64_t n_cols);
 /* Sparse expression as scipy holds it — the input every real Visium / Xenium object has (`adata.X` CSR float32; the
  * reference densifies `vals` feature block by feature block on the host, gr/_ppatterns.py:154-185 + scanpy's metrics):
  * CSR (rows = cells: indptr[n_rows + 1], indices = columns) or CSC (columns = features: indptr[n_cols + 1], indices = rows),

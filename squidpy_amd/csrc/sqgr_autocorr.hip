@@ -1485,6 +1485,7 @@ struct sqgr_matrix {
     DevBuf<int32_t> indices;
     int64_t nnz = 0;
     // CSR matrices: the same entries by column, built on the device the first time a column LIST is asked for (ensure_by_column)
+    int64_t cols_pending = -1;  // sqgr_matrix_alloc_dense: columns still to be uploaded (a streaming session is open while > 0)
     mutable bool by_col_ready = false;
     mutable DevBuf<int64_t> c_indptr;
     mutable DevBuf<int32_t> c_rows;
@@ -2035,6 +2036,56 @@ int sqgr_matrix_create_dense(sqgr_ctx* ctx, const void* x, int32_t value_bytes, 
     return SQGR_OK;
 }
 
+// The same matrix filled column block by column block WHILE the first blocks are being worked on: sqgr_matrix_alloc_dense reserves
+// the device array, sqgr_matrix_upload_columns copies a column range of the host matrix into it on the context's copy stream and
+// waits for that stream only — it may be called from another host thread than the one that runs the statistics (the pool and the
+// error state are thread-safe; nothing else of the context is touched).  16 GB of dense float64 cross PCIe in 0.29 s; uploaded
+// whole before the first feature block, config 3 took 0.29 + 0.58 s.
+int sqgr_matrix_alloc_dense(sqgr_ctx* ctx, int32_t value_bytes, int64_t n_rows, int64_t n_cols, sqgr_matrix** out) {
+    SQGR_REQUIRE(ctx && out && n_rows > 0 && n_cols > 0, "null argument or empty matrix");
+    SQGR_REQUIRE(value_bytes == 4 || value_bytes == 8, "value_bytes must be 4 (float32) or 8 (float64), found %d", value_bytes);
+    *out = nullptr;
+    SQGR_HIP(hipSetDevice(ctx->device));
+    sqgr_matrix* m = new sqgr_matrix();
+    m->ctx = ctx;
+    m->n_rows = n_rows;
+    m->n_cols = n_cols;
+    m->ld = n_cols;
+    m->f32 = value_bytes == 4;
+    const size_t count = (size_t)n_rows * n_cols;
+    const int rc = m->f32 ? m->data32.alloc_pooled(count) : m->data.alloc_pooled(count);  // (every column is uploaded before it is read)
+    if (rc != SQGR_OK) {
+        delete m;
+        return rc;
+    }
+    m->cols_pending = n_cols;
+    streaming_upload_begin();  // closed by the upload of the last column (or by sqgr_matrix_destroy)
+    *out = m;
+    return SQGR_OK;
+}
+
+int sqgr_matrix_upload_columns(sqgr_matrix* m, const void* x, int64_t ld, int64_t col0, int64_t n_cols) {
+    SQGR_REQUIRE(m && x && m->kind == 0, "null argument or not a dense matrix");
+    SQGR_REQUIRE(col0 >= 0 && n_cols > 0 && col0 + n_cols <= m->n_cols && ld >= n_cols, "columns [%lld, %lld) of %lld, row pitch %lld", (long long)col0,
+                 (long long)(col0 + n_cols), (long long)m->n_cols, (long long)ld);
+    sqgr_ctx* ctx = m->ctx;
+    SQGR_HIP(hipSetDevice(ctx->device));
+    const size_t vb = m->f32 ? 4 : 8;
+    char* dst = (m->f32 ? reinterpret_cast<char*>(m->data32.p) : reinterpret_cast<char*>(m->data.p)) + (size_t)col0 * vb;
+    hipError_t e = hipMemcpy2DAsync(dst, (size_t)m->n_cols * vb, x, (size_t)ld * vb, (size_t)n_cols * vb, (size_t)m->n_rows, hipMemcpyHostToDevice,
+                                    ctx->copy_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy_stream);
+    if (e != hipSuccess) {
+        set_error("matrix upload failed: %s", hipGetErrorString(e));
+        return SQGR_ERR_HIP;
+    }
+    if (m->cols_pending > 0) {
+        m->cols_pending -= std::min<int64_t>(n_cols, m->cols_pending);
+        if (m->cols_pending == 0) streaming_upload_end();
+    }
+    return SQGR_OK;
+}
+
 int sqgr_matrix_create(sqgr_ctx* ctx, const double* x, int64_t n_rows, int64_t n_cols, sqgr_matrix** out) {
     return sqgr_matrix_create_dense(ctx, x, 8, n_rows, n_cols, n_cols, out);
 }
@@ -2131,6 +2182,7 @@ int sqgr_matrix_create_csc(sqgr_ctx* ctx, int64_t n_rows, int64_t n_cols, int64_
 int sqgr_matrix_destroy(sqgr_matrix* m) {
     if (!m) return SQGR_OK;
     (void)hipSetDevice(m->ctx->device);
+    if (m->cols_pending > 0) streaming_upload_end();  // a streaming session that was never completed
     delete m;
     return SQGR_OK;
 }

@@ -59,6 +59,7 @@ struct sqgr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // producer stream of two-stage pipelines (label shuffles overlap counting)
+    hipStream_t copy_stream = nullptr;  // host-to-device uploads that overlap the compute stream (sqgr_matrix_upload_columns: its own host thread)
     int cu_count = 0;
     bool timing = false;
     std::vector<std::string> timer_names;
@@ -121,10 +122,20 @@ struct AllocStats {
 extern AllocStats g_alloc_stats;
 hipError_t dev_malloc(void** p, size_t bytes);
 hipError_t dev_free(void* p);
+void streaming_upload_begin();  // between these two, dev_free puts its pointers aside (hipFree would wait for the upload's copy stream)
+void streaming_upload_end();
+void flush_deferred_frees();
 void* pool_take(size_t bytes, size_t* capacity);  // a parked buffer of [bytes, 1.5 * bytes] on the current device, or NULL
 void pool_give(void* p, size_t capacity);         // parks p or frees it
 void pool_flush();                                // frees everything parked on the current device
 void pool_trim(int device, size_t keep_bytes);    // frees parked buffers of `device` until at most keep_bytes stay parked
+// Waits for the COMPUTE streams (stream, stream2) of every context on the current device — what a previous owner of a parked buffer
+// can have in flight.  Not hipDeviceSynchronize: that also waits for the copy streams, i.e. for a whole matrix upload running on
+// another host thread (sqgr_matrix_upload_columns), which then never overlaps the kernels it is meant to hide behind (round 6:
+// the first feature block of config 3 became ready after all ten column blocks had arrived).
+hipError_t pool_quiesce();
+void pool_register_streams(int device, hipStream_t a, hipStream_t b);
+void pool_unregister_streams(hipStream_t a, hipStream_t b);
 
 template <typename T>
 struct DevBuf {
@@ -149,7 +160,7 @@ struct DevBuf {
         if (bytes >= POOL_MIN_BYTES) {
             size_t cap = 0;
             if (void* q = pool_take(bytes, &cap)) {
-                hipError_t e = hipDeviceSynchronize();  // nothing of the previous owner is in flight any more
+                hipError_t e = pool_quiesce();  // nothing of the previous owner is in flight any more
                 if (e == hipSuccess && zero_reused) {
                     e = hipMemsetAsync(q, 0, bytes, nullptr);
                     if (e == hipSuccess) e = hipStreamSynchronize(nullptr);

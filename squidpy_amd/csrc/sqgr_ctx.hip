@@ -63,12 +63,39 @@ hipError_t dev_malloc(void** p, size_t bytes) {
     if (e == hipSuccess) g_alloc_stats.malloc_bytes += (int64_t)bytes;
     return e;
 }
-hipError_t dev_free(void* p) {
+// hipFree waits for the whole device — also for the copy stream of a matrix upload that runs on another host thread
+// (sqgr_matrix_alloc_dense ... the last sqgr_matrix_upload_columns): while such an upload is under way the frees are put aside and
+// handed to the driver by the first free after it has ended (or by sqgr_ctx_trim / sqgr_ctx_destroy).  Round 6: the ~20 small
+// buffers a feature block frees made its kernels wait for the entire 16 GB upload they were meant to overlap.
+static std::atomic<int> g_streaming_uploads{0};
+static std::mutex g_deferred_mutex;
+static std::vector<void*> g_deferred_frees;
+
+void streaming_upload_begin() { g_streaming_uploads += 1; }
+void streaming_upload_end() { g_streaming_uploads -= 1; }
+static hipError_t free_now(void* p) {
     const int64_t t0 = now_ns();
     const hipError_t e = hipFree(p);
     g_alloc_stats.free_ns += now_ns() - t0;
     g_alloc_stats.frees += 1;
     return e;
+}
+void flush_deferred_frees() {
+    std::vector<void*> todo;
+    {
+        std::lock_guard<std::mutex> lock(g_deferred_mutex);
+        todo.swap(g_deferred_frees);
+    }
+    for (void* q : todo) (void)free_now(q);
+}
+hipError_t dev_free(void* p) {
+    if (g_streaming_uploads.load() > 0) {
+        std::lock_guard<std::mutex> lock(g_deferred_mutex);
+        g_deferred_frees.push_back(p);
+        return hipSuccess;
+    }
+    flush_deferred_frees();
+    return free_now(p);
 }
 
 // ---- parked device buffers (declared in sqgr_common.h)
@@ -100,6 +127,43 @@ static size_t pool_limit(int dev) {
     const size_t lim = total ? total / 4 : (size_t)32 << 30;
     by_dev[dev] = lim;
     return lim;
+}
+
+struct ComputeStream {
+    int device;
+    hipStream_t s;
+};
+static std::mutex g_streams_mutex;
+static std::vector<ComputeStream> g_compute_streams;
+
+void pool_register_streams(int device, hipStream_t a, hipStream_t b) {
+    std::lock_guard<std::mutex> lock(g_streams_mutex);
+    g_compute_streams.push_back({device, a});
+    g_compute_streams.push_back({device, b});
+}
+void pool_unregister_streams(hipStream_t a, hipStream_t b) {
+    std::lock_guard<std::mutex> lock(g_streams_mutex);
+    for (size_t k = 0; k < g_compute_streams.size();) {
+        if (g_compute_streams[k].s == a || g_compute_streams[k].s == b) g_compute_streams.erase(g_compute_streams.begin() + (long)k);
+        else ++k;
+    }
+}
+hipError_t pool_quiesce() {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::vector<hipStream_t> mine;
+    {
+        std::lock_guard<std::mutex> lock(g_streams_mutex);
+        for (const ComputeStream& c : g_compute_streams)
+            if (c.device == dev) mine.push_back(c.s);
+    }
+    if (mine.empty()) return hipDeviceSynchronize();  // (no context on this device registered: be safe)
+    for (hipStream_t s : mine) {
+        e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 void* pool_take(size_t bytes, size_t* capacity) {
@@ -607,11 +671,13 @@ int sqgr_ctx_create(int device, sqgr_ctx** out_ctx) {
     ctx->cu_count = prop.multiProcessorCount;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete ctx;
         set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
         return SQGR_ERR_HIP;
     }
+    sqgr::pool_register_streams(device, ctx->stream, ctx->stream2);
     *out_ctx = ctx;
     return SQGR_OK;
 }
@@ -641,6 +707,9 @@ int sqgr_ctx_destroy(sqgr_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamSynchronize(ctx->stream2);
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    sqgr::pool_unregister_streams(ctx->stream, ctx->stream2);
+    sqgr::flush_deferred_frees();
     sqgr::pool_flush();
     for (auto& tl : ctx->launches) {
         (void)hipEventDestroy(tl.start);
@@ -653,6 +722,7 @@ int sqgr_ctx_destroy(sqgr_ctx* ctx) {
         if (sc.first) (void)sqgr::dev_free(sc.first);
     (void)hipStreamDestroy(ctx->stream);
     (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     delete ctx;
     return SQGR_OK;
 }
@@ -661,6 +731,7 @@ int sqgr_ctx_trim(sqgr_ctx* ctx, int64_t keep_bytes) {
     SQGR_REQUIRE(ctx && keep_bytes >= 0, "ctx is NULL or keep_bytes < 0");
     SQGR_HIP(hipSetDevice(ctx->device));
     SQGR_HIP(hipDeviceSynchronize());  // nothing of a previous owner may be in flight when a parked buffer goes back to the driver
+    sqgr::flush_deferred_frees();
     sqgr::pool_trim(ctx->device, (size_t)keep_bytes);
     return SQGR_OK;
 }

