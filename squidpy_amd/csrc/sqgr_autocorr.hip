@@ -1850,10 +1850,13 @@ static int autocorr_create(sqgr_ctx* ctx, const sqgr_graph* g, const double* val
         (rc = h->tmpG.alloc((size_t)G)) || (rc = h->isconst.alloc((size_t)G)) ||
         (rc = h->colpart.alloc((size_t)h->ntiles * h->Rcol * GT)))
         return fail(rc);
-    // stage the gene-major input in blocks of <= 256 genes (and <= ~256 MB)
+    // stage the gene-major input in blocks of <= 256 genes (and <= ~256 MB) when it comes from the host; a block cut out of a matrix
+    // that is resident on the device is staged whole (<= 2 GB: no wait for the staging buffer between its pieces — seven stream
+    // synchronisations per 2048-gene block of config 3)
     int64_t gc_max = std::max<int64_t>(GT, std::min<int64_t>(256, ((int64_t)1 << 28) / (n * 8) / GT * GT));
+    if (dm && (int64_t)n * G * 8 <= ((int64_t)2 << 30)) gc_max = std::max<int64_t>(gc_max, ceil_div(G, GT) * GT);
     DevBuf<double> X, D;
-    if ((rc = X.alloc((size_t)gc_max * n))) return fail(rc);
+    if ((rc = X.alloc_pooled((size_t)gc_max * n))) return fail(rc);
     hipError_t e = hipSuccess;
     const double* cm_src = dev_x ? dev_x + dev_col0 : nullptr;  // cell-major source on the device and its row pitch
     int64_t cm_ld = dev_x ? dev_ld : G;
