@@ -84,6 +84,7 @@ vals = {
     "MORANFRAC": f"{sec['roofline']['frac']:.2f}", "MORANPAT": f"{sec['roofline'].get('frac_of_pattern_ceiling', 0):.2f}",
     "MORANCPU": f"{(sec.get('cpu_baseline') or {}).get('value', 0):.1f}",
     "GEARY": k(legs["geary_c"]["value"], 1), "GEARYG": k(legs["geary_general"]["value"], 1), "MORAN100": k(legs["moran_p100"]["value"]),
+    "C3RES": k((legs['config3_full'].get('moran_resident') or {}).get('value', 0), 1),
     "C3M": f"{legs['config3_full']['moran']['seconds']:.2f}", "C3G": f"{legs['config3_full']['geary']['seconds']:.2f}",
     "COMS": f"{co.get('kernel_ms', 0):.0f}", "COPAIRS": f"{co.get('value', 0):.2e}", "COWALL": f"{co.get('wall_s', 0):.2f}",
     "COVALU": f"{(co.get('roofline') or {}).get('frac', 0):.2f}",
