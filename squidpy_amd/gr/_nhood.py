@@ -95,7 +95,7 @@ def nhood_enrichment(
     rng
         ``None`` = ``"numpy"`` (the default since round 5 — a BREAKING change against rounds 1-4, whose default was ``"philox"``:
         the z-scores of a given ``seed`` are now Squidpy's, not the device generator's; a default call that is large enough for the
-        17x slower stream to matter — ``n_obs * n_perms >= 5e9`` — says so once, and so does a multi-rank call that has to gather
+        11x slower stream to matter — ``n_obs * n_perms >= 5e9`` — says so once, and so does a multi-rank call that has to gather
         the per-permutation counts through the host).  ``"numpy"``: the reference's own streams (``SeedSequence(seed).spawn(n_perms)`` -> PCG64 ->
         ``Generator.shuffle``, gr/_nhood.py:213, 530-539) are reproduced bit for bit *on the GPU* (LCG jump-ahead draws; long
         arrays replay the swaps phase by phase through LDS, ``csrc/sqgr_pcg.hip``), and the z-score is formed with the
@@ -126,7 +126,7 @@ def nhood_enrichment(
     if rng_defaulted and adata.n_obs * n_perms >= DEFAULT_STREAM_NOTICE_WORK:
         warnings.warn(
             f"nhood_enrichment: {n_perms} permutations of {adata.n_obs} observations with the default `rng='numpy'` (Squidpy's own PCG64 streams, "
-            "reproduced on the GPU: ~60 k permutations/s at 1e6 spots).  `rng='philox'` runs the same test ~17x faster with the device "
+            "reproduced on the GPU: ~90 k permutations/s at 1e6 spots).  `rng='philox'` runs the same test ~11x faster with the device "
             "generator (same null distribution, other digits); pass `rng='numpy'` explicitly to keep Squidpy's numbers without this note.",
             UserWarning, stacklevel=2)
 
@@ -229,7 +229,7 @@ def _broadcast_seed(key: int) -> int:
     return int(_dist.broadcast_object(int(key), src=0))
 
 
-DEFAULT_STREAM_NOTICE_WORK = 5_000_000_000   # n_obs * n_perms from which a DEFAULTED `rng` (numpy's streams, ~17x slower than "philox") is pointed out
+DEFAULT_STREAM_NOTICE_WORK = 5_000_000_000   # n_obs * n_perms from which a DEFAULTED `rng` (numpy's streams, ~11x slower than "philox") is pointed out
 HOST_GATHER_NOTICE_ENTRIES = 64_000_000      # n_perms * K * K from which the host gather of several ranks' per-permutation counts is pointed out
 PROGRESS_STEP = 40_960  # permutations per progress update: 16 launch groups of 2560
 MAX_DEVICE_SHUFFLE_CLUSTERS = 2048  # batched permutation kernels: uint8 labels + LDS counters up to 256 clusters, uint16 labels + device-scope
