@@ -177,8 +177,9 @@ struct DevBuf {
             }
         }
         hipError_t e = dev_malloc(reinterpret_cast<void**>(&p), bytes);
-        if (e == hipErrorOutOfMemory) {  // give the parked buffers back to the driver and try once more
+        if (e == hipErrorOutOfMemory) {  // give the parked buffers (and the frees put aside during an upload) back to the driver and try once more
             (void)hipGetLastError();
+            flush_deferred_frees();
             pool_flush();
             e = dev_malloc(reinterpret_cast<void**>(&p), bytes);
         }
