@@ -1975,8 +1975,8 @@ static int nhood_build(sqgr_ctx* ctx, const sqgr_graph* g, int64_t n, const int3
     SQGR_REQUIRE(K >= 2, "Expected at least `2` clusters, found `%d`.", K);
     // with a graph: K*K*16 device-scope counters per batch bound the cluster count; the label generators alone (ligrec's
     // shuffler: no graph) address 16-bit labels
-    if (K > (g ? 2048 : 65535)) {
-        set_error(g ? "K=%d > 2048 clusters is not supported by the batched permutation kernels"
+    if (K > (g ? 4096 : 65535)) {  // (4096 clusters: 1 GiB of counters per batch of 16 permutations, 2 x 2 GiB of accumulator slots)
+        set_error(g ? "K=%d > 4096 clusters is not supported by the batched permutation kernels"
                     : "K=%d > 65535 clusters: the label generators write 16-bit labels", K);
         return SQGR_ERR_UNSUPPORTED;
     }

@@ -232,8 +232,8 @@ def _broadcast_seed(key: int) -> int:
 DEFAULT_STREAM_NOTICE_WORK = 5_000_000_000   # n_obs * n_perms from which a DEFAULTED `rng` (numpy's streams, ~11x slower than "philox") is pointed out
 HOST_GATHER_NOTICE_ENTRIES = 64_000_000      # n_perms * K * K from which the host gather of several ranks' per-permutation counts is pointed out
 PROGRESS_STEP = 40_960  # permutations per progress update: 16 launch groups of 2560
-MAX_DEVICE_SHUFFLE_CLUSTERS = 2048  # batched permutation kernels: uint8 labels + LDS counters up to 256 clusters, uint16 labels + device-scope
-# counters up to 2048 (K*K*16 counters per batch); beyond that the any-K edge-pair kernel counts host-drawn numpy shuffles
+MAX_DEVICE_SHUFFLE_CLUSTERS = 4096  # batched permutation kernels: uint8 labels + LDS counters up to 256 clusters, uint16 labels + device-scope
+# counters up to 4096 (K*K*16 counters per batch: 1 GiB); beyond that the any-K edge-pair kernel counts host-drawn numpy shuffles
 
 
 def _zscore_many_clusters(
@@ -247,7 +247,7 @@ def _zscore_many_clusters(
     n_perms: int,
     count: np.ndarray,
 ) -> np.ndarray:
-    """More than 2048 clusters: the batched device shuffle does not apply (K*K*16 counters per pass), so each
+    """More than 4096 clusters: the batched device shuffle does not apply (K*K*16 counters per pass), so each
     permutation is drawn with the reference's own numpy stream on the host (gr/_nhood.py:213, 530-539) and counted by the
     general edge-pair kernel (`sqgr_nhood_counts`, any K) — Squidpy's z-scores for the seed, at ~1 ms per permutation
     plus the shuffle.  Permutation ranges are split over ranks like the other paths."""

@@ -634,7 +634,7 @@ def test_skewed_cluster_sizes(L, ctx):
 
 
 def test_more_than_256_clusters_run_batched_on_the_device(L, ctx):
-    """256 < K <= 2048: 16-bit label slab + device-scope counters, device shuffles in both rng modes — the
+    """256 < K <= 4096: 16-bit label slab + device-scope counters, device shuffles in both rng modes — the
     device generator against its oracle restatement, numpy streams against Squidpy's z-scores for the seed, bit for bit."""
     import squidpy_amd as sq
 
@@ -711,12 +711,12 @@ def test_300_clusters_at_1e5_spots_is_a_device_path(L, ctx):
     assert dt < 1.0, f"{P} permutations took {dt:.2f} s"
 
 
-def test_more_than_2048_clusters_use_the_general_path(L, ctx):
-    """K > 2048: numpy streams on the host + the any-K edge-pair kernel; Squidpy's z-scores for the seed for either `rng`."""
+def test_more_than_4096_clusters_use_the_general_path(L, ctx):
+    """K > 4096: numpy streams on the host + the any-K edge-pair kernel; Squidpy's z-scores for the seed for either `rng`."""
     import squidpy_amd as sq
 
-    k = 2100
-    adata = hex_adata(50, 60, 6, seed=8)
+    k = 4200
+    adata = hex_adata(70, 80, 6, seed=8)
     n = adata.n_obs
     lab = np.random.default_rng(8).integers(0, k, n).astype(np.int32)
     lab[:k] = np.arange(k)
@@ -808,3 +808,33 @@ def test_graph_stays_resident_between_calls_and_is_keyed_by_content(L, ctx):
     assert len(L._graph_cache) == L._GRAPH_CACHE_SLOTS and g1.h is None
     sq.clear_graph_cache()
     assert not L._graph_cache
+
+
+@pytest.mark.parametrize("k", [3000, 4096])
+def test_thousands_of_clusters_run_batched_on_the_device(L, ctx, k):
+    """2048 < K <= 4096 (round 6; the reference has no limit): 16-bit labels, K*K*16 device-scope counters per batch (0.6 GB at
+    3000 clusters), the device generator reading its label boundaries where they fit — per-permutation counts against the oracle in
+    both generators, the front end's z-scores in numpy's streams against the reference's arithmetic."""
+    import squidpy_amd as sq
+
+    adata = hex_adata(60, 100, 6, seed=9)
+    n = adata.n_obs
+    lab = np.random.default_rng(9).integers(0, k, n).astype(np.int32)
+    lab[:k] = np.arange(k)
+    adata.obs["cluster"] = pd.Categorical.from_codes(lab, [f"c{i:04d}" for i in range(k)])
+    adj = adata.obsp["spatial_connectivities"]
+    g = L.Graph(ctx, adj, with_data=False)
+    plan = L.NhoodPlan(ctx, g, lab, k)
+    _, _, perms = plan.run(3, 5, 23, return_perms=True)
+    np.testing.assert_array_equal(perms, O.nhood_perm_counts_philox(adj.indices, adj.indptr, lab, k, 3, 5, 23).astype(np.uint32))
+    from squidpy_amd._utils import pcg64_states
+
+    _, _, perms = plan.run_pcg64(pcg64_states(4, 7), return_perms=True)
+    ref = O.nhood_perm_counts_numpy(adj.indices, adj.indptr, lab, k, 4, 7)
+    np.testing.assert_array_equal(perms, ref.astype(np.uint32))
+    plan.close()
+    g.close()
+    res = sq.gr.nhood_enrichment(adata, "cluster", n_perms=7, seed=4, copy=True)
+    want = O.nhood_zscore(O.nhood_counts(adj.indices, adj.indptr, lab, k), ref)
+    ok = np.isfinite(want)
+    np.testing.assert_array_equal(res.zscore[ok], want[ok])
