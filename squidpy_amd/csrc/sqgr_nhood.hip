@@ -263,8 +263,8 @@ __global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __re
                     }
                     const uint32_t e = blk_at(a * 4u);  // the table again: nearly always enough
                     uint32_t l = (e & 0xFFFFu) + (b >= (e >> 16) ? 1u : 0u);
-                    if (l >= (uint32_t)K) {  // a block the two-field form cannot describe: rank against the boundaries
-                        l = 0;
+                    if (l >= (uint32_t)K) {  // a block the two-field form cannot describe: rank against the boundaries, from the
+                        l = K <= 255 ? (e >> 8) & 0xFFu : 0u;  // block's first label on (skewed cluster sizes: 1-3 steps instead of ~K/2)
                         while (x >= tab[l]) ++l;  // sentinel UINT_MAX stops it
                     }
                     word = (word & ~(0xFFu << (8 * j))) | (l << (8 * j));
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void k_shuffle_indep(int64_t n, const uint32_t
                     const uint32_t e = blk_at(a * 4u);
                     uint32_t l = (e & 0xFFFFu) + (b >= (e >> 16) ? 1u : 0u);
                     if (l >= (uint32_t)K) {
-                        l = 0;
+                        l = K <= 255 ? (e >> 8) & 0xFFu : 0u;  // (the block's first label: k_shuffle)
                         while (x >= tab[l]) ++l;
                     }
                     word = (word & ~(0xFFu << (8 * j))) | (l << (8 * j));
@@ -2085,8 +2085,8 @@ static int nhood_build(sqgr_ctx* ctx, const sqgr_graph* g, int64_t n, const int3
                         word = lab | (0xFFFFu << 16);
                     else if (events == 1 && ev_label == lab + 1 && ev_pos > 0)
                         word = lab | ((uint32_t)ev_pos << 16);
-                    else
-                        word = SENT;
+                    else  // the exact route ranks x against the boundaries: from this block's first label on (byte 1: free in the
+                        word = SENT | (K <= 255 ? lab << 8 : 0u);  // two-field form, which reads byte 0 and the upper half)
                 }
                 blk[doms[l].aoff + a] = word;
             }
