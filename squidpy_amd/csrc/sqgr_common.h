@@ -236,6 +236,17 @@ struct sqgr_graph {
     mutable int64_t n_half = 0;  // edges with r < c
     mutable int64_t n_self = 0;  // self loops, stored behind them
     int ensure_half() const;
+    // Directed graphs (kNN graphs are, gr/neighbors.py: KNNBuilder does not symmetrise): most of their edges still come in mutual
+    // pairs, and a pair needs ONE walk — its contribution to the counts is h + h^T like a half edge's.  `split` =
+    // [mutual edges with r < c | LIST_PAD zeros | edges without a mirror | LIST_PAD zeros], built on first use on graphs in
+    // canonical CSR form without self loops; split_state: 0 not tried, 1 built, -1 not applicable (symmetric, self loops, not
+    // canonical, or fewer than an eighth of the entries would be spared).
+    mutable int split_state = 0;
+    mutable bool canonical_rows = false;  // ensure_half's check: rows strictly increasing
+    mutable sqgr::DevBuf<int2> split;
+    mutable int64_t n_mutual = 0;  // mutual pairs (edges with r < c that have a mirror)
+    mutable int64_t n_oneway = 0;  // edges without a mirror
+    int ensure_split() const;
     // The pass kernel of the permutation test (51 <= K <= 202 clusters, sqgr_nhood.hip: k_count_pass) reads the SAME list in
     // another order and with other offsets: inside every aligned group of 4*J entries (J = 32 | 64 edge slots of a wavefront)
     // slot j of gather instruction u = 0..3 — physical position 4*j + u — holds the list's entry (u/R)*(J*R) + j*R + u%R, so

@@ -278,11 +278,34 @@ __global__ __launch_bounds__(256) void k_sym_check(const int64_t* __restrict__ i
     if (lo >= indptr[c + 1] || indices[lo] != r) flags[0] = 1;
 }
 
+// class of every edge of a directed graph in canonical form: 1 mutual with r < c (kept: one walk serves the pair), 0 its mirror
+// (dropped), 2 no mirror; flags[0]: a self loop exists (the split list is not built then)
+__global__ __launch_bounds__(256) void k_split_classify(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                                        const int32_t* __restrict__ erow, int64_t nnz, uint8_t* __restrict__ cls,
+                                                        int* __restrict__ flags) {
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= nnz) return;
+    const int32_t r = erow[e], c = indices[e];
+    if (r == c) {
+        flags[0] = 1;
+        cls[e] = 2;
+        return;
+    }
+    int64_t lo = indptr[c], hi = indptr[c + 1];  // first position in row c with index >= r
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (indices[mid] < r) lo = mid + 1; else hi = mid;
+    }
+    const bool mutual = lo < indptr[c + 1] && indices[lo] == r;
+    cls[e] = mutual ? (r < c ? 1 : 0) : 2;
+}
+
 constexpr int HALF_TILE = 1024;  // edges per block of the stable compaction
 
 // pass 1: per tile, the number of edges with r < c and of self loops
+// (cls != NULL: the two classes are cls[e] == 1 and cls[e] == 2 instead — sqgr_graph::ensure_split)
 __global__ __launch_bounds__(HALF_TILE) void k_half_count(const int2* __restrict__ coo, int64_t nnz, uint32_t* __restrict__ tile_lt,
-                                                          uint32_t* __restrict__ tile_self) {
+                                                          uint32_t* __restrict__ tile_self, const uint8_t* __restrict__ cls = nullptr) {
     __shared__ uint32_t s_lt, s_self;
     if (threadIdx.x == 0) s_lt = s_self = 0;
     __syncthreads();
@@ -290,8 +313,8 @@ __global__ __launch_bounds__(HALF_TILE) void k_half_count(const int2* __restrict
     bool lt = false, self = false;
     if (e < nnz) {
         const int2 rc = coo[e];
-        lt = rc.x < rc.y;
-        self = rc.x == rc.y;
+        lt = cls ? cls[e] == 1 : rc.x < rc.y;
+        self = cls ? cls[e] == 2 : rc.x == rc.y;
     }
     const uint64_t m_lt = __ballot(lt), m_self = __ballot(self);
     if ((threadIdx.x & 63) == 0) {
@@ -348,15 +371,16 @@ __global__ __launch_bounds__(1024) void k_half_scan(uint32_t* __restrict__ tile_
 
 // pass 3: stable scatter — edges with r < c keep their CSR order in out[0, n_lt), self loops follow in out[n_lt, ...)
 __global__ __launch_bounds__(HALF_TILE) void k_half_scatter(const int2* __restrict__ coo, int64_t nnz, const uint32_t* __restrict__ tile_lt,
-                                                            const uint32_t* __restrict__ tile_self, uint32_t n_lt, int2* __restrict__ out) {
+                                                            const uint32_t* __restrict__ tile_self, uint32_t n_lt, int2* __restrict__ out,
+                                                            const uint8_t* __restrict__ cls = nullptr) {
     __shared__ uint32_t w_lt[HALF_TILE / 64], w_self[HALF_TILE / 64];
     const int64_t e = blockIdx.x * (int64_t)HALF_TILE + threadIdx.x;
     int2 rc = make_int2(0, 0);
     bool lt = false, self = false;
     if (e < nnz) {
         rc = coo[e];
-        lt = rc.x < rc.y;
-        self = rc.x == rc.y;
+        lt = cls ? cls[e] == 1 : rc.x < rc.y;
+        self = cls ? cls[e] == 2 : rc.x == rc.y;
     }
     const uint64_t m_lt = __ballot(lt), m_self = __ballot(self);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -445,6 +469,7 @@ int sqgr_graph::ensure_half() const {
     int h_flags[2] = {1, 1};
     SQGR_HIP(hipMemcpyAsync(h_flags, flags.p, 8, hipMemcpyDeviceToHost, st));
     SQGR_HIP(hipStreamSynchronize(st));
+    canonical_rows = h_flags[1] == 0;
     if (h_flags[0] || h_flags[1]) return SQGR_OK;  // not symmetric (or not canonical): the full edge list is used
     SQGR_TRY(t_lt.alloc((size_t)ntiles));
     SQGR_TRY(t_self.alloc((size_t)ntiles));
@@ -472,6 +497,53 @@ int sqgr_graph::ensure_half() const {
     n_self = (int64_t)h_tot[1];
     sym_state = 1;
     SQGR_TRY(tile_edge_list(ctx, half.p, n_half, n));
+    return SQGR_OK;
+}
+
+int sqgr_graph::ensure_split() const {
+    if (split_state != 0) return SQGR_OK;
+    SQGR_TRY(ensure_half());
+    split_state = -1;
+    if (sym_state != -1 || !canonical_rows || nnz < 2 || nnz >= ((int64_t)1 << 31) || getenv("SQGR_NO_SPLIT")) return SQGR_OK;
+    SQGR_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int64_t ntiles = ceil_div(nnz, HALF_TILE);
+    DevBuf<int> flags;
+    DevBuf<uint8_t> cls;
+    DevBuf<uint32_t> t_a, t_b;
+    DevBuf<unsigned long long> totals;
+    SQGR_TRY(flags.alloc(2));
+    SQGR_TRY(cls.alloc((size_t)nnz));
+    SQGR_TRY(t_a.alloc((size_t)ntiles));
+    SQGR_TRY(t_b.alloc((size_t)ntiles));
+    SQGR_TRY(totals.alloc(2));
+    SQGR_HIP(hipMemsetAsync(flags.p, 0, 8, st));
+    LaunchTimer t(ctx, "graph_split_list");
+    k_split_classify<<<(unsigned)ceil_div(nnz, 256), 256, 0, st>>>(indptr.p, indices.p, erow.p, nnz, cls.p, flags.p);
+    k_half_count<<<(unsigned)ntiles, HALF_TILE, 0, st>>>(coo.p, nnz, t_a.p, t_b.p, cls.p);
+    k_half_scan<<<1, 1024, 0, st>>>(t_a.p, t_b.p, ntiles, totals.p);
+    SQGR_HIP(hipGetLastError());
+    int h_flags[2] = {1, 1};
+    unsigned long long h_tot[2] = {0, 0};
+    SQGR_HIP(hipMemcpyAsync(h_flags, flags.p, 8, hipMemcpyDeviceToHost, st));
+    SQGR_HIP(hipMemcpyAsync(h_tot, totals.p, 16, hipMemcpyDeviceToHost, st));
+    SQGR_HIP(hipStreamSynchronize(st));
+    if (h_flags[0]) return SQGR_OK;                                                    // self loops
+    if (2 * h_tot[0] + h_tot[1] != (unsigned long long)nnz) {
+        set_error("internal error: split list of a directed graph has 2 x %llu + %llu entries for nnz=%lld", h_tot[0], h_tot[1], (long long)nnz);
+        return SQGR_ERR_HIP;
+    }
+    if (h_tot[0] * 8 < (unsigned long long)nnz) return SQGR_OK;                        // fewer than an eighth of the entries spared
+    const size_t m = (size_t)h_tot[0], o = (size_t)h_tot[1];
+    SQGR_TRY(split.alloc(m + o + 2 * (size_t)LIST_PAD));
+    SQGR_HIP(hipMemsetAsync(split.p + m, 0, (size_t)LIST_PAD * sizeof(int2), st));
+    SQGR_HIP(hipMemsetAsync(split.p + m + LIST_PAD + o, 0, (size_t)LIST_PAD * sizeof(int2), st));
+    k_half_scatter<<<(unsigned)ntiles, HALF_TILE, 0, st>>>(coo.p, nnz, t_a.p, t_b.p, (uint32_t)(m + LIST_PAD), split.p, cls.p);
+    SQGR_HIP(hipGetLastError());
+    SQGR_HIP(hipStreamSynchronize(st));
+    n_mutual = (int64_t)m;
+    n_oneway = (int64_t)o;
+    split_state = 1;
     return SQGR_OK;
 }
 

@@ -581,11 +581,27 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
     __syncthreads();
 
     const uint8_t* slab = slab_all + (size_t)blockIdx.y * n * B;
-    const uint32_t chunk = (uint32_t)xcd_chunk(blockIdx.x, gridDim.x);
+    uint32_t chunk = (uint32_t)xcd_chunk(blockIdx.x, gridDim.x);
+    // add_transposed >= 2 (round 6, !SELF): the SPLIT list of a directed graph (sqgr_graph::ensure_split) — `self_begin` mutual pairs
+    // walked by the first add_transposed >> 2 chunks (their partial is h + h^T), LIST_PAD zeros, then the nnz - self_begin edges
+    // without a mirror walked by the other chunks (their partial is h)
+    bool transposed = add_transposed == 1;
+    uint32_t lim = nnz;
+    if (add_transposed >= 2) {
+        const uint32_t nblk1 = (uint32_t)add_transposed >> 2;
+        transposed = chunk < nblk1;
+        if (transposed) {
+            lim = self_begin;
+        } else {
+            chunk -= nblk1;
+            coo += self_begin + (uint32_t)LIST_PAD;
+            lim = nnz - self_begin;
+        }
+    }
     const uint32_t e0 = chunk * edges_per_block;
-    const uint32_t e1 = min(nnz, e0 + edges_per_block);
+    const uint32_t e1 = min(lim, e0 + edges_per_block);
     // block-uniform: every edge slot of every iteration is a real edge of one weight -> no per-edge bookkeeping at all
-    const bool uniform_block = (e0 + edges_per_block <= nnz) && (!SELF || e0 + edges_per_block <= self_begin);
+    const bool uniform_block = (e0 + edges_per_block <= lim) && (!SELF || e0 + edges_per_block <= self_begin);
     const uint32_t q = tid & 3;
     const uint32_t el = tid >> 2;
     const uint32_t rot = (el & (BPL - 1)) * 8;  // bits to rotate right
@@ -796,7 +812,7 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
             e += STEP;
         }
     };
-    if (e0 < nnz) {  // (chunks past the end of a short list stay empty; their look-ahead would leave the padding)
+    if (e0 < lim) {  // (chunks past the end of a short list stay empty; their look-ahead would leave the padding)
         if (uniform_block)
             sweep(std::false_type{});
         else
@@ -816,7 +832,7 @@ __global__ __launch_bounds__(COUNT_THREADS, MIN_WAVES) void k_count(uint32_t nnz
         for (int i = tid; i < hist_words; i += COUNT_THREADS) dst[i] = hist[i];
         return;
     }
-    if (add_transposed) {  // half list: the block's contribution to count = h + h^T is formed here, out of LDS
+    if (transposed) {  // half list: the block's contribution to count = h + h^T is formed here, out of LDS
         constexpr int LOGB = (B == 32) ? 5 : 4;
         for (int i = tid; i < hist_words; i += COUNT_THREADS) {
             const int pair = i >> LOGB, la = pair / K, lb = pair - la * K;
@@ -1752,12 +1768,25 @@ int sqgr_nhood::count_batches(int nb, int buf) {
         // LDS-histogram kernels: on a structurally symmetric graph they walk the half list (see sqgr_graph::ensure_half)
         SQGR_TRY(g->ensure_half());
         const bool half = g->sym_state == 1;
-        const int2* list = half ? g->half.p : g->coo.p;
-        const uint32_t m = (uint32_t)(half ? g->n_half + g->n_self : nnz);
-        const uint32_t self_begin = (uint32_t)(half ? g->n_half : nnz);
+        // a directed graph (K <= 50, 16 permutations per pass): its mutual pairs once + its edges without a mirror (ensure_split)
+        bool split_list = false;
+        if (!half && B == 16 && !mode && nblk >= 2) {
+            SQGR_TRY(g->ensure_split());
+            split_list = g->split_state == 1;
+        }
+        const int2* list = half ? g->half.p : (split_list ? g->split.p : g->coo.p);
+        const uint32_t m = (uint32_t)(half ? g->n_half + g->n_self : (split_list ? g->n_mutual + g->n_oneway : nnz));
+        const uint32_t self_begin = (uint32_t)(half ? g->n_half : (split_list ? g->n_mutual : nnz));
         const bool self = half && g->n_self > 0;
         sym_launch = self ? 2 : 0;  // the blocks' partials already hold h + h^T; half lists with self loops are in doubled units
-        const uint32_t epb = (uint32_t)(ceil_div(ceil_div((int64_t)m, nblk), 1024) * 1024);  // whole iterations of a block
+        uint32_t epb = (uint32_t)(ceil_div(ceil_div((int64_t)m, nblk), 1024) * 1024);  // whole iterations of a block
+        int addt = half ? 1 : 0;
+        if (split_list) {  // the chunks are shared out in proportion to the two parts' lengths
+            const int64_t M = g->n_mutual, O = g->n_oneway;
+            const int nblk1 = (int)std::min<int64_t>(nblk - 1, std::max<int64_t>(1, (M * nblk + (M + O) / 2) / std::max<int64_t>(M + O, 1)));
+            epb = (uint32_t)(ceil_div(std::max(ceil_div(M, nblk1), ceil_div(std::max<int64_t>(O, 1), nblk - nblk1)), 1024) * 1024);
+            addt = 2 | (nblk1 << 2);
+        }
         const size_t lds = mode ? (size_t)ncell * 32 : (size_t)hw * 4;
         const dim3 grid(nblk, nb);
         if (mode) {  // 51 <= K <= 100 (71 on directed graphs): 16-bit counters, all 16 permutations in one pass
@@ -1783,9 +1812,9 @@ int sqgr_nhood::count_batches(int nb, int buf) {
             return SQGR_OK;
         }
 #define SQGR_COUNT(BB, MW, SELF) \
-    k_count<BB, MW, SELF><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, hw, epb, self_begin, half ? 1 : 0, partial.p)
+    k_count<BB, MW, SELF><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, hw, epb, self_begin, addt, partial.p)
 #define SQGR_COUNT_D(BB, MW, SELF) \
-    k_count<BB, MW, SELF, true><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, hw, epb, self_begin, half ? 1 : 0, partial.p)
+    k_count<BB, MW, SELF, true><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, hw, epb, self_begin, addt, partial.p)
         static const bool dot2 = [] { const char* e = getenv("SQGR_COUNT_DOT2"); return !(e && atoi(e) == 0); }();
         if (B == 32) {
             LaunchTimer t(ctx, half ? "nhood_count_b32_half" : "nhood_count_b32");
@@ -1797,14 +1826,14 @@ int sqgr_nhood::count_batches(int nb, int buf) {
                 SQGR_COUNT(32, 4, false);
             }
         } else {
-            LaunchTimer t(ctx, half ? "nhood_count_b16_half" : "nhood_count_b16");
+            LaunchTimer t(ctx, half ? "nhood_count_b16_half" : (split_list ? "nhood_count_b16_split" : "nhood_count_b16"));
             static const int dbg = [] { const char* e = getenv("SQGR_COUNT_DEBUG"); return e ? atoi(e) : 0; }();
             if (dot2 && dbg && lds * 2 <= LDS_BUDGET && !self) {
 #define SQGR_COUNT_DBG(D) \
-    case D: k_count<16, 8, false, true, D><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, hw, epb, self_begin, half ? 1 : 0, partial.p); break
+    case D: k_count<16, 8, false, true, D><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, hw, epb, self_begin, addt, partial.p); break
                 switch (dbg) {
                     SQGR_COUNT_DBG(1); SQGR_COUNT_DBG(2); SQGR_COUNT_DBG(3); SQGR_COUNT_DBG(4); SQGR_COUNT_DBG(5); SQGR_COUNT_DBG(6);
-                    default: k_count<16, 8, false, true, 7><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, hw, epb, self_begin, half ? 1 : 0, partial.p);
+                    default: k_count<16, 8, false, true, 7><<<grid, COUNT_THREADS, lds, st>>>(m, list, slab_p, n, K, hw, epb, self_begin, addt, partial.p);
                 }
 #undef SQGR_COUNT_DBG
             } else if (dot2) {
