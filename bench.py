@@ -1010,7 +1010,7 @@ def nhood_variant_legs(ctx, adj, graph, n: int, headline_value: float | None, pe
         xy = hex_grid(rows, rows) + np.random.default_rng(1).normal(0.0, 5.0, (n, 2))
         knn = knn_directed_graph(xy, 6, ctx)
         gk = _lib.Graph(ctx, knn, with_data=False)
-        run("nhood_knn6_directed", gk, int(knn.nnz), lab30, N_CLS, "directed 6-nearest-neighbour graph of the jittered lattice (full edge list), 30 uniform clusters")
+        run("nhood_knn6_directed", gk, int(knn.nnz), lab30, N_CLS, "directed 6-nearest-neighbour graph of the jittered lattice (split list: its mutual pairs once + its edges without a mirror), 30 uniform clusters")
         gk.close()
     lab_rng = np.random.default_rng(0)
     skew = lab_rng.choice(N_CLS, size=n, p=lab_rng.dirichlet(np.full(N_CLS, 0.5))).astype(np.int32)

@@ -1589,7 +1589,12 @@ struct sqgr_nhood {
     // 16-bit counters: the most edges one block may count — no counter can pass 65 535 whatever the labels are (a block's cell
     // receives at most weight x edges; weight 2 on half lists with self loops) — in whole iterations of the kernel that runs
     uint32_t edge_step() const { return be() == 16 ? 1024u : (be() == 8 ? 2048u : 4096u); }
-    int64_t list_edges() const { return g ? ((lds_path() && g->sym_state == 1) ? g->n_half + g->n_self : g->nnz) : 0; }
+    int64_t list_edges() const {  // entries of the list the count kernel walks: half list | split list of a directed graph | all edges
+        if (!g) return 0;
+        if (lds_path() && g->sym_state == 1) return g->n_half + g->n_self;
+        if (lds_path() && B == 16 && be() == 16 && !cm() && g->split_state == 1) return g->n_mutual + g->n_oneway;
+        return g->nnz;
+    }
     // ... unless the labels themselves bound it: a cell {a, b} receives only list entries with an endpoint in cluster a, at most
     // (size of a) x (longest row) of them, and a shuffle keeps the cluster sizes.  That argument needs every one of the slab's 16
     // columns to BE a shuffle of the base labels: `columns_valid` — true inside sqgr_nhood_run only (the device generator always
