@@ -310,3 +310,28 @@ def test_rendezvous_survives_a_dial_that_gave_up_before_the_acknowledgement():
     assert out["a"] == [b"zero", b"one"]
     g1.close()
     box["g0"].close()
+
+
+def test_spot_order_helpers():
+    """squidpy_amd/_order.py: `edge_span` tells scan order from random order, `spatial_order` (Morton curve of the coordinates,
+    reverse Cuthill-McKee of the graph) brings a randomly ordered grid back to a short span, and is a permutation."""
+    import scipy.sparse as sp
+
+    import squidpy_amd as sq
+    from squidpy_amd._synthetic import hex_grid, hex_grid_graph
+
+    rows = cols = 60
+    adj = hex_grid_graph(rows, cols).tocsr()
+    n = adj.shape[0]
+    xy = hex_grid(rows, cols)
+    assert sq.edge_span(adj) < 0.02
+    perm = np.random.default_rng(1).permutation(n)
+    inv = np.empty(n, np.int64)
+    inv[perm] = np.arange(n)
+    coo = adj.tocoo()
+    shuf = sp.csr_matrix((coo.data, (inv[coo.row], inv[coo.col])), shape=(n, n))
+    assert sq.edge_span(shuf) > 0.25
+    for order in (sq.spatial_order(coords=xy[perm]), sq.spatial_order(shuf)):
+        assert sorted(order.tolist()) == list(range(n))
+        back = shuf[order][:, order]
+        assert sq.edge_span(sp.csr_matrix(back)) < 0.06
