@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SQGR_ABI_VERSION 6
+#define SQGR_ABI_VERSION 7
 
 typedef enum sqgr_status {
     SQGR_OK = 0,
@@ -110,6 +110,13 @@ int sqgr_graph_create(sqgr_ctx* ctx, int64_t n, int64_t nnz, const int64_t* indp
 int sqgr_graph_create_f64(sqgr_ctx* ctx, int64_t n, int64_t nnz, const int64_t* indptr, const int32_t* indices,
                           const double* data, sqgr_graph** out_graph);
 int sqgr_graph_destroy(sqgr_graph* g);
+/* Observations in no spatial order cost the permutation test's count kernel up to 8x: it gathers the label rows of an edge's two
+ * endpoints (no counterpart in the reference, whose loop does not care).  `sqgr_graph_renumbered` builds the twin P A P^T of a graph
+ * (structure only, canonical CSR) on the device for `order[new] = old`; `sqgr_spatial_order` computes such an order from coordinates
+ * xy float64[n][2] (Z-order curve).  A plan created on the twin with the labels in twin order and `sqgr_nhood_set_spot_map(plan,
+ * order)` returns exactly the moments of the plan on the caller's own graph (sqgr_nhood_run; ABI v7). */
+int sqgr_graph_renumbered(sqgr_ctx* ctx, const sqgr_graph* g, const int32_t* order, sqgr_graph** out_graph);
+int sqgr_spatial_order(sqgr_ctx* ctx, const double* xy, int64_t n, int32_t* out_order);
 
 /* ------------------------------------------------------------------ nhood_enrichment
  * replaces the generated numba kernel `_nenrich_{K}_{parallel}` (gr/_nhood.py:54-141):
@@ -168,6 +175,11 @@ int sqgr_nhood_info(sqgr_nhood* plan, int64_t* out_info);
 
 /* Attaches (comm != NULL) or detaches an RCCL communicator: see "multi-GPU" above. */
 int sqgr_nhood_set_comm(sqgr_nhood* plan, sqgr_comm* comm);
+/* The plan lives on a renumbered twin of the caller's graph (sqgr_graph_renumbered): spot_of int32[n], slab row i belongs to the
+ * caller's observation spot_of[i] — the device generator permutes THAT observation's rank, so sqgr_nhood_run returns the moments of
+ * the plan on the caller's own graph, bit for bit.  No libraries, at most 256 clusters; the numpy-stream and injected-label entry
+ * points refuse such a plan (they permute positions).  NULL removes the map. */
+int sqgr_nhood_set_spot_map(sqgr_nhood* plan, const int32_t* spot_of);
 
 /* numpy's `Generator.permutation(n)` for n_perms generator states (layout as above), on the device:
  * out_idx int32[n_perms][n] — the row permutations of `_score_helper` (gr/_ppatterns.py:269-271). */

@@ -9,7 +9,7 @@ from ._anndata_lite import AnnDataLite
 from ._dist import init as init_distributed
 from ._dist import shutdown as shutdown_distributed
 from ._lib import clear_graph_cache, trim_device_memory
-from ._order import edge_span, spatial_order
+from ._order import edge_locality, edge_span, spatial_order
 
-__all__ = ["gr", "AnnDataLite", "init_distributed", "shutdown_distributed", "clear_graph_cache", "trim_device_memory", "edge_span", "spatial_order"]
+__all__ = ["gr", "AnnDataLite", "init_distributed", "shutdown_distributed", "clear_graph_cache", "trim_device_memory", "edge_locality", "edge_span", "spatial_order"]
 __version__ = "0.1.0"

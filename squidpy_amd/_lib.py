@@ -50,6 +50,9 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "sqgr_graph_create": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, c_i64p, c_i32p, c_f32p, C.POINTER(C.c_void_p)]),
     "sqgr_graph_create_f64": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, c_i64p, c_i32p, c_f64p, C.POINTER(C.c_void_p)]),
     "sqgr_graph_destroy": (C.c_int, [C.c_void_p]),
+    "sqgr_graph_renumbered": (C.c_int, [C.c_void_p, C.c_void_p, c_i32p, C.POINTER(C.c_void_p)]),
+    "sqgr_spatial_order": (C.c_int, [C.c_void_p, c_f64p, C.c_int64, c_i32p]),
+    "sqgr_nhood_set_spot_map": (C.c_int, [C.c_void_p, c_i32p]),
     "sqgr_nhood_counts": (C.c_int, [C.c_void_p, C.c_void_p, c_i32p, C.c_int32, c_u32p]),
     "sqgr_nhood_counts_batch": (C.c_int, [C.c_void_p, C.c_void_p, c_u8p, C.c_int64, C.c_int32, c_u32p]),
     "sqgr_nhood_create": (C.c_int, [C.c_void_p, C.c_void_p, c_i32p, C.c_int32, c_i32p, C.c_int32, C.POINTER(C.c_void_p)]),
@@ -98,7 +101,7 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
 }
 
 
-ABI_VERSION = 6  # SQGR_ABI_VERSION of include/sqgr.h
+ABI_VERSION = 7  # SQGR_ABI_VERSION of include/sqgr.h
 
 
 class SqgrError(RuntimeError):
@@ -323,8 +326,29 @@ class Graph:
             rc = ctx.lib.sqgr_graph_create(ctx.h, self.n, self.nnz, _ptr(indptr, c_i64p), _ptr(indices, c_i32p), _ptr(data, c_f32p), C.byref(h))
         _check(ctx.lib, rc)
         self.h = h
+        self._twin = None  # (order, renumbered Graph): see renumbered()
+
+    def renumbered(self, order: np.ndarray) -> "Graph":
+        """The twin ``P A P^T`` of this graph (structure only) for ``order[new] = old``, built on the device
+        (``sqgr_graph_renumbered``); kept with the graph and reused while ``order`` stays the same."""
+        order = _as(order, np.int32)
+        if self._twin is not None and np.array_equal(self._twin[0], order):
+            return self._twin[1]
+        if len(order) != self.n:
+            raise ValueError(f"Expected an order of {self.n} observations, found {len(order)}.")
+        h = C.c_void_p()
+        _check(self.ctx.lib, self.ctx.lib.sqgr_graph_renumbered(self.ctx.h, self.h, _ptr(order, c_i32p), C.byref(h)))
+        twin = Graph.__new__(Graph)
+        twin.ctx, twin.n, twin.nnz, twin.h, twin._twin = self.ctx, self.n, self.nnz, h, None
+        if self._twin is not None:
+            self._twin[1].close()
+        self._twin = (order.copy(), twin)
+        return twin
 
     def close(self) -> None:
+        if getattr(self, "_twin", None) is not None:
+            self._twin[1].close()
+            self._twin = None
         if getattr(self, "h", None):
             self.ctx.lib.sqgr_graph_destroy(self.h)
             self.h = None
@@ -396,6 +420,15 @@ import atexit  # noqa: E402
 atexit.register(clear_graph_cache)  # before the contexts they live on are torn down
 
 
+def spatial_order_device(ctx: Context, xy: np.ndarray) -> np.ndarray:
+    """``order[new] = old`` along the Z-order curve of the coordinates ``xy`` (n x 2), computed on the device (``sqgr_spatial_order``:
+    ~1 ms per million observations + the upload)."""
+    xy = np.ascontiguousarray(np.asarray(xy, dtype=np.float64)[:, :2])
+    out = np.empty(len(xy), dtype=np.int32)
+    _check(ctx.lib, ctx.lib.sqgr_spatial_order(ctx.h, _ptr(xy, c_f64p), len(xy), _ptr(out, c_i32p)))
+    return out
+
+
 def nhood_counts(ctx: Context, g: Graph, labels: np.ndarray, n_cls: int) -> np.ndarray:
     labels = _as(labels, np.int32)
     out = np.zeros((n_cls, n_cls), dtype=np.uint32)
@@ -456,6 +489,13 @@ class NhoodPlan:
             "symmetric": int(v[4]) != 0, "self_loops": int(v[6]), "hist_words": int(v[5]), "generator_group": int(v[7]),
             "partial_bytes_per_chunk": int(v[11]), "partial_bytes_per_launch": int(v[1]) * int(v[2]) * int(v[11]),
         }
+
+    def set_spot_map(self, spot_of: np.ndarray | None) -> None:
+        """The plan lives on a renumbered twin of the caller's graph (:meth:`Graph.renumbered`): slab row ``i`` belongs to the
+        caller's observation ``spot_of[i]`` — :meth:`run` then returns the moments of the plan on the caller's own graph, bit for bit
+        (``sqgr_nhood_set_spot_map``; no libraries, at most 256 clusters; the numpy-stream entry points refuse such a plan)."""
+        m = _as(spot_of, np.int32) if spot_of is not None else None
+        _check(self.ctx.lib, self.ctx.lib.sqgr_nhood_set_spot_map(self.h, _ptr(m, c_i32p)))
 
     def set_comm(self, comm: "Comm | None") -> None:
         """Attach an RCCL communicator: :meth:`run` / :meth:`run_pcg64` then return the moments summed over all ranks

@@ -260,6 +260,57 @@ __global__ void k_expand_rows(const int64_t* __restrict__ indptr, const int32_t*
     coo[e] = make_int2((int)((uint32_t)lo * 16u), (int)((uint32_t)indices[e] * 16u));  // byte offsets of 16-byte label rows
 }
 
+// ---------------------------------------------------------------------------------------------- renumbered twin of a graph
+// The count kernel of the permutation test gathers the label rows of an edge's endpoints: observations in no spatial order cost it
+// up to 8x (tools/spot_order_time.py).  sqgr_graph_renumbered builds P A P^T in canonical CSR form on the device for an order given
+// as `order[new] = old`; sqgr_spatial_order computes such an order from coordinates (Z-order curve: 16-bit cells, one radix sort).
+__global__ void k_order_inverse(const int32_t* __restrict__ order, int64_t n, int32_t* __restrict__ pos, int* __restrict__ flags) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t o = order[i];
+    if (o < 0 || o >= n) { flags[0] = 1; return; }
+    if (atomicExch(&pos[o], (int32_t)i) != -1) flags[0] = 1;  // an index listed twice: not a permutation
+}
+__global__ void k_order_degrees(const int64_t* __restrict__ indptr, const int32_t* __restrict__ order, int64_t n, int64_t* __restrict__ deg) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t o = order[i];
+    deg[i] = indptr[o + 1] - indptr[o];
+}
+// one thread per new row: the old row's entries mapped to their new numbers, in ascending order (insertion sort in place: rows of a
+// spatial graph hold a handful of entries)
+__global__ void k_order_rows(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const int32_t* __restrict__ order,
+                             const int32_t* __restrict__ pos, const int64_t* __restrict__ new_indptr, int64_t n, int32_t* __restrict__ out) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t src = indptr[order[i]], len = indptr[order[i] + 1] - src;
+    int32_t* dst = out + new_indptr[i];
+    for (int64_t k = 0; k < len; ++k) {
+        const int32_t v = pos[indices[src + k]];
+        int64_t j = k;
+        while (j > 0 && dst[j - 1] > v) {
+            dst[j] = dst[j - 1];
+            --j;
+        }
+        dst[j] = v;
+    }
+}
+__global__ void k_morton_keys(const double* __restrict__ xy, int64_t n, double x0, double y0, double sx, double sy, uint32_t* __restrict__ keys,
+                              int32_t* __restrict__ idx) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    auto spread = [](uint32_t v) {  // 16 bits -> every second bit of 32
+        v = (v | (v << 8)) & 0x00FF00FFu;
+        v = (v | (v << 4)) & 0x0F0F0F0Fu;
+        v = (v | (v << 2)) & 0x33333333u;
+        return (v | (v << 1)) & 0x55555555u;
+    };
+    const double fx = (xy[2 * i] - x0) * sx, fy = (xy[2 * i + 1] - y0) * sy;
+    const uint32_t qx = (uint32_t)fmin(fmax(fx, 0.0), 65535.0), qy = (uint32_t)fmin(fmax(fy, 0.0), 65535.0);
+    keys[i] = spread(qx) | (spread(qy) << 1);
+    idx[i] = (int32_t)i;
+}
+
 // ---------------------------------------------------------------------------------------------- symmetric half list
 // flags[0]: some edge has no mirror; flags[1]: a row is not strictly increasing (unsorted or duplicate entries — the
 // binary search below is then meaningless and the graph is treated as not symmetric).
@@ -952,6 +1003,111 @@ int sqgr_graph_create(sqgr_ctx* ctx, int64_t n, int64_t nnz, const int64_t* indp
 int sqgr_graph_create_f64(sqgr_ctx* ctx, int64_t n, int64_t nnz, const int64_t* indptr, const int32_t* indices,
                           const double* data, sqgr_graph** out_graph) {
     return graph_create_impl(ctx, n, nnz, indptr, indices, nullptr, data, out_graph);
+}
+
+int sqgr_graph_renumbered(sqgr_ctx* ctx, const sqgr_graph* g, const int32_t* order, sqgr_graph** out_graph) {
+    SQGR_REQUIRE(ctx && g && order && out_graph, "null argument");
+    *out_graph = nullptr;
+    SQGR_REQUIRE(g->ctx == ctx, "graph belongs to a different context");
+    SQGR_REQUIRE(g->max_row_len <= 4096, "a row of %lld entries: rows are sorted by insertion", (long long)g->max_row_len);
+    SQGR_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int64_t n = g->n, nnz = g->nnz;
+    DevBuf<int32_t> d_order, d_pos;
+    DevBuf<int64_t> deg;
+    DevBuf<int> flags;
+    SQGR_TRY(d_order.alloc((size_t)n));
+    SQGR_TRY(d_pos.alloc((size_t)n));
+    SQGR_TRY(deg.alloc((size_t)n + 1));
+    SQGR_TRY(flags.alloc(2));
+    sqgr_graph* t = new sqgr_graph();
+    t->ctx = ctx;
+    t->n = n;
+    t->nnz = nnz;
+    t->max_row_len = g->max_row_len;
+    auto fail = [&](int code) {
+        delete t;
+        return code;
+    };
+    int rc = SQGR_OK;
+    if ((rc = t->indptr.alloc((size_t)n + 1)) || (rc = t->indices.alloc((size_t)std::max<int64_t>(nnz, 1))) ||
+        (rc = t->erow.alloc((size_t)std::max<int64_t>(nnz, 1))) || (rc = t->coo.alloc((size_t)nnz + LIST_PAD)))
+        return fail(rc);
+    hipError_t e = hipMemcpyAsync(d_order.p, order, (size_t)n * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(d_pos.p, 0xFF, (size_t)n * 4, st);
+    if (e == hipSuccess) e = hipMemsetAsync(flags.p, 0, 8, st);
+    if (e == hipSuccess) e = hipMemsetAsync(t->coo.p + nnz, 0, (size_t)LIST_PAD * sizeof(int2), st);
+    if (e == hipSuccess) e = hipMemsetAsync(deg.p + n, 0, 8, st);
+    if (e != hipSuccess) {
+        set_error("graph renumbering failed: %s", hipGetErrorString(e));
+        return fail(SQGR_ERR_HIP);
+    }
+    {
+        LaunchTimer tm(ctx, "graph_renumber");
+        const unsigned gn = (unsigned)ceil_div(n, 256);
+        k_order_inverse<<<gn, 256, 0, st>>>(d_order.p, n, d_pos.p, flags.p);
+        k_order_degrees<<<gn, 256, 0, st>>>(g->indptr.p, d_order.p, n, deg.p);
+        size_t tmp_bytes = 0;
+        e = hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, deg.p, t->indptr.p, (int)(n + 1), st);
+        DevBuf<uint8_t> tmp;
+        if (e == hipSuccess && (rc = tmp.alloc(tmp_bytes)) != SQGR_OK) return fail(rc);
+        if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, deg.p, t->indptr.p, (int)(n + 1), st);
+        int h_flags[2] = {1, 0};
+        if (e == hipSuccess) e = hipMemcpyAsync(h_flags, flags.p, 8, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e == hipSuccess && h_flags[0]) {
+            set_error("`order` is not a permutation of 0 .. %lld", (long long)(n - 1));
+            return fail(SQGR_ERR_INVALID);
+        }
+        if (e == hipSuccess && nnz) {
+            k_order_rows<<<gn, 256, 0, st>>>(g->indptr.p, g->indices.p, d_order.p, d_pos.p, t->indptr.p, n, t->indices.p);
+            k_expand_rows<<<(unsigned)ceil_div(nnz, 256), 256, 0, st>>>(t->indptr.p, t->indices.p, n, nnz, t->erow.p, t->coo.p);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    if (e != hipSuccess) {
+        set_error("graph renumbering failed: %s", hipGetErrorString(e));
+        return fail(SQGR_ERR_HIP);
+    }
+    t->has_data = false;  // (structure only: what the permutation test reads)
+    *out_graph = t;
+    return SQGR_OK;
+}
+
+int sqgr_spatial_order(sqgr_ctx* ctx, const double* xy, int64_t n, int32_t* out_order) {
+    SQGR_REQUIRE(ctx && xy && out_order && n > 0 && n < (int64_t)0x7fffffff, "null argument or n out of range");
+    double lo[2] = {xy[0], xy[1]}, hi[2] = {xy[0], xy[1]};
+    for (int64_t i = 0; i < n; ++i)
+        for (int d = 0; d < 2; ++d) {
+            const double v = xy[2 * i + d];
+            SQGR_REQUIRE(v == v && v - v == 0.0, "coordinate %lld is not finite", (long long)i);
+            lo[d] = std::min(lo[d], v);
+            hi[d] = std::max(hi[d], v);
+        }
+    SQGR_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DevBuf<double> d_xy;
+    DevBuf<uint32_t> keys, keys_out;
+    DevBuf<int32_t> idx, idx_out;
+    SQGR_TRY(d_xy.alloc((size_t)2 * n));
+    SQGR_TRY(keys.alloc((size_t)n));
+    SQGR_TRY(keys_out.alloc((size_t)n));
+    SQGR_TRY(idx.alloc((size_t)n));
+    SQGR_TRY(idx_out.alloc((size_t)n));
+    SQGR_HIP(hipMemcpyAsync(d_xy.p, xy, (size_t)n * 16, hipMemcpyHostToDevice, st));
+    LaunchTimer tm(ctx, "graph_spatial_order");
+    const double sx = hi[0] > lo[0] ? 65535.0 / (hi[0] - lo[0]) : 0.0, sy = hi[1] > lo[1] ? 65535.0 / (hi[1] - lo[1]) : 0.0;
+    k_morton_keys<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(d_xy.p, n, lo[0], lo[1], sx, sy, keys.p, idx.p);
+    SQGR_HIP(hipGetLastError());
+    size_t tmp_bytes = 0;
+    SQGR_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys.p, keys_out.p, idx.p, idx_out.p, (int)n, 0, 32, st));
+    DevBuf<uint8_t> tmp;
+    SQGR_TRY(tmp.alloc(tmp_bytes));
+    SQGR_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, keys.p, keys_out.p, idx.p, idx_out.p, (int)n, 0, 32, st));
+    SQGR_HIP(hipMemcpyAsync(out_order, idx_out.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    SQGR_HIP(hipStreamSynchronize(st));
+    return SQGR_OK;
 }
 
 int sqgr_graph_destroy(sqgr_graph* g) {

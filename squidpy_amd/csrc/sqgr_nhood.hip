@@ -157,7 +157,11 @@ template <int B, bool HAS_LIBS, bool SMALLK>
 __global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __restrict__ cum, int kpad, int blk_words, int K,
                                                  const uint32_t* __restrict__ keys, LibDom dom0, int n_libs, int nrows,
                                                  const int32_t* __restrict__ lib_of, const int32_t* __restrict__ rank_of,
-                                                 const LibDom* __restrict__ libdoms, uint8_t* __restrict__ slab_all, int pw) {
+                                                 const LibDom* __restrict__ libdoms, uint8_t* __restrict__ slab_all, int pw,
+                                                 const int32_t* __restrict__ spot_of) {
+    // spot_of != NULL (no libraries): the plan lives on a RENUMBERED twin of the caller's graph (sqgr_graph_renumbered) — slab row i
+    // belongs to the caller's observation spot_of[i], whose rank the generator permutes: the labels are the ones the plan on the
+    // caller's own graph gives that observation, stored where the renumbered edge lists look for them
     extern __shared__ uint32_t s_lds[];               // [blk_words] block table (byte offset 0), then [n_libs][kpad] boundaries
     uint32_t* s_cum = s_lds + blk_words;
     for (int t = threadIdx.x; t < n_libs * kpad; t += 256) s_cum[t] = cum[t];
@@ -187,6 +191,8 @@ __global__ __launch_bounds__(256) void k_shuffle(int64_t n, const uint32_t* __re
         lib = (uint32_t)lib_of[i];
         ld = libdoms[lib];
         x0 = (uint32_t)rank_of[i];
+    } else if (spot_of) {
+        x0 = (uint32_t)spot_of[i];
     }
     const FeistelDomain dom = ld.dom;
     const uint32_t* tab = s_cum + lib * kpad + 1;  // tab[k] = cum[k + 1]
@@ -1532,6 +1538,8 @@ struct sqgr_nhood {
     size_t keys_stride() const { return (size_t)nbatch * key_words_per_row(B, n_libs); }
     bool wide() const { return K > 256; }  // 16-bit labels, device-scope counters
     bool tab_lds = true;                   // the label-boundary table fits LDS next to the block table (nhood_build)
+    DevBuf<int32_t> spot_of;               // sqgr_nhood_set_spot_map: slab row i holds the labels of the caller's observation spot_of[i]
+    bool mapped() const { return spot_of.p != nullptr; }
     size_t slab_stride() const { return (size_t)nbatch * n * B * (wide() ? 2 : 1); }  // bytes
     DevBuf<uint32_t> partial;
     DevBuf<int64_t> acc_sum;
@@ -2245,7 +2253,7 @@ static int launch_shuffle_raw(sqgr_nhood* p, int B, int nb, const uint32_t* keys
     const unsigned gy = (unsigned)(B == 32 ? nb : (nb + 1) / 2);  // 16-permutation rows are shuffled in pairs
 #define SQGR_SHUFFLE(BB, LIBS, SK)                                                                                               \
     k_shuffle<BB, LIBS, SK><<<dim3(gx, gy), 256, lds, st>>>(p->n, p->cum.p, p->kpad, p->blk_bytes, p->K, keys, p->dom0, p->n_libs, nb, \
-                                                            p->lib_of.p, p->rank_of.p, p->libs.p, slab, pw)
+                                                            p->lib_of.p, p->rank_of.p, p->libs.p, slab, pw, p->spot_of.p)
 #define SQGR_SHUFFLE_K(BB, LIBS) \
     if (p->K <= 126) SQGR_SHUFFLE(BB, LIBS, true); else SQGR_SHUFFLE(BB, LIBS, false)
     if (B == 32) {
@@ -2280,6 +2288,7 @@ int sqgr_nhood_run(sqgr_nhood* plan, uint64_t seed, int64_t perm_begin, int64_t 
         const char* e = getenv("SQGR_SHUFFLE_INDEPENDENT");
         p->independent = e && atoi(e) == 1;
         SQGR_REQUIRE(!p->independent || (p->B == 16 && !p->has_libs && !p->wide()), "SQGR_SHUFFLE_INDEPENDENT needs 16-wide rows, K <= 256 and no libraries");
+        SQGR_REQUIRE(!p->independent || !p->mapped(), "SQGR_SHUFFLE_INDEPENDENT: no spot map");
     }
     auto local = [&]() -> int {
     SQGR_TRY(p->ensure_workspace(out_perms != nullptr));
@@ -2356,6 +2365,7 @@ int sqgr_nhood_run(sqgr_nhood* plan, uint64_t seed, int64_t perm_begin, int64_t 
 int sqgr_nhood_shuffled_labels(sqgr_nhood* plan, uint64_t seed, int64_t perm, uint8_t* out_labels) {
     SQGR_REQUIRE(plan && out_labels && perm >= 0, "plan/out_labels is NULL or perm < 0");
     SQGR_REQUIRE(plan->K <= 256, "sqgr_nhood_shuffled_labels returns uint8 labels: K=%d > 256", plan->K);
+    SQGR_REQUIRE(!plan->mapped(), "a plan with a spot map (sqgr_nhood_set_spot_map) runs sqgr_nhood_run only");
     sqgr_nhood* p = plan;
     sqgr_ctx* ctx = p->ctx;
     SQGR_HIP(hipSetDevice(ctx->device));
@@ -2439,6 +2449,7 @@ int sqgr_nhood_counts_batch(sqgr_ctx* ctx, const sqgr_graph* g, const uint8_t* l
 static int run_pcg64_impl(sqgr_nhood* plan, const uint64_t* pcg_states, int64_t n_perms, const int64_t* shift, int64_t* out_sum,
                           uint64_t* out_sumsq, uint32_t* out_perms, bool keep_perms) {
     SQGR_REQUIRE(plan && pcg_states && out_sum && out_sumsq && n_perms >= 0, "null argument or n_perms < 0");
+    SQGR_REQUIRE(!plan->mapped(), "a plan with a spot map (sqgr_nhood_set_spot_map) runs sqgr_nhood_run only: numpy's streams permute positions");
     sqgr_nhood* p = plan;
     keep_perms = keep_perms || out_perms != nullptr;
     SQGR_REQUIRE(p->has_labels, "plan was created without labels");
@@ -2651,6 +2662,21 @@ int sqgr_nhood_info(sqgr_nhood* plan, int64_t* out_info) {
     out_info[9] = p->split();
     out_info[10] = p->cm();
     out_info[11] = (int64_t)p->part_words() * 4;                // bytes of one chunk's partial histograms (all passes)
+    return SQGR_OK;
+}
+
+int sqgr_nhood_set_spot_map(sqgr_nhood* plan, const int32_t* spot_of) {
+    SQGR_REQUIRE(plan, "plan is NULL");
+    if (!spot_of) {
+        plan->spot_of.release();
+        return SQGR_OK;
+    }
+    SQGR_REQUIRE(!plan->has_libs && !plan->wide(), "a spot map needs a plan without libraries and at most 256 clusters");
+    for (int64_t i = 0; i < plan->n; ++i)
+        SQGR_REQUIRE(spot_of[i] >= 0 && spot_of[i] < plan->n, "spot_of[%lld]=%d outside [0,%lld)", (long long)i, spot_of[i], (long long)plan->n);
+    SQGR_HIP(hipSetDevice(plan->ctx->device));
+    SQGR_TRY(plan->spot_of.alloc((size_t)plan->n));
+    SQGR_HIP(hipMemcpy(plan->spot_of.p, spot_of, (size_t)plan->n * 4, hipMemcpyHostToDevice));
     return SQGR_OK;
 }
 

@@ -131,17 +131,6 @@ def nhood_enrichment(
             UserWarning, stacklevel=2)
 
     adj = adata.obsp[connectivity_key]
-    if rng == "philox" and adata.n_obs * n_perms >= SPOT_ORDER_NOTICE_WORK:
-        from .._order import edge_span
-
-        span = edge_span(adj)
-        if span > SPOT_ORDER_NOTICE_SPAN:  # (a 2-D grid in scan order: ~1 / sqrt(n); random order: ~1/3)
-            warnings.warn(
-                f"nhood_enrichment: neighbouring observations lie far apart in `obs` order (mean |row - col| of the graph = {span:.2f} n): the count "
-                "kernel gathers their label rows from all over the array and runs up to ~8x slower than on spatially ordered observations.  "
-                "`order = squidpy_amd.spatial_order(coords=adata.obsm['spatial'])` (or `spatial_order(adj)`) and `adata = adata[order].copy()` "
-                "before building the graph bring the speed back; the test is the same (a seed then draws another arrangement).",
-                UserWarning, stacklevel=2)
     int_clust, n_cls = category_codes(adata.obs[cluster_key])
     if library_key is not None:
         _assert_categorical_obs(adata, key=library_key)
@@ -195,7 +184,14 @@ def nhood_enrichment(
         lo, hi = _dist.shard_range(n_perms, rank, world)
         shift = expected_counts(int_clust, n_cls, graph.nnz)
         comm = _device_comm(ctx)
-        plan = NhoodPlan(ctx, graph, int_clust, n_cls, lib_codes, n_libs)
+        # observations in no spatial order: the plan runs on a renumbered twin of the graph (built on the device, kept with the
+        # graph) and the generator permutes the ranks of the CALLER's observations — the same moments, bit for bit
+        order = _internal_order(ctx, adata, adj, n_cls, lib_codes, n_perms)
+        if order is not None:
+            plan = NhoodPlan(ctx, graph.renumbered(order), int_clust[order], n_cls)
+            plan.set_spot_map(order)
+        else:
+            plan = NhoodPlan(ctx, graph, int_clust, n_cls, lib_codes, n_libs)
         try:
             key = _broadcast_seed(resolve_seed(seed))
             plan.set_comm(comm)  # the exact integer moments are all-reduced on the device (RCCL inside libsqgr)
@@ -240,8 +236,48 @@ def _broadcast_seed(key: int) -> int:
     return int(_dist.broadcast_object(int(key), src=0))
 
 
-SPOT_ORDER_NOTICE_WORK = 2_000_000_000       # n_obs * n_perms from which rng="philox" looks at the order of the observations (squidpy_amd/_order.py)
-SPOT_ORDER_NOTICE_SPAN = 0.05                # mean |row - col| / n of the graph's edges above which the order is pointed out
+RENUMBER_MIN_OBS = 32_768      # observations from which rng="philox" looks at their order (squidpy_amd/_order.py) ...
+RENUMBER_MIN_PERMS = 256       # ... and permutations: the twin graph costs a few ms
+RENUMBER_NEAR = 0.2            # fraction of the edges whose endpoints lie within 8 positions of each other below which ...
+RENUMBER_SPAN = 0.02           # ... or mean |row - col| / n above which the order counts as "not spatial"
+RENUMBER_RCM_PERMS = 50_000    # without coordinates: permutations from which a reverse Cuthill-McKee order on the host (~0.1 s per 1e6) pays
+
+
+def _internal_order(ctx: Context, adata: Any, adj: Any, n_cls: int, lib_codes: Any, n_perms: int) -> np.ndarray | None:
+    """``order[new] = old`` for the plan-internal renumbering of ``rng="philox"``, or ``None``: the observations are in a spatial
+    order already (grids in scan order, cells listed tile by tile), the call is small, or the plan cannot carry a spot map
+    (libraries, more than 256 clusters).  ``SQGR_NHOOD_RENUMBER=0`` switches it off, ``=1`` forces it where admissible.
+    tools/spot_order_time.py: random order 240 k permutations/s, fields of view of 100 x 100 cells in random order inside 448 k,
+    renumbered 875 k (scan order: 900 k) at 1e6 spots."""
+    import os
+
+    from .._lib import spatial_order_device
+    from .._order import edge_locality, spatial_order
+
+    mode = os.environ.get("SQGR_NHOOD_RENUMBER", "auto")
+    if mode == "0" or lib_codes is not None or n_cls > 256:
+        return None
+    n = adata.n_obs
+    if mode != "1":
+        if n < RENUMBER_MIN_OBS or n_perms < RENUMBER_MIN_PERMS:
+            return None
+        near, span = edge_locality(adj)
+        if near >= RENUMBER_NEAR and span <= RENUMBER_SPAN:
+            return None
+    xy = None
+    try:
+        xy = np.asarray(adata.obsm[Key.obsm.spatial])
+        if xy.ndim != 2 or xy.shape[0] != n or xy.shape[1] < 2 or not np.issubdtype(xy.dtype, np.number):
+            xy = None
+    except Exception:
+        xy = None
+    if xy is not None:
+        return spatial_order_device(ctx, xy)
+    if mode == "1" or n_perms >= RENUMBER_RCM_PERMS:
+        return spatial_order(adj).astype(np.int32)
+    return None
+
+
 DEFAULT_STREAM_NOTICE_WORK = 5_000_000_000   # n_obs * n_perms from which a DEFAULTED `rng` (numpy's streams, ~11x slower than "philox") is pointed out
 HOST_GATHER_NOTICE_ENTRIES = 64_000_000      # n_perms * K * K from which the host gather of several ranks' per-permutation counts is pointed out
 PROGRESS_STEP = 40_960  # permutations per progress update: 16 launch groups of 2560

@@ -36,7 +36,7 @@ def test_header_symbols_are_exported_and_bound(lib_path):
 
 def test_library_loads_and_reports_abi(lib_path):
     lib = _lib.load_library()
-    assert lib.sqgr_abi_version() == 6
+    assert lib.sqgr_abi_version() == 7
     assert isinstance(lib.sqgr_last_error(), bytes)
 
 

@@ -838,3 +838,91 @@ def test_thousands_of_clusters_run_batched_on_the_device(L, ctx, k):
     want = O.nhood_zscore(O.nhood_counts(adj.indices, adj.indptr, lab, k), ref)
     ok = np.isfinite(want)
     np.testing.assert_array_equal(res.zscore[ok], want[ok])
+
+
+def _shuffled_grid(rows, cols, k, seed, directed=False):
+    """A hex grid (or its directed 6-nearest-neighbour graph) whose observations come in RANDOM order."""
+    import squidpy_amd as sq
+    from squidpy_amd._synthetic import hex_grid, hex_grid_graph, knn_directed_graph
+
+    rng = np.random.default_rng(seed)
+    n = rows * cols
+    xy = hex_grid(rows, cols) + (rng.normal(0.0, 3.0, (n, 2)) if directed else 0.0)
+    adj = (knn_directed_graph(xy, 6) if directed else hex_grid_graph(rows, cols)).tocoo()
+    perm = rng.permutation(n)  # new -> old
+    inv = np.empty(n, np.int64)
+    inv[perm] = np.arange(n)
+    shuf = sp.csr_matrix((adj.data, (inv[adj.row], inv[adj.col])), shape=(n, n))
+    shuf.sort_indices()
+    lab = rng.integers(0, k, n).astype(np.int32)
+    adata = sq.AnnDataLite(obs=pd.DataFrame({"cluster": pd.Categorical.from_codes(lab, [f"c{i:03d}" for i in range(k)])}),
+                           obsm={"spatial": xy[perm]}, obsp={"spatial_connectivities": shuf})
+    return adata, lab
+
+
+@pytest.mark.parametrize("k,directed,coords", [(12, False, True), (12, True, True), (60, False, True), (130, True, True), (9, False, False)])
+def test_observations_in_no_spatial_order_run_on_a_renumbered_twin(L, ctx, k, directed, coords, monkeypatch):
+    """Round 6: rng="philox" on observations in random order builds a renumbered twin of the graph on the device (Z-order curve of
+    obsm['spatial'], or reverse Cuthill-McKee of the graph) and lets the generator permute the ranks of the CALLER's observations
+    (sqgr_graph_renumbered, sqgr_spatial_order, sqgr_nhood_set_spot_map): counts and z-scores equal the ones of the plan on the
+    caller's own graph, bit for bit — symmetric and directed graphs, the LDS counter layouts, with and without coordinates."""
+    import squidpy_amd as sq
+    from squidpy_amd import _order
+
+    adata, lab = _shuffled_grid(190, 200, k, seed=k, directed=directed)
+    if not coords:
+        del adata.obsm["spatial"]
+        monkeypatch.setattr(sq.gr._nhood, "RENUMBER_RCM_PERMS", 1)
+    near, span = _order.edge_locality(adata.obsp["spatial_connectivities"])
+    assert near < 0.05 and span > 0.2
+    monkeypatch.setenv("SQGR_NHOOD_RENUMBER", "0")
+    plain = sq.gr.nhood_enrichment(adata, "cluster", n_perms=300, seed=5, copy=True, rng="philox")
+    monkeypatch.setenv("SQGR_NHOOD_RENUMBER", "auto")
+    used = []
+    real = L.NhoodPlan.set_spot_map
+    monkeypatch.setattr(L.NhoodPlan, "set_spot_map", lambda self, m: (used.append(len(m)), real(self, m))[1])
+    twin = sq.gr.nhood_enrichment(adata, "cluster", n_perms=300, seed=5, copy=True, rng="philox")
+    assert used == [adata.n_obs], "the renumbered twin was not used"
+    np.testing.assert_array_equal(twin.counts, plain.counts)
+    np.testing.assert_array_equal(twin.zscore, plain.zscore)
+    # the default stream keeps the caller's order (numpy permutes positions) and still returns the reference's z-scores
+    adj = adata.obsp["spatial_connectivities"]
+    res = sq.gr.nhood_enrichment(adata, "cluster", n_perms=6, seed=2, copy=True)
+    want = O.nhood_zscore(O.nhood_counts(adj.indices, adj.indptr, lab, k), O.nhood_perm_counts_numpy(adj.indices, adj.indptr, lab, k, 2, 6))
+    ok = np.isfinite(want)
+    np.testing.assert_array_equal(res.zscore[ok], want[ok])
+
+
+def test_renumbered_graph_and_spot_map_through_the_c_abi(L, ctx):
+    """sqgr_graph_renumbered gives P A P^T (the observed counts of the twin with the labels in twin order are the graph's), the
+    device order is a permutation that restores locality, a plan with a spot map refuses numpy's streams, bad orders are refused."""
+    from squidpy_amd import _order
+    from squidpy_amd._utils import pcg64_states
+
+    adata, lab = _shuffled_grid(60, 70, 7, seed=3)
+    adj = adata.obsp["spatial_connectivities"]
+    n = adj.shape[0]
+    g = L.Graph(ctx, adj, with_data=False)
+    order = L.spatial_order_device(ctx, adata.obsm["spatial"])
+    assert sorted(order.tolist()) == list(range(n))
+    twin = g.renumbered(order)
+    np.testing.assert_array_equal(L.nhood_counts(ctx, twin, lab[order], 7), L.nhood_counts(ctx, g, lab, 7))
+    back = adj[order][:, order]
+    assert _order.edge_locality(sp.csr_matrix(back))[0] > 0.2
+    plan = L.NhoodPlan(ctx, twin, lab[order], 7)
+    plan.set_spot_map(order)
+    ref = L.NhoodPlan(ctx, g, lab, 7)
+    a = plan.run(11, 3, 77, None, return_perms=True)
+    b = ref.run(11, 3, 77, None, return_perms=True)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+    with pytest.raises(L.SqgrError, match="spot map"):
+        plan.run_pcg64(pcg64_states(1, 4))
+    plan.set_spot_map(None)
+    plan.close()
+    ref.close()
+    bad = order.copy()
+    bad[0] = bad[1]
+    with pytest.raises(L.SqgrError, match="not a permutation"):
+        g.renumbered(bad)
+    g.close()

@@ -32,6 +32,17 @@ inv = np.empty(n, np.int64); inv[perm] = np.arange(n)
 coo = adj.tocoo()
 shuf = sp.csr_matrix((coo.data, (inv[coo.row], inv[coo.col])), shape=(n, n))
 run("random order", shuf, labels[perm])
+def renumber(A, lab, order):   # order: new position -> old index
+    invo = np.empty(n, np.int64); invo[order] = np.arange(n)
+    c = A.tocoo()
+    return sp.csr_matrix((c.data, (invo[c.row], invo[c.col])), shape=(n, n)), lab[order]
+# cells listed field of view by field of view (tiles of T x T spots), in random order inside a field of view
+for T in (250, 100, 32):
+    r, c = np.divmod(np.arange(n), cols)
+    key = ((r // T) * (cols // T + 1) + (c // T)).astype(np.int64) * n + rng.permutation(n)
+    order = np.argsort(key)
+    A2, l2 = renumber(adj, labels, order)
+    run(f"fields of view of {T} x {T} spots, random order inside", A2, l2)
 t = time.perf_counter()
 from scipy.sparse.csgraph import reverse_cuthill_mckee
 rcm = reverse_cuthill_mckee(shuf, symmetric_mode=True)
@@ -40,3 +51,9 @@ inv2 = np.empty(n, np.int64); inv2[rcm] = np.arange(n)
 c2 = shuf.tocoo()
 back = sp.csr_matrix((c2.data, (inv2[c2.row], inv2[c2.col])), shape=(n, n))
 run("random order, renumbered by RCM", back, labels[perm][rcm])
+import squidpy_amd as sq
+from squidpy_amd._synthetic import hex_grid
+xy = hex_grid(rows, cols)[perm]           # coordinates in the random order
+t = time.perf_counter(); mo = sq.spatial_order(coords=xy); print("Morton order on the host: %.2f s" % (time.perf_counter() - t))
+A3, l3 = renumber(shuf, labels[perm], mo)
+run("random order, renumbered along the Morton curve", A3, l3)
