@@ -63,6 +63,23 @@ while (it < ITERS) if ITERS else (time.time() - t0 < budget):
     with np.errstate(divide="ignore", invalid="ignore"):
         assert np.array_equal(res.counts, cnt) and np.array_equal(res.zscore, O.nhood_zscore(cnt, perms), equal_nan=True), ("nhood", n, K, P)
 
+    # ---- nhood_enrichment with the device generator: against its restatement, on the caller's graph and (observations of a random
+    # cloud come in no spatial order) on the renumbered twin — the same moments, bit for bit; also the directed kNN graph
+    if rng.random() < 0.5:
+        from squidpy_amd._synthetic import knn_directed_graph
+        gconn = conn if rng.random() < 0.5 else knn_directed_graph(xy, min(int(rng.choice([3, 6])), n - 1))
+        ad2 = sq.AnnDataLite(obs=obs, obsm={"spatial": xy}, obsp={"spatial_connectivities": gconn})
+        zs = []
+        for ren in ("0", "1"):
+            os.environ["SQGR_NHOOD_RENUMBER"] = ren
+            zs.append(sq.gr.nhood_enrichment(ad2, "cl", n_perms=P, seed=sd, copy=True, rng="philox", show_progress_bar=False))
+        os.environ.pop("SQGR_NHOOD_RENUMBER", None)
+        cnt2 = O.nhood_counts(gconn.indices, gconn.indptr, labels, K)
+        want = O.nhood_zscore(cnt2, O.nhood_perm_counts_philox(gconn.indices, gconn.indptr, labels, K, sd, 0, P))
+        ok = np.isfinite(want)
+        assert np.array_equal(zs[0].counts, cnt2) and np.array_equal(zs[0].zscore, zs[1].zscore, equal_nan=True), ("nhood philox twin", n, K, P)
+        assert np.allclose(zs[0].zscore[ok], want[ok], rtol=1e-9), ("nhood philox", n, K, P)
+
     # ---- spatial_autocorr
     mode = str(rng.choice(["moran", "geary"])); two = bool(rng.random() < 0.5); trans = bool(rng.random() < 0.7)
     corr = "fdr_bh" if rng.random() < 0.7 else None; Pa = None if rng.random() < 0.3 else int(rng.integers(1, 50))
