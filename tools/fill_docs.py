@@ -73,6 +73,8 @@ vals = {
     "K64": k(legs["nhood_K64"]["value"]), "K100": k(legs["nhood_K100"]["value"]), "K200": k(legs["nhood_K200"]["value"]),
     "K64R": f"{legs['nhood_K64']['vs_k30']:.2f}", "K100R": f"{legs['nhood_K100']['vs_k30']:.2f}", "K200R": f"{legs['nhood_K200']['vs_k30']:.2f}",
     "KNNR": f"{legs['nhood_knn6_directed']['vs_k30']:.2f}",
+    "RANDR": f"{(legs.get('nhood_random_order') or {}).get('vs_k30') or 0:.2f}", "RAND": k((legs.get('nhood_random_order') or {}).get('value') or 0),
+    "RANDGIVEN": k((legs.get('nhood_random_order') or {}).get('as_given') or 0),
     "KNN": k(legs["nhood_knn6_directed"]["value"]), "DIRI": k(legs["nhood_dirichlet"]["value"]), "DIRIR": f"{legs['nhood_dirichlet']['vs_k30']:.2f}",
     "INDEP": k(ind.get("value", 0)), "INDEPR": f"{ind.get('vs_k30', 0):.2f}", "INDEPSH": f"{ind.get('shuffle_ms_per_step', 0):.1f}",
     "KSWEEP": "\n".join(rows),
