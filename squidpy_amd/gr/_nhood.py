@@ -272,7 +272,10 @@ def _internal_order(ctx: Context, adata: Any, adj: Any, n_cls: int, lib_codes: A
     except Exception:
         xy = None
     if xy is not None:
-        return spatial_order_device(ctx, xy)
+        try:
+            return spatial_order_device(ctx, xy)
+        except Exception:  # coordinates that are not finite, ...: the graph alone decides below
+            pass
     if mode == "1" or n_perms >= RENUMBER_RCM_PERMS:
         return spatial_order(adj).astype(np.int32)
     return None
